@@ -1,0 +1,462 @@
+// Per-pair arithmetic of the real-space multipolar PME kernel and its hand-coded adjoint.
+//
+// One translation of the reference's quasi-internal-frame pair energy
+// (reference admp/pme.py:258-334 calc_e_perm, :379-475 calc_e_ind, :479-624 pme_real_kernel,
+//  admp/spatial.py:149-178 build_quasi_internal, admp/multipole.py:80-179 rotations)
+// written as plain inline functions so that the HIP kernels (pair_kernels.hip) and the
+// host-compiled test shim (tests/hostshim) execute the very same arithmetic.
+//
+// What the reference obtains by jax.value_and_grad (admp/pme.py:108) is coded explicitly:
+//   * d(coef)/dr by forward-mode dual numbers through the coefficient formulas
+//     (same branch semantics as reverse-mode AD: clamped branches carry zero derivative);
+//   * dE/d(multipole components) from the bilinear form;
+//   * the two transverse gradient components from rotational invariance: displacing dr
+//     by eps along the pair-frame x (y) axis turns the frame about y (x) by eps/r, so
+//     g_x = (1/r) sum_sites P . (G_y q),  g_y = (1/r) sum_sites P . (G_x q)
+//     with G the l<=2 real-harmonic rotation generators written out below.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define ADMP_HD __host__ __device__ __forceinline__
+#else
+#define ADMP_HD inline
+#endif
+
+namespace admp {
+
+constexpr double kDielectric = 1389.35455846;   // admp/pme.py:16
+constexpr double kDefaultTholeWidth = 0.3;      // admp/pme.py:17
+constexpr double kSqrt3 = 1.7320508075688772;
+constexpr double kTwoOverSqrtPi = 1.1283791670955126;
+
+// ---------------------------------------------------------------- dual numbers (value, d/dr)
+template <class T>
+struct Dual {
+  T v, d;
+  ADMP_HD Dual() {}
+  ADMP_HD Dual(T v_) : v(v_), d(T(0)) {}
+  ADMP_HD Dual(T v_, T d_) : v(v_), d(d_) {}
+};
+template <class T> ADMP_HD Dual<T> operator+(Dual<T> a, Dual<T> b) { return {a.v + b.v, a.d + b.d}; }
+template <class T> ADMP_HD Dual<T> operator-(Dual<T> a, Dual<T> b) { return {a.v - b.v, a.d - b.d}; }
+template <class T> ADMP_HD Dual<T> operator*(Dual<T> a, Dual<T> b) { return {a.v * b.v, a.v * b.d + a.d * b.v}; }
+template <class T> ADMP_HD Dual<T> operator+(Dual<T> a, T b) { return {a.v + b, a.d}; }
+template <class T> ADMP_HD Dual<T> operator+(T b, Dual<T> a) { return {a.v + b, a.d}; }
+template <class T> ADMP_HD Dual<T> operator-(Dual<T> a, T b) { return {a.v - b, a.d}; }
+template <class T> ADMP_HD Dual<T> operator-(T b, Dual<T> a) { return {b - a.v, -a.d}; }
+template <class T> ADMP_HD Dual<T> operator*(Dual<T> a, T b) { return {a.v * b, a.d * b}; }
+template <class T> ADMP_HD Dual<T> operator*(T b, Dual<T> a) { return {a.v * b, a.d * b}; }
+template <class T> ADMP_HD Dual<T> operator-(Dual<T> a) { return {-a.v, -a.d}; }
+
+template <class T> ADMP_HD T val(T a) { return a; }
+template <class T> ADMP_HD T val(Dual<T> a) { return a.v; }
+
+ADMP_HD float m_exp(float x) { return expf(x); }
+ADMP_HD double m_exp(double x) { return exp(x); }
+ADMP_HD float m_erfc(float x) { return erfcf(x); }
+ADMP_HD double m_erfc(double x) { return erfc(x); }
+ADMP_HD float m_sqrt(float x) { return sqrtf(x); }
+ADMP_HD double m_sqrt(double x) { return sqrt(x); }
+ADMP_HD float m_floor(float x) { return floorf(x); }
+ADMP_HD double m_floor(double x) { return floor(x); }
+ADMP_HD float m_ceil(float x) { return ceilf(x); }
+ADMP_HD double m_ceil(double x) { return ceil(x); }
+ADMP_HD float m_abs(float x) { return fabsf(x); }
+ADMP_HD double m_abs(double x) { return fabs(x); }
+template <class T> ADMP_HD Dual<T> m_exp(Dual<T> a) { T e = m_exp(a.v); return {e, e * a.d}; }
+// erfc'(x) = -2/sqrt(pi) exp(-x^2)
+template <class T> ADMP_HD Dual<T> m_erfc(Dual<T> a) {
+  return {m_erfc(a.v), -T(kTwoOverSqrtPi) * m_exp(-a.v * a.v) * a.d};
+}
+template <class T> ADMP_HD Dual<T> recip(Dual<T> a) { T i = T(1) / a.v; return {i, -a.d * i * i}; }
+template <class T> ADMP_HD T recip(T a) { return T(1) / a; }
+// trim_val_infty (admp/pme.py:365-376): x >= thresh -> constant thresh
+template <class T> ADMP_HD T trim_inf(T a, T th) { return a < th ? a : th; }
+template <class T> ADMP_HD Dual<T> trim_inf(Dual<T> a, T th) { return a.v < th ? a : Dual<T>(th, T(0)); }
+
+// ---------------------------------------------------------------- geometry
+template <class T>
+struct Box {
+  T h[9];     // lattice vectors in rows (admp/pme.py:159)
+  T hinv[9];  // inverse
+};
+
+// admp/spatial.py:13-32: ds = dr . box^-1 ; ds -= floor(ds + 1/2) ; dr = ds . box
+template <class T>
+ADMP_HD void min_image(const Box<T>& b, T d[3]) {
+  T s0 = d[0] * b.hinv[0] + d[1] * b.hinv[3] + d[2] * b.hinv[6];
+  T s1 = d[0] * b.hinv[1] + d[1] * b.hinv[4] + d[2] * b.hinv[7];
+  T s2 = d[0] * b.hinv[2] + d[1] * b.hinv[5] + d[2] * b.hinv[8];
+  s0 -= m_floor(s0 + T(0.5));
+  s1 -= m_floor(s1 + T(0.5));
+  s2 -= m_floor(s2 + T(0.5));
+  d[0] = s0 * b.h[0] + s1 * b.h[3] + s2 * b.h[6];
+  d[1] = s0 * b.h[1] + s1 * b.h[4] + s2 * b.h[7];
+  d[2] = s0 * b.h[2] + s1 * b.h[5] + s2 * b.h[8];
+}
+
+// Pair frame with z || dr (admp/spatial.py:149-178).  The reference picks the helper axis
+// e_x unless the raw y and z coordinates coincide (spatial.py:172); the pair energy does not
+// depend on that choice (it is invariant under rotation about z), so the helper is chosen
+// here by conditioning instead: e_x unless z is within ~37 deg of it.
+template <class T>
+ADMP_HD void qi_frame(const T z[3], T x[3], T y[3]) {
+  T hx = T(1), hy = T(0);
+  if (m_abs(z[0]) > T(0.8)) { hx = T(0); hy = T(1); }
+  T dot = z[0] * hx + z[1] * hy;
+  x[0] = hx - z[0] * dot;
+  x[1] = hy - z[1] * dot;
+  x[2] = -z[2] * dot;
+  T inv = T(1) / m_sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  x[0] *= inv; x[1] *= inv; x[2] *= inv;
+  y[0] = z[1] * x[2] - z[2] * x[1];
+  y[1] = z[2] * x[0] - z[0] * x[2];
+  y[2] = z[0] * x[1] - z[1] * x[0];
+}
+
+// Components, in the frame with rows (x,y,z), of a harmonic multipole given in the global
+// frame.  Same map as rot_global2local (admp/multipole.py:92-179), evaluated through the
+// Cartesian traceless tensor instead of the 25-entry matrix: Theta' = R Theta R^T.
+// Harmonic order [00, 10, 11c, 11s, 20, 21c, 21s, 22c, 22s]; dipole (10,11c,11s) = (z,x,y).
+// The map is orthogonal, so the adjoint (cotangent local -> global) is the same routine
+// with the transposed frame: pass (cx,cy,cz) = columns.
+template <class T>
+ADMP_HD void rot_dip(const T* q, const T x[3], const T y[3], const T z[3], T* o) {
+  // q = (dz, dx, dy)
+  T dx = q[1], dy = q[2], dz = q[0];
+  o[0] = z[0] * dx + z[1] * dy + z[2] * dz;
+  o[1] = x[0] * dx + x[1] * dy + x[2] * dz;
+  o[2] = y[0] * dx + y[1] * dy + y[2] * dz;
+}
+
+template <class T>
+ADMP_HD void rot_quad(const T* q, const T x[3], const T y[3], const T z[3], T* o) {
+  const T h = T(0.5 * kSqrt3);
+  T tzz = q[0];
+  T txx = T(0.5) * (-q[0] + T(kSqrt3) * q[3]);
+  T tyy = T(0.5) * (-q[0] - T(kSqrt3) * q[3]);
+  T txz = h * q[1], tyz = h * q[2], txy = h * q[4];
+  // t_k = Theta . r_k
+  T ax = txx * x[0] + txy * x[1] + txz * x[2];
+  T ay = txy * x[0] + tyy * x[1] + tyz * x[2];
+  T az = txz * x[0] + tyz * x[1] + tzz * x[2];
+  T bx = txx * y[0] + txy * y[1] + txz * y[2];
+  T by = txy * y[0] + tyy * y[1] + tyz * y[2];
+  T bz = txz * y[0] + tyz * y[1] + tzz * y[2];
+  T cx = txx * z[0] + txy * z[1] + txz * z[2];
+  T cy = txy * z[0] + tyy * z[1] + tyz * z[2];
+  T cz = txz * z[0] + tyz * z[1] + tzz * z[2];
+  T nzz = z[0] * cx + z[1] * cy + z[2] * cz;
+  T nxz = x[0] * cx + x[1] * cy + x[2] * cz;
+  T nyz = y[0] * cx + y[1] * cy + y[2] * cz;
+  T nxx = x[0] * ax + x[1] * ay + x[2] * az;
+  T nyy = y[0] * bx + y[1] * by + y[2] * bz;
+  T nxy = x[0] * bx + x[1] * by + x[2] * bz;
+  const T g = T(2.0 / kSqrt3);
+  o[0] = nzz;
+  o[1] = g * nxz;
+  o[2] = g * nyz;
+  o[3] = T(1.0 / kSqrt3) * (nxx - nyy);
+  o[4] = g * nxy;
+}
+
+template <class T>
+ADMP_HD void rot_harm(const T Q[9], const T x[3], const T y[3], const T z[3], T o[9]) {
+  o[0] = Q[0];
+  rot_dip(Q + 1, x, y, z, o + 1);
+  rot_quad(Q + 4, x, y, z, o + 4);
+}
+
+// transposed frame helper: columns of the (x,y,z)-row matrix
+template <class T>
+ADMP_HD void frame_cols(const T x[3], const T y[3], const T z[3], T cx[3], T cy[3], T cz[3]) {
+  cx[0] = x[0]; cx[1] = y[0]; cx[2] = z[0];
+  cy[0] = x[1]; cy[1] = y[1]; cy[2] = z[1];
+  cz[0] = x[2]; cz[1] = y[2]; cz[2] = z[2];
+}
+
+// Rotation generators in the real-harmonic basis (derivation in the file header).
+// gen_toward_x: d(components)/d(theta) when the frame turns about its y axis (z -> x).
+template <class T>
+ADMP_HD T gen_toward_x(const T* P, const T* q) {   // 9-component sets
+  return P[1] * q[2] - P[2] * q[1] + T(kSqrt3) * (P[4] * q[5] - P[5] * q[4]) + P[5] * q[7] - P[7] * q[5] +
+         P[6] * q[8] - P[8] * q[6];
+}
+// gen_toward_y: frame turns z -> y.
+template <class T>
+ADMP_HD T gen_toward_y(const T* P, const T* q) {
+  return P[1] * q[3] - P[3] * q[1] + T(kSqrt3) * (P[4] * q[6] - P[6] * q[4]) + P[5] * q[8] - P[8] * q[5] -
+         P[6] * q[7] + P[7] * q[6];
+}
+// rotation of the object about the third axis of the basis the components are given in
+template <class T>
+ADMP_HD T gen_about_z(const T* P, const T* q) {
+  return -P[2] * q[3] + P[3] * q[2] - P[5] * q[6] + P[6] * q[5] + T(2) * (P[8] * q[7] - P[7] * q[8]);
+}
+
+// ---------------------------------------------------------------- radial coefficients
+// Shared Ewald pieces (admp/pme.py:283-300).  bVec is kept in the complementary form
+// Bn = 1 + b_n (so that m + b_n = (m - 1) + Bn): B1 = erfc(x), B2 = B1 + xX, ...
+// which avoids the 1 - erf cancellation in single precision.
+template <class S, class T>
+struct Radial {
+  S R1, R2, R3, R4, R5;   // DIELECTRIC * r^-n
+  S x2, x3X, x5X, xX;     // powers of x = kappa r times X = 2 exp(-x^2)/sqrt(pi)
+  S B2, B3, B4;
+  ADMP_HD void init(S r, T kappa) {
+    S ri = recip(r);
+    R1 = ri * T(kDielectric);
+    R2 = R1 * ri; R3 = R2 * ri; R4 = R3 * ri; R5 = R4 * ri;
+    S x = r * kappa;
+    x2 = x * x;
+    S X = m_exp(-x2) * T(kTwoOverSqrtPi);
+    xX = x * X;
+    x3X = xX * x2;
+    x5X = x3X * x2;
+    S B1 = m_erfc(x);
+    B2 = B1 + xX;
+    B3 = B2 + x3X * T(2.0 / 3.0);
+    B4 = B3 + x5X * T(4.0 / 15.0);
+  }
+};
+
+// ten permanent coefficients (admp/pme.py:303-324); mm = mscale - 1
+enum { CC, CD, DD0, DD1, CQ, DQ0, DQ1, QQ0, QQ1, QQ2, CUD, DUD0, DUD1, UDQ0, UDQ1, UDUD0, UDUD1, NCOEF };
+
+template <class S, class T>
+ADMP_HD void perm_coefs(const Radial<S, T>& a, T mm, S* c) {
+  c[CC] = a.R1 * (mm + a.B2 - a.xX);
+  c[CD] = a.R2 * (mm + a.B2);
+  c[DD0] = a.R3 * ((mm + a.B3) * T(3) + a.x3X) * T(-2.0 / 3.0);
+  c[DD1] = a.R3 * (mm + a.B3 - a.x3X * T(2.0 / 3.0));
+  c[CQ] = a.R3 * (mm + a.B3);
+  c[DQ0] = a.R4 * ((mm + a.B3) * T(3) + a.x5X * T(4.0 / 3.0));
+  c[DQ1] = a.R4 * (mm + a.B3) * T(-kSqrt3);
+  c[QQ0] = a.R5 * ((mm + a.B4) * T(6) + (a.x2 * T(10) - T(3)) * a.x5X * T(4.0 / 45.0));
+  c[QQ1] = a.R5 * ((mm + a.B4) * T(15) + a.x5X) * T(-4.0 / 15.0);
+  c[QQ2] = a.R5 * (mm + a.B4 - a.x5X * T(4.0 / 15.0));
+}
+
+// seven induced coefficients (admp/pme.py:408-475).
+//   aw   : Thole width after the Fermi switch on pscale (pme.py:411; r-independent)
+//   dmp  : (pol_i pol_j)^(1/6), floored at 1e-8 by the caller (pme.py:413)
+//   pm   : pscale ; the Ewald part enters as (p*thole + b_n) = p*thole - 1 + Bn
+template <class S, class T>
+ADMP_HD void ind_coefs(const Radial<S, T>& a, S r, T aw, T dmp, T p, S* c) {
+  S u = trim_inf(r * (T(1) / dmp), T(1e8));
+  S au = u * aw;
+  S expau = (val(au) < T(50)) ? m_exp(-au) : S(T(0));
+  S au2 = trim_inf(au * au, T(1e8));
+  S au3 = trim_inf(au2 * au, T(1e8));
+  S au4 = trim_inf(au3 * au, T(1e8));
+  S base = au + T(1) + au2 * T(0.5);
+  S th_c = T(1) - expau * base;
+  S th_d0 = T(1) - expau * (base + au3 * T(0.25));
+  S th_q1 = T(1) - expau * (base + au3 * T(1.0 / 6.0));
+  S th_q0 = T(1) - expau * (base + au3 * T(1.0 / 6.0) + au4 * T(1.0 / 18.0));
+  // th_d1 == th_c (pme.py:430)
+  c[CUD] = a.R2 * (th_c * p - T(1) + a.B2) * T(2);
+  c[DUD0] = a.R3 * ((th_d0 * p - T(1) + a.B3) * T(3) + a.x3X) * T(-4.0 / 3.0);
+  c[DUD1] = a.R3 * (th_c * p - T(1) + a.B3 - a.x3X * T(2.0 / 3.0)) * T(2);
+  c[UDQ0] = a.R4 * ((th_q0 * p - T(1) + a.B3) * T(3) + a.x5X * T(4.0 / 3.0)) * T(2);
+  c[UDQ1] = a.R4 * (th_q1 * p - T(1) + a.B3) * T(-2.0 * kSqrt3);
+  // uscales = 1 (pme.py:472): dscales is ignored by the reference
+  c[UDUD0] = a.R3 * ((th_d0 - T(1) + a.B3) * T(3) + a.x3X) * T(-2.0 / 3.0);
+  c[UDUD1] = a.R3 * (th_c - T(1) + a.B3 - a.x3X * T(2.0 / 3.0));
+}
+
+// ---------------------------------------------------------------- the pair
+// Per-site data as the kernels keep it (global frame).
+template <class T>
+struct Site {
+  T r[3];
+  T Q[9];    // permanent multipoles, global harmonics
+  T U[3];    // induced dipole, global harmonic order (z,x,y)  (admp/pme.py:235)
+  T p6;      // pol^(1/6)  (dmp = p6_i p6_j, admp/pme.py:732-735)
+  T thole;
+};
+
+template <class T>
+struct PairScales {
+  T mm;    // mscale - 1
+  T p;     // pscale
+  T w0;    // Fermi weight of DEFAULT_THOLE_WIDTH at this pscale (admp/pme.py:337-348, 411)
+};
+
+// Full evaluation, centre = site I (dr = r_I - r_J, reference ordering admp/pme.py:713).
+//   returns the pair energy; adds to gI (dE/dr_I = -dE/dr_J), potI (dE/dQ_I global),
+//   fldI (dE/dU_I global harmonic).  If WITH_J also adds site J's potJ / fldJ.
+template <class T, bool LPOL, bool WITH_J>
+ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J, const PairScales<T>& sc, T kappa,
+                           T gI[3], T potI[9], T fldI[3], T potJ[9], T fldJ[3]) {
+  T d[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+  min_image(box, d);
+  T r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  T r = m_sqrt(r2);
+  T rinv = T(1) / r;
+  T z[3] = {d[0] * rinv, d[1] * rinv, d[2] * rinv};
+  T x[3], y[3];
+  qi_frame(z, x, y);
+
+  T A[9], B[9], UA[3], UB[3];
+  rot_harm(I.Q, x, y, z, A);
+  rot_harm(J.Q, x, y, z, B);
+
+  typedef Dual<T> S;
+  S c[NCOEF];
+  Radial<S, T> rad;
+  rad.init(S(r, T(1)), kappa);
+  perm_coefs(rad, sc.mm, c);
+  if (LPOL) {
+    rot_dip(I.U, x, y, z, UA);
+    rot_dip(J.U, x, y, z, UB);
+    T aw = sc.w0 * T(kDefaultTholeWidth) + (T(1) - sc.w0) * (I.thole + J.thole);
+    T dmp = I.p6 * J.p6;
+    dmp = dmp < T(1e-8) ? T(1e-8) : dmp;
+    ind_coefs(rad, S(r, T(1)), aw, dmp, sc.p, c);
+  }
+
+  // bilinear shapes S_c with E = sum_c coef_c S_c   (admp/pme.py:525-624 collected per coefficient)
+  T s[NCOEF];
+  s[CC] = A[0] * B[0];
+  s[CD] = A[0] * B[1] - A[1] * B[0];
+  s[CQ] = A[0] * B[4] + A[4] * B[0];
+  s[DD0] = A[1] * B[1];
+  s[DQ0] = A[4] * B[1] - A[1] * B[4];
+  s[DD1] = A[2] * B[2] + A[3] * B[3];
+  s[DQ1] = A[5] * B[2] + A[6] * B[3] - A[2] * B[5] - A[3] * B[6];
+  s[QQ0] = A[4] * B[4];
+  s[QQ1] = A[5] * B[5] + A[6] * B[6];
+  s[QQ2] = A[7] * B[7] + A[8] * B[8];
+  T e = T(0), dedr = T(0);
+#define ADMP_ACC(k) e += c[k].v * s[k]; dedr += c[k].d * s[k];
+  ADMP_ACC(CC) ADMP_ACC(CD) ADMP_ACC(CQ) ADMP_ACC(DD0) ADMP_ACC(DQ0) ADMP_ACC(DD1) ADMP_ACC(DQ1) ADMP_ACC(QQ0)
+  ADMP_ACC(QQ1) ADMP_ACC(QQ2)
+  if (LPOL) {
+    const T hf = T(0.5);
+    s[CUD] = hf * (A[0] * UB[0] - B[0] * UA[0]);
+    s[DUD0] = hf * (B[1] * UA[0] + A[1] * UB[0]);
+    s[DUD1] = hf * (B[2] * UA[1] + B[3] * UA[2] + A[2] * UB[1] + A[3] * UB[2]);
+    s[UDQ0] = hf * (A[4] * UB[0] - B[4] * UA[0]);
+    s[UDQ1] = hf * (A[5] * UB[1] + A[6] * UB[2] - B[5] * UA[1] - B[6] * UA[2]);
+    s[UDUD0] = UA[0] * UB[0];
+    s[UDUD1] = UA[1] * UB[1] + UA[2] * UB[2];
+    ADMP_ACC(CUD) ADMP_ACC(DUD0) ADMP_ACC(DUD1) ADMP_ACC(UDQ0) ADMP_ACC(UDQ1) ADMP_ACC(UDUD0) ADMP_ACC(UDUD1)
+  }
+#undef ADMP_ACC
+
+  // dE/d(pair-frame components)
+  T PA[9], PB[9], FA[3] = {T(0), T(0), T(0)}, FB[3] = {T(0), T(0), T(0)};
+  PA[0] = c[CC].v * B[0] + c[CD].v * B[1] + c[CQ].v * B[4];
+  PA[1] = -c[CD].v * B[0] + c[DD0].v * B[1] - c[DQ0].v * B[4];
+  PA[2] = c[DD1].v * B[2] - c[DQ1].v * B[5];
+  PA[3] = c[DD1].v * B[3] - c[DQ1].v * B[6];
+  PA[4] = c[CQ].v * B[0] + c[DQ0].v * B[1] + c[QQ0].v * B[4];
+  PA[5] = c[DQ1].v * B[2] + c[QQ1].v * B[5];
+  PA[6] = c[DQ1].v * B[3] + c[QQ1].v * B[6];
+  PA[7] = c[QQ2].v * B[7];
+  PA[8] = c[QQ2].v * B[8];
+  PB[0] = c[CC].v * A[0] - c[CD].v * A[1] + c[CQ].v * A[4];
+  PB[1] = c[CD].v * A[0] + c[DD0].v * A[1] + c[DQ0].v * A[4];
+  PB[2] = c[DD1].v * A[2] + c[DQ1].v * A[5];
+  PB[3] = c[DD1].v * A[3] + c[DQ1].v * A[6];
+  PB[4] = c[CQ].v * A[0] - c[DQ0].v * A[1] + c[QQ0].v * A[4];
+  PB[5] = -c[DQ1].v * A[2] + c[QQ1].v * A[5];
+  PB[6] = -c[DQ1].v * A[3] + c[QQ1].v * A[6];
+  PB[7] = c[QQ2].v * A[7];
+  PB[8] = c[QQ2].v * A[8];
+  if (LPOL) {
+    const T hf = T(0.5);
+    T hcud = hf * c[CUD].v, hd0 = hf * c[DUD0].v, hd1 = hf * c[DUD1].v, hq0 = hf * c[UDQ0].v, hq1 = hf * c[UDQ1].v;
+    PA[0] += hcud * UB[0];
+    PA[1] += hd0 * UB[0];
+    PA[2] += hd1 * UB[1];
+    PA[3] += hd1 * UB[2];
+    PA[4] += hq0 * UB[0];
+    PA[5] += hq1 * UB[1];
+    PA[6] += hq1 * UB[2];
+    PB[0] -= hcud * UA[0];
+    PB[1] += hd0 * UA[0];
+    PB[2] += hd1 * UA[1];
+    PB[3] += hd1 * UA[2];
+    PB[4] -= hq0 * UA[0];
+    PB[5] -= hq1 * UA[1];
+    PB[6] -= hq1 * UA[2];
+    FA[0] = -hcud * B[0] + hd0 * B[1] - hq0 * B[4] + c[UDUD0].v * UB[0];
+    FA[1] = hd1 * B[2] - hq1 * B[5] + c[UDUD1].v * UB[1];
+    FA[2] = hd1 * B[3] - hq1 * B[6] + c[UDUD1].v * UB[2];
+    FB[0] = hcud * A[0] + hd0 * A[1] + hq0 * A[4] + c[UDUD0].v * UA[0];
+    FB[1] = hd1 * A[2] + hq1 * A[5] + c[UDUD1].v * UA[1];
+    FB[2] = hd1 * A[3] + hq1 * A[6] + c[UDUD1].v * UA[2];
+  }
+
+  // transverse gradient from rotational invariance
+  T gx = gen_toward_x(PA, A) + gen_toward_x(PB, B);
+  T gy = gen_toward_y(PA, A) + gen_toward_y(PB, B);
+  if (LPOL) {
+    gx += FA[0] * UA[1] - FA[1] * UA[0] + FB[0] * UB[1] - FB[1] * UB[0];
+    gy += FA[0] * UA[2] - FA[2] * UA[0] + FB[0] * UB[2] - FB[2] * UB[0];
+  }
+  gx *= rinv;
+  gy *= rinv;
+  gI[0] += x[0] * gx + y[0] * gy + z[0] * dedr;
+  gI[1] += x[1] * gx + y[1] * gy + z[1] * dedr;
+  gI[2] += x[2] * gx + y[2] * gy + z[2] * dedr;
+
+  // back to the global frame (adjoint of an orthogonal map = the map with the transposed frame)
+  T cx[3], cy[3], cz[3], t[9];
+  frame_cols(x, y, z, cx, cy, cz);
+  rot_harm(PA, cx, cy, cz, t);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) potI[k] += t[k];
+  if (LPOL) {
+    rot_dip(FA, cx, cy, cz, t);
+    fldI[0] += t[0]; fldI[1] += t[1]; fldI[2] += t[2];
+  }
+  if (WITH_J) {
+    rot_harm(PB, cx, cy, cz, t);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) potJ[k] += t[k];
+    if (LPOL) {
+      rot_dip(FB, cx, cy, cz, t);
+      fldJ[0] += t[0]; fldJ[1] += t[1]; fldJ[2] += t[2];
+    }
+  }
+  return e;
+}
+
+// Field-only evaluation for the SCF (dE/dU_I of the real-space term, admp/pme.py:133):
+// only the seven induced coefficients, no radial derivative, no torque.
+template <class T>
+ADMP_HD void pair_field(const Box<T>& box, const Site<T>& I, const Site<T>& J, const PairScales<T>& sc, T kappa,
+                        T fldI[3]) {
+  T d[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+  min_image(box, d);
+  T r = m_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  T rinv = T(1) / r;
+  T z[3] = {d[0] * rinv, d[1] * rinv, d[2] * rinv};
+  T x[3], y[3];
+  qi_frame(z, x, y);
+  T B[9], UB[3];
+  rot_harm(J.Q, x, y, z, B);
+  rot_dip(J.U, x, y, z, UB);
+  T c[NCOEF];
+  Radial<T, T> rad;
+  rad.init(r, kappa);
+  T aw = sc.w0 * T(kDefaultTholeWidth) + (T(1) - sc.w0) * (I.thole + J.thole);
+  T dmp = I.p6 * J.p6;
+  dmp = dmp < T(1e-8) ? T(1e-8) : dmp;
+  ind_coefs(rad, r, aw, dmp, sc.p, c);
+  const T hf = T(0.5);
+  T FA[3];
+  FA[0] = hf * (-c[CUD] * B[0] + c[DUD0] * B[1] - c[UDQ0] * B[4]) + c[UDUD0] * UB[0];
+  FA[1] = hf * (c[DUD1] * B[2] - c[UDQ1] * B[5]) + c[UDUD1] * UB[1];
+  FA[2] = hf * (c[DUD1] * B[3] - c[UDQ1] * B[6]) + c[UDUD1] * UB[2];
+  T cx[3], cy[3], cz[3], t[3];
+  frame_cols(x, y, z, cx, cy, cz);
+  rot_dip(FA, cx, cy, cz, t);
+  fldI[0] += t[0]; fldI[1] += t[1]; fldI[2] += t[2];
+}
+
+}  // namespace admp
