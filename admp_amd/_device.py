@@ -1,0 +1,174 @@
+"""Device plumbing shared by the force classes: handle lifetime, array staging, pair-list cache.
+
+PyTorch is used only for what it is here for: device memory, streams and (in bench/tests)
+torch.distributed.  Every computation is done by libadmp_hip through raw device pointers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, settings
+
+
+def _torch_dtype(nbytes):
+    return torch.float32 if nbytes == 4 else torch.float64
+
+
+def covalent_to_csr(covalent_map, n_atoms):
+    """covalent_map (dense ndarray / scipy sparse / None) -> CSR triple of int32 arrays."""
+    if covalent_map is None:
+        return np.zeros(n_atoms + 1, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)
+    if hasattr(covalent_map, 'tocsr'):
+        csr = covalent_map.tocsr()
+        csr.sort_indices()
+        ptr, col, val = csr.indptr, csr.indices, csr.data
+    else:
+        dense = np.asarray(covalent_map)
+        if dense.ndim != 2 or dense.shape[0] != dense.shape[1]:
+            raise ValueError('covalent_map must be (Na, Na)')
+        rows, col = np.nonzero(dense)
+        val = dense[rows, col]
+        ptr = np.zeros(dense.shape[0] + 1, dtype=np.int64)
+        np.add.at(ptr, rows + 1, 1)
+        ptr = np.cumsum(ptr)
+    val = np.asarray(val).astype(np.int64)
+    if val.size and (val.min() < 0 or val.max() > 15):
+        raise ValueError('covalent_map entries must lie in 0..15')
+    return (np.ascontiguousarray(ptr, dtype=np.int32), np.ascontiguousarray(col, dtype=np.int32),
+            np.ascontiguousarray(val, dtype=np.int32))
+
+
+class HipForceBase:
+    """Owns one admp_handle (one GPU, one stream) and the static environment."""
+
+    def __init__(self, n_atoms, covalent_map, axis_type=None, axis_indices=None, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('admp_amd needs a ROCm GPU (torch.cuda.is_available() is False); '
+                               'the PME path has no CPU implementation')
+        self._L = _lib.load()
+        self._nbytes = settings.precision_bytes()
+        self._dtype = _torch_dtype(self._nbytes)
+        self._dev_index = torch.cuda.current_device() if device is None else int(device)
+        self._device = torch.device('cuda', self._dev_index)
+        self._h = ctypes.c_void_p()
+        rc = self._L.admp_create(ctypes.byref(self._h), self._dev_index, self._nbytes)
+        if rc != 0:
+            raise _lib.AdmpHipError('admp_create failed (code %d): %s' % (rc, self._L.admp_last_error(None).decode()))
+        self.n_atoms = int(n_atoms)
+        ptr, col, val = covalent_to_csr(covalent_map, self.n_atoms)
+        if len(ptr) != self.n_atoms + 1:
+            raise ValueError('covalent_map size does not match the number of atoms')
+        at = None if axis_type is None else np.ascontiguousarray(np.asarray(axis_type), dtype=np.int32)
+        ai = None if axis_indices is None else np.ascontiguousarray(np.asarray(axis_indices), dtype=np.int32)
+        if at is not None and at.shape != (self.n_atoms,):
+            raise ValueError('axis_type must have one entry per atom')
+        if ai is not None and ai.shape != (self.n_atoms, 3):
+            raise ValueError('axis_indices must be (Na, 3)')
+
+        def p(a):
+            return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(self._h, self._L.admp_set_topology(self._h, self.n_atoms, p(at), p(ai), p(ptr), p(col), p(val)),
+                   'admp_set_topology')
+        self._pairs_key = None
+        self._pairs_keep = None
+        self._stream = None
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) is not None and self._h.value:
+                self._L.admp_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---- staging -----------------------------------------------------------------------------------------
+    def _use_current_stream(self):
+        s = torch.cuda.current_stream(self._device).cuda_stream
+        if s != self._stream:
+            _lib.check(self._h, self._L.admp_set_stream(self._h, ctypes.c_void_p(s)), 'admp_set_stream')
+            self._stream = s
+
+    def _real(self, x, shape=None):
+        """array-like -> contiguous device tensor of the handle's precision."""
+        if isinstance(x, torch.Tensor):
+            t = x.detach().to(device=self._device, dtype=self._dtype).contiguous()
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float64)), dtype=self._dtype).to(self._device)
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError('expected shape %s, got %s' % (tuple(shape), tuple(t.shape)))
+        return t
+
+    @staticmethod
+    def _host64(x, n=None):
+        a = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+        if n is not None and a.size != n:
+            raise ValueError('expected %d values, got %d' % (n, a.size))
+        return a
+
+    @staticmethod
+    def _like(result, template):
+        """return `result` (device tensor) in the container type of `template`."""
+        if isinstance(template, torch.Tensor):
+            return result.to(device=template.device)
+        return result.cpu().numpy()
+
+    @staticmethod
+    def _ptr(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    # ---- pair list -----------------------------------------------------------------------------------------
+    def _pairs_fingerprint(self, pairs):
+        if isinstance(pairs, torch.Tensor):
+            return ('t', id(pairs), pairs.data_ptr(), tuple(pairs.shape), pairs._version)
+        a = np.asarray(pairs)
+        n = a.shape[0]
+        step = max(1, n // 4096)
+        sample = a[::step]
+        return ('n', id(pairs), a.shape, int(np.asarray(sample, dtype=np.int64).sum()),
+                tuple(np.asarray(a[-1]).tolist()) if n else ())
+
+    def set_pairs(self, pairs):
+        """Compile the (Np, 2) pair list into the device neighbour table (rows with i >= j are dropped,
+        reference admp/pme.py:671).  Called automatically by get_energy/get_forces when `pairs` changes."""
+        key = self._pairs_fingerprint(pairs)
+        if key == self._pairs_key:
+            return
+        self._use_current_stream()
+        if isinstance(pairs, torch.Tensor):
+            t = pairs.detach().to(device=self._device, dtype=torch.int32).contiguous()
+        else:
+            a = np.asarray(pairs)
+            if a.ndim != 2 or a.shape[1] != 2:
+                raise ValueError('pairs must be (Np, 2)')
+            t = torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self._device)
+        if t.dim() != 2 or t.shape[1] != 2:
+            raise ValueError('pairs must be (Np, 2)')
+        _lib.check(self._h, self._L.admp_set_pairs(self._h, t.shape[0], self._ptr(t), 1), 'admp_set_pairs')
+        self._pairs_key = key
+        self._pairs_keep = pairs      # keeps id() unique while cached
+
+    @property
+    def n_pairs(self):
+        return int(self._L.admp_num_pairs(self._h))
+
+    # ---- measurement ---------------------------------------------------------------------------------------
+    def profile(self, on=True):
+        _lib.check(self._h, self._L.admp_profile_enable(self._h, 1 if on else 0), 'admp_profile_enable')
+
+    def profile_reset(self):
+        _lib.check(self._h, self._L.admp_profile_reset(self._h), 'admp_profile_reset')
+
+    def profile_report(self):
+        """{kernel label: (total_ms, launches)} measured with HIP events on the handle's stream."""
+        n = self._L.admp_profile_count(self._h)
+        out = {}
+        for k in range(max(n, 0)):
+            label = ctypes.c_char_p()
+            ms = ctypes.c_double()
+            cnt = ctypes.c_int64()
+            _lib.check(self._h, self._L.admp_profile_entry(self._h, k, ctypes.byref(label), ctypes.byref(ms),
+                                                           ctypes.byref(cnt)), 'admp_profile_entry')
+            out[label.value.decode()] = (ms.value, cnt.value)
+        return out

@@ -1,0 +1,73 @@
+"""ctypes binding of libadmp_hip.so (include/admp_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or cannot be loaded the
+import fails loudly -- the PME path exists only as MI355X kernels.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libadmp_hip.so')
+
+_c = ctypes
+_vp, _i32, _i64, _dbl = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double
+_dp = _c.POINTER(_c.c_double)
+_ip = _c.POINTER(_c.c_int)
+
+# name -> (restype, argtypes): every symbol include/admp_hip.h declares
+PROTOTYPES = {
+    'admp_version': (_c.c_char_p, []),
+    'admp_create': (_i32, [_c.POINTER(_vp), _i32, _i32]),
+    'admp_destroy': (_i32, [_vp]),
+    'admp_last_error': (_c.c_char_p, [_vp]),
+    'admp_set_stream': (_i32, [_vp, _vp]),
+    'admp_synchronize': (_i32, [_vp]),
+    'admp_set_topology': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'admp_set_ewald': (_i32, [_vp, _dbl, _i32, _i32, _i32, _i32, _i32]),
+    'admp_set_pairs': (_i32, [_vp, _i64, _vp, _i32]),
+    'admp_num_pairs': (_i64, [_vp]),
+    'admp_pme_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _dp, _vp, _i32, _dbl, _dp, _vp, _vp,
+                                    _ip, _ip, _i32]),
+    'admp_disp_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _i32, _dp, _dp, _vp, _i32]),
+    'admp_tt_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _dp, _vp, _i32]),
+    'admp_profile_enable': (_i32, [_vp, _i32]),
+    'admp_profile_reset': (_i32, [_vp]),
+    'admp_profile_count': (_i32, [_vp]),
+    'admp_profile_entry': (_i32, [_vp, _i32, _c.POINTER(_c.c_char_p), _dp, _c.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+class AdmpHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and attach prototypes (does not touch the GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'admp_amd: %s not found. Build it with `python -m admp_amd.build` (needs hipcc); '
+            'there is no CPU fallback for the PME path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(handle, rc, what):
+    if rc != 0:
+        msg = load().admp_last_error(handle)
+        raise AdmpHipError('%s failed (code %d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def darr(values):
+    """ctypes double array from a python/numpy sequence."""
+    vals = [float(v) for v in values]
+    return (ctypes.c_double * len(vals))(*vals)

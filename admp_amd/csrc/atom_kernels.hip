@@ -1,0 +1,226 @@
+// Per-atom kernels of the PME path: site table construction (local frames + local->global
+// rotation, reference admp/pme.py:220-238), SCF field assembly and Jacobi update
+// (admp/pme.py:130-138), and the closing kernel that adds the self term (admp/pme.py:738-757),
+// the polarization penalty (admp/pme.py:760-774) and the local-frame adjoint.
+//
+// One thread per atom; 20-real site rows are written as whole 16/32-byte vectors.
+#include "launch.h"
+#include "reduce.h"
+
+namespace admp {
+
+constexpr int kAtomBlock = 256;
+
+template <class T>
+__device__ __forceinline__ void load3(const T* a, int i, T o[3]) {
+  o[0] = a[3 * i]; o[1] = a[3 * i + 1]; o[2] = a[3 * i + 2];
+}
+
+template <class T>
+__device__ __forceinline__ void frame_of(const Topology& top, const T* pos, const Box<T>& box, int i, int& type,
+                                         int& iz, int& ix, int& iy, FrameWork<T>& w) {
+  type = top.axis_type[i];
+  iz = top.axis_idx[3 * i];
+  ix = top.axis_idx[3 * i + 1];
+  iy = top.axis_idx[3 * i + 2];
+  T p[3], pz[3] = {0, 0, 0}, px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+  load3(pos, i, p);
+  if (iz >= 0) load3(pos, iz, pz); else if (type != NoAxisType) type = NoAxisType;
+  if (ix >= 0) load3(pos, ix, px);
+  if (iy >= 0) load3(pos, iy, py);
+  local_frame_fwd(type, box, p, pz, px, py, w);
+}
+
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, const T* __restrict__ pos,
+                                                              const T* __restrict__ Qlocal,
+                                                              const T* __restrict__ Ucart, const T* __restrict__ pol,
+                                                              const T* __restrict__ thole, Box<T> box,
+                                                              Site<T>* __restrict__ sites) {
+  int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (i >= top.na) return;
+  int type, iz, ix, iy;
+  FrameWork<T> w;
+  frame_of(top, pos, box, i, type, iz, ix, iy, w);
+  T ql[9], cx[3], cy[3], cz[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ql[k] = Qlocal[9 * i + k];
+  Site<T> s;
+  frame_cols(w.X, w.Y, w.Z, cx, cy, cz);
+  rot_harm(ql, cx, cy, cz, s.Q);   // rot_local2global = rotation with the transposed frame (multipole.py:201)
+  load3(pos, i, s.r);
+  if (Ucart) {                     // C1_c2h: harmonic order (z, x, y) (admp/pme.py:235)
+    s.U[0] = Ucart[3 * i + 2]; s.U[1] = Ucart[3 * i]; s.U[2] = Ucart[3 * i + 1];
+  } else {
+    s.U[0] = s.U[1] = s.U[2] = T(0);
+  }
+  T a = pol ? pol[i] : T(0);
+  s.p6 = a > T(0) ? (T)pow((double)a, 1.0 / 6.0) : T(0);
+  s.thole = thole ? thole[i] : T(0);
+  s.pad[0] = s.pad[1] = s.pad[2] = T(0);
+  sites[i] = s;
+}
+
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_update_U(int na, const T* __restrict__ Ucart,
+                                                         Site<T>* __restrict__ sites) {
+  int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (i >= na) return;
+  sites[i].U[0] = Ucart[3 * i + 2];
+  sites[i].U[1] = Ucart[3 * i];
+  sites[i].U[2] = Ucart[3 * i + 1];
+}
+
+__device__ __forceinline__ unsigned long long nonneg_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_field_finish(int na, const Site<T>* __restrict__ sites,
+                                                             const T* __restrict__ pol, const T* __restrict__ Ucart,
+                                                             const T* __restrict__ fld_pair,
+                                                             const T* __restrict__ fld_recip, T kappa,
+                                                             T* __restrict__ field, unsigned long long* fmax_bits) {
+  int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  double fm = 0.0;
+  if (i < na) {
+    T f[3];
+    self_factors(kappa, f);
+    const T twoDf1 = T(2.0 * kDielectric) * f[1];
+    const Site<T>& s = sites[i];
+    T a = pol[i];
+    T ainv = T(kDielectric) / (a < T(1e-8) ? T(1e-8) : a);   // d/dU of D U^2 / (2 max(pol, 1e-8))
+    // pair field is in harmonic order (z,x,y); recip field is cartesian already
+    T hz = fld_pair[3 * i] - twoDf1 * (s.Q[1] + s.U[0]);
+    T hx = fld_pair[3 * i + 1] - twoDf1 * (s.Q[2] + s.U[1]);
+    T hy = fld_pair[3 * i + 2] - twoDf1 * (s.Q[3] + s.U[2]);
+    T fx = hx + fld_recip[3 * i] + ainv * Ucart[3 * i];
+    T fy = hy + fld_recip[3 * i + 1] + ainv * Ucart[3 * i + 1];
+    T fz = hz + fld_recip[3 * i + 2] + ainv * Ucart[3 * i + 2];
+    field[3 * i] = fx; field[3 * i + 1] = fy; field[3 * i + 2] = fz;
+    if (a > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
+  }
+  fm = block_reduce_max<kAtomBlock>(fm);
+  if (threadIdx.x == 0 && fm > 0.0) atomicMax(fmax_bits, nonneg_bits(fm));
+}
+
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_jacobi_update(int na, const T* __restrict__ pol,
+                                                              const T* __restrict__ field, T* __restrict__ Ucart,
+                                                              Site<T>* __restrict__ sites) {
+  int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (i >= na) return;
+  T s = pol[i] * T(1.0 / kDielectric);
+  T ux = Ucart[3 * i] - field[3 * i] * s;
+  T uy = Ucart[3 * i + 1] - field[3 * i + 1] * s;
+  T uz = Ucart[3 * i + 2] - field[3 * i + 2] * s;
+  Ucart[3 * i] = ux; Ucart[3 * i + 1] = uy; Ucart[3 * i + 2] = uz;
+  sites[i].U[0] = uz; sites[i].U[1] = ux; sites[i].U[2] = uy;
+}
+
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_finish(Topology top, const T* __restrict__ pos, Box<T> box,
+                                                       const Site<T>* __restrict__ sites, const T* __restrict__ pol,
+                                                       const T* __restrict__ Ucart, int lpol, T kappa,
+                                                       T* __restrict__ pot, T* __restrict__ grad,
+                                                       T* __restrict__ dQlocal, double* energies) {
+  int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  double eself = 0.0, epen = 0.0;
+  if (i < top.na) {
+    T f[3];
+    self_factors(kappa, f);
+    const Site<T>& s = sites[i];
+    T Qt[9], P[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { Qt[k] = s.Q[k]; P[k] = pot[9 * i + k]; }
+    if (lpol) { Qt[1] += s.U[0]; Qt[2] += s.U[1]; Qt[3] += s.U[2]; }
+    // E_self = -D sum_h f_l Qtot_h^2 ; dE/dQ_global = -2 D f_l Qtot_h
+    double es = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      T fl = k == 0 ? f[0] : (k < 4 ? f[1] : f[2]);
+      es += (double)(fl * Qt[k] * Qt[k]);
+      P[k] -= T(2.0 * kDielectric) * fl * Qt[k];
+    }
+    eself = -kDielectric * es;
+    if (lpol) {
+      T a = pol[i];
+      a = a < T(1e-8) ? T(1e-8) : a;
+      double u2 = (double)Ucart[3 * i] * Ucart[3 * i] + (double)Ucart[3 * i + 1] * Ucart[3 * i + 1] +
+                  (double)Ucart[3 * i + 2] * Ucart[3 * i + 2];
+      epen = kDielectric * 0.5 * u2 / (double)a;
+    }
+    if (grad) {
+      // adjoint of the local frame: torque of the PERMANENT multipoles (the induced dipole is a global
+      // Cartesian input held fixed, admp/pme.py:81-85)
+      int type, iz, ix, iy;
+      FrameWork<T> w;
+      frame_of(top, pos, box, i, type, iz, ix, iy, w);
+      T tau[3], gp[3], gz[3], gx[3], gy[3];
+      multipole_torque(P, s.Q, tau);
+      local_frame_bwd(type, w, tau, gp, gz, gx, gy);
+      if (type != NoAxisType) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          atomicAdd(&grad[3 * i + k], gp[k]);
+          atomicAdd(&grad[3 * iz + k], gz[k]);
+          if (type != Zonly) atomicAdd(&grad[3 * ix + k], gx[k]);
+          if (type == ZBisect || type == ThreeFold) atomicAdd(&grad[3 * iy + k], gy[k]);
+        }
+      }
+      if (dQlocal) {
+        T dl[9];
+        rot_harm(P, w.X, w.Y, w.Z, dl);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dQlocal[9 * i + k] = dl[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pot[9 * i + k] = P[k];
+  }
+  eself = block_reduce_sum<kAtomBlock>(eself);
+  epen = block_reduce_sum<kAtomBlock>(epen);
+  if (threadIdx.x == 0) {
+    atomicAdd(&energies[E_SELF], eself);
+    if (lpol) atomicAdd(&energies[E_PEN], epen);
+  }
+}
+
+static inline int nblk(int n) { return (n + kAtomBlock - 1) / kAtomBlock; }
+
+template <class T>
+void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
+                          const T* pol, const T* thole, const Box<T>& box, Site<T>* sites) {
+  k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites);
+}
+template <class T>
+void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites) {
+  k_update_U<T><<<nblk(na), kAtomBlock, 0, st>>>(na, Ucart, sites);
+}
+template <class T>
+void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* pol, const T* Ucart, const T* fld_pair,
+                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits) {
+  k_field_finish<T><<<nblk(na), kAtomBlock, 0, st>>>(na, sites, pol, Ucart, fld_pair, fld_recip, kappa, field, fmax_bits);
+}
+template <class T>
+void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, T* Ucart, Site<T>* sites) {
+  k_jacobi_update<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pol, field, Ucart, sites);
+}
+template <class T>
+void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
+                   const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies) {
+  k_finish<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal, energies);
+}
+
+#define INST(T)                                                                                                        \
+  template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
+                                        const Box<T>&, Site<T>*);                                                       \
+  template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \
+  template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
+                                       unsigned long long*);                                                            \
+  template void launch_jacobi_update<T>(hipStream_t, int, const T*, const T*, T*, Site<T>*);                             \
+  template void launch_finish<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const Site<T>*, const T*,        \
+                                 const T*, int, T, T*, T*, T*, double*);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace admp

@@ -1,0 +1,107 @@
+// Kernel launchers shared between the translation units of libadmp_hip.
+// Every launcher enqueues on `st` and returns immediately; T is float or double.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "frame_math.h"
+#include "pme_math.h"
+#include "spline_math.h"
+
+namespace admp {
+
+// Per-nbonds scale tables (nbonds 0..15 -> scales[(nbonds-1) mod n], admp/pme.py:681-683) and the
+// Fermi weight of the Thole-width switch at that pscale (admp/pme.py:337-348,411).
+template <class T>
+struct ScaleTab {
+  T mm[16];   // mscale - 1
+  T p[16];    // pscale
+  T w0[16];
+};
+
+// i-grouped neighbour table: row i lists every partner of atom i (both directions of each i<j
+// pair), entry = partner index | nbonds << 28.
+struct NbrTable {
+  int* rowptr = nullptr;   // na + 1
+  int* col = nullptr;      // 2 * n_half
+  int64_t n_half = 0;
+  int64_t cap = 0;         // allocated entries of col
+};
+constexpr int kColMask = 0x0fffffff;
+
+struct Topology {
+  int na = 0;
+  int* axis_type = nullptr;   // na
+  int* axis_idx = nullptr;    // na * 3
+  int* excl_ptr = nullptr;    // na + 1
+  int* excl_col = nullptr;
+  int* excl_nb = nullptr;
+};
+
+// energies[] slots on the device
+enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SLOTS = 8 };
+
+// ---- atom_kernels.hip
+template <class T>
+void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
+                          const T* pol, const T* thole, const Box<T>& box, Site<T>* sites);
+template <class T>
+void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites);
+// field (Cartesian dE/dU) = pair (harmonic order) + recip (cartesian) + self + penalty; also max |field| over
+// sites with pol > 0.001 (admp/pme.py:130,136) into *fmax_bits (order-preserving bit pattern of a non-negative real)
+template <class T>
+void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* pol, const T* Ucart, const T* fld_pair,
+                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits);
+// U <- U - field * pol / DIELECTRIC (admp/pme.py:138), refreshing the packed harmonic copy
+template <class T>
+void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, T* Ucart, Site<T>* sites);
+// self term + polarization penalty energies, self potential, local-frame adjoint, dE/dQ_local
+template <class T>
+void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
+                   const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies);
+
+// ---- pair_kernels.hip
+template <class T>
+void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies);
+template <class T>
+void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                       const ScaleTab<T>& tab, T kappa, T* fld_pair);
+int pair_lanes_per_row();            // tuning knob (env ADMP_PAIR_LPR), default chosen per precision
+template <class T>
+void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
+                      const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies);
+template <class T>
+void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* abqc, const Box<T>& box,
+                    const ScaleTab<T>& tab, T* grad, double* energies);
+
+// ---- recip_kernels.hip
+template <class T>
+void launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, T* mesh);
+// scalar (lmax = 0) channel of the dispersion path: value column `chan` of a (na, stride) array
+template <class T>
+void launch_spread_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
+                          const RecipGeom<T>& g, T* mesh);
+// which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels
+template <class T>
+void launch_gtab(hipStream_t st, const int K[3], const double* box_inv, double volume, double kappa, int which, T* gtab);
+// spec <- spec * gtab ; energies[slot] += sum_k w_k (gtab/2) |S_k|^2
+template <class T>
+void launch_kspace(hipStream_t st, const int K[3], const T* gtab, T* spec /* interleaved complex */, double* energies,
+                   int slot);
+template <class T>
+void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
+                   T* grad);
+template <class T>
+void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
+                         T* fld_recip);
+template <class T>
+void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
+                          const RecipGeom<T>& g, const T* phi, T* grad);
+
+// ---- nbr_kernels.hip
+// builds nb from (n_rows, 2) device pairs; scratch (deg/cursor) is managed inside. Returns hipError_t as int.
+int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, const int* pairs_dev, NbrTable& nb,
+                          void** scratch, size_t* scratch_bytes);
+
+}  // namespace admp

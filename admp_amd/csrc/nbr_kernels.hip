@@ -1,0 +1,102 @@
+// Neighbour-table compiler: turns the caller's (n_rows, 2) pair list into the i-grouped table the pair
+// kernels walk.  Replaces the per-call `pairs[pairs[:,0] < pairs[:,1]]` filter, the covalent_map lookup
+// `nbonds = covalent_map[pairs[:,0], pairs[:,1]]` and the per-pair gathers of the reference
+// (admp/pme.py:671-693, admp/pairwise.py:68-75).
+//   1. count: degree of each atom over valid rows (0 <= i < j < na)            -- int atomics
+//   2. exclusive scan of the degrees (hipcub)                                   -- rowptr
+//   3. fill: both directions of each pair, nbonds from the CSR covalent map packed in bits 28..31
+//   4. sort each row by partner index (short rows: in-thread insertion sort)    -- deterministic order
+#include <hipcub/hipcub.hpp>
+
+#include "launch.h"
+
+namespace admp {
+
+__global__ void k_nbr_count(int64_t n_rows, const int* __restrict__ pairs, int na, int* __restrict__ deg,
+                            unsigned long long* n_valid) {
+  unsigned long long local = 0;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_rows; p += (int64_t)gridDim.x * blockDim.x) {
+    int i = pairs[2 * p], j = pairs[2 * p + 1];
+    if (i >= 0 && i < j && j < na) {
+      atomicAdd(&deg[i], 1);
+      atomicAdd(&deg[j], 1);
+      ++local;
+    }
+  }
+  if (local) atomicAdd(n_valid, local);
+}
+
+__device__ __forceinline__ int lookup_nbonds(const Topology& top, int i, int j) {
+  if (!top.excl_ptr) return 0;
+  for (int k = top.excl_ptr[i]; k < top.excl_ptr[i + 1]; ++k)
+    if (top.excl_col[k] == j) return top.excl_nb[k] & 15;
+  return 0;
+}
+
+__global__ void k_nbr_fill(int64_t n_rows, const int* __restrict__ pairs, Topology top, int* __restrict__ cursor,
+                           int* __restrict__ col) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_rows; p += (int64_t)gridDim.x * blockDim.x) {
+    int i = pairs[2 * p], j = pairs[2 * p + 1];
+    if (i >= 0 && i < j && j < top.na) {
+      int nb = lookup_nbonds(top, i, j) << 28;
+      col[atomicAdd(&cursor[i], 1)] = j | nb;
+      col[atomicAdd(&cursor[j], 1)] = i | nb;
+    }
+  }
+}
+
+__global__ void k_nbr_sort(int na, const int* __restrict__ rowptr, int* __restrict__ col) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= na) return;
+  int b = rowptr[r], e = rowptr[r + 1];
+  for (int a = b + 1; a < e; ++a) {
+    int v = col[a], key = v & kColMask, k = a - 1;
+    while (k >= b && (col[k] & kColMask) > key) { col[k + 1] = col[k]; --k; }
+    col[k + 1] = v;
+  }
+}
+
+#define NB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, const int* pairs_dev, NbrTable& nb,
+                          void** scratch, size_t* scratch_bytes) {
+  const int na = top.na;
+  if (!nb.rowptr) NB_CHECK(hipMalloc(&nb.rowptr, sizeof(int) * (na + 1)));
+  // na + 1 degrees (reused as the fill cursor), padded to an even count, then one 64-bit pair counter
+  const size_t ndeg = (size_t)((na + 2) & ~1);
+  int* deg = nullptr;
+  NB_CHECK(hipMalloc(&deg, sizeof(int) * ndeg + sizeof(unsigned long long)));
+  unsigned long long* n_valid = (unsigned long long*)(deg + ndeg);
+  NB_CHECK(hipMemsetAsync(deg, 0, sizeof(int) * ndeg + sizeof(unsigned long long), st));
+  int blocks = (int)((n_rows + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  if (n_rows > 0) k_nbr_count<<<blocks, 256, 0, st>>>(n_rows, pairs_dev, na, deg, n_valid);
+  size_t need = 0;
+  NB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, deg, nb.rowptr, na + 1, st));
+  if (need > *scratch_bytes) {
+    if (*scratch) NB_CHECK(hipFree(*scratch));
+    NB_CHECK(hipMalloc(scratch, need));
+    *scratch_bytes = need;
+  }
+  NB_CHECK(hipcub::DeviceScan::ExclusiveSum(*scratch, need, deg, nb.rowptr, na + 1, st));
+  unsigned long long nv = 0;
+  NB_CHECK(hipMemcpyAsync(&nv, n_valid, sizeof(nv), hipMemcpyDeviceToHost, st));
+  NB_CHECK(hipStreamSynchronize(st));
+  nb.n_half = (int64_t)nv;
+  if (2 * nb.n_half > nb.cap) {
+    if (nb.col) NB_CHECK(hipFree(nb.col));
+    nb.cap = 2 * nb.n_half + 1024;
+    NB_CHECK(hipMalloc(&nb.col, sizeof(int) * nb.cap));
+  }
+  NB_CHECK(hipMemcpyAsync(deg, nb.rowptr, sizeof(int) * (na + 1), hipMemcpyDeviceToDevice, st));
+  if (n_rows > 0) {
+    k_nbr_fill<<<blocks, 256, 0, st>>>(n_rows, pairs_dev, top, deg, nb.col);
+    k_nbr_sort<<<(na + 127) / 128, 128, 0, st>>>(na, nb.rowptr, nb.col);
+  }
+  NB_CHECK(hipStreamSynchronize(st));
+  NB_CHECK(hipFree(deg));
+  return 0;
+}
+
+}  // namespace admp

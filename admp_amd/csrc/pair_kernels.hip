@@ -1,0 +1,210 @@
+// Real-space pair kernels (reference admp/pme.py:628-729 pme_real + :479-624 pme_real_kernel,
+// admp/disp_pme.py:126-216, admp/pairwise.py:45-113).
+//
+// Layout: the pair list is compiled (nbr_kernels.hip) into an i-grouped table holding BOTH
+// directions of every i<j pair.  LPR lanes of a wavefront share one row: each lane walks every
+// LPR-th partner, gathers its 20-real site row with 16-byte loads, evaluates the pair from the
+// row atom's side only (energy halved), and the row's 15 accumulators (dE/dr 3, dE/dQ 9, dE/dU 3)
+// are folded across the LPR lanes with DPP-class shuffles and written once -- no global atomics,
+// bitwise reproducible for a fixed table.
+#include <cstdlib>
+
+#include "disp_math.h"
+#include "launch.h"
+#include "reduce.h"
+
+namespace admp {
+
+constexpr int kPairBlock = 256;
+
+template <class T, int LPR>
+__device__ __forceinline__ T row_reduce(T v) {
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <class T>
+__device__ __forceinline__ void stage_tab(const ScaleTab<T>& tab, T* s) {
+  if (threadIdx.x < 16) {
+    s[threadIdx.x] = tab.mm[threadIdx.x];
+    s[16 + threadIdx.x] = tab.p[threadIdx.x];
+    s[32 + threadIdx.x] = tab.w0[threadIdx.x];
+  }
+  __syncthreads();
+}
+
+template <class T, bool LPOL, int LPR>
+__global__ __launch_bounds__(kPairBlock) void k_pair_full(int na, const int* __restrict__ rowptr,
+                                                          const int* __restrict__ col,
+                                                          const Site<T>* __restrict__ sites, Box<T> box,
+                                                          ScaleTab<T> tab, T kappa, T* __restrict__ grad,
+                                                          T* __restrict__ pot, double* energies) {
+  __shared__ T s_tab[48];
+  stage_tab(tab, s_tab);
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  T g[3] = {0, 0, 0}, P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[3] = {0, 0, 0};
+  double e = 0.0;
+  if (row < na) {
+    const Site<T> I = sites[row];
+    const int end = rowptr[row + 1];
+#pragma unroll 1
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = (c >> 28) & 15;
+      const Site<T> J = sites[c & kColMask];
+      const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
+      e += (double)pair_energy_grad<T, LPOL, false>(box, I, J, sc, kappa, g, P, F, nullptr, nullptr);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g[k] = row_reduce<T, LPR>(g[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) P[k] = row_reduce<T, LPR>(P[k]);
+  if (row < na && sub == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) grad[3 * row + k] = g[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pot[9 * row + k] = P[k];
+  }
+  e = block_reduce_sum<kPairBlock>(e);
+  if (threadIdx.x == 0) atomicAdd(&energies[E_REAL], 0.5 * e);
+}
+
+template <class T, int LPR>
+__global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ col,
+                                                           const Site<T>* __restrict__ sites, Box<T> box,
+                                                           ScaleTab<T> tab, T kappa, T* __restrict__ fld) {
+  __shared__ T s_tab[48];
+  stage_tab(tab, s_tab);
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  T F[3] = {0, 0, 0};
+  if (row < na) {
+    const Site<T> I = sites[row];
+    const int end = rowptr[row + 1];
+#pragma unroll 1
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = (c >> 28) & 15;
+      const Site<T> J = sites[c & kColMask];
+      const PairScales<T> sc = {T(0), s_tab[16 + nb], s_tab[32 + nb]};
+      pair_field(box, I, J, sc, kappa, F);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) F[k] = row_reduce<T, LPR>(F[k]);
+  if (row < na && sub == 0) {
+    fld[3 * row] = F[0]; fld[3 * row + 1] = F[1]; fld[3 * row + 2] = F[2];
+  }
+}
+
+// dispersion / Tang-Toennies: scalar pair terms, same row layout
+template <class T, int LPR, bool TT>
+__global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* __restrict__ rowptr,
+                                                            const int* __restrict__ col, const T* __restrict__ pos,
+                                                            const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
+                                                            T kappa, int pmax, T* __restrict__ grad, double* energies) {
+  __shared__ T s_tab[48];
+  stage_tab(tab, s_tab);
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  constexpr int NP = TT ? 4 : 3;
+  T g[3] = {0, 0, 0};
+  double e = 0.0;
+  if (row < na) {
+    T ri[3] = {pos[3 * row], pos[3 * row + 1], pos[3 * row + 2]}, pi[4] = {0, 0, 0, 0};
+    for (int k = 0; k < NP; ++k) pi[k] = par[NP * row + k];
+    const int end = rowptr[row + 1];
+#pragma unroll 1
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = (c >> 28) & 15, j = c & kColMask;
+      T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]}, pj[4] = {0, 0, 0, 0};
+      for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
+      if (TT) e += (double)tt_pair(box, ri, rj, pi, pj, s_tab[nb] + T(1), g);
+      else e += (double)disp_pair(box, ri, rj, pi, pj, s_tab[nb], kappa, pmax, g);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g[k] = row_reduce<T, LPR>(g[k]);
+  if (row < na && sub == 0) {
+    grad[3 * row] = g[0]; grad[3 * row + 1] = g[1]; grad[3 * row + 2] = g[2];
+  }
+  e = block_reduce_sum<kPairBlock>(e);
+  if (threadIdx.x == 0) atomicAdd(&energies[E_REAL], 0.5 * e);
+}
+
+int pair_lanes_per_row() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("ADMP_PAIR_LPR");
+    int x = s ? atoi(s) : 8;
+    v = (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32) ? x : 8;
+  }
+  return v;
+}
+
+static inline unsigned grid_for(int na, int lpr) { return (unsigned)(((long)na * lpr + kPairBlock - 1) / kPairBlock); }
+
+#define ADMP_LPR_SWITCH(lpr, CALL) \
+  switch (lpr) {                   \
+    case 1: CALL(1); break;        \
+    case 2: CALL(2); break;        \
+    case 4: CALL(4); break;        \
+    case 16: CALL(16); break;      \
+    case 32: CALL(32); break;      \
+    default: CALL(8); break;       \
+  }
+
+template <class T>
+void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies) {
+  const int lpr = pair_lanes_per_row();
+#define CALL(L)                                                                                                        \
+  if (lpol) k_pair_full<T, true, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab,   \
+                                                                            kappa, grad, pot, energies);               \
+  else k_pair_full<T, false, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
+                                                                        grad, pot, energies)
+  ADMP_LPR_SWITCH(lpr, CALL)
+#undef CALL
+}
+
+template <class T>
+void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                       const ScaleTab<T>& tab, T kappa, T* fld) {
+  const int lpr = pair_lanes_per_row();
+#define CALL(L) k_pair_field<T, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, fld)
+  ADMP_LPR_SWITCH(lpr, CALL)
+#undef CALL
+}
+
+template <class T>
+void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
+                      const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies) {
+  k_pair_scalar<T, 8, false><<<grid_for(na, 8), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, clist, box, tab, kappa,
+                                                                     pmax, grad, energies);
+}
+template <class T>
+void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* abqc, const Box<T>& box,
+                    const ScaleTab<T>& tab, T* grad, double* energies) {
+  k_pair_scalar<T, 8, true><<<grid_for(na, 8), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, abqc, box, tab, T(0), 0,
+                                                                    grad, energies);
+}
+
+#define INST(T)                                                                                                     \
+  template void launch_pair_full<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,               \
+                                    const ScaleTab<T>&, T, int, T*, T*, double*);                                   \
+  template void launch_pair_field<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
+                                     const ScaleTab<T>&, T, T*);                                                    \
+  template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,           \
+                                    const ScaleTab<T>&, T, int, T*, double*);                                       \
+  template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,             \
+                                  const ScaleTab<T>&, T*, double*);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace admp

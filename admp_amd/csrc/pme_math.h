@@ -18,6 +18,7 @@
 #include <cmath>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define ADMP_HD __host__ __device__ __forceinline__
 #else
 #define ADMP_HD inline
@@ -268,13 +269,15 @@ ADMP_HD void ind_coefs(const Radial<S, T>& a, S r, T aw, T dmp, T p, S* c) {
 
 // ---------------------------------------------------------------- the pair
 // Per-site data as the kernels keep it (global frame).
+// 20 reals = five 16-byte (f32) / 32-byte (f64) vectors: one gathered row of the site table.
 template <class T>
-struct Site {
+struct alignas(16) Site {
   T r[3];
   T Q[9];    // permanent multipoles, global harmonics
   T U[3];    // induced dipole, global harmonic order (z,x,y)  (admp/pme.py:235)
   T p6;      // pol^(1/6)  (dmp = p6_i p6_j, admp/pme.py:732-735)
   T thole;
+  T pad[3];
 };
 
 template <class T>

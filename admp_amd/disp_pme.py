@@ -1,0 +1,78 @@
+"""ADMPDispPmeForce -- counterpart of the reference's admp/disp_pme.py:20-77 on MI355X.
+
+    disp = ADMPDispPmeForce(box, covalent_map, rc, ethresh, pmax)
+    disp.update_env('kappa', 0.657065221219616)
+    E, G = disp.get_forces(positions, box, pairs, c_list, mScales)      # c_list (Na, (pmax-4)/2): C6[, C8[, C10]]
+
+Real-space (m + g_p - 1) c_i c_j / r^p pair sum, one scalar PME reciprocal pass per power with the
+Ck_6/8/10 kernels (gamma point included), and the self term (admp/disp_pme.py:80-279).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._device import HipForceBase
+from .pme import setup_ewald_parameters
+
+
+class ADMPDispPmeForce(HipForceBase):
+    def __init__(self, box, covalent_map, rc, ethresh, pmax, device=None):
+        self.covalent_map = covalent_map
+        self.rc = rc
+        self.ethresh = ethresh
+        self.pmax = int(pmax)
+        if self.pmax not in (6, 8, 10):
+            raise ValueError('pmax must be 6, 8 or 10')
+        kappa, K1, K2, K3 = setup_ewald_parameters(rc, ethresh, box)
+        self.kappa = kappa
+        self.K1, self.K2, self.K3 = K1, K2, K3
+        self.pme_order = 6
+        super().__init__(int(covalent_map.shape[0]), covalent_map, None, None, device)
+        self.energy_parts = None
+        self.refresh_calculators()
+
+    def update_env(self, attr, val):
+        setattr(self, attr, val)
+        self.refresh_calculators()
+
+    def refresh_calculators(self):
+        _lib.check(self._h, self._L.admp_set_ewald(self._h, float(self.kappa), int(self.K1), int(self.K2), int(self.K3),
+                                                   0, 0), 'admp_set_ewald')
+        self.get_energy = self.generate_get_energy()
+        self.get_forces = self._generate_get_forces()
+
+    def _evaluate(self, positions, box, pairs, c_list, mScales, want_grad):
+        na = self.n_atoms
+        self._use_current_stream()
+        self.set_pairs(pairs)
+        pos = self._real(positions, (na, 3))
+        if isinstance(c_list, torch.Tensor):
+            c = c_list.detach().to(device=self._device, dtype=self._dtype)
+        else:
+            c = torch.as_tensor(np.asarray(c_list, dtype=np.float64), dtype=self._dtype).to(self._device)
+        nc = (self.pmax - 4) // 2
+        if c.dim() != 2 or c.shape[0] != na or c.shape[1] < nc:
+            raise ValueError('c_list must be (Na, >= (pmax-4)/2)')
+        c3 = torch.zeros((na, 3), dtype=self._dtype, device=self._device)
+        c3[:, :nc] = c[:, :nc]
+        mS = self._host64(mScales)
+        E = (ctypes.c_double * 3)()
+        grad = torch.empty((na, 3), dtype=self._dtype, device=self._device) if want_grad else None
+        rc = self._L.admp_disp_energy_grad(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(c3),
+                                           self.pmax, len(mS), _lib.darr(mS), E, self._ptr(grad), 1)
+        _lib.check(self._h, rc, 'admp_disp_energy_grad')
+        self.energy_parts = tuple(E)
+        return np.float64(E[0] + E[1] + E[2]), grad
+
+    def generate_get_energy(self):
+        def get_energy(positions, box, pairs, c_list, mScales):
+            return self._evaluate(positions, box, pairs, c_list, mScales, False)[0]
+        return get_energy
+
+    def _generate_get_forces(self):
+        def get_forces(positions, box, pairs, c_list, mScales):
+            e, g = self._evaluate(positions, box, pairs, c_list, mScales, True)
+            return e, self._like(g, positions)
+        return get_forces

@@ -1,0 +1,81 @@
+"""Pairwise short-range interactions -- counterpart of the reference's admp/pairwise.py:45-113.
+
+The reference builds a calculator from an arbitrary JAX kernel:
+
+    pot = generate_pairwise_interaction(TT_damping_qq_c6_kernel, covalent_map, static_args={})
+    E, G = value_and_grad(pot)(positions, box, pairs, mScales, a_list, b_list, q_list, c_list)
+
+There is no tracing compiler here; a "kernel" is a named HIP kernel of libadmp_hip.  The one the
+reference ships, TT_damping_qq_c6_kernel, is provided; any other object raises NotImplementedError.
+`value_and_grad` below plays the role of jax.value_and_grad for these calculators (argnums = 0 only).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._device import HipForceBase
+
+
+class _HipPairKernel:
+    def __init__(self, name, n_params):
+        self.name = name
+        self.n_params = n_params
+
+    def __repr__(self):
+        return '<HIP pair kernel %s>' % self.name
+
+
+#: Tang-Toennies damped exchange / charge-penetration / C6 kernel (admp/pairwise.py:94-113);
+#: atomic parameters in the reference's order: a (Hartree), b (Bohr^-1), q (e), c6.
+TT_damping_qq_c6_kernel = _HipPairKernel('tt_damping_qq_c6', 4)
+
+
+class _PairInteraction(HipForceBase):
+    def __init__(self, kernel, covalent_map, static_args):
+        super().__init__(int(covalent_map.shape[0]), covalent_map, None, None, None)
+        self.kernel = kernel
+        self.static_args = dict(static_args or {})
+
+    def _evaluate(self, positions, box, pairs, mScales, atomic_params, want_grad):
+        na = self.n_atoms
+        if len(atomic_params) != self.kernel.n_params:
+            raise TypeError('%s takes %d atomic parameter lists' % (self.kernel.name, self.kernel.n_params))
+        self._use_current_stream()
+        self.set_pairs(pairs)
+        pos = self._real(positions, (na, 3))
+        par = torch.stack([self._real(p, (na,)) for p in atomic_params], dim=1).contiguous()
+        mS = self._host64(mScales)
+        E = (ctypes.c_double * 1)()
+        grad = torch.empty((na, 3), dtype=self._dtype, device=self._device) if want_grad else None
+        rc = self._L.admp_tt_energy_grad(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(par),
+                                         len(mS), _lib.darr(mS), E, self._ptr(grad), 1)
+        _lib.check(self._h, rc, 'admp_tt_energy_grad')
+        return np.float64(E[0]), grad
+
+    def __call__(self, positions, box, pairs, mScales, *atomic_params):
+        return self._evaluate(positions, box, pairs, mScales, atomic_params, False)[0]
+
+    def value_and_grad(self, positions, box, pairs, mScales, *atomic_params):
+        e, g = self._evaluate(positions, box, pairs, mScales, atomic_params, True)
+        return e, self._like(g, positions)
+
+
+def generate_pairwise_interaction(pair_int_kernel, covalent_map, static_args):
+    """(kernel, covalent_map, static_args) -> pair_int(positions, box, pairs, mScales, *atomic_params)
+    (admp/pairwise.py:45-91)."""
+    if not isinstance(pair_int_kernel, _HipPairKernel):
+        raise NotImplementedError('only the HIP kernels exported by admp_amd.pairwise can be used '
+                                  '(arbitrary Python kernels need a tracing compiler, which this path does not have)')
+    return _PairInteraction(pair_int_kernel, covalent_map, static_args)
+
+
+def value_and_grad(fn, argnums=0):
+    """Stand-in for jax.value_and_grad on the calculators of this package (positions only)."""
+    if argnums != 0:
+        raise NotImplementedError('only the gradient with respect to positions (argnums=0) is available')
+    if isinstance(fn, _PairInteraction):
+        return fn.value_and_grad
+    owner = getattr(fn, '__self__', None)
+    raise NotImplementedError('value_and_grad: use the get_forces attribute of %r' % (owner or fn))

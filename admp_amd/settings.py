@@ -1,0 +1,24 @@
+"""Global switches of the PME path, same names as the reference's admp/settings.py:6-30.
+
+PRECISION selects the arithmetic of the HIP kernels ('double' -> f64, 'single' -> f32; energies are
+accumulated in f64 either way).  DO_JIT / jit_condition are kept for source compatibility and do
+nothing: there is no tracing compiler on this path.
+"""
+PRECISION = 'double'      # 'single' | 'double'   (admp/settings.py:6)
+DO_JIT = True             # no-op here            (admp/settings.py:8)
+
+# DEFAULT THRESHOLDS (admp/settings.py:29-30)
+POL_CONV = 10.0           # gradient convergence threshold for the induced dipoles, kJ/mol/(e A)
+MAX_N_POL = 30            # maximum number of SCF cycles
+
+
+def jit_condition(*args, **kwargs):
+    def deco(func):
+        return func
+    return deco
+
+
+def precision_bytes():
+    if PRECISION not in ('single', 'double'):
+        raise ValueError("settings.PRECISION must be 'single' or 'double'")
+    return 4 if PRECISION == 'single' else 8

@@ -1,0 +1,109 @@
+/* libadmp_hip -- C ABI of the MI355X-native multipolar PME path.
+ *
+ * The reference (Roy-Kid/ADMP) has no FFI layer: its boundary is the Python callable API of
+ * admp/pme.py:30-143 (ADMPPmeForce), admp/disp_pme.py:20-77 (ADMPDispPmeForce) and
+ * admp/pairwise.py:45-113 (generate_pairwise_interaction + TT kernel).  This header is the layer
+ * BENEATH that API: admp_amd/{pme,disp_pme,pairwise}.py keep the reference's class / method names
+ * and bind these entry points through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ADMP_E_* code; nothing throws or aborts;
+ *     admp_last_error() gives the message of the last failure on that handle.
+ *   - `real` arrays are float (precision 4) or double (precision 8), fixed at admp_create.
+ *   - array arguments marked [dev|host] are device pointers when `on_device` is non-zero, host
+ *     pointers otherwise (the library then stages them); the caller owns every buffer.
+ *   - one handle = one GPU + one HIP stream; a handle is not thread-safe, distinct handles are
+ *     independent.  Energies are always returned as double, in kJ/mol; lengths in Angstrom.
+ */
+#ifndef ADMP_HIP_H
+#define ADMP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct admp_handle admp_handle;
+
+enum {
+  ADMP_OK = 0,
+  ADMP_E_ARG = -1,      /* bad argument / call order */
+  ADMP_E_HIP = -2,      /* HIP runtime error */
+  ADMP_E_FFT = -3,      /* rocFFT error */
+  ADMP_E_NOGPU = -4,    /* no usable device */
+  ADMP_E_STATE = -5     /* topology / ewald / pairs not set */
+};
+
+/* library version, and the gfx target the kernels were built for ("gfx950") */
+const char* admp_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* replaces: ADMPPmeForce.__init__ (admp/pme.py:37-55) -- device side of the object */
+int admp_create(admp_handle** out, int device, int precision /* 4 | 8 */);
+int admp_destroy(admp_handle* h);
+const char* admp_last_error(const admp_handle* h);
+/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int admp_set_stream(admp_handle* h, void* hip_stream);
+int admp_synchronize(admp_handle* h);
+
+/* ---- static environment -------------------------------------------------------------------- */
+/* replaces: axis_type / axis_indices / covalent_map ctor arguments (admp/pme.py:37-51,
+ * generate_construct_local_frames admp/spatial.py:44-74).  covalent_map is passed in CSR form
+ * (row i: atoms j with covalent_map[i,j] = nbonds > 0); all pointers are HOST pointers.
+ * axis_type[i] in 0..5 (ZThenX, Bisector, ZBisect, ThreeFold, Zonly, NoAxisType);
+ * axis_idx[i*3 + {0,1,2}] = z, x, y atom (-1 = none). */
+int admp_set_topology(admp_handle* h, int n_atoms, const int32_t* axis_type, const int32_t* axis_idx,
+                      const int32_t* excl_rowptr, const int32_t* excl_col, const int32_t* excl_nbonds);
+
+/* replaces: the kappa / K1..K3 / lmax / lpol environment (admp/pme.py:42-50, update_env :89-94) */
+int admp_set_ewald(admp_handle* h, double kappa, int K1, int K2, int K3, int lmax, int lpol);
+
+/* replaces: `pairs = pairs[pairs[:,0] < pairs[:,1]]` + the per-pair gathers of pme_real
+ * (admp/pme.py:671-683).  pairs is (n_rows, 2) int32 [dev|host]; rows with i >= j (padding) are
+ * dropped.  The list is compiled into an i-grouped neighbour table that stays valid until the
+ * next call. */
+int admp_set_pairs(admp_handle* h, int64_t n_rows, const int32_t* pairs, int on_device);
+int64_t admp_num_pairs(const admp_handle* h);   /* pairs kept (i < j) */
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* replaces: ADMPPmeForce.get_energy / get_forces (admp/pme.py:58-86, 108) including the induced
+ * dipole SCF optimize_Uind (admp/pme.py:111-143) when the handle is polarizable.
+ *   positions  (Na,3) real [dev|host]         box        9 doubles, lattice vectors in rows (host)
+ *   Q_local    (Na,9) real [dev|host]         harmonics [00,10,11c,11s,20,21c,21s,22c,22s], zero-padded above lmax
+ *   pol,tholes (Na) real [dev|host]           NULL unless polarizable
+ *   mScales/pScales/dScales                   n_scales doubles each (host); index (nbonds-1) wraps like the reference
+ *   U_inout    (Na,3) real [dev|host]         in: SCF start (global Cartesian), out: converged dipoles; NULL unless polarizable
+ *   max_cycle, thresh                         MAX_N_POL / POL_CONV of admp/settings.py:29-30
+ *   E_out[4]                                  real-space, reciprocal, self, polarization penalty
+ *   dE_dpos    (Na,3) real [dev|host]         +dE/dpositions (the reference returns the gradient, not the force); may be NULL (energy only)
+ *   dE_dQlocal (Na,9) real [dev|host]         optional (NULL to skip)
+ *   n_cycle, converged                        loop index at exit and `i != max_cycle-1` (admp/pme.py:139-143) */
+int admp_pme_energy_grad(admp_handle* h, const void* positions, const double* box, const void* Q_local,
+                         const void* pol, const void* tholes, int n_scales, const double* mScales,
+                         const double* pScales, const double* dScales, void* U_inout, int max_cycle, double thresh,
+                         double* E_out, void* dE_dpos, void* dE_dQlocal, int* n_cycle, int* converged,
+                         int on_device);
+
+/* replaces: ADMPDispPmeForce.get_energy / get_forces (admp/disp_pme.py:44-77, 80-279).
+ *   c_list (Na,3) real: C6, C8, C10 per atom (columns above pmax ignored); E_out[3] = real, recip, self */
+int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* box, const void* c_list, int pmax,
+                          int n_scales, const double* mScales, double* E_out, void* dE_dpos, int on_device);
+
+/* replaces: generate_pairwise_interaction(TT_damping_qq_c6_kernel, ...) (admp/pairwise.py:45-113).
+ *   abqc (Na,4) real: a, b, q, c6 per atom */
+int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
+                        const double* mScales, double* E_out, void* dE_dpos, int on_device);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by HIP events on the handle's stream. */
+int admp_profile_enable(admp_handle* h, int on);
+int admp_profile_reset(admp_handle* h);
+/* number of distinct kernel labels seen; label / accumulated ms / launch count of entry idx */
+int admp_profile_count(admp_handle* h);
+int admp_profile_entry(admp_handle* h, int idx, const char** label, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADMP_HIP_H */

@@ -1,0 +1,190 @@
+"""Parity of the HIP path (through the C ABI, via the admp_amd calculators) against the oracle
+and the committed golden fixtures.  Tolerances (BASELINE.json north_star): 1e-4 relative in double,
+1e-2 in single; the double-precision checks below are far tighter because both sides evaluate the
+same formulas in float64."""
+import os
+
+import numpy as np
+import pytest
+
+from admp_amd import settings
+from admp_amd import systems as S
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+@pytest.fixture()
+def precision():
+    old = settings.PRECISION
+    yield
+    settings.PRECISION = old
+
+
+def water_system(n_mol, seed, polarizable, rc=4.0):
+    pos, box = S.synthetic_water_box(n_mol, seed=seed)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, polarizable=polarizable)
+    pairs = S.build_pairs(pos, box, rc)
+    return pos, box, at, ai, cov, par, pairs
+
+
+def oracle_es(pos, box, at, ai, cov, par, pairs, kappa, K, lpol, want_dQ=False):
+    from oracle import admp_oracle as O
+    sysm = O.PmeSystem(at, ai, cov, kappa, K, 2, lpol)
+    if lpol:
+        return O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], par['pol'], par['tholes'],
+                                     par['pScales'], want_dQ=want_dQ)
+    return O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], want_dQ=want_dQ)
+
+
+@pytest.mark.parametrize('prec,tolE,tolG', [('double', 1e-9, 1e-8), ('single', 2e-4, 2e-4)])
+def test_nonpolarizable_water_vs_oracle(precision, prec, tolE, tolG):
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = prec
+    pos, box, at, ai, cov, par, pairs = water_system(216, 11, False)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    E, G, dQ = f.get_forces_and_dQ(pos, box, pairs, par['Q_local'], par['mScales'])
+    ref = oracle_es(pos, box, at, ai, cov, par, pairs, f.kappa, (f.K1, f.K2, f.K3), False, want_dQ=True)
+    scale = max(abs(p) for p in ref['parts'])
+    for got, want in zip(f.energy_parts, ref['parts']):
+        assert abs(got - want) <= tolE * scale
+    assert rel(G, ref['grad']) < tolG
+    assert rel(dQ, ref['dQ_local']) < tolG
+    assert f.n_pairs == len(pairs)
+    # energy-only entry point gives the same number
+    assert abs(f.get_energy(pos, box, pairs, par['Q_local'], par['mScales']) - E) <= 1e-12 * scale + tolE * scale
+
+
+@pytest.mark.parametrize('prec,tolE,tolG', [('double', 1e-9, 1e-8), ('single', 2e-4, 5e-4)])
+def test_polarizable_water_vs_oracle(precision, prec, tolE, tolG):
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = prec
+    pos, box, at, ai, cov, par, pairs = water_system(125, 5, True)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    args = (pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    E, G = f.get_forces(*args)
+    ref = oracle_es(pos, box, at, ai, cov, par, pairs, f.kappa, (f.K1, f.K2, f.K3), True)
+    scale = max(abs(p) for p in ref['parts'])
+    assert f.n_cycle == ref['n_cycle'] and f.lconverg == ref['lconverg']
+    for got, want in zip(f.energy_parts, ref['parts']):
+        assert abs(got - want) <= tolE * scale
+    assert rel(f.U_ind, ref['U_ind']) < tolG
+    assert rel(G, ref['grad']) < tolG
+    # warm start from the converged dipoles: zero further cycles needed beyond the first check
+    E2, G2 = f.get_forces(*args, U_init=f.U_ind)
+    assert f.n_cycle <= ref['n_cycle']
+    # optimize_Uind alone
+    U, flag, i = f.optimize_Uind(*args)
+    assert i == ref['n_cycle'] and flag == ref['lconverg'] and rel(U, ref['U_ind']) < tolG
+
+
+def test_toy_two_waters_golden():
+    from admp_amd.pme import ADMPPmeForce
+    g = np.load(os.path.join(GOLD, 'toy_water2.npz'))
+    at, ai, cov = S.water_topology(2)
+    par = S.water_parameters(2, True)
+    f = ADMPPmeForce(g['box'], at, ai, cov.toarray(), float(g['rc']), 1e-4, 2, lpol=True)
+    assert (f.K1, f.K2, f.K3) == tuple(int(k) for k in g['K'])
+    E, G = f.get_forces(g['positions'], g['box'], g['pairs'], par['Q_local'], par['pol'], par['tholes'], par['mScales'],
+                        par['pScales'], par['dScales'])
+    scale = np.abs(g['parts']).max()
+    np.testing.assert_allclose(f.energy_parts, g['parts'], atol=1e-9 * scale)
+    assert rel(G, g['grad']) < 1e-8 and rel(f.U_ind, g['U_ind']) < 1e-8 and f.n_cycle == int(g['n_cycle'])
+
+
+def test_p1_water1024_golden_all_terms():
+    """Reference example geometry (water_1024): electrostatics, dispersion PME and Tang-Toennies."""
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
+    g = np.load(os.path.join(GOLD, 'p1_water1024.npz'))
+    pos, box, pairs = g['positions'], g['box'], g['pairs']
+    nm = len(pos) // 3
+    at, ai, cov = S.water_topology(nm)
+    par = S.water_parameters(nm, False)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    f.update_env('kappa', float(g['kappa']))
+    assert (f.K1, f.K2, f.K3) == tuple(int(k) for k in g['K'])
+    E, G, dQ = f.get_forces_and_dQ(pos, box, pairs, par['Q_local'], par['mScales'])
+    scale = np.abs(g['es_parts']).max()
+    np.testing.assert_allclose(f.energy_parts[:3], g['es_parts'][:3], atol=1e-9 * scale)
+    assert abs(E - g['es_parts'].sum()) < 1e-9 * scale
+    assert rel(G, g['es_grad']) < 1e-8 and rel(dQ, g['es_dQ']) < 1e-8
+    d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+    d.update_env('kappa', float(g['kappa']))
+    Ed, Gd = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+    np.testing.assert_allclose(d.energy_parts, g['disp_parts'], rtol=1e-9)
+    assert rel(Gd, g['disp_grad']) < 1e-8
+    tt = value_and_grad(generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={}))
+    Et, Gt = tt(pos, box, pairs, par['mScales'], par['a_list'], par['b_list'], par['q_list'], par['c_list'][:, 0])
+    assert abs(Et - float(g['tt_E'])) < 1e-9 * abs(float(g['tt_E']))
+    assert rel(Gt, g['tt_grad']) < 1e-8
+
+
+def test_s1_polarizable_golden():
+    from admp_amd.pme import ADMPPmeForce
+    g = np.load(os.path.join(GOLD, 's1_water_pol.npz'))
+    nm = int(g['n_mol'])
+    pos, box = S.synthetic_water_box(nm, seed=int(g['seed']))
+    np.testing.assert_allclose([pos.sum(), (pos ** 2).sum()], g['pos_checksum'], rtol=1e-12)
+    at, ai, cov = S.water_topology(nm)
+    par = S.water_parameters(nm, True)
+    pairs = S.build_pairs(pos, box, 4.0)
+    assert len(pairs) == int(g['n_pairs'])
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    E, G, dQ = f.get_forces_and_dQ(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
+                                   par['pScales'], par['dScales'])
+    scale = np.abs(g['parts']).max()
+    np.testing.assert_allclose(f.energy_parts, g['parts'], atol=1e-9 * scale)
+    assert f.n_cycle == int(g['n_cycle']) and f.lconverg == bool(g['lconverg'])
+    assert rel(G, g['grad']) < 1e-8 and rel(f.U_ind, g['U_ind']) < 1e-8 and rel(dQ, g['dQ']) < 1e-8
+
+
+def test_pair_list_conventions():
+    """Padding rows (i >= j) are dropped (admp/pme.py:671); order of rows is irrelevant; torch inputs work."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    pos, box, at, ai, cov, par, pairs = water_system(64, 3, False)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    E0, G0 = f.get_forces(pos, box, pairs, par['Q_local'], par['mScales'])
+    na = len(pos)
+    rng = np.random.default_rng(0)
+    padded = np.concatenate([pairs, np.full((37, 2), na, dtype=np.int32), pairs[:5, ::-1]], axis=0)
+    padded = padded[rng.permutation(len(padded))]
+    E1, G1 = f.get_forces(torch.as_tensor(pos).cuda(), torch.as_tensor(box), torch.as_tensor(padded).cuda(),
+                          torch.as_tensor(par['Q_local']), torch.as_tensor(par['mScales']))
+    assert isinstance(G1, torch.Tensor) and G1.is_cuda
+    assert abs(E1 - E0) < 1e-9 * abs(f.energy_parts[0]) and rel(G1.cpu().numpy(), G0) < 1e-10
+    assert f.n_pairs == len(pairs)
+
+
+def test_invariances_at_scale():
+    """Size-independent properties on a 98 304-atom box (config C scale), single precision:
+    translation of all atoms by a lattice vector and by an arbitrary vector, and sum of the
+    real-space + self-consistent parts of the gradient."""
+    from admp_amd.pme import ADMPPmeForce
+    settings_old = settings.PRECISION
+    settings.PRECISION = 'single'
+    try:
+        nm = 32768
+        pos, box = S.synthetic_water_box(nm, seed=20240)
+        at, ai, cov = S.water_topology(nm)
+        par = S.water_parameters(nm, False)
+        pairs = S.build_pairs(pos, box, 4.0)
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+        for k in ('K1', 'K2', 'K3'):
+            f.update_env(k, 128)
+        E0, G0 = f.get_forces(pos, box, pairs, par['Q_local'], par['mScales'])
+        E1, G1 = f.get_forces(pos + box[0] - 2 * box[2], box, pairs, par['Q_local'], par['mScales'])
+        scale = max(abs(p) for p in f.energy_parts)
+        assert abs(E1 - E0) < 2e-5 * scale and rel(G1, G0) < 2e-3
+        # net force: only the PME mesh breaks momentum conservation, and only slightly
+        assert np.abs(G0.sum(axis=0)).max() < 1e-3 * np.abs(G0).sum(axis=0).max()
+    finally:
+        settings.PRECISION = settings_old
