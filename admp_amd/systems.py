@@ -130,27 +130,27 @@ def synthetic_water_box(n_mol, seed=20240, density=WATER_DENSITY, jitter=0.3,
         return centre[:, None, :] + np.einsum('nij,kj->nki', rot, body)
 
     mol = draw(np.arange(n_mol))                      # (n_mol, 3 atoms, 3)
-    offs = [(dx, dy, dz) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)
-            if (dx, dy, dz) > (0, 0, 0)]
+    offs = np.array([(dx, dy, dz) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)
+                     if (dx, dy, dz) != (0, 0, 0)])
+    active = np.arange(n_mol)                         # molecules whose contacts must be (re)checked
     for _ in range(max_sweeps):
         bad = np.zeros(n_mol, dtype=bool)
+        prio = rng.random(n_mol)                      # of a clashing pair, the lower priority is redrawn
         for off in offs:
-            nb_ijk = (ijk + np.array(off)) % n
+            nb_ijk = (ijk[active] + off) % n
             nb = site_to_mol[np.ravel_multi_index(nb_ijk.T, (n, n, n))]
-            ok = nb >= 0
-            if n < 3:
-                ok &= nb != np.arange(n_mol)
-            i_idx = np.nonzero(ok)[0]
-            j_idx = nb[ok]
-            d = mol[i_idx][:, :, None, :] - mol[j_idx][:, None, :, :]
+            ok = (nb >= 0) & (nb != active)
+            sel = np.nonzero(ok)[0]
+            d = mol[active[sel]][:, :, None, :] - mol[nb[sel]][:, None, :, :]
             d -= L * np.round(d / L)
-            r = np.linalg.norm(d, axis=-1)            # (m, 3, 3)
-            clash = (r[:, 0, 0] < min_oo) | (r.reshape(len(i_idx), 9).min(axis=1) < min_any)
-            bad[i_idx[clash]] = True
-        idx = np.nonzero(bad)[0]
-        if len(idx) == 0:
+            r2 = np.einsum('mabk,mabk->mab', d, d)    # (m, 3, 3) squared distances
+            clash = (r2[:, 0, 0] < min_oo ** 2) | (r2.reshape(len(sel), 9).min(axis=1) < min_any ** 2)
+            ca, cb = active[sel[clash]], nb[sel[clash]]
+            bad[np.where(prio[ca] < prio[cb], ca, cb)] = True
+        active = np.nonzero(bad)[0]
+        if len(active) == 0:
             break
-        mol[idx] = draw(idx)
+        mol[active] = draw(active)
     else:
         raise RuntimeError('synthetic_water_box: could not remove close contacts')
     positions = mol.reshape(3 * n_mol, 3)

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the PME hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S1|S2|S3] [--no-scale] [--no-cpu]
+
+A "step" is one `ADMPPmeForce.get_forces` call (electrostatics incl. the induced-dipole SCF from the
+previous step's dipoles, fixed pair list) = one MD step's worth of the hot path.  The reference has no
+integrator; ns/day is defined with dt = 1 fs:  ns/day = 0.0864 / t_step[s].
+
+Default workload (N = 1): S1 = BASELINE.json configs[1] -- 1024 polarizable MPID waters, double precision,
+on the seeded synthetic liquid box (the shipped water1024.pdb geometry has 0.67 A contacts on which the
+reference's own Jacobi SCF diverges).  With N > 1 ranks (one process per GPU, launched by
+torch.distributed.run) every rank steps an independent replica of the workload: the path's multi-GPU
+slab decomposition is not built yet (DESIGN.md "multi-GPU"), so N > 1 is "replicas only", weak scaling,
+and `value` is the aggregate ns/day of all replicas.
+
+One JSON line is printed by rank 0 (contract in the task statement), with `roofline` (real-space pair
+kernel, HBM bound, measured with HIP events inside the timed region) and `cpu_baseline` (the float64
+oracle timed on the host cores for the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+DT_FS = 1.0
+
+WORKLOADS = {
+    # name: (n_mol, precision, K (None = reference rule), description)
+    'S1': (1024, 'double', None, 'water_pol_1024 (BASELINE configs[1]): 1024 polarizable MPID waters = 3072 atoms, '
+                                 'seeded liquid box L=31.289 A, rc 4 A, f64'),
+    'S2': (32768, 'single', 128, '98 304-atom polarizable water box (configs[2] size), K=128, rc 4 A, f32'),
+    'S3': (349525, 'single', 256, '1 048 575-atom polarizable water box (configs[3] size), K=256, rc 4 A, f32'),
+}
+
+
+def pair_kernel_bytes(n_pairs, n_atoms, wbytes, polarizable):
+    """Algorithmic bytes of one energy+adjoint pass of the pair kernel:
+    per pair 8 B of indices + j-side read nr*w + j-side accumulate nw*w + i-side (nr+nw)*w / nbar."""
+    nr, nw = (17, 15) if polarizable else (12, 12)
+    nbar = n_pairs / float(n_atoms)
+    per_pair = 8 + (nr + nw) * wbytes + (nr + nw) * wbytes / nbar
+    return per_pair * n_pairs, per_pair
+
+
+def make_workload(name):
+    from admp_amd import systems as S
+    n_mol, prec, K, desc = WORKLOADS[name]
+    pos, box = S.synthetic_water_box(n_mol, seed=20240)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, polarizable=True)
+    pairs = S.build_pairs(pos, box, 4.0)
+    return dict(name=name, n_mol=n_mol, prec=prec, K=K, desc=desc, pos=pos, box=box, at=at, ai=ai, cov=cov, par=par,
+                pairs=pairs)
+
+
+def make_force(w):
+    import torch
+    from admp_amd import settings
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = w['prec']
+    f = ADMPPmeForce(w['box'], w['at'], w['ai'], w['cov'], 4.0, 1e-4, 2, lpol=True)
+    if w['K'] is not None:
+        for k in ('K1', 'K2', 'K3'):
+            f.update_env(k, w['K'])
+    dt = torch.float32 if w['prec'] == 'single' else torch.float64
+    dev = torch.device('cuda', torch.cuda.current_device())
+    par = w['par']
+    # inputs resident in HBM before the timed region
+    args = dict(positions=torch.as_tensor(w['pos'], dtype=dt, device=dev), box=w['box'],
+                pairs=torch.as_tensor(w['pairs'], dtype=torch.int32, device=dev),
+                Q_local=torch.as_tensor(par['Q_local'], dtype=dt, device=dev),
+                pol=torch.as_tensor(par['pol'], dtype=dt, device=dev),
+                tholes=torch.as_tensor(par['tholes'], dtype=dt, device=dev),
+                mScales=par['mScales'], pScales=par['pScales'], dScales=par['dScales'])
+    return f, args
+
+
+def step(f, a, U):
+    return f.get_forces(a['positions'], a['box'], a['pairs'], a['Q_local'], a['pol'], a['tholes'], a['mScales'],
+                        a['pScales'], a['dScales'], U_init=U)
+
+
+def run_timed(f, a, steps, warmup, barrier=None):
+    import torch
+    U = None
+    for _ in range(warmup):
+        step(f, a, U)
+        U = f.U_ind
+    f.profile(True)
+    f.profile_reset()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    cycles = 0
+    for _ in range(steps):
+        step(f, a, U)
+        U = f.U_ind
+        cycles += f.n_cycle + 1
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    rep = f.profile_report()
+    f.profile(False)
+    return dt, rep, cycles / float(steps)
+
+
+def roofline_of(rep, w, n_pairs):
+    wbytes = 4 if w['prec'] == 'single' else 8
+    n_atoms = 3 * w['n_mol']
+    total, per_pair = pair_kernel_bytes(n_pairs, n_atoms, wbytes, True)
+    ms, cnt = rep.get('pair_full', (0.0, 0))
+    avg_s = (ms / cnt) * 1e-3 if cnt else float('nan')
+    achieved = total / avg_s / 1e9 if cnt else float('nan')
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(w['name'], {}).get('pair_full_bytes_per_launch')
+        except Exception:
+            traffic = None
+    return {'bound': 'hbm', 'kernel': 'k_pair_full', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+            'algorithmic_bytes_per_launch': int(total), 'bytes_per_pair': round(per_pair, 2),
+            'avg_launch_us': round(avg_s * 1e6, 2), 'launches': int(cnt)}
+
+
+def cpu_baseline(w):
+    """The float64 oracle (CPU restatement of the reference's algorithm) on the same workload, one call."""
+    import torch
+    from oracle import admp_oracle as O
+    from admp_amd.pme import setup_ewald_parameters
+    kappa, K1, K2, K3 = setup_ewald_parameters(4.0, 1e-4, w['box'])
+    if w['K'] is not None:
+        K1 = K2 = K3 = w['K']
+    par = w['par']
+    sysm = O.PmeSystem(w['at'], w['ai'], w['cov'], kappa, (K1, K2, K3), 2, True)
+    t0 = time.perf_counter()
+    r = O.pme_energy_and_grad(sysm, w['pos'], w['box'], w['pairs'], par['Q_local'], par['mScales'], par['pol'],
+                              par['tholes'], par['pScales'])
+    dt = time.perf_counter() - t0
+    return {'value': round(0.0864 * DT_FS / dt, 6), 'unit': 'ns/day', 'cores': int(torch.get_num_threads()),
+            'kind': 'port', 'sample': '1 get_forces call of the %s workload (SCF from zero, %d cycles), %.1f s wall; '
+            'torch-CPU float64 restatement of the reference algorithm (the reference\'s JAX path is not '
+            'installable offline)' % (w['name'], r['n_cycle'] + 1, dt)}, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='S1', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-scale', action='store_true', help='skip the extra 1M-atom measurement (N=1 only)')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    opt = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    w = make_workload(opt.workload)
+    f, a = make_force(w)
+    n_atoms = 3 * w['n_mol']
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    dt, rep, cyc = run_timed(f, a, opt.steps, opt.warmup, barrier if dist is not None else None)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    t_step = dt / opt.steps
+    value = world * 0.0864 * DT_FS / t_step
+
+    if rank == 0:
+        out = {
+            'metric': 'ns/day (electrostatics get_forces per 1 fs step, polarizable PME incl. SCF)',
+            'value': round(value, 4), 'unit': 'ns/day', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
+            'ms_per_step': round(t_step * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64' if w['prec'] == 'double' else 'f32', 'data': 'synthetic',
+            'config': {'workload': w['desc'], 'n_atoms': n_atoms, 'n_pairs': int(f.n_pairs),
+                       'pme_grid': [f.K1, f.K2, f.K3], 'kappa': round(float(f.kappa), 6), 'dt_fs': DT_FS,
+                       'scf_cycles_per_step': round(cyc, 2),
+                       'parallelism': 'single GPU' if world == 1 else 'replicas only (%d independent boxes)' % world},
+            'roofline': roofline_of(rep, w, f.n_pairs),
+            'kernel_ms_per_step': {k: round(v[0] / opt.steps, 5) for k, v in sorted(rep.items())},
+        }
+        if world == 1 and not opt.no_cpu:
+            cb, ref = cpu_baseline(w) if opt.workload == 'S1' else (None, None)
+            if cb is not None:
+                out['cpu_baseline'] = cb
+                E, G = step(f, a, None)
+                Gh = G.cpu().numpy()
+                out['force_rel_l2_vs_oracle'] = float(np.linalg.norm(Gh - ref['grad']) / np.linalg.norm(ref['grad']))
+                out['energy_rel_vs_oracle'] = float(abs(E - ref['E']) / abs(ref['E']))
+        if world == 1 and not opt.no_scale and opt.workload == 'S1':
+            try:
+                del f
+                w3 = make_workload('S3')
+                f3, a3 = make_force(w3)
+                dt3, rep3, cyc3 = run_timed(f3, a3, 5, 2)
+                out['at_scale'] = {'workload': w3['desc'], 'n_atoms': 3 * w3['n_mol'], 'n_pairs': int(f3.n_pairs),
+                                   'ms_per_step': round(dt3 / 5 * 1e3, 3), 'ns_per_day': round(0.0864 / (dt3 / 5), 3),
+                                   'scf_cycles_per_step': round(cyc3, 2), 'dtype': 'f32',
+                                   'roofline': roofline_of(rep3, w3, f3.n_pairs),
+                                   'kernel_ms_per_step': {k: round(v[0] / 5, 4) for k, v in sorted(rep3.items())}}
+            except Exception as e:      # the headline line must still be printed
+                out['at_scale'] = {'error': repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
