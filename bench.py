@@ -154,6 +154,21 @@ def cpu_baseline(w):
             'installable offline)' % (w['name'], r['n_cycle'] + 1, dt)}, r
 
 
+def reduce_max_seconds(dt, dist, device):
+    """MAX over ranks of the timed region (every rank returns the same number)."""
+    if dist is None:
+        return float(dt)
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_ns_per_day(t_step_s, world):
+    """Whole-job throughput: `world` independent replicas each advance dt per step."""
+    return world * 0.0864 * DT_FS / t_step_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -184,12 +199,9 @@ def main():
             dist.barrier()
 
     dt, rep, cyc = run_timed(f, a, opt.steps, opt.warmup, barrier if dist is not None else None)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = reduce_max_seconds(dt, dist, 'cuda')
     t_step = dt / opt.steps
-    value = world * 0.0864 * DT_FS / t_step
+    value = aggregate_ns_per_day(t_step, world)
 
     if rank == 0:
         out = {

@@ -1,0 +1,122 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/admp_hip.h declares
+(no compute calls without a GPU), and the host logic around it (covalent map -> CSR, Ewald
+parameters, pair-list builder, scale-table wrap, synthetic box generator)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    from admp_amd import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, 'include', 'admp_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(admp_[a-z_0-9]+)\s*\(', header))
+    assert len(declared) >= 15
+    from admp_amd import _lib
+    assert declared == set(_lib.PROTOTYPES), 'ctypes prototypes and header disagree'
+    lib = ctypes.CDLL(built_lib)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    L = _lib.load()
+    assert b'gfx950' in L.admp_version()
+
+
+def test_no_gpu_fails_loudly(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from admp_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    assert L.admp_create(ctypes.byref(h), 0, 8) != 0          # ADMP_E_NOGPU, no fallback
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd import systems as S
+    at, ai, cov = S.water_topology(2)
+    with pytest.raises(RuntimeError):
+        ADMPPmeForce(np.eye(3) * 20.0, at, ai, cov, 4.0, 1e-4, 2)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'admp_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), f
+                assert 'hostshim_util' not in text, f
+
+
+def test_ewald_parameters_match_reference_rule():
+    from admp_amd.pme import setup_ewald_parameters
+    kappa, K1, K2, K3 = setup_ewald_parameters(4, 1e-4, np.eye(3) * 50.0)
+    assert abs(kappa - 0.7296057664681077) < 1e-15 and (K1, K2, K3) == (154, 154, 154)
+    kappa, K1, K2, K3 = setup_ewald_parameters(4.0, 1e-4, np.diag([31.289, 40.0, 25.0]))
+    assert (K1, K2, K3) == (97, 123, 77)
+
+
+def test_covalent_map_to_csr_dense_and_sparse():
+    from admp_amd._device import covalent_to_csr
+    from admp_amd import systems as S
+    _, _, cov = S.water_topology(3)
+    for form in (cov, cov.toarray()):
+        ptr, col, val = covalent_to_csr(form, 9)
+        assert ptr.tolist() == [0, 2, 4, 6, 8, 10, 12, 14, 16, 18]
+        assert col[:6].tolist() == [1, 2, 0, 2, 0, 1] and val[:6].tolist() == [1, 1, 1, 2, 1, 2]
+    ptr, col, val = covalent_to_csr(None, 4)
+    assert ptr.tolist() == [0] * 5 and len(col) == 0
+    with pytest.raises(ValueError):
+        covalent_to_csr(np.full((2, 2), 99), 2)
+
+
+def test_scale_table_wraps_like_python_indexing():
+    from tests.hostshim_util import scale_tables
+    mS = np.array([0.1, 0.2, 0.3, 0.4, 0.5])
+    mtab, ptab, w0 = scale_tables(mS, np.array([0.0, 0.0, 0.0, 1.0, 1.0]))
+    assert mtab[0] == mS[-1]            # nbonds = 0 -> mScales[-1] (admp/pme.py:682-683)
+    assert mtab[1:6].tolist() == mS.tolist()
+    assert w0[1] == pytest.approx(1.0) and w0[4] == 0.0 and w0[0] == 0.0
+
+
+def test_pair_builder_matches_brute_force():
+    from admp_amd import systems as S
+    pos, box = S.synthetic_water_box(27, seed=1)
+    pairs = S.build_pairs(pos + 100.0, box, 4.0)          # positions outside the cell are wrapped
+    L = box[0, 0]
+    i, j = np.triu_indices(len(pos), 1)
+    d = pos[i] - pos[j]
+    d -= L * np.round(d / L)
+    r = np.linalg.norm(d, axis=1)
+    want = set(zip(i[r < 4.0].tolist(), j[r < 4.0].tolist()))
+    assert set(map(tuple, pairs.tolist())) == want and (pairs[:, 0] < pairs[:, 1]).all()
+
+
+def test_synthetic_box_is_seeded_and_physical():
+    from admp_amd import systems as S
+    a, box = S.synthetic_water_box(216, seed=20240)
+    b, _ = S.synthetic_water_box(216, seed=20240)
+    assert np.array_equal(a, b)
+    assert abs(box[0, 0] - (216 / S.WATER_DENSITY) ** (1 / 3)) < 1e-12
+    mol = a.reshape(-1, 3, 3)
+    np.testing.assert_allclose(np.linalg.norm(mol[:, 1] - mol[:, 0], axis=1), S.R_OH, atol=1e-12)
+    pairs = S.build_pairs(a, box, 3.0)
+    inter = pairs[:, 0] // 3 != pairs[:, 1] // 3
+    d = a[pairs[inter, 0]] - a[pairs[inter, 1]]
+    d -= box[0, 0] * np.round(d / box[0, 0])
+    assert np.linalg.norm(d, axis=1).min() >= 1.5 - 1e-9
+
+
+def test_bench_pair_kernel_bytes_formula():
+    import bench
+    total, per_pair = bench.pair_kernel_bytes(13_826_823, 1_048_575, 4, True)
+    assert abs(per_pair - (8 + 68 + 60 + 128 / (13_826_823 / 1_048_575))) < 1e-9     # 145.6 B/pair
+    assert abs(per_pair - 145.7) < 0.1

@@ -1,0 +1,120 @@
+"""Independent checks of the oracle's hot-path restatement (the reference holds no test for
+pme.py / recip.py / disp_pme.py, so parity there is otherwise unpinned -- oracle/__init__.py):
+Ewald-parameter independence, agreement of the quasi-internal-frame multipole interaction with a
+direct Coulomb sum over point-charge models of the multipoles, and finite differences."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import admp_oracle as O
+from admp_amd import systems as S
+
+F64 = torch.float64
+
+
+def T(x):
+    return torch.as_tensor(np.asarray(x, dtype=np.float64))
+
+
+def small_water(n_mol=8, seed=4):
+    pos, box = S.synthetic_water_box(n_mol, seed=seed, density=0.008)     # L = 10 A for 8 waters
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, True)
+    pairs = S.build_pairs(pos, box, 0.4999 * box[0, 0])
+    return pos, box, at, ai, cov, par, pairs
+
+
+def test_total_energy_is_independent_of_kappa():
+    pos, box, at, ai, cov, par, pairs = small_water()
+    rng = np.random.default_rng(0)
+    U = rng.normal(size=(len(pos), 3)) * 0.05 * (par['pol'] > 0)[:, None]
+    es, dp, mag = [], [], []
+    for kappa in (0.95, 1.15):
+        sysm = O.PmeSystem(at, ai, cov, kappa, (72, 72, 72), 2, True)
+        parts = O.energy_pme_parts(sysm, T(pos), T(box), pairs, T(par['Q_local']), T(U), T(par['pol']),
+                                   T(par['tholes']), T(par['mScales']), T(par['pScales']))
+        es.append(float(sum(parts)))
+        mag.append(max(abs(float(p)) for p in parts))
+        dparts = O.disp_pme_parts(T(pos), T(box), pairs, T(par['c_list']), T(par['mScales']), cov, kappa, (72, 72, 72), 10)
+        dp.append(float(sum(dparts)))
+        dmag = max(abs(float(p)) for p in dparts)
+    # the three Ewald parts are each ~1e4 kJ/mol and change by O(1e3) between the two kappas; their sum must not
+    # (residual = order-6 B-spline interpolation error of the mesh)
+    assert mag[0] > 100 * abs(es[0]) and abs(es[0] - es[1]) < 1e-6 * mag[0]
+    assert abs(dp[0] - dp[1]) < 1e-5 * dmag
+
+
+def _charge_model(center, Qh, h=2e-3):
+    """Point charges reproducing a site's charge, dipole and traceless quadrupole (harmonic input)."""
+    q0, dz, dx, dy = Qh[0], Qh[1], Qh[2], Qh[3]
+    pts, qs = [center.copy()], [q0]
+    d = np.array([dx, dy, dz])
+    nd = np.linalg.norm(d)
+    if nd > 0:
+        n = d / nd
+        pts += [center + h * n, center - h * n]
+        qs += [nd / (2 * h), -nd / (2 * h)]
+    r3 = np.sqrt(3.0)
+    th = np.zeros((3, 3))
+    th[2, 2] = Qh[4]
+    th[0, 0] = 0.5 * (-Qh[4] + r3 * Qh[7])
+    th[1, 1] = 0.5 * (-Qh[4] - r3 * Qh[7])
+    th[0, 2] = th[2, 0] = 0.5 * r3 * Qh[5]
+    th[1, 2] = th[2, 1] = 0.5 * r3 * Qh[6]
+    th[0, 1] = th[1, 0] = 0.5 * r3 * Qh[8]
+    lam, vec = np.linalg.eigh(th)
+    for k in range(3):      # Theta = sum_k lam_k v v^T (traceless) = sum_k c_k h^2 (3 v v^T - 1), c_k = lam_k / (3 h^2)
+        c = lam[k] / (3 * h * h)
+        pts += [center + h * vec[:, k], center - h * vec[:, k], center.copy()]
+        qs += [c, c, -2 * c]
+    return np.array(pts), np.array(qs)
+
+
+def test_multipole_pair_energy_matches_point_charge_model():
+    rng = np.random.default_rng(12)
+    for trial in range(3):
+        pos = np.array([[500.0, 500.0, 500.0], [500.0, 500.0, 500.0] + rng.normal(size=3) * 2.2])
+        Q = rng.normal(size=(2, 9)) * np.array([1, .4, .4, .4, .3, .3, .3, .3, .3])
+        box = np.eye(3) * 1000.0
+        e = float(O.pme_real(T(pos), T(box), np.array([[0, 1]]), T(Q), None, None, None, T([1.0]), None,
+                             np.zeros((2, 2), dtype=np.int64), 1e-9, 2, False))
+        pa, qa = _charge_model(pos[0], Q[0])
+        pb, qb = _charge_model(pos[1], Q[1])
+        r = np.linalg.norm(pa[:, None, :] - pb[None, :, :], axis=-1)
+        direct = O.DIELECTRIC * np.sum(qa[:, None] * qb[None, :] / r)
+        assert abs(e - direct) < 2e-4 * abs(direct) + 1e-3
+
+
+def test_gradient_matches_finite_differences():
+    pos, box, at, ai, cov, par, pairs = small_water(8, seed=9)
+    kappa, K = 0.8, (40, 40, 40)
+    sysm = O.PmeSystem(at, ai, cov, kappa, K, 2, True)
+    r = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], par['pol'], par['tholes'],
+                              par['pScales'])
+    U = r['U_ind']
+
+    def energy(p):
+        return float(O.energy_pme(sysm, T(p), T(box), pairs, T(par['Q_local']), T(U), T(par['pol']), T(par['tholes']),
+                                  T(par['mScales']), T(par['pScales'])))
+    h = 1e-5
+    for (a, c) in [(0, 0), (4, 2), (11, 1)]:
+        pp, pm = pos.copy(), pos.copy()
+        pp[a, c] += h
+        pm[a, c] -= h
+        fd = (energy(pp) - energy(pm)) / (2 * h)
+        assert abs(fd - r['grad'][a, c]) < 1e-5 * max(1.0, abs(fd))
+
+
+def test_scf_fixed_point_and_flags():
+    pos, box, at, ai, cov, par, pairs = small_water(8, seed=2)
+    sysm = O.PmeSystem(at, ai, cov, 0.8, (40, 40, 40), 2, True)
+    hist = []
+    U, flag, i = O.optimize_Uind(sysm, pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
+                                 par['pScales'], thresh=1e-6, history=hist)
+    assert flag and len(hist) == i + 1 and hist[-1] < 1e-6
+    assert all(b < a for a, b in zip(hist, hist[1:]))                   # Jacobi contracts on a physical geometry
+    assert np.abs(U[par['pol'] == 0]).max() == 0.0
+    # exhausting the cycle budget reports False even if the last check would pass (admp/pme.py:139-143)
+    U2, flag2, i2 = O.optimize_Uind(sysm, pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
+                                    par['pScales'], thresh=1e-6, maxiter=i + 1)
+    assert i2 == i and flag2 is False
