@@ -235,7 +235,8 @@ struct Engine : EngineBase {
   // staging for host-pointer calls
   DevBuf s_pos, s_Q, s_pol, s_thole, s_U, s_out, s_dQ, s_par;
   // mesh
-  DevBuf mesh, spec, gtab, fft_work, binv_d;
+  DevBuf mesh, spec, gtab, fft_work, binv_d, bin_cells, bin_sorted, bin_scan;
+  BinScratch bins;
   rocfft_plan plan_f = nullptr, plan_b = nullptr;
   rocfft_execution_info info_f = nullptr, info_b = nullptr;
   int planK[3] = {0, 0, 0};
@@ -246,7 +247,8 @@ struct Engine : EngineBase {
   ~Engine() override {
     destroy_plans();
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &fmax_d, &s_pos, &s_Q, &s_pol,
-                      &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtab, &fft_work, &binv_d, &scan_scratch})
+                      &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtab, &fft_work, &binv_d, &scan_scratch, &bin_cells,
+                      &bin_sorted, &bin_scan})
       b->release();
     free_topology();
     prof.destroy();
@@ -367,12 +369,28 @@ struct Engine : EngineBase {
     return b.as<T>();
   }
 
+  void ensure_bins(int na) {
+    const BrickGrid bg = make_bricks(K);
+    bin_cells.need(sizeof(int) * 2 * (size_t)(bg.ncell + 1));
+    bin_sorted.need(sizeof(int) * 8 * (size_t)na);
+    bin_scan.need(spread_scan_bytes(bg.ncell));
+    bins.cell_start = bin_cells.as<int>();
+    bins.cursor = bin_cells.as<int>() + (bg.ncell + 1);
+    bins.sorted = bin_sorted.as<int>();
+    bins.scan_tmp = bin_scan.p;
+    bins.scan_bytes = bin_scan.bytes;
+  }
+
   void recip_pass(int na, const RecipGeom<T>& g, bool field_only) {
-    const size_t nreal = (size_t)K[0] * K[1] * K[2];
-    HIP_TRY(hipMemsetAsync(mesh.p, 0, nreal * sizeof(T), stream));
-    { TIMED("spread"); launch_spread<T>(stream, na, sites.as<Site<T>>(), lpol, g, mesh.as<T>()); }
+    ensure_bins(na);
+    {
+      TIMED("spread");
+      int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), lpol, g, bins, mesh.as<T>());
+      if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+    }
     fft_forward();
-    { TIMED("kspace"); launch_kspace<T>(stream, K, gtab.as<T>(), spec.as<T>(), energies_d.as<double>(), field_only ? E_SLOTS - 1 : E_RECIP); }
+    if (field_only) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_SCF_RECIP, 0, sizeof(double), stream));
+    { TIMED("kspace"); launch_kspace<T>(stream, K, gtab.as<T>(), spec.as<T>(), energies_d.as<double>(), field_only ? E_SCF_RECIP : E_RECIP); }
     fft_inverse();
   }
 
@@ -422,8 +440,12 @@ struct Engine : EngineBase {
     Site<T>* S = sites.as<Site<T>>();
     double* Ed = energies_d.as<double>();
 
+    HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     { TIMED("prepare_sites"); launch_prepare_sites<T>(stream, top, pos, Ql, U, pol, thole, bx, S); }
 
+    // phi_valid: the mesh holds phi = c2r(G S) of the CURRENT dipoles (last SCF field evaluation, no update since):
+    // the closing gather can then reuse it instead of spreading and transforming again.
+    bool phi_valid = false;
     int cyc = 0, flag = 1;
     if (lpol) {
       fld_pair.need(3 * (size_t)na * sizeof(T));
@@ -444,7 +466,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamSynchronize(stream));
         double fmax;
         std::memcpy(&fmax, &bits, sizeof(fmax));
-        if (fmax < thresh) break;
+        if (fmax < thresh) { phi_valid = true; break; }
         { TIMED("jacobi_update"); launch_jacobi_update<T>(stream, na, pol, field.as<T>(), U, S); }
       }
       if (i == max_cycle) i = max_cycle - 1;   // python's loop variable after exhaustion
@@ -452,9 +474,8 @@ struct Engine : EngineBase {
       flag = (i != max_cycle - 1);             // admp/pme.py:139-143
     }
 
-    HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     { TIMED("pair_full"); launch_pair_full<T>(stream, na, nbr, S, bx, tab, (T)kappa, lpol, gbuf, pot.as<T>(), Ed); }
-    recip_pass(na, g, false);
+    if (!phi_valid) recip_pass(na, g, false);
     { TIMED("gather"); launch_gather<T>(stream, na, S, lpol, g, mesh.as<T>(), pot.as<T>(), gbuf); }
     { TIMED("finish");
       launch_finish<T>(stream, top, pos, bx, S, pol, U, lpol, (T)kappa, pot.as<T>(), dpos ? gbuf : nullptr, dQl, Ed); }
@@ -467,7 +488,7 @@ struct Engine : EngineBase {
       if (lpol) HIP_TRY(hipMemcpyAsync(U_, U, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
-    E[0] = Eh[E_REAL]; E[1] = Eh[E_RECIP]; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
+    E[0] = Eh[E_REAL]; E[1] = phi_valid ? Eh[E_SCF_RECIP] : Eh[E_RECIP]; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
     if (ncyc) *ncyc = cyc;
     if (conv) *conv = flag;
   }

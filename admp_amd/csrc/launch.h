@@ -39,7 +39,7 @@ struct Topology {
 };
 
 // energies[] slots on the device
-enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SLOTS = 8 };
+enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SCF_RECIP = 6, E_SLOTS = 8 };
 
 // ---- atom_kernels.hip
 template <class T>
@@ -75,9 +75,42 @@ template <class T>
 void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* abqc, const Box<T>& box,
                     const ScaleTab<T>& tab, T* grad, double* energies);
 
+// Mesh bricks for the LDS-tiled spread: dimension d is cut into nb[d] = ceil(K/16) bricks of 15..16
+// (>= 6) points, brick b covering [b*K/nb, (b+1)*K/nb).  An atom is binned by the brick of its
+// lowest stencil point; its 6-point stencil then reaches at most the next brick.
+struct BrickGrid {
+  int nb[3];
+  int ncell;
+};
+inline BrickGrid make_bricks(const int K[3]) {
+  BrickGrid b;
+  for (int d = 0; d < 3; ++d) b.nb[d] = (K[d] + 15) / 16;
+  b.ncell = b.nb[0] * b.nb[1] * b.nb[2];
+  return b;
+}
+// below this atom count the spread uses global atomics (8 lanes per atom) instead of binned LDS bricks
+// (default 20000; env ADMP_SPREAD_BRICK_MIN overrides, 0 forces the brick path -- used by the parity tests)
+int spread_brick_min_atoms();
+// scratch for the per-call binning: brick offsets cell_start[ncell+1] (+cursor copy) and the
+// (atom, brick) entry list sorted[<= 8 na] (a stencil touches at most 2 bricks per axis)
+struct BinScratch {
+  int* cell_start = nullptr;   // ncell + 1
+  int* cursor = nullptr;       // ncell + 1
+  int* sorted = nullptr;       // 8 * na
+  void* scan_tmp = nullptr;
+  size_t scan_bytes = 0;
+};
+
 // ---- recip_kernels.hip
+// v1 spread (one thread per atom, global float atomics); mesh must be zeroed first
 template <class T>
-void launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, T* mesh);
+void launch_spread_atomic(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, T* mesh);
+// LDS-brick spread: bins the atoms, accumulates every brick in LDS, writes each mesh point exactly once
+// (no memset, no global atomics).  Returns a hipError_t as int.
+template <class T>
+int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
+                  T* mesh);
+size_t spread_scan_bytes(int ncell);
 // scalar (lmax = 0) channel of the dispersion path: value column `chan` of a (na, stride) array
 template <class T>
 void launch_spread_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,

@@ -2,6 +2,9 @@
 // the K1 x K2 x K3 mesh, the k-space multiply with the cached table G_k = 2 D C_k / theta_k^2, and the
 // gather that produces dE/dQ and dE/dr from phi = c2r(G S) (the adjoint the reference leaves to jax.grad).
 // The 3-D transforms themselves are rocFFT r2c / c2r plans driven from engine.hip.
+#include <cstdlib>
+#include <hipcub/hipcub.hpp>
+
 #include "disp_math.h"
 #include "launch.h"
 #include "reduce.h"
@@ -27,6 +30,152 @@ __global__ __launch_bounds__(kRecipBlock) void k_spread(int na, const Site<T>* _
   T r[3], Q[9];
   site_qtot(sites[i], lpol, r, Q);
   spread_atom(g, r, Q, [&](long idx, T v) { atomicAdd(&mesh[idx], v); });
+}
+
+// ---- LDS-brick spread -------------------------------------------------------------------------------
+// brick index of mesh index i on an axis of K points cut into nb bricks [b*K/nb, (b+1)*K/nb)
+__device__ __forceinline__ int brick_of(int i, int nb, int K) { return ((i + 1) * nb - 1) / K; }
+
+// The bricks (at most 2 per axis) that the 6-point stencil starting at `base` touches on one axis.
+__device__ __forceinline__ int bricks_on_axis(int base, int nb, int K, int out[2]) {
+  out[0] = brick_of(base, nb, K);
+  if (nb == 1) return 1;
+  const int end = ((out[0] + 1) * K) / nb;          // first index past the brick of `base`
+  if (base + 5 < end) return 1;
+  out[1] = out[0] + 1 == nb ? 0 : out[0] + 1;       // periodic wrap
+  return 2;
+}
+
+// Wave-aggregated counter update: lanes of the wavefront that target the same counter are combined into one
+// global atomic (atoms arrive in a spatially coherent order, so a wave touches only a handful of bricks);
+// returns this lane's slot (counter value before the add + rank among the lanes sharing the key), -1 if !pred.
+__device__ __forceinline__ int wave_agg_add(int* __restrict__ counter, int key, bool pred) {
+  const int lane = threadIdx.x & 63;
+  int slot = -1;
+  unsigned long long remaining = __ballot(pred);
+  while (remaining) {
+    const int leader = __ffsll((long long)remaining) - 1;
+    const int k = __shfl(key, leader, 64);
+    const unsigned long long same = __ballot(pred && key == k);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counter[k], __popcll(same));
+    base = __shfl(base, leader, 64);
+    if (pred && key == k) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+    remaining &= ~same;
+  }
+  return slot;
+}
+
+// mode 0: count the (atom, brick) entries per brick; mode 1: write them (counter = running offsets)
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__ sites, RecipGeom<T> g, BrickGrid bg,
+                                             int* __restrict__ counter, int* __restrict__ entries) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int b[3][2] = {{0, 0}, {0, 0}, {0, 0}}, n[3] = {0, 0, 0};
+  if (i < na) {
+    T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
+    for (int d = 0; d < 3; ++d) { int base; grid_ref(g, r, d, base); n[d] = bricks_on_axis(base, bg.nb[d], g.K[d], b[d]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {      // wave-uniform trip count: every lane takes part in the ballots
+    const int x = e & 1, y = (e >> 1) & 1, z = e >> 2;
+    const bool pred = x < n[0] && y < n[1] && z < n[2];
+    const int cid = (b[0][x] * bg.nb[1] + b[1][y]) * bg.nb[2] + b[2][z];
+    const int slot = wave_agg_add(counter, cid, pred);
+    if (MODE == 1 && pred) entries[slot] = i;
+  }
+}
+
+// One workgroup per brick: each listed atom adds the part of its stencil that falls inside the brick into a
+// 16^3 LDS tile (ds_add_f32/f64); the tile is then stored once -- no memset, no global atomics.  The spline
+// weights are recomputed per (atom, brick) entry: ~0.5 kflop against up to 216 LDS atomics.
+template <class T>
+__global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
+                                                       BrickGrid bg, const int* __restrict__ brick_start,
+                                                       const int* __restrict__ entries, T* __restrict__ mesh) {
+  __shared__ T tile[16 * 16 * 16];
+  const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
+  const int bb[3] = {bx, by, bz};
+  int lo[3], n[3];
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = (bb[d] * g.K[d]) / bg.nb[d];
+    n[d] = ((bb[d] + 1) * g.K[d]) / bg.nb[d] - lo[d];
+  }
+  for (int t = threadIdx.x; t < 4096; t += 256) tile[t] = T(0);
+  __syncthreads();
+  const int end = brick_start[blockIdx.x + 1];
+  for (int k = brick_start[blockIdx.x] + threadIdx.x; k < end; k += 256) {
+    T r[3], Q[9];
+    site_qtot(sites[entries[k]], lpol, r, Q);
+    Stencil<T> st;
+    st.init(g, r);
+    T c1[3], c2[6];
+    fold_multipole(g, Q, c1, c2);
+    const T q = Q[0];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int ja = wrap_add(st.base[0], a, g.K[0]) - lo[0];
+      if ((unsigned)ja >= (unsigned)n[0]) continue;
+      const T m0 = st.M[0][a], d0 = st.D1[0][a], e0 = st.D2[0][a];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int jb = wrap_add(st.base[1], b, g.K[1]) - lo[1];
+        if ((unsigned)jb >= (unsigned)n[1]) continue;
+        const T m1 = st.M[1][b], d1 = st.D1[1][b], e1 = st.D2[1][b];
+        const T mm = m0 * m1;
+        const T P0 = q * mm + c1[0] * d0 * m1 + c1[1] * m0 * d1 + c2[0] * e0 * m1 + c2[1] * m0 * e1 + c2[3] * d0 * d1;
+        const T P1 = c1[2] * mm + c2[4] * d0 * m1 + c2[5] * m0 * d1;
+        const T P2 = c2[2] * mm;
+        T* row = tile + (ja * 16 + jb) * 16;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int jc = wrap_add(st.base[2], c, g.K[2]) - lo[2];
+          if ((unsigned)jc < (unsigned)n[2]) atomicAdd(&row[jc], P0 * st.M[2][c] + P1 * st.D1[2][c] + P2 * st.D2[2][c]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nyz = n[1] * n[2], ntot = n[0] * nyz;
+  for (int t = threadIdx.x; t < ntot; t += 256) {
+    const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
+    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = tile[(ja * 16 + jb) * 16 + jc];
+  }
+}
+
+// Small systems (too few atoms to fill the chip brick by brick, and launch-latency bound): global float
+// atomics, 8-lane groups, lanes 0..5 each spread one x-plane (36 points) of the atom's stencil.
+template <class T>
+__global__ __launch_bounds__(256) void k_spread_planes(int na, const Site<T>* __restrict__ sites, int lpol,
+                                                       RecipGeom<T> g, T* __restrict__ mesh) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t >> 3, a = t & 7;
+  if (i >= na || a >= 6) return;
+  T r[3], Q[9];
+  site_qtot(sites[i], lpol, r, Q);
+  Stencil<T> st;
+  st.init(g, r);
+  T c1[3], c2[6];
+  fold_multipole(g, Q, c1, c2);
+  T m0 = 0, d0 = 0, e0 = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (k == a) { m0 = st.M[0][k]; d0 = st.D1[0][k]; e0 = st.D2[0][k]; }
+  const int ia = wrap_add(st.base[0], a, g.K[0]);
+  const T q = Q[0];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const int ib = wrap_add(st.base[1], b, g.K[1]);
+    const T m1 = st.M[1][b], d1 = st.D1[1][b], e1 = st.D2[1][b];
+    const T mm = m0 * m1;
+    const T P0 = q * mm + c1[0] * d0 * m1 + c1[1] * m0 * d1 + c2[0] * e0 * m1 + c2[1] * m0 * e1 + c2[3] * d0 * d1;
+    const T P1 = c1[2] * mm + c2[4] * d0 * m1 + c2[5] * m0 * d1;
+    const T P2 = c2[2] * mm;
+    const long row = ((long)ia * g.K[1] + ib) * g.K[2];
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+      atomicAdd(&mesh[row + wrap_add(st.base[2], c, g.K[2])], P0 * st.M[2][c] + P1 * st.D1[2][c] + P2 * st.D2[2][c]);
+  }
 }
 
 template <class T>
@@ -91,33 +240,81 @@ __global__ __launch_bounds__(256) void k_kspace(int K0, int K1, int K2, const T*
   if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
 }
 
+// Gather: 8-lane groups, one atom per group, lanes 0..5 each take one x-plane of the 6^3 stencil (36 mesh
+// loads in flight per lane), the 20 (or 3) partial sums are folded across the group with xor shuffles and
+// lane 0 converts them to dE/dQ, dE/dr.
+constexpr int kGatherBlock = 256;
+
 template <class T>
-__global__ __launch_bounds__(kRecipBlock) void k_gather(int na, const Site<T>* __restrict__ sites, int lpol,
-                                                        RecipGeom<T> g, const T* __restrict__ phi,
-                                                        T* __restrict__ pot, T* __restrict__ grad) {
-  int i = blockIdx.x * kRecipBlock + threadIdx.x;
-  if (i >= na) return;
-  T r[3], Q[9], F[NF];
-  site_qtot(sites[i], lpol, r, Q);
-  gather_atom(g, r, [&](long idx) { return phi[idx]; }, F);
-  T P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gr[3] = {0, 0, 0};
-  unfold_potential(g, Q, F, P, gr);
+__device__ __forceinline__ T group8_sum(T v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+template <class T>
+__device__ __forceinline__ void plane_weights(const Stencil<T>& st, int a, T w[4]) {
+  w[0] = w[1] = w[2] = w[3] = T(0);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) pot[9 * i + k] += P[k];
-  if (grad) {
-    grad[3 * i] += gr[0]; grad[3 * i + 1] += gr[1]; grad[3 * i + 2] += gr[2];
+  for (int k = 0; k < 6; ++k)
+    if (k == a) { w[0] = st.M[0][k]; w[1] = st.D1[0][k]; w[2] = st.D2[0][k]; w[3] = st.D3[0][k]; }
+}
+
+template <class T>
+__global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* __restrict__ sites, int lpol,
+                                                         RecipGeom<T> g, const T* __restrict__ phi,
+                                                         T* __restrict__ pot, T* __restrict__ grad) {
+  const int t = blockIdx.x * kGatherBlock + threadIdx.x;
+  const int i = t >> 3, a = t & 7;
+  T F[NF];
+#pragma unroll
+  for (int k = 0; k < NF; ++k) F[k] = T(0);
+  T r[3] = {0, 0, 0}, Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < na) {
+    site_qtot(sites[i], lpol, r, Q);
+    if (a < 6) {
+      Stencil<T> st;
+      st.init(g, r);
+      T w[4];
+      plane_weights(st, a, w);
+      gather_plane(g, st, wrap_add(st.base[0], a, g.K[0]), w, [&](long idx) { return phi[idx]; }, F);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NF; ++k) F[k] = group8_sum(F[k]);
+  if (i < na && a == 0) {
+    T P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gr[3] = {0, 0, 0};
+    unfold_potential(g, Q, F, P, gr);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pot[9 * i + k] += P[k];
+    if (grad) {
+      grad[3 * i] += gr[0]; grad[3 * i + 1] += gr[1]; grad[3 * i + 2] += gr[2];
+    }
   }
 }
 
 template <class T>
-__global__ __launch_bounds__(kRecipBlock) void k_gather_field(int na, const Site<T>* __restrict__ sites,
-                                                              RecipGeom<T> g, const T* __restrict__ phi,
-                                                              T* __restrict__ fld) {
-  int i = blockIdx.x * kRecipBlock + threadIdx.x;
-  if (i >= na) return;
-  T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]}, gx[3];
-  gather_atom_field(g, r, [&](long idx) { return phi[idx]; }, gx);
-  fld[3 * i] = gx[0]; fld[3 * i + 1] = gx[1]; fld[3 * i + 2] = gx[2];
+__global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Site<T>* __restrict__ sites,
+                                                               RecipGeom<T> g, const T* __restrict__ phi,
+                                                               T* __restrict__ fld) {
+  const int t = blockIdx.x * kGatherBlock + threadIdx.x;
+  const int i = t >> 3, a = t & 7;
+  T f[3] = {0, 0, 0};
+  if (i < na && a < 6) {
+    T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
+    Stencil<T> st;
+    st.init(g, r);
+    T w[4];
+    plane_weights(st, a, w);
+    gather_plane_field(g, st, wrap_add(st.base[0], a, g.K[0]), w[0], w[1], [&](long idx) { return phi[idx]; }, f);
+  }
+  f[0] = group8_sum(f[0]); f[1] = group8_sum(f[1]); f[2] = group8_sum(f[2]);
+  if (i < na && a == 0) {
+    const T* A = g.Aop;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fld[3 * i + k] = A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
+  }
 }
 
 template <class T>
@@ -137,8 +334,47 @@ __global__ __launch_bounds__(kRecipBlock) void k_gather_scalar(int na, const T* 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 
 template <class T>
-void launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, T* mesh) {
+void launch_spread_atomic(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, T* mesh) {
   k_spread<T><<<nblk(na, kRecipBlock), kRecipBlock, 0, st>>>(na, sites, lpol, g, mesh);
+}
+
+#define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+template <class T>
+int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
+                  T* mesh) {
+  const BrickGrid bg = make_bricks(g.K);
+  if (na < spread_brick_min_atoms()) {
+    RC(hipMemsetAsync(mesh, 0, sizeof(T) * (size_t)g.K[0] * g.K[1] * g.K[2], st));
+    k_spread_planes<T><<<nblk(na * 8, 256), 256, 0, st>>>(na, sites, lpol, g, mesh);
+    return 0;
+  }
+  RC(hipMemsetAsync(bs.cursor, 0, sizeof(int) * (bg.ncell + 1), st));
+  k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr);
+  size_t need = bs.scan_bytes;
+  RC(hipcub::DeviceScan::ExclusiveSum(bs.scan_tmp, need, bs.cursor, bs.cell_start, bg.ncell + 1, st));
+  RC(hipMemcpyAsync(bs.cursor, bs.cell_start, sizeof(int) * (bg.ncell + 1), hipMemcpyDeviceToDevice, st));
+  k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, bs.sorted);
+  k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh);
+  return 0;
+}
+#undef RC
+
+int spread_brick_min_atoms() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ADMP_SPREAD_BRICK_MIN");
+    v = e ? atoi(e) : 20000;
+    if (v < 0) v = 0;
+  }
+  return v;
+}
+
+// bytes of hipcub scan scratch for a mesh (used by the engine to size BinScratch)
+size_t spread_scan_bytes(int ncell) {
+  size_t need = 0;
+  int* p = nullptr;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need, p, p, ncell + 1, (hipStream_t)0);
+  return need + 256;
 }
 template <class T>
 void launch_spread_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
@@ -162,11 +398,11 @@ void launch_kspace(hipStream_t st, const int K[3], const T* gtab, T* spec, doubl
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
                    T* grad) {
-  k_gather<T><<<nblk(na, kRecipBlock), kRecipBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad);
+  k_gather<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad);
 }
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld) {
-  k_gather_field<T><<<nblk(na, kRecipBlock), kRecipBlock, 0, st>>>(na, sites, g, phi, fld);
+  k_gather_field<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, g, phi, fld);
 }
 template <class T>
 void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
@@ -178,7 +414,8 @@ void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, i
 }
 
 #define INST(T)                                                                                                       \
-  template void launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, T*);                     \
+  template void launch_spread_atomic<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, T*);              \
+  template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*);         \
   template void launch_spread_scalar<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, T*);     \
   template void launch_gtab<T>(hipStream_t, const int*, const double*, double, double, int, T*);                      \
   template void launch_kspace<T>(hipStream_t, const int*, const T*, T*, double*, int);                                \

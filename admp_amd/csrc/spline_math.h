@@ -223,6 +223,76 @@ ADMP_HD void gather_atom(const RecipGeom<T>& g, const T r[3], LoadF phi, T* F) {
   }
 }
 
+// One x-plane (stencil index a along dimension 0) of gather_atom: the kernels give each of 6 lanes of an
+// 8-lane group one plane and fold the 20 sums across the group.  w0[4] = (M, M1, M2, M3): the spline and
+// its first three derivatives of dimension 0 at that plane.
+template <class T, class LoadF>
+ADMP_HD void gather_plane(const RecipGeom<T>& g, const Stencil<T>& st, int ia, const T w0[4], LoadF phi, T* F) {
+  T s00 = 0, s10 = 0, s20 = 0, s30 = 0, s01 = 0, s11 = 0, s21 = 0, s02 = 0, s12 = 0, s03 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int b = 0; b < 6; ++b) {
+    const int ib = wrap_add(st.base[1], b, g.K[1]);
+    const long row = ((long)ia * g.K[1] + ib) * g.K[2];
+    T t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 6; ++c) {
+      const T v = phi(row + wrap_add(st.base[2], c, g.K[2]));
+      t0 += v * st.M[2][c];
+      t1 += v * st.D1[2][c];
+      t2 += v * st.D2[2][c];
+      t3 += v * st.D3[2][c];
+    }
+    const T m1 = st.M[1][b], d1 = st.D1[1][b], e1 = st.D2[1][b], g1 = st.D3[1][b];
+    s00 += t0 * m1; s10 += t0 * d1; s20 += t0 * e1; s30 += t0 * g1;
+    s01 += t1 * m1; s11 += t1 * d1; s21 += t1 * e1;
+    s02 += t2 * m1; s12 += t2 * d1;
+    s03 += t3 * m1;
+  }
+  const T m0 = w0[0], d0 = w0[1], e0 = w0[2], g0 = w0[3];
+  F[F000] = m0 * s00; F[F100] = d0 * s00; F[F200] = e0 * s00; F[F300] = g0 * s00;
+  F[F010] = m0 * s10; F[F110] = d0 * s10; F[F210] = e0 * s10;
+  F[F020] = m0 * s20; F[F120] = d0 * s20;
+  F[F030] = m0 * s30;
+  F[F001] = m0 * s01; F[F101] = d0 * s01; F[F201] = e0 * s01;
+  F[F011] = m0 * s11; F[F111] = d0 * s11;
+  F[F021] = m0 * s21;
+  F[F002] = m0 * s02; F[F102] = d0 * s02;
+  F[F012] = m0 * s12;
+  F[F003] = m0 * s03;
+}
+
+// first-derivative part of one plane: f[3] = (F100, F010, F001) contributions
+template <class T, class LoadF>
+ADMP_HD void gather_plane_field(const RecipGeom<T>& g, const Stencil<T>& st, int ia, T m0, T d0, LoadF phi, T f[3]) {
+  T s00 = 0, s10 = 0, s01 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int b = 0; b < 6; ++b) {
+    const int ib = wrap_add(st.base[1], b, g.K[1]);
+    const long row = ((long)ia * g.K[1] + ib) * g.K[2];
+    T t0 = 0, t1 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 6; ++c) {
+      const T v = phi(row + wrap_add(st.base[2], c, g.K[2]));
+      t0 += v * st.M[2][c];
+      t1 += v * st.D1[2][c];
+    }
+    s00 += t0 * st.M[1][b];
+    s10 += t0 * st.D1[1][b];
+    s01 += t1 * st.M[1][b];
+  }
+  f[0] = d0 * s00;
+  f[1] = m0 * s10;
+  f[2] = m0 * s01;
+}
+
 // First-derivative sums only (the SCF needs just dE/d(dipole)): returns cartesian-operator gradient
 // gxyz[i] = sum_j Aop[i][j] F1_j.
 template <class T, class LoadF>

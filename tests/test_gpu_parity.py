@@ -146,6 +146,35 @@ def test_s1_polarizable_golden():
     assert rel(G, g['grad']) < 1e-8 and rel(f.U_ind, g['U_ind']) < 1e-8 and rel(dQ, g['dQ']) < 1e-8
 
 
+def test_brick_spread_path_vs_oracle(precision):
+    """The LDS-brick spread (default only above 20k atoms) forced on a small box, in a child process because the
+    switch is read once per process; both precisions against the oracle."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_parity import water_system, oracle_es, rel
+from admp_amd import settings
+from admp_amd.pme import ADMPPmeForce
+pos, box, at, ai, cov, par, pairs = water_system(216, 11, True)
+ref = None
+for prec, tol in (('double', 1e-8), ('single', 5e-4)):
+    settings.PRECISION = prec
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    if ref is None:
+        ref = oracle_es(pos, box, at, ai, cov, par, pairs, f.kappa, (f.K1, f.K2, f.K3), True)
+    scale = max(abs(p) for p in ref['parts'])
+    assert abs(f.energy_parts[1] - ref['parts'][1]) < tol * scale, (prec, f.energy_parts, ref['parts'])
+    assert rel(G, ref['grad']) < tol and rel(f.U_ind, ref['U_ind']) < tol and f.n_cycle == ref['n_cycle'], prec
+print('BRICK-OK')
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADMP_SPREAD_BRICK_MIN='0')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'BRICK-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_pair_list_conventions():
     """Padding rows (i >= j) are dropped (admp/pme.py:671); order of rows is irrelevant; torch inputs work."""
     import torch
