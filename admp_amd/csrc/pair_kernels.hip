@@ -34,8 +34,8 @@ __device__ __forceinline__ void stage_tab(const ScaleTab<T>& tab, T* s) {
   __syncthreads();
 }
 
-template <class T, bool LPOL, int LPR>
-__global__ __launch_bounds__(kPairBlock) void k_pair_full(int na, const int* __restrict__ rowptr,
+template <class T, bool LPOL, int LPR, int MINW>
+__global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const int* __restrict__ rowptr,
                                                           const int* __restrict__ col,
                                                           const Site<T>* __restrict__ sites, Box<T> box,
                                                           ScaleTab<T> tab, T kappa, T* __restrict__ grad,
@@ -147,6 +147,17 @@ int pair_lanes_per_row() {
   return v;
 }
 
+// minimum waves per SIMD requested from the register allocator for the polarizable kernel
+// (env ADMP_PAIR_MINW: 1 = no constraint, 2 = at most 256 registers)
+static int pair_min_waves() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("ADMP_PAIR_MINW");
+    v = s ? atoi(s) : 2;   // measured on S2: 0.125 ms vs 0.161 ms unconstrained (1 wave/SIMD)
+  }
+  return v;
+}
+
 static inline unsigned grid_for(int na, int lpr) { return (unsigned)(((long)na * lpr + kPairBlock - 1) / kPairBlock); }
 
 #define ADMP_LPR_SWITCH(lpr, CALL) \
@@ -163,10 +174,16 @@ template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies) {
   const int lpr = pair_lanes_per_row();
+  const int minw = pair_min_waves();
 #define CALL(L)                                                                                                        \
-  if (lpol) k_pair_full<T, true, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab,   \
-                                                                            kappa, grad, pot, energies);               \
-  else k_pair_full<T, false, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
+  if (lpol && minw >= 2)                                                                                               \
+    k_pair_full<T, true, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \
+                                                                       grad, pot, energies);                           \
+  else if (lpol)                                                                                                       \
+    k_pair_full<T, true, L, 1><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \
+                                                                       grad, pot, energies);                           \
+  else                                                                                                                 \
+    k_pair_full<T, false, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
                                                                         grad, pot, energies)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL

@@ -65,13 +65,25 @@ ADMP_HD float m_ceil(float x) { return ceilf(x); }
 ADMP_HD double m_ceil(double x) { return ceil(x); }
 ADMP_HD float m_abs(float x) { return fabsf(x); }
 ADMP_HD double m_abs(double x) { return fabs(x); }
+// reciprocal / reciprocal square root: hardware 1-ulp forms for f32 on the device, exact elsewhere
+#if defined(__HIP_DEVICE_COMPILE__)
+ADMP_HD float m_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+ADMP_HD float m_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#define ADMP_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+ADMP_HD float m_rcp(float x) { return 1.0f / x; }
+ADMP_HD float m_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#define ADMP_PHASE() ((void)0)
+#endif
+ADMP_HD double m_rcp(double x) { return 1.0 / x; }
+ADMP_HD double m_rsqrt(double x) { return 1.0 / sqrt(x); }
 template <class T> ADMP_HD Dual<T> m_exp(Dual<T> a) { T e = m_exp(a.v); return {e, e * a.d}; }
 // erfc'(x) = -2/sqrt(pi) exp(-x^2)
 template <class T> ADMP_HD Dual<T> m_erfc(Dual<T> a) {
   return {m_erfc(a.v), -T(kTwoOverSqrtPi) * m_exp(-a.v * a.v) * a.d};
 }
-template <class T> ADMP_HD Dual<T> recip(Dual<T> a) { T i = T(1) / a.v; return {i, -a.d * i * i}; }
-template <class T> ADMP_HD T recip(T a) { return T(1) / a; }
+template <class T> ADMP_HD Dual<T> recip(Dual<T> a) { T i = m_rcp(a.v); return {i, -a.d * i * i}; }
+template <class T> ADMP_HD T recip(T a) { return m_rcp(a); }
 // trim_val_infty (admp/pme.py:365-376): x >= thresh -> constant thresh
 template <class T> ADMP_HD T trim_inf(T a, T th) { return a < th ? a : th; }
 template <class T> ADMP_HD Dual<T> trim_inf(Dual<T> a, T th) { return a.v < th ? a : Dual<T>(th, T(0)); }
@@ -109,7 +121,7 @@ ADMP_HD void qi_frame(const T z[3], T x[3], T y[3]) {
   x[0] = hx - z[0] * dot;
   x[1] = hy - z[1] * dot;
   x[2] = -z[2] * dot;
-  T inv = T(1) / m_sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  T inv = m_rsqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
   x[0] *= inv; x[1] *= inv; x[2] *= inv;
   y[0] = z[1] * x[2] - z[2] * x[1];
   y[1] = z[2] * x[0] - z[0] * x[2];
@@ -293,108 +305,153 @@ struct PairScales {
 template <class T, bool LPOL, bool WITH_J>
 ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J, const PairScales<T>& sc, T kappa,
                            T gI[3], T potI[9], T fldI[3], T potJ[9], T fldJ[3]) {
+  // ---- phase 1: geometry, pair frame, moments rotated into it
   T d[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
   min_image(box, d);
-  T r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-  T r = m_sqrt(r2);
-  T rinv = T(1) / r;
+  const T r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const T rinv = m_rsqrt(r2);
+  const T r = r2 * rinv;
   T z[3] = {d[0] * rinv, d[1] * rinv, d[2] * rinv};
   T x[3], y[3];
   qi_frame(z, x, y);
-
-  T A[9], B[9], UA[3], UB[3];
+  T A[9], B[9], UA[3] = {T(0), T(0), T(0)}, UB[3] = {T(0), T(0), T(0)};
   rot_harm(I.Q, x, y, z, A);
   rot_harm(J.Q, x, y, z, B);
-
-  typedef Dual<T> S;
-  S c[NCOEF];
-  Radial<S, T> rad;
-  rad.init(S(r, T(1)), kappa);
-  perm_coefs(rad, sc.mm, c);
+  T aw = T(0), dmp = T(1);
   if (LPOL) {
     rot_dip(I.U, x, y, z, UA);
     rot_dip(J.U, x, y, z, UB);
-    T aw = sc.w0 * T(kDefaultTholeWidth) + (T(1) - sc.w0) * (I.thole + J.thole);
-    T dmp = I.p6 * J.p6;
+    aw = sc.w0 * T(kDefaultTholeWidth) + (T(1) - sc.w0) * (I.thole + J.thole);
+    dmp = I.p6 * J.p6;
     dmp = dmp < T(1e-8) ? T(1e-8) : dmp;
-    ind_coefs(rad, S(r, T(1)), aw, dmp, sc.p, c);
   }
+  ADMP_PHASE();
 
-  // bilinear shapes S_c with E = sum_c coef_c S_c   (admp/pme.py:525-624 collected per coefficient)
-  T s[NCOEF];
-  s[CC] = A[0] * B[0];
-  s[CD] = A[0] * B[1] - A[1] * B[0];
-  s[CQ] = A[0] * B[4] + A[4] * B[0];
-  s[DD0] = A[1] * B[1];
-  s[DQ0] = A[4] * B[1] - A[1] * B[4];
-  s[DD1] = A[2] * B[2] + A[3] * B[3];
-  s[DQ1] = A[5] * B[2] + A[6] * B[3] - A[2] * B[5] - A[3] * B[6];
-  s[QQ0] = A[4] * B[4];
-  s[QQ1] = A[5] * B[5] + A[6] * B[6];
-  s[QQ2] = A[7] * B[7] + A[8] * B[8];
+  // ---- phase 2: permanent coefficients (admp/pme.py:303-324), streamed: each coefficient (value, d/dr) is
+  // consumed at once into the energy, dE/dr and the frame-component gradients PA = dE/dA, PB = dE/dB
+  typedef Dual<T> S;
+  Radial<S, T> rad;
+  rad.init(S(r, T(1)), kappa);
   T e = T(0), dedr = T(0);
-#define ADMP_ACC(k) e += c[k].v * s[k]; dedr += c[k].d * s[k];
-  ADMP_ACC(CC) ADMP_ACC(CD) ADMP_ACC(CQ) ADMP_ACC(DD0) ADMP_ACC(DQ0) ADMP_ACC(DD1) ADMP_ACC(DQ1) ADMP_ACC(QQ0)
-  ADMP_ACC(QQ1) ADMP_ACC(QQ2)
-  if (LPOL) {
-    const T hf = T(0.5);
-    s[CUD] = hf * (A[0] * UB[0] - B[0] * UA[0]);
-    s[DUD0] = hf * (B[1] * UA[0] + A[1] * UB[0]);
-    s[DUD1] = hf * (B[2] * UA[1] + B[3] * UA[2] + A[2] * UB[1] + A[3] * UB[2]);
-    s[UDQ0] = hf * (A[4] * UB[0] - B[4] * UA[0]);
-    s[UDQ1] = hf * (A[5] * UB[1] + A[6] * UB[2] - B[5] * UA[1] - B[6] * UA[2]);
-    s[UDUD0] = UA[0] * UB[0];
-    s[UDUD1] = UA[1] * UB[1] + UA[2] * UB[2];
-    ADMP_ACC(CUD) ADMP_ACC(DUD0) ADMP_ACC(DUD1) ADMP_ACC(UDQ0) ADMP_ACC(UDQ1) ADMP_ACC(UDUD0) ADMP_ACC(UDUD1)
-  }
-#undef ADMP_ACC
-
-  // dE/d(pair-frame components)
   T PA[9], PB[9], FA[3] = {T(0), T(0), T(0)}, FB[3] = {T(0), T(0), T(0)};
-  PA[0] = c[CC].v * B[0] + c[CD].v * B[1] + c[CQ].v * B[4];
-  PA[1] = -c[CD].v * B[0] + c[DD0].v * B[1] - c[DQ0].v * B[4];
-  PA[2] = c[DD1].v * B[2] - c[DQ1].v * B[5];
-  PA[3] = c[DD1].v * B[3] - c[DQ1].v * B[6];
-  PA[4] = c[CQ].v * B[0] + c[DQ0].v * B[1] + c[QQ0].v * B[4];
-  PA[5] = c[DQ1].v * B[2] + c[QQ1].v * B[5];
-  PA[6] = c[DQ1].v * B[3] + c[QQ1].v * B[6];
-  PA[7] = c[QQ2].v * B[7];
-  PA[8] = c[QQ2].v * B[8];
-  PB[0] = c[CC].v * A[0] - c[CD].v * A[1] + c[CQ].v * A[4];
-  PB[1] = c[CD].v * A[0] + c[DD0].v * A[1] + c[DQ0].v * A[4];
-  PB[2] = c[DD1].v * A[2] + c[DQ1].v * A[5];
-  PB[3] = c[DD1].v * A[3] + c[DQ1].v * A[6];
-  PB[4] = c[CQ].v * A[0] - c[DQ0].v * A[1] + c[QQ0].v * A[4];
-  PB[5] = -c[DQ1].v * A[2] + c[QQ1].v * A[5];
-  PB[6] = -c[DQ1].v * A[3] + c[QQ1].v * A[6];
-  PB[7] = c[QQ2].v * A[7];
-  PB[8] = c[QQ2].v * A[8];
-  if (LPOL) {
-    const T hf = T(0.5);
-    T hcud = hf * c[CUD].v, hd0 = hf * c[DUD0].v, hd1 = hf * c[DUD1].v, hq0 = hf * c[UDQ0].v, hq1 = hf * c[UDQ1].v;
-    PA[0] += hcud * UB[0];
-    PA[1] += hd0 * UB[0];
-    PA[2] += hd1 * UB[1];
-    PA[3] += hd1 * UB[2];
-    PA[4] += hq0 * UB[0];
-    PA[5] += hq1 * UB[1];
-    PA[6] += hq1 * UB[2];
-    PB[0] -= hcud * UA[0];
-    PB[1] += hd0 * UA[0];
-    PB[2] += hd1 * UA[1];
-    PB[3] += hd1 * UA[2];
-    PB[4] -= hq0 * UA[0];
-    PB[5] -= hq1 * UA[1];
-    PB[6] -= hq1 * UA[2];
-    FA[0] = -hcud * B[0] + hd0 * B[1] - hq0 * B[4] + c[UDUD0].v * UB[0];
-    FA[1] = hd1 * B[2] - hq1 * B[5] + c[UDUD1].v * UB[1];
-    FA[2] = hd1 * B[3] - hq1 * B[6] + c[UDUD1].v * UB[2];
-    FB[0] = hcud * A[0] + hd0 * A[1] + hq0 * A[4] + c[UDUD0].v * UA[0];
-    FB[1] = hd1 * A[2] + hq1 * A[5] + c[UDUD1].v * UA[1];
-    FB[2] = hd1 * A[3] + hq1 * A[6] + c[UDUD1].v * UA[2];
+  const T mm = sc.mm;
+#define ADMP_TERM(c, shape) { const T s_ = (shape); e += (c).v * s_; dedr += (c).d * s_; }
+  {  // cc
+    const S c = rad.R1 * (mm + rad.B2 - rad.xX);
+    ADMP_TERM(c, A[0] * B[0])
+    PA[0] = c.v * B[0]; PB[0] = c.v * A[0];
   }
+  {  // cd
+    const S c = rad.R2 * (mm + rad.B2);
+    ADMP_TERM(c, A[0] * B[1] - A[1] * B[0])
+    PA[0] += c.v * B[1]; PA[1] = -c.v * B[0]; PB[0] -= c.v * A[1]; PB[1] = c.v * A[0];
+  }
+  const S mB3 = mm + rad.B3;
+  {  // cq
+    const S c = rad.R3 * mB3;
+    ADMP_TERM(c, A[0] * B[4] + A[4] * B[0])
+    PA[0] += c.v * B[4]; PA[4] = c.v * B[0]; PB[0] += c.v * A[4]; PB[4] = c.v * A[0];
+  }
+  {  // dd_m0
+    const S c = rad.R3 * (mB3 * T(3) + rad.x3X) * T(-2.0 / 3.0);
+    ADMP_TERM(c, A[1] * B[1])
+    PA[1] += c.v * B[1]; PB[1] += c.v * A[1];
+  }
+  {  // dd_m1
+    const S c = rad.R3 * (mB3 - rad.x3X * T(2.0 / 3.0));
+    ADMP_TERM(c, A[2] * B[2] + A[3] * B[3])
+    PA[2] = c.v * B[2]; PA[3] = c.v * B[3]; PB[2] = c.v * A[2]; PB[3] = c.v * A[3];
+  }
+  {  // dq_m0
+    const S c = rad.R4 * (mB3 * T(3) + rad.x5X * T(4.0 / 3.0));
+    ADMP_TERM(c, A[4] * B[1] - A[1] * B[4])
+    PA[1] -= c.v * B[4]; PA[4] += c.v * B[1]; PB[1] += c.v * A[4]; PB[4] -= c.v * A[1];
+  }
+  {  // dq_m1
+    const S c = rad.R4 * mB3 * T(-kSqrt3);
+    ADMP_TERM(c, A[5] * B[2] + A[6] * B[3] - A[2] * B[5] - A[3] * B[6])
+    PA[2] -= c.v * B[5]; PA[3] -= c.v * B[6]; PA[5] = c.v * B[2]; PA[6] = c.v * B[3];
+    PB[2] += c.v * A[5]; PB[3] += c.v * A[6]; PB[5] = -c.v * A[2]; PB[6] = -c.v * A[3];
+  }
+  const S mB4 = mm + rad.B4;
+  {  // qq_m0
+    const S c = rad.R5 * (mB4 * T(6) + (rad.x2 * T(10) - T(3)) * rad.x5X * T(4.0 / 45.0));
+    ADMP_TERM(c, A[4] * B[4])
+    PA[4] += c.v * B[4]; PB[4] += c.v * A[4];
+  }
+  {  // qq_m1
+    const S c = rad.R5 * (mB4 * T(15) + rad.x5X) * T(-4.0 / 15.0);
+    ADMP_TERM(c, A[5] * B[5] + A[6] * B[6])
+    PA[5] += c.v * B[5]; PA[6] += c.v * B[6]; PB[5] += c.v * A[5]; PB[6] += c.v * A[6];
+  }
+  {  // qq_m2
+    const S c = rad.R5 * (mB4 - rad.x5X * T(4.0 / 15.0));
+    ADMP_TERM(c, A[7] * B[7] + A[8] * B[8])
+    PA[7] = c.v * B[7]; PA[8] = c.v * B[8]; PB[7] = c.v * A[7]; PB[8] = c.v * A[8];
+  }
+  ADMP_PHASE();
 
-  // transverse gradient from rotational invariance
+  // ---- phase 3: induced coefficients (admp/pme.py:408-475), Thole factors as duals in r
+  if (LPOL) {
+    const S u = trim_inf(S(r, T(1)) * m_rcp(dmp), T(1e8));
+    const S au = u * aw;
+    const S expau = (val(au) < T(50)) ? m_exp(-au) : S(T(0));
+    const S au2 = trim_inf(au * au, T(1e8));
+    const S au3 = trim_inf(au2 * au, T(1e8));
+    const S au4 = trim_inf(au3 * au, T(1e8));
+    const S base = au + T(1) + au2 * T(0.5);
+    const S th_c = T(1) - expau * base;                       // == thole_d1 (pme.py:430)
+    const S th_d0 = T(1) - expau * (base + au3 * T(0.25));
+    const S th_q1 = T(1) - expau * (base + au3 * T(1.0 / 6.0));
+    const S th_q0 = T(1) - expau * (base + au3 * T(1.0 / 6.0) + au4 * T(1.0 / 18.0));
+    const T p = sc.p, hf = T(0.5);
+    {  // cud
+      const S c = rad.R2 * (th_c * p - T(1) + rad.B2) * T(2);
+      ADMP_TERM(c, hf * (A[0] * UB[0] - B[0] * UA[0]))
+      const T h = hf * c.v;
+      PA[0] += h * UB[0]; PB[0] -= h * UA[0]; FA[0] = -h * B[0]; FB[0] = h * A[0];
+    }
+    {  // dud_m0
+      const S c = rad.R3 * ((th_d0 * p - T(1) + rad.B3) * T(3) + rad.x3X) * T(-4.0 / 3.0);
+      ADMP_TERM(c, hf * (B[1] * UA[0] + A[1] * UB[0]))
+      const T h = hf * c.v;
+      PA[1] += h * UB[0]; PB[1] += h * UA[0]; FA[0] += h * B[1]; FB[0] += h * A[1];
+    }
+    {  // dud_m1
+      const S c = rad.R3 * (th_c * p - T(1) + rad.B3 - rad.x3X * T(2.0 / 3.0)) * T(2);
+      ADMP_TERM(c, hf * (B[2] * UA[1] + B[3] * UA[2] + A[2] * UB[1] + A[3] * UB[2]))
+      const T h = hf * c.v;
+      PA[2] += h * UB[1]; PA[3] += h * UB[2]; PB[2] += h * UA[1]; PB[3] += h * UA[2];
+      FA[1] = h * B[2]; FA[2] = h * B[3]; FB[1] = h * A[2]; FB[2] = h * A[3];
+    }
+    {  // udq_m0
+      const S c = rad.R4 * ((th_q0 * p - T(1) + rad.B3) * T(3) + rad.x5X * T(4.0 / 3.0)) * T(2);
+      ADMP_TERM(c, hf * (A[4] * UB[0] - B[4] * UA[0]))
+      const T h = hf * c.v;
+      PA[4] += h * UB[0]; PB[4] -= h * UA[0]; FA[0] -= h * B[4]; FB[0] += h * A[4];
+    }
+    {  // udq_m1
+      const S c = rad.R4 * (th_q1 * p - T(1) + rad.B3) * T(-2.0 * kSqrt3);
+      ADMP_TERM(c, hf * (A[5] * UB[1] + A[6] * UB[2] - B[5] * UA[1] - B[6] * UA[2]))
+      const T h = hf * c.v;
+      PA[5] += h * UB[1]; PA[6] += h * UB[2]; PB[5] -= h * UA[1]; PB[6] -= h * UA[2];
+      FA[1] -= h * B[5]; FA[2] -= h * B[6]; FB[1] += h * A[5]; FB[2] += h * A[6];
+    }
+    {  // udud_m0 (uscales = 1, pme.py:472)
+      const S c = rad.R3 * ((th_d0 - T(1) + rad.B3) * T(3) + rad.x3X) * T(-2.0 / 3.0);
+      ADMP_TERM(c, UA[0] * UB[0])
+      FA[0] += c.v * UB[0]; FB[0] += c.v * UA[0];
+    }
+    {  // udud_m1
+      const S c = rad.R3 * (th_c - T(1) + rad.B3 - rad.x3X * T(2.0 / 3.0));
+      ADMP_TERM(c, UA[1] * UB[1] + UA[2] * UB[2])
+      FA[1] += c.v * UB[1]; FA[2] += c.v * UB[2]; FB[1] += c.v * UA[1]; FB[2] += c.v * UA[2];
+    }
+    ADMP_PHASE();
+  }
+#undef ADMP_TERM
+
+  // ---- phase 4: transverse gradient from rotational invariance, back to the global frame
   T gx = gen_toward_x(PA, A) + gen_toward_x(PB, B);
   T gy = gen_toward_y(PA, A) + gen_toward_y(PB, B);
   if (LPOL) {
@@ -406,14 +463,15 @@ ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J
   gI[0] += x[0] * gx + y[0] * gy + z[0] * dedr;
   gI[1] += x[1] * gx + y[1] * gy + z[1] * dedr;
   gI[2] += x[2] * gx + y[2] * gy + z[2] * dedr;
+  ADMP_PHASE();
 
-  // back to the global frame (adjoint of an orthogonal map = the map with the transposed frame)
+  // adjoint of an orthogonal map = the map with the transposed frame
   T cx[3], cy[3], cz[3], t[9];
   frame_cols(x, y, z, cx, cy, cz);
   rot_harm(PA, cx, cy, cz, t);
 #pragma unroll
   for (int k = 0; k < 9; ++k) potI[k] += t[k];
-  if (LPOL) {
+  if (LPOL && fldI) {
     rot_dip(FA, cx, cy, cz, t);
     fldI[0] += t[0]; fldI[1] += t[1]; fldI[2] += t[2];
   }

@@ -87,13 +87,16 @@ __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__
 }
 
 // One workgroup per brick: each listed atom adds the part of its stencil that falls inside the brick into a
-// 16^3 LDS tile (ds_add_f32/f64); the tile is then stored once -- no memset, no global atomics.  The spline
-// weights are recomputed per (atom, brick) entry: ~0.5 kflop against up to 216 LDS atomics.
+// 16^3 LDS tile; the tile is then stored once -- no memset, no global atomics.  The spline weights are
+// recomputed per (atom, brick) entry: ~0.5 kflop against up to 216 LDS atomics.
+// The tile is DOUBLE in both precisions: measured on MI355X (tools/ubench/lds_atomics.hip) ds_add_f32 sustains
+// only 0.33 lane-adds/clk/CU whereas ds_add_f64 sustains 7.4 (ds_add_u32: 13.6) -- a 22x difference that made
+// the f32 tile the bottleneck of the whole step; the f64 tile also makes the mesh sums precision-independent.
 template <class T>
 __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                        BrickGrid bg, const int* __restrict__ brick_start,
                                                        const int* __restrict__ entries, T* __restrict__ mesh) {
-  __shared__ T tile[16 * 16 * 16];
+  __shared__ double tile[16 * 16 * 16];
   const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
   const int bb[3] = {bx, by, bz};
   int lo[3], n[3];
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     lo[d] = (bb[d] * g.K[d]) / bg.nb[d];
     n[d] = ((bb[d] + 1) * g.K[d]) / bg.nb[d] - lo[d];
   }
-  for (int t = threadIdx.x; t < 4096; t += 256) tile[t] = T(0);
+  for (int t = threadIdx.x; t < 4096; t += 256) tile[t] = 0.0;
   __syncthreads();
   const int end = brick_start[blockIdx.x + 1];
   for (int k = brick_start[blockIdx.x] + threadIdx.x; k < end; k += 256) {
@@ -126,11 +129,12 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
         const T P0 = q * mm + c1[0] * d0 * m1 + c1[1] * m0 * d1 + c2[0] * e0 * m1 + c2[1] * m0 * e1 + c2[3] * d0 * d1;
         const T P1 = c1[2] * mm + c2[4] * d0 * m1 + c2[5] * m0 * d1;
         const T P2 = c2[2] * mm;
-        T* row = tile + (ja * 16 + jb) * 16;
+        double* row = tile + (ja * 16 + jb) * 16;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           const int jc = wrap_add(st.base[2], c, g.K[2]) - lo[2];
-          if ((unsigned)jc < (unsigned)n[2]) atomicAdd(&row[jc], P0 * st.M[2][c] + P1 * st.D1[2][c] + P2 * st.D2[2][c]);
+          if ((unsigned)jc < (unsigned)n[2])
+            atomicAdd(&row[jc], (double)(P0 * st.M[2][c] + P1 * st.D1[2][c] + P2 * st.D2[2][c]));
         }
       }
     }
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   const int nyz = n[1] * n[2], ntot = n[0] * nyz;
   for (int t = threadIdx.x; t < ntot; t += 256) {
     const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
-    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = tile[(ja * 16 + jb) * 16 + jc];
+    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * 16 + jc];
   }
 }
 
