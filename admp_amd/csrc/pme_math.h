@@ -70,10 +70,21 @@ ADMP_HD double m_abs(double x) { return fabs(x); }
 ADMP_HD float m_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 ADMP_HD float m_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 #define ADMP_PHASE() __builtin_amdgcn_sched_barrier(0)
+// "register fence": an empty volatile asm that reads and writes the given values.  Volatile asms keep their
+// program order, so everything that produces these values is scheduled before the fence and everything that
+// consumes them after it -- the only way to stop the machine scheduler from interleaving the phases of the
+// pair function (which costs ~100 extra live registers); emits no instruction.
+#define ADMP_FENCE3(a) asm volatile("" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]))
+#define ADMP_FENCE9(a) asm volatile("" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]), "+v"((a)[4]), \
+                                         "+v"((a)[5]), "+v"((a)[6]), "+v"((a)[7]), "+v"((a)[8]))
+#define ADMP_FENCE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #else
 ADMP_HD float m_rcp(float x) { return 1.0f / x; }
 ADMP_HD float m_rsqrt(float x) { return 1.0f / sqrtf(x); }
 #define ADMP_PHASE() ((void)0)
+#define ADMP_FENCE3(a) ((void)0)
+#define ADMP_FENCE9(a) ((void)0)
+#define ADMP_FENCE2(a, b) ((void)0)
 #endif
 ADMP_HD double m_rcp(double x) { return 1.0 / x; }
 ADMP_HD double m_rsqrt(double x) { return 1.0 / sqrt(x); }
@@ -232,6 +243,11 @@ struct Radial {
     B3 = B2 + x3X * T(2.0 / 3.0);
     B4 = B3 + x5X * T(4.0 / 15.0);
   }
+  ADMP_HD void fence() {
+    ADMP_FENCE2(R1.v, R1.d); ADMP_FENCE2(R2.v, R2.d); ADMP_FENCE2(R3.v, R3.d); ADMP_FENCE2(R4.v, R4.d);
+    ADMP_FENCE2(R5.v, R5.d); ADMP_FENCE2(x2.v, x2.d); ADMP_FENCE2(x3X.v, x3X.d); ADMP_FENCE2(x5X.v, x5X.d);
+    ADMP_FENCE2(xX.v, xX.d); ADMP_FENCE2(B2.v, B2.d); ADMP_FENCE2(B3.v, B3.d); ADMP_FENCE2(B4.v, B4.d);
+  }
 };
 
 // ten permanent coefficients (admp/pme.py:303-324); mm = mscale - 1
@@ -325,13 +341,15 @@ ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J
     dmp = I.p6 * J.p6;
     dmp = dmp < T(1e-8) ? T(1e-8) : dmp;
   }
-  ADMP_PHASE();
+  ADMP_FENCE9(A); ADMP_FENCE9(B);
+  if (LPOL) { ADMP_FENCE3(UA); ADMP_FENCE3(UB); }
 
   // ---- phase 2: permanent coefficients (admp/pme.py:303-324), streamed: each coefficient (value, d/dr) is
   // consumed at once into the energy, dE/dr and the frame-component gradients PA = dE/dA, PB = dE/dB
   typedef Dual<T> S;
   Radial<S, T> rad;
   rad.init(S(r, T(1)), kappa);
+  rad.fence();
   T e = T(0), dedr = T(0);
   T PA[9], PB[9], FA[3] = {T(0), T(0), T(0)}, FB[3] = {T(0), T(0), T(0)};
   const T mm = sc.mm;
@@ -389,7 +407,7 @@ ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J
     ADMP_TERM(c, A[7] * B[7] + A[8] * B[8])
     PA[7] = c.v * B[7]; PA[8] = c.v * B[8]; PB[7] = c.v * A[7]; PB[8] = c.v * A[8];
   }
-  ADMP_PHASE();
+  ADMP_FENCE9(PA); ADMP_FENCE9(PB); ADMP_FENCE2(e, dedr);
 
   // ---- phase 3: induced coefficients (admp/pme.py:408-475), Thole factors as duals in r
   if (LPOL) {
@@ -447,7 +465,7 @@ ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J
       ADMP_TERM(c, UA[1] * UB[1] + UA[2] * UB[2])
       FA[1] += c.v * UB[1]; FA[2] += c.v * UB[2]; FB[1] += c.v * UA[1]; FB[2] += c.v * UA[2];
     }
-    ADMP_PHASE();
+    ADMP_FENCE9(PA); ADMP_FENCE9(PB); ADMP_FENCE3(FA); ADMP_FENCE3(FB); ADMP_FENCE2(e, dedr);
   }
 #undef ADMP_TERM
 
@@ -463,7 +481,7 @@ ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J
   gI[0] += x[0] * gx + y[0] * gy + z[0] * dedr;
   gI[1] += x[1] * gx + y[1] * gy + z[1] * dedr;
   gI[2] += x[2] * gx + y[2] * gy + z[2] * dedr;
-  ADMP_PHASE();
+  ADMP_FENCE3(gI); ADMP_FENCE9(PA);
 
   // adjoint of an orthogonal map = the map with the transposed frame
   T cx[3], cy[3], cz[3], t[9];
