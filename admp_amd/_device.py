@@ -84,10 +84,18 @@ class HipForceBase:
 
     # ---- staging -----------------------------------------------------------------------------------------
     def _use_current_stream(self):
-        s = torch.cuda.current_stream(self._device).cuda_stream
-        if s != self._stream:
-            _lib.check(self._h, self._L.admp_set_stream(self._h, ctypes.c_void_p(s)), 'admp_set_stream')
-            self._stream = s
+        """Bind the library to this object's own torch stream (created once) and order that stream after the
+        caller's current stream; the torch ops of a call and the HIP kernels of the library then share ONE
+        stream (never the legacy null stream, which non-blocking HIP streams do not synchronise with)."""
+        if self._stream is None:
+            self._tstream = torch.cuda.Stream(device=self._device)
+            self._stream = self._tstream.cuda_stream
+            _lib.check(self._h, self._L.admp_set_stream(self._h, ctypes.c_void_p(self._stream)), 'admp_set_stream')
+        self._tstream.wait_stream(torch.cuda.current_stream(self._device))
+
+    def _on_stream(self):
+        self._use_current_stream()
+        return torch.cuda.stream(self._tstream)
 
     def _real(self, x, shape=None):
         """array-like -> contiguous device tensor of the handle's precision."""
@@ -135,7 +143,10 @@ class HipForceBase:
         key = self._pairs_fingerprint(pairs)
         if key == self._pairs_key:
             return
-        self._use_current_stream()
+        with self._on_stream():
+            self._set_pairs_now(pairs, key)
+
+    def _set_pairs_now(self, pairs, key):
         if isinstance(pairs, torch.Tensor):
             t = pairs.detach().to(device=self._device, dtype=torch.int32).contiguous()
         else:

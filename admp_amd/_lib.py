@@ -30,11 +30,19 @@ PROTOTYPES = {
                                     _ip, _ip, _i32]),
     'admp_disp_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _i32, _dp, _dp, _vp, _i32]),
     'admp_tt_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _dp, _vp, _i32]),
+    'admp_slab_configure': (_i32, [_vp, _i32, _i32]),
+    'admp_slab_info': (_i32, [_vp, _c.POINTER(_i64)]),
+    'admp_stage_begin': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _ip]),
+    'admp_stage': (_i32, [_vp, _i32, _vp, _vp, _i32, _dp]),
     'admp_profile_enable': (_i32, [_vp, _i32]),
     'admp_profile_reset': (_i32, [_vp]),
     'admp_profile_count': (_i32, [_vp]),
     'admp_profile_entry': (_i32, [_vp, _i32, _c.POINTER(_c.c_char_p), _dp, _c.POINTER(_i64)]),
 }
+
+# stage codes of admp_stage (include/admp_hip.h)
+ST_SET_U, ST_PAIR_FIELD, ST_SPREAD, ST_FFT_YZ, ST_FFT_X, ST_KSPACE, ST_GATHER_FIELD, ST_FIELD_FINISH, ST_JACOBI, \
+    ST_PAIR_FULL, ST_GATHER, ST_FINISH = range(1, 13)
 
 _lib = None
 

@@ -78,10 +78,12 @@ __global__ __launch_bounds__(kAtomBlock) void k_field_finish(int na, const Site<
                                                              const T* __restrict__ pol, const T* __restrict__ Ucart,
                                                              const T* __restrict__ fld_pair,
                                                              const T* __restrict__ fld_recip, T kappa,
-                                                             T* __restrict__ field, unsigned long long* fmax_bits) {
-  int i = blockIdx.x * kAtomBlock + threadIdx.x;
+                                                             T* __restrict__ field, unsigned long long* fmax_bits,
+                                                             const int* __restrict__ list) {
+  const int slot = blockIdx.x * kAtomBlock + threadIdx.x;
   double fm = 0.0;
-  if (i < na) {
+  if (slot < na) {
+    const int i = list ? list[slot] : slot;
     T f[3];
     self_factors(kappa, f);
     const T twoDf1 = T(2.0 * kDielectric) * f[1];
@@ -102,17 +104,21 @@ __global__ __launch_bounds__(kAtomBlock) void k_field_finish(int na, const Site<
   if (threadIdx.x == 0 && fm > 0.0) atomicMax(fmax_bits, nonneg_bits(fm));
 }
 
+// Unew may alias Ucart (single GPU); with a home list only the listed atoms are written (the other ranks'
+// entries of Unew stay zero so that a sum all-reduce assembles the full array).
 template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_jacobi_update(int na, const T* __restrict__ pol,
-                                                              const T* __restrict__ field, T* __restrict__ Ucart,
-                                                              Site<T>* __restrict__ sites) {
-  int i = blockIdx.x * kAtomBlock + threadIdx.x;
-  if (i >= na) return;
+                                                              const T* __restrict__ field, const T* Ucart, T* Unew,
+                                                              Site<T>* __restrict__ sites,
+                                                              const int* __restrict__ list) {
+  const int slot = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (slot >= na) return;
+  const int i = list ? list[slot] : slot;
   T s = pol[i] * T(1.0 / kDielectric);
   T ux = Ucart[3 * i] - field[3 * i] * s;
   T uy = Ucart[3 * i + 1] - field[3 * i + 1] * s;
   T uz = Ucart[3 * i + 2] - field[3 * i + 2] * s;
-  Ucart[3 * i] = ux; Ucart[3 * i + 1] = uy; Ucart[3 * i + 2] = uz;
+  Unew[3 * i] = ux; Unew[3 * i + 1] = uy; Unew[3 * i + 2] = uz;
   sites[i].U[0] = uz; sites[i].U[1] = ux; sites[i].U[2] = uy;
 }
 
@@ -121,10 +127,12 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish(Topology top, const T* __
                                                        const Site<T>* __restrict__ sites, const T* __restrict__ pol,
                                                        const T* __restrict__ Ucart, int lpol, T kappa,
                                                        T* __restrict__ pot, T* __restrict__ grad,
-                                                       T* __restrict__ dQlocal, double* energies) {
-  int i = blockIdx.x * kAtomBlock + threadIdx.x;
+                                                       T* __restrict__ dQlocal, double* energies,
+                                                       const int* __restrict__ list, int nlist) {
+  const int slot = blockIdx.x * kAtomBlock + threadIdx.x;
   double eself = 0.0, epen = 0.0;
-  if (i < top.na) {
+  if (slot < nlist) {
+    const int i = list ? list[slot] : slot;
     T f[3];
     self_factors(kappa, f);
     const Site<T>& s = sites[i];
@@ -197,17 +205,20 @@ void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites) {
 }
 template <class T>
 void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* pol, const T* Ucart, const T* fld_pair,
-                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits) {
-  k_field_finish<T><<<nblk(na), kAtomBlock, 0, st>>>(na, sites, pol, Ucart, fld_pair, fld_recip, kappa, field, fmax_bits);
+                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits, const int* list) {
+  k_field_finish<T><<<nblk(na), kAtomBlock, 0, st>>>(na, sites, pol, Ucart, fld_pair, fld_recip, kappa, field, fmax_bits, list);
 }
 template <class T>
-void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, T* Ucart, Site<T>* sites) {
-  k_jacobi_update<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pol, field, Ucart, sites);
+void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, const T* Ucart, T* Unew,
+                          Site<T>* sites, const int* list) {
+  k_jacobi_update<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pol, field, Ucart, Unew, sites, list);
 }
 template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
-                   const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies) {
-  k_finish<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal, energies);
+                   const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
+                   const int* list, int nlist) {
+  k_finish<T><<<nblk(nlist), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
+                                                  energies, list, nlist);
 }
 
 #define INST(T)                                                                                                        \
@@ -215,10 +226,10 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
                                         const Box<T>&, Site<T>*);                                                       \
   template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
-                                       unsigned long long*);                                                            \
-  template void launch_jacobi_update<T>(hipStream_t, int, const T*, const T*, T*, Site<T>*);                             \
+                                       unsigned long long*, const int*);                                                \
+  template void launch_jacobi_update<T>(hipStream_t, int, const T*, const T*, const T*, T*, Site<T>*, const int*);       \
   template void launch_finish<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const Site<T>*, const T*,        \
-                                 const T*, int, T, T*, T*, T*, double*);
+                                 const T*, int, T, T*, T*, T*, double*, const int*, int);
 INST(float)
 INST(double)
 #undef INST

@@ -150,6 +150,7 @@ struct EngineBase {
   double kappa = 0;
   int K[3] = {0, 0, 0};
   int lmax = 2, lpol = 0;
+  int srank = 0, snranks = 1;   // x-slab decomposition (admp_slab_configure)
   DevBuf scan_scratch;
   size_t scan_bytes = 0;
 
@@ -161,6 +162,11 @@ struct EngineBase {
                     void* dpos, int on_device) = 0;
   virtual void tt(const void* pos, const double* box, const void* abqc, int ns, const double* mS, double* E, void* dpos,
                   int on_device) = 0;
+  // staged evaluation (device pointers only)
+  virtual void slab_info(int64_t* out) = 0;
+  virtual int v_stage_begin(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole,
+                            int ns, const double* mS, const double* pS, void* U) = 0;
+  virtual void v_stage(int what, void* a, void* b, int iarg, double* dout) = 0;
 
   void free_topology() {
     if (top.axis_type) (void)hipFree(top.axis_type);
@@ -237,18 +243,19 @@ struct Engine : EngineBase {
   // mesh
   DevBuf mesh, spec, gtab, fft_work, binv_d, bin_cells, bin_sorted, bin_scan;
   BinScratch bins;
-  rocfft_plan plan_f = nullptr, plan_b = nullptr;
-  rocfft_execution_info info_f = nullptr, info_b = nullptr;
-  int planK[3] = {0, 0, 0};
+  rocfft_plan plan_f = nullptr, plan_b = nullptr, plan_xf = nullptr, plan_xb = nullptr;
+  rocfft_execution_info info_f = nullptr;
+  int planK[3] = {0, 0, 0}, planR = 0, planRank = 0;
+  DevBuf home_list;
   // validity of the cached G table
   double tab_box[9] = {0}, tab_kappa = -1;
-  int tab_which = 0, tabK[3] = {0, 0, 0};
+  int tab_which = 0, tabK[3] = {0, 0, 0}, tabY0 = 0;
 
   ~Engine() override {
     destroy_plans();
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &fmax_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtab, &fft_work, &binv_d, &scan_scratch, &bin_cells,
-                      &bin_sorted, &bin_scan})
+                      &bin_sorted, &bin_scan, &home_list})
       b->release();
     free_topology();
     prof.destroy();
@@ -258,10 +265,11 @@ struct Engine : EngineBase {
   void destroy_plans() {
     if (plan_f) rocfft_plan_destroy(plan_f);
     if (plan_b) rocfft_plan_destroy(plan_b);
+    if (plan_xf) rocfft_plan_destroy(plan_xf);
+    if (plan_xb) rocfft_plan_destroy(plan_xb);
     if (info_f) rocfft_execution_info_destroy(info_f);
-    if (info_b) rocfft_execution_info_destroy(info_b);
-    plan_f = plan_b = nullptr;
-    info_f = info_b = nullptr;
+    plan_f = plan_b = plan_xf = plan_xb = nullptr;
+    info_f = nullptr;
     planK[0] = planK[1] = planK[2] = 0;
   }
 
@@ -273,46 +281,90 @@ struct Engine : EngineBase {
     have_ewald = true;
   }
 
+  // ---- slab decomposition state (nranks == 1: the whole mesh is local) ---------------------------------
+  // rank s owns mesh planes [X0, X1) along x and, in the transposed (k-space) layout, rows [Y0, Y1) along y;
+  // the local real mesh additionally carries kGhost planes above X1 (stencil overhang / phi halo).
+  static constexpr int kGhost = 5;
+  int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0;
+  void update_slab() {
+    X0 = (int)((long)srank * K[0] / snranks); X1 = (int)((long)(srank + 1) * K[0] / snranks);
+    Y0 = (int)((long)srank * K[1] / snranks); Y1 = (int)((long)(srank + 1) * K[1] / snranks);
+    if (snranks > 1) {
+      for (int s = 0; s < snranks; ++s) {
+        int w = (int)((long)(s + 1) * K[0] / snranks) - (int)((long)s * K[0] / snranks);
+        ARG_CHECK(w >= 6, "slab decomposition needs at least 6 mesh planes per rank along x");
+        int wy = (int)((long)(s + 1) * K[1] / snranks) - (int)((long)s * K[1] / snranks);
+        ARG_CHECK(wy >= 1, "slab decomposition needs at least 1 mesh row per rank along y");
+      }
+    }
+  }
+  int nloc0() const { return snranks > 1 ? (X1 - X0) + kGhost : K[0]; }
+  int nxown() const { return snranks > 1 ? (X1 - X0) : K[0]; }
+  int nyown() const { return snranks > 1 ? (Y1 - Y0) : K[1]; }
+
   void ensure_mesh() {
-    const size_t nreal = (size_t)K[0] * K[1] * K[2];
-    const size_t nspec = (size_t)K[0] * K[1] * (K[2] / 2 + 1);
+    update_slab();
+    const size_t K2h = (size_t)(K[2] / 2 + 1);
+    const size_t nreal = (size_t)nloc0() * K[1] * K[2];
+    size_t nspec = (size_t)nxown() * K[1] * K2h;
+    const size_t nspec_t = (size_t)K[0] * nyown() * K2h;
+    if (nspec_t > nspec) nspec = nspec_t;
     mesh.need(nreal * sizeof(T));
     spec.need(nspec * 2 * sizeof(T));
-    gtab.need(nspec * sizeof(T));
+    gtab.need(nspec_t * sizeof(T));
     binv_d.need(9 * sizeof(double));
-    if (planK[0] == K[0] && planK[1] == K[1] && planK[2] == K[2] && plan_f) return;
+    if (planK[0] == K[0] && planK[1] == K[1] && planK[2] == K[2] && planR == snranks && planRank == srank && plan_f) return;
     destroy_plans();
     std::call_once(g_fft_once, [] { rocfft_setup(); });
-    const size_t len[3] = {(size_t)K[2], (size_t)K[1], (size_t)K[0]};   // rocFFT: fastest dimension first
     const rocfft_precision pr = sizeof(T) == 4 ? rocfft_precision_single : rocfft_precision_double;
-    FFT_TRY(rocfft_plan_create(&plan_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 3, len, 1, nullptr));
-    FFT_TRY(rocfft_plan_create(&plan_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 3, len, 1, nullptr));
-    size_t wf = 0, wb = 0;
-    FFT_TRY(rocfft_plan_get_work_buffer_size(plan_f, &wf));
-    FFT_TRY(rocfft_plan_get_work_buffer_size(plan_b, &wb));
-    fft_work.need((wf > wb ? wf : wb) + 16);
+    size_t wmax = 0, w = 0;
+    if (snranks == 1) {
+      const size_t len[3] = {(size_t)K[2], (size_t)K[1], (size_t)K[0]};   // rocFFT: fastest dimension first
+      FFT_TRY(rocfft_plan_create(&plan_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 3, len, 1, nullptr));
+      FFT_TRY(rocfft_plan_create(&plan_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 3, len, 1, nullptr));
+    } else {
+      // distributed transform = batched 2-D r2c over the owned planes, all-to-all transpose (done by the caller over
+      // RCCL), batched strided 1-D c2c along x
+      const size_t len2[2] = {(size_t)K[2], (size_t)K[1]};
+      FFT_TRY(rocfft_plan_create(&plan_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 2, len2, (size_t)nxown(), nullptr));
+      FFT_TRY(rocfft_plan_create(&plan_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 2, len2, (size_t)nxown(), nullptr));
+      const size_t len1[1] = {(size_t)K[0]};
+      const size_t stride[1] = {(size_t)nyown() * K2h};
+      const size_t batch = (size_t)nyown() * K2h;
+      for (int dir = 0; dir < 2; ++dir) {
+        rocfft_plan_description desc = nullptr;
+        FFT_TRY(rocfft_plan_description_create(&desc));
+        FFT_TRY(rocfft_plan_description_set_data_layout(desc, rocfft_array_type_complex_interleaved,
+                                                        rocfft_array_type_complex_interleaved, nullptr, nullptr, 1, stride, 1,
+                                                        1, stride, 1));
+        FFT_TRY(rocfft_plan_create(dir == 0 ? &plan_xf : &plan_xb, rocfft_placement_inplace,
+                                   dir == 0 ? rocfft_transform_type_complex_forward : rocfft_transform_type_complex_inverse,
+                                   pr, 1, len1, batch, desc));
+        FFT_TRY(rocfft_plan_description_destroy(desc));
+      }
+      FFT_TRY(rocfft_plan_get_work_buffer_size(plan_xf, &w)); if (w > wmax) wmax = w;
+      FFT_TRY(rocfft_plan_get_work_buffer_size(plan_xb, &w)); if (w > wmax) wmax = w;
+    }
+    FFT_TRY(rocfft_plan_get_work_buffer_size(plan_f, &w)); if (w > wmax) wmax = w;
+    FFT_TRY(rocfft_plan_get_work_buffer_size(plan_b, &w)); if (w > wmax) wmax = w;
+    fft_work.need(wmax + 16);
     FFT_TRY(rocfft_execution_info_create(&info_f));
-    FFT_TRY(rocfft_execution_info_create(&info_b));
-    if (wf) FFT_TRY(rocfft_execution_info_set_work_buffer(info_f, fft_work.p, wf));
-    if (wb) FFT_TRY(rocfft_execution_info_set_work_buffer(info_b, fft_work.p, wb));
-    planK[0] = K[0]; planK[1] = K[1]; planK[2] = K[2];
+    if (wmax) FFT_TRY(rocfft_execution_info_set_work_buffer(info_f, fft_work.p, wmax));
+    planK[0] = K[0]; planK[1] = K[1]; planK[2] = K[2]; planR = snranks; planRank = srank;
     tab_kappa = -1;   // mesh changed: table stale
   }
 
-  void fft_forward() {
-    TIMED("rocfft_r2c");
+  void run_plan(const char* label, rocfft_plan plan, void* in, void* out) {
+    TIMED(label);
     FFT_TRY(rocfft_execution_info_set_stream(info_f, stream));
-    void* in[1] = {mesh.p};
-    void* out[1] = {spec.p};
-    FFT_TRY(rocfft_execute(plan_f, in, out, info_f));
+    void* i[1] = {in};
+    void* o[1] = {out};
+    FFT_TRY(rocfft_execute(plan, i, o, info_f));
   }
-  void fft_inverse() {
-    TIMED("rocfft_c2r");
-    FFT_TRY(rocfft_execution_info_set_stream(info_b, stream));
-    void* in[1] = {spec.p};
-    void* out[1] = {mesh.p};
-    FFT_TRY(rocfft_execute(plan_b, in, out, info_b));
-  }
+  // real mesh (owned planes) <-> half spectrum in `spec`: full 3-D transform (1 rank) or its y-z part (slabs)
+  void fft_forward(T* mesh_p, T* spec_p) { run_plan("rocfft_r2c", plan_f, mesh_p, spec_p); }
+  void fft_inverse(T* spec_p, T* mesh_p) { run_plan("rocfft_c2r", plan_b, spec_p, mesh_p); }
+  void fft_x(T* buf, int inverse) { run_plan(inverse ? "rocfft_x_inv" : "rocfft_x_fwd", inverse ? plan_xb : plan_xf, buf, buf); }
 
   Box<T> make_box(const double* h, double* inv, double* vol) {
     Box<T> b;
@@ -331,21 +383,24 @@ struct Engine : EngineBase {
         g.Aop[3 * i + j] = (T)(-(double)K[i] * inv[3 * j + i]);   // -Nj_Aji_star[i][j] (admp/recip.py:52,177)
         g.Jac[3 * i + j] = (T)(-(double)K[j] * inv[3 * i + j]);   // d u_j / d x_i     (admp/recip.py:75-77)
       }
+    g.whole_mesh();
+    if (snranks > 1) { g.xoff = X0; g.nloc0 = nloc0(); g.wrap0 = 1 << 30; }
     return g;
   }
 
   void ensure_gtab(const double* box, const double* inv, double vol, int which) {
-    bool same = tab_kappa == kappa && tab_which == which && tabK[0] == K[0] && tabK[1] == K[1] && tabK[2] == K[2];
+    bool same = tab_kappa == kappa && tab_which == which && tabK[0] == K[0] && tabK[1] == K[1] && tabK[2] == K[2] &&
+                tabY0 == (snranks > 1 ? Y0 : 0);
     for (int k = 0; k < 9 && same; ++k) same = tab_box[k] == box[k];
     if (same) return;
     HIP_TRY(hipMemcpyAsync(binv_d.p, inv, 9 * sizeof(double), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));   // `inv` is a caller stack array
     {
       TIMED("gtab");
-      launch_gtab<T>(stream, K, binv_d.as<double>(), std::fabs(vol), kappa, which, gtab.as<T>());
+      launch_gtab<T>(stream, K, snranks > 1 ? Y0 : 0, nyown(), binv_d.as<double>(), std::fabs(vol), kappa, which, gtab.as<T>());
     }
     std::memcpy(tab_box, box, sizeof(tab_box));
-    tab_kappa = kappa; tab_which = which; tabK[0] = K[0]; tabK[1] = K[1]; tabK[2] = K[2];
+    tab_kappa = kappa; tab_which = which; tabK[0] = K[0]; tabK[1] = K[1]; tabK[2] = K[2]; tabY0 = snranks > 1 ? Y0 : 0;
   }
 
   ScaleTab<T> make_tab(int ns, const double* mS, const double* pS) {
@@ -370,7 +425,8 @@ struct Engine : EngineBase {
   }
 
   void ensure_bins(int na) {
-    const BrickGrid bg = make_bricks(K);
+    const int dims[3] = {nloc0(), K[1], K[2]};
+    const BrickGrid bg = make_bricks(dims);
     bin_cells.need(sizeof(int) * 2 * (size_t)(bg.ncell + 1));
     bin_sorted.need(sizeof(int) * 8 * (size_t)na);
     bin_scan.need(spread_scan_bytes(bg.ncell));
@@ -381,40 +437,163 @@ struct Engine : EngineBase {
     bins.scan_bytes = bin_scan.bytes;
   }
 
-  void recip_pass(int na, const RecipGeom<T>& g, bool field_only) {
-    ensure_bins(na);
-    {
-      TIMED("spread");
-      int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), lpol, g, bins, mesh.as<T>());
-      if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+  // ---- one evaluation, stage by stage -------------------------------------------------------------------
+  // The single-GPU entry point pme() runs the stages back to back; with a slab decomposition the caller
+  // (admp_amd/parallel.py) runs them itself and puts RCCL collectives in between (stage_* C ABI).
+  struct Eval {
+    const T* pos = nullptr; const T* Ql = nullptr; const T* pol = nullptr; const T* thole = nullptr;
+    T* U = nullptr;
+    Box<T> bx; RecipGeom<T> g; ScaleTab<T> tab;
+    int n_home = 0; const int* home = nullptr;   // this rank's atoms (nullptr = all, in order)
+    bool active = false;
+  } ev;
+
+  int stage_begin(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
+                  const double* mS, const double* pS, void* U_) {
+    ARG_CHECK(have_top && have_ewald && have_pairs, "topology, ewald parameters and pairs must be set first");
+    ARG_CHECK(pos_ && box && Ql_, "null argument");
+    if (lpol) ARG_CHECK(pol_ && thole_ && U_ && pS, "polarizable handle needs pol, tholes, pScales and U_inout");
+    const int na = top.na;
+    double inv[9], vol;
+    ensure_mesh();
+    ev.bx = make_box(box, inv, &vol);
+    ev.g = make_geom(inv);
+    ev.tab = make_tab(ns, mS, pS);
+    ensure_gtab(box, inv, vol, 1);
+    ev.pos = reinterpret_cast<const T*>(pos_);
+    ev.Ql = reinterpret_cast<const T*>(Ql_);
+    ev.pol = lpol ? reinterpret_cast<const T*>(pol_) : nullptr;
+    ev.thole = lpol ? reinterpret_cast<const T*>(thole_) : nullptr;
+    ev.U = lpol ? reinterpret_cast<T*>(U_) : nullptr;
+    sites.need(sizeof(Site<T>) * (size_t)na);
+    pot.need(9 * (size_t)na * sizeof(T));
+    energies_d.need(E_SLOTS * sizeof(double));
+    fmax_d.need(sizeof(unsigned long long));
+    if (lpol) {
+      fld_pair.need(3 * (size_t)na * sizeof(T));
+      fld_recip.need(3 * (size_t)na * sizeof(T));
+      field.need(3 * (size_t)na * sizeof(T));
     }
-    fft_forward();
-    if (field_only) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_SCF_RECIP, 0, sizeof(double), stream));
-    { TIMED("kspace"); launch_kspace<T>(stream, K, gtab.as<T>(), spec.as<T>(), energies_d.as<double>(), field_only ? E_SCF_RECIP : E_RECIP); }
-    fft_inverse();
+    ensure_bins(na);
+    HIP_TRY(hipMemsetAsync(energies_d.p, 0, E_SLOTS * sizeof(double), stream));
+    { TIMED("prepare_sites"); launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, ev.U, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>()); }
+    if (snranks > 1) {
+      home_list.need(sizeof(int) * (size_t)na + sizeof(int));
+      int* cnt = home_list.as<int>() + na;
+      HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), stream));
+      { TIMED("home_list"); launch_home_list<T>(stream, na, sites.as<Site<T>>(), ev.g, X1 - X0, home_list.as<int>(), cnt); }
+      int n = 0;
+      HIP_TRY(hipMemcpyAsync(&n, cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      ev.n_home = n;
+      ev.home = home_list.as<int>();
+    } else {
+      ev.n_home = na;
+      ev.home = nullptr;
+    }
+    ev.active = true;
+    return ev.n_home;
+  }
+
+  void need_eval() { ARG_CHECK(ev.active, "admp_stage_begin has not been called"); }
+
+  void stage_set_U(const void* U_) {   // refresh the packed harmonic dipoles of ALL atoms from a full U array
+    need_eval();
+    ev.U = reinterpret_cast<T*>(const_cast<void*>(U_));
+    TIMED("update_U");
+    launch_update_U<T>(stream, top.na, ev.U, sites.as<Site<T>>());
+  }
+  void stage_pair_field() {
+    need_eval();
+    TIMED("pair_field");
+    launch_pair_field<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(), ev.home);
+  }
+  void stage_spread(T* mesh_p) {
+    need_eval();
+    TIMED("spread");
+    int rc = launch_spread<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, bins, mesh_p, ev.home);
+    if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+  }
+  // spectrum buffer in the k-space layout [K0][ny][K2/2+1]: energy into `slot`, multiply by G
+  void stage_kspace(T* spec_p, int slot) {
+    need_eval();
+    HIP_TRY(hipMemsetAsync(energies_d.as<double>() + slot, 0, sizeof(double), stream));
+    TIMED("kspace");
+    launch_kspace<T>(stream, K, nyown(), gtab.as<T>(), spec_p, energies_d.as<double>(), slot);
+  }
+  void stage_gather_field(const T* mesh_p) {
+    need_eval();
+    TIMED("gather_field");
+    launch_gather_field<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.g, mesh_p, fld_recip.as<T>(), ev.home);
+  }
+  double stage_field_finish() {
+    need_eval();
+    HIP_TRY(hipMemsetAsync(fmax_d.p, 0, sizeof(unsigned long long), stream));
+    { TIMED("field_finish");
+      launch_field_finish<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
+                             (T)kappa, field.as<T>(), fmax_d.as<unsigned long long>(), ev.home); }
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, fmax_d.p, sizeof(bits), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    double fmax;
+    std::memcpy(&fmax, &bits, sizeof(fmax));
+    return fmax;
+  }
+  void stage_jacobi(T* Unew) {   // Unew == U: in place (single rank); else only the home entries of Unew are written
+    need_eval();
+    TIMED("jacobi_update");
+    launch_jacobi_update<T>(stream, ev.n_home, ev.pol, field.as<T>(), ev.U, Unew, sites.as<Site<T>>(), ev.home);
+  }
+  void stage_pair_full(T* grad_p) {
+    need_eval();
+    if (ev.home) {   // rows of other ranks stay zero so that a sum all-reduce assembles the gradient
+      HIP_TRY(hipMemsetAsync(grad_p, 0, 3 * (size_t)top.na * sizeof(T), stream));
+      HIP_TRY(hipMemsetAsync(pot.p, 0, 9 * (size_t)top.na * sizeof(T), stream));
+    }
+    TIMED("pair_full");
+    launch_pair_full<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, lpol, grad_p, pot.as<T>(),
+                        energies_d.as<double>(), ev.home);
+  }
+  void stage_gather(const T* mesh_p, T* grad_p) {
+    need_eval();
+    TIMED("gather");
+    launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home);
+  }
+  // closes the evaluation: E_out = (real, recip[slot], self, penalty) of THIS rank's share
+  void stage_finish(T* grad_p, T* dQl, int recip_slot, double* E) {
+    need_eval();
+    { TIMED("finish");
+      launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
+                       dQl, energies_d.as<double>(), ev.home, ev.n_home); }
+    double Eh[E_SLOTS];
+    HIP_TRY(hipMemcpyAsync(Eh, energies_d.p, sizeof(Eh), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    E[0] = Eh[E_REAL]; E[1] = Eh[recip_slot]; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
+    ev.active = false;
+  }
+
+  // full reciprocal pass on one rank: spread -> r2c -> G multiply (+energy) -> c2r ; mesh then holds phi
+  void recip_pass(int slot) {
+    stage_spread(mesh.as<T>());
+    fft_forward(mesh.as<T>(), spec.as<T>());
+    stage_kspace(spec.as<T>(), slot);
+    fft_inverse(spec.as<T>(), mesh.as<T>());
   }
 
   void pme(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
            const double* mS, const double* pS, void* U_, int max_cycle, double thresh, double* E, void* dpos_,
            void* dQl_, int* ncyc, int* conv, int on_device) override {
-    ARG_CHECK(have_top && have_ewald && have_pairs, "topology, ewald parameters and pairs must be set first");
+    ARG_CHECK(snranks == 1, "this handle is slab-decomposed: drive it through the admp_stage_* entry points");
     ARG_CHECK(pos_ && box && Ql_ && E, "null argument");
-    if (lpol) ARG_CHECK(pol_ && thole_ && U_ && pS, "polarizable handle needs pol, tholes, pScales and U_inout");
     const int na = top.na;
     HIP_TRY(hipSetDevice(device));
-    double inv[9], vol;
-    Box<T> bx = make_box(box, inv, &vol);
-    RecipGeom<T> g = make_geom(inv);
-    ScaleTab<T> tab = make_tab(ns, mS, pS);
-    ensure_mesh();
-    ensure_gtab(box, inv, vol, 1);
-
     const T* pos = stage_in(s_pos, pos_, 3 * (size_t)na, on_device);
     const T* Ql = stage_in(s_Q, Ql_, 9 * (size_t)na, on_device);
     const T* pol = lpol ? stage_in(s_pol, pol_, na, on_device) : nullptr;
     const T* thole = lpol ? stage_in(s_thole, thole_, na, on_device) : nullptr;
     T* U = nullptr;
     if (lpol) {
+      ARG_CHECK(U_, "polarizable handle needs U_inout");
       if (on_device) U = reinterpret_cast<T*>(U_);
       else { s_U.need(3 * (size_t)na * sizeof(T)); HIP_TRY(hipMemcpyAsync(s_U.p, U_, 3 * (size_t)na * sizeof(T), hipMemcpyHostToDevice, stream)); U = s_U.as<T>(); }
     }
@@ -429,74 +608,79 @@ struct Engine : EngineBase {
       if (on_device) dQl = reinterpret_cast<T*>(dQl_);
       else { s_dQ.need(9 * (size_t)na * sizeof(T)); dQl = s_dQ.as<T>(); }
     }
-    // the gradient buffer is needed internally even for energy-only calls
-    grad.need(3 * (size_t)na * sizeof(T));
+    grad.need(3 * (size_t)na * sizeof(T));   // the gradient buffer is needed internally even for energy-only calls
     T* gbuf = dpos ? dpos : grad.as<T>();
 
-    sites.need(sizeof(Site<T>) * (size_t)na);
-    pot.need(9 * (size_t)na * sizeof(T));
-    energies_d.need(E_SLOTS * sizeof(double));
-    fmax_d.need(sizeof(unsigned long long));
-    Site<T>* S = sites.as<Site<T>>();
-    double* Ed = energies_d.as<double>();
-
-    HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
-    { TIMED("prepare_sites"); launch_prepare_sites<T>(stream, top, pos, Ql, U, pol, thole, bx, S); }
+    stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, U);
 
     // phi_valid: the mesh holds phi = c2r(G S) of the CURRENT dipoles (last SCF field evaluation, no update since):
     // the closing gather can then reuse it instead of spreading and transforming again.
     bool phi_valid = false;
     int cyc = 0, flag = 1;
     if (lpol) {
-      fld_pair.need(3 * (size_t)na * sizeof(T));
-      fld_recip.need(3 * (size_t)na * sizeof(T));
-      field.need(3 * (size_t)na * sizeof(T));
       ARG_CHECK(max_cycle >= 1, "max_cycle must be >= 1");
       int i = 0;
       for (i = 0; i < max_cycle; ++i) {     // admp/pme.py:132-138
-        HIP_TRY(hipMemsetAsync(fmax_d.p, 0, sizeof(unsigned long long), stream));
-        { TIMED("pair_field"); launch_pair_field<T>(stream, na, nbr, S, bx, tab, (T)kappa, fld_pair.as<T>()); }
-        recip_pass(na, g, true);
-        { TIMED("gather_field"); launch_gather_field<T>(stream, na, S, g, mesh.as<T>(), fld_recip.as<T>()); }
-        { TIMED("field_finish");
-          launch_field_finish<T>(stream, na, S, pol, U, fld_pair.as<T>(), fld_recip.as<T>(), (T)kappa, field.as<T>(),
-                                 fmax_d.as<unsigned long long>()); }
-        unsigned long long bits = 0;
-        HIP_TRY(hipMemcpyAsync(&bits, fmax_d.p, sizeof(bits), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        double fmax;
-        std::memcpy(&fmax, &bits, sizeof(fmax));
+        stage_pair_field();
+        recip_pass(E_SCF_RECIP);
+        stage_gather_field(mesh.as<T>());
+        const double fmax = stage_field_finish();
         if (fmax < thresh) { phi_valid = true; break; }
-        { TIMED("jacobi_update"); launch_jacobi_update<T>(stream, na, pol, field.as<T>(), U, S); }
+        stage_jacobi(U);
       }
       if (i == max_cycle) i = max_cycle - 1;   // python's loop variable after exhaustion
       cyc = i;
       flag = (i != max_cycle - 1);             // admp/pme.py:139-143
     }
 
-    { TIMED("pair_full"); launch_pair_full<T>(stream, na, nbr, S, bx, tab, (T)kappa, lpol, gbuf, pot.as<T>(), Ed); }
-    if (!phi_valid) recip_pass(na, g, false);
-    { TIMED("gather"); launch_gather<T>(stream, na, S, lpol, g, mesh.as<T>(), pot.as<T>(), gbuf); }
-    { TIMED("finish");
-      launch_finish<T>(stream, top, pos, bx, S, pol, U, lpol, (T)kappa, pot.as<T>(), dpos ? gbuf : nullptr, dQl, Ed); }
+    stage_pair_full(gbuf);
+    if (!phi_valid) recip_pass(E_RECIP);
+    stage_gather(mesh.as<T>(), gbuf);
+    stage_finish(dpos ? gbuf : nullptr, dQl, phi_valid ? E_SCF_RECIP : E_RECIP, E);
 
-    double Eh[E_SLOTS];
-    HIP_TRY(hipMemcpyAsync(Eh, Ed, sizeof(Eh), hipMemcpyDeviceToHost, stream));
     if (!on_device) {
       if (dpos_) HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
       if (dQl_) HIP_TRY(hipMemcpyAsync(dQl_, dQl, 9 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
       if (lpol) HIP_TRY(hipMemcpyAsync(U_, U, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
     }
-    HIP_TRY(hipStreamSynchronize(stream));
-    E[0] = Eh[E_REAL]; E[1] = phi_valid ? Eh[E_SCF_RECIP] : Eh[E_RECIP]; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
     if (ncyc) *ncyc = cyc;
     if (conv) *conv = flag;
+  }
+
+  void slab_info(int64_t* o) override {
+    ARG_CHECK(have_ewald, "admp_set_ewald first");
+    update_slab();
+    o[0] = X0; o[1] = X1; o[2] = Y0; o[3] = Y1; o[4] = nloc0(); o[5] = kGhost; o[6] = K[0]; o[7] = K[1]; o[8] = K[2] / 2 + 1;
+    o[9] = srank; o[10] = snranks;
+  }
+  int v_stage_begin(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
+                    const double* mS, const double* pS, void* U) override {
+    return stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, U);
+  }
+  void v_stage(int what, void* a, void* b, int iarg, double* dout) override {
+    switch (what) {
+      case ADMP_ST_SET_U: stage_set_U(a); break;
+      case ADMP_ST_PAIR_FIELD: stage_pair_field(); break;
+      case ADMP_ST_SPREAD: stage_spread((T*)a); break;
+      case ADMP_ST_FFT_YZ: if (iarg) fft_inverse((T*)b, (T*)a); else fft_forward((T*)a, (T*)b); break;
+      case ADMP_ST_FFT_X: ARG_CHECK(snranks > 1, "FFT_X is a slab stage"); fft_x((T*)a, iarg); break;
+      case ADMP_ST_KSPACE: stage_kspace((T*)a, iarg ? E_SCF_RECIP : E_RECIP); break;
+      case ADMP_ST_GATHER_FIELD: stage_gather_field((const T*)a); break;
+      case ADMP_ST_FIELD_FINISH: ARG_CHECK(dout, "null"); dout[0] = stage_field_finish(); break;
+      case ADMP_ST_JACOBI: stage_jacobi((T*)a); break;
+      case ADMP_ST_PAIR_FULL: stage_pair_full((T*)a); break;
+      case ADMP_ST_GATHER: stage_gather((const T*)a, (T*)b); break;
+      case ADMP_ST_FINISH: ARG_CHECK(dout, "null"); stage_finish((T*)a, (T*)b, iarg ? E_SCF_RECIP : E_RECIP, dout); break;
+      default: throw Err{ADMP_E_ARG, "unknown stage"};
+    }
   }
 
   // dispersion PME (admp/disp_pme.py:80-123): real-space pairs + one scalar reciprocal pass per power
   void disp(const void* pos_, const double* box, const void* clist_, int pmax, int ns, const double* mS, double* E,
             void* dpos_, int on_device) override {
     ARG_CHECK(have_top && have_ewald && have_pairs, "topology, ewald parameters and pairs must be set first");
+    ARG_CHECK(snranks == 1, "dispersion PME is not slab-decomposed");
     ARG_CHECK(pos_ && box && clist_ && E, "null argument");
     ARG_CHECK(pmax == 6 || pmax == 8 || pmax == 10, "pmax must be 6, 8 or 10");
     const int na = top.na;
@@ -530,9 +714,9 @@ struct Engine : EngineBase {
       ensure_gtab(box, inv, vol, 6 + 2 * c);
       HIP_TRY(hipMemsetAsync(mesh.p, 0, nreal * sizeof(T), stream));
       { TIMED("spread_scalar"); launch_spread_scalar<T>(stream, na, pos, cl, 3, c, g, mesh.as<T>()); }
-      fft_forward();
-      { TIMED("kspace"); launch_kspace<T>(stream, K, gtab.as<T>(), spec.as<T>(), Ed, E_RECIP); }
-      fft_inverse();
+      fft_forward(mesh.as<T>(), spec.as<T>());
+      { TIMED("kspace"); launch_kspace<T>(stream, K, K[1], gtab.as<T>(), spec.as<T>(), Ed, E_RECIP); }
+      fft_inverse(spec.as<T>(), mesh.as<T>());
       { TIMED("gather_scalar"); launch_gather_scalar<T>(stream, na, pos, cl, 3, c, g, mesh.as<T>(), dpos); }
     }
     double Eh[E_SLOTS];
@@ -676,6 +860,27 @@ int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* b
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
                         const double* mScales, double* E_out, void* dE_dpos, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.tt(positions, box, abqc, n_scales, mScales, E_out, dE_dpos, on_device); });
+}
+
+int admp_slab_configure(admp_handle* h, int rank, int nranks) {
+  return guarded(h, [&](EngineBase& e) {
+    ARG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    e.srank = rank; e.snranks = nranks;
+  });
+}
+int admp_slab_info(admp_handle* h, int64_t* out11) {
+  return guarded(h, [&](EngineBase& e) { ARG_CHECK(out11, "null"); e.slab_info(out11); });
+}
+int admp_stage_begin(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                     const void* tholes, int n_scales, const double* mScales, const double* pScales, void* U,
+                     int* n_home) {
+  return guarded(h, [&](EngineBase& e) {
+    int n = e.v_stage_begin(positions, box, Q_local, pol, tholes, n_scales, mScales, pScales, U);
+    if (n_home) *n_home = n;
+  });
+}
+int admp_stage(admp_handle* h, int what, void* a, void* b, int iarg, double* dout) {
+  return guarded(h, [&](EngineBase& e) { e.v_stage(what, a, b, iarg, dout); });
 }
 
 int admp_profile_enable(admp_handle* h, int on) {

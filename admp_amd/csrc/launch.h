@@ -49,24 +49,32 @@ template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites);
 // field (Cartesian dE/dU) = pair (harmonic order) + recip (cartesian) + self + penalty; also max |field| over
 // sites with pol > 0.001 (admp/pme.py:130,136) into *fmax_bits (order-preserving bit pattern of a non-negative real)
+// Every per-atom / per-row launcher below takes an optional index list (`list`/`rows`, nullptr = atoms 0..n-1):
+// with the x-slab decomposition a rank works on its "home" atoms only and n is the list length.
 template <class T>
 void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* pol, const T* Ucart, const T* fld_pair,
-                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits);
-// U <- U - field * pol / DIELECTRIC (admp/pme.py:138), refreshing the packed harmonic copy
+                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits, const int* list);
+// Unew <- U - field * pol / DIELECTRIC (admp/pme.py:138), refreshing the packed harmonic copy (Unew may be U)
 template <class T>
-void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, T* Ucart, Site<T>* sites);
+void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, const T* Ucart, T* Unew,
+                          Site<T>* sites, const int* list);
 // self term + polarization penalty energies, self potential, local-frame adjoint, dE/dQ_local
 template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
-                   const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies);
+                   const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
+                   const int* list, int nlist);
+// atoms whose lowest stencil plane lies in the local slab (local base index < width): appended to `list`
+template <class T>
+void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
+                      int* count);
 
 // ---- pair_kernels.hip
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies);
+                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows);
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                       const ScaleTab<T>& tab, T kappa, T* fld_pair);
+                       const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows);
 int pair_lanes_per_row();            // tuning knob (env ADMP_PAIR_LPR), default chosen per precision
 template <class T>
 void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
@@ -109,25 +117,27 @@ void launch_spread_atomic(hipStream_t st, int na, const Site<T>* sites, int lpol
 // (no memset, no global atomics).  Returns a hipError_t as int.
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
-                  T* mesh);
+                  T* mesh, const int* list);
 size_t spread_scan_bytes(int ncell);
 // scalar (lmax = 0) channel of the dispersion path: value column `chan` of a (na, stride) array
 template <class T>
 void launch_spread_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
                           const RecipGeom<T>& g, T* mesh);
+// k-space layout [K0][ny][K2/2+1] holding mesh rows y0 .. y0+ny-1 (ny = K1, y0 = 0 on one rank).
 // which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels
 template <class T>
-void launch_gtab(hipStream_t st, const int K[3], const double* box_inv, double volume, double kappa, int which, T* gtab);
+void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* box_inv, double volume, double kappa,
+                 int which, T* gtab);
 // spec <- spec * gtab ; energies[slot] += sum_k w_k (gtab/2) |S_k|^2
 template <class T>
-void launch_kspace(hipStream_t st, const int K[3], const T* gtab, T* spec /* interleaved complex */, double* energies,
-                   int slot);
+void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec /* interleaved complex */,
+                   double* energies, int slot);
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad);
+                   T* grad, const int* list);
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
-                         T* fld_recip);
+                         T* fld_recip, const int* list);
 template <class T>
 void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
                           const RecipGeom<T>& g, const T* phi, T* grad);

@@ -39,14 +39,17 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
                                                           const int* __restrict__ col,
                                                           const Site<T>* __restrict__ sites, Box<T> box,
                                                           ScaleTab<T> tab, T kappa, T* __restrict__ grad,
-                                                          T* __restrict__ pot, double* energies) {
+                                                          T* __restrict__ pot, double* energies,
+                                                          const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
+  // `na` counts the rows this launch owns; with a row list (multi-GPU: the rank's home atoms) slot -> atom
+  const int row = slot < na ? (rows ? rows[slot] : slot) : na;
   T g[3] = {0, 0, 0}, P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[3] = {0, 0, 0};
   double e = 0.0;
-  if (row < na) {
+  if (slot < na) {
     const Site<T> I = sites[row];
     const int end = rowptr[row + 1];
 #pragma unroll 1
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
   for (int k = 0; k < 3; ++k) g[k] = row_reduce<T, LPR>(g[k]);
 #pragma unroll
   for (int k = 0; k < 9; ++k) P[k] = row_reduce<T, LPR>(P[k]);
-  if (row < na && sub == 0) {
+  if (slot < na && sub == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) grad[3 * row + k] = g[k];
 #pragma unroll
@@ -76,13 +79,15 @@ template <class T, int LPR>
 __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __restrict__ rowptr,
                                                            const int* __restrict__ col,
                                                            const Site<T>* __restrict__ sites, Box<T> box,
-                                                           ScaleTab<T> tab, T kappa, T* __restrict__ fld) {
+                                                           ScaleTab<T> tab, T kappa, T* __restrict__ fld,
+                                                           const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
+  const int row = slot < na ? (rows ? rows[slot] : slot) : na;
   T F[3] = {0, 0, 0};
-  if (row < na) {
+  if (slot < na) {
     const Site<T> I = sites[row];
     const int end = rowptr[row + 1];
 #pragma unroll 1
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) F[k] = row_reduce<T, LPR>(F[k]);
-  if (row < na && sub == 0) {
+  if (slot < na && sub == 0) {
     fld[3 * row] = F[0]; fld[3 * row + 1] = F[1]; fld[3 * row + 2] = F[2];
   }
 }
@@ -172,28 +177,28 @@ static inline unsigned grid_for(int na, int lpr) { return (unsigned)(((long)na *
 
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies) {
+                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows) {
   const int lpr = pair_lanes_per_row();
   const int minw = pair_min_waves();
 #define CALL(L)                                                                                                        \
   if (lpol && minw >= 2)                                                                                               \
     k_pair_full<T, true, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \
-                                                                       grad, pot, energies);                           \
+                                                                       grad, pot, energies, rows);                     \
   else if (lpol)                                                                                                       \
     k_pair_full<T, true, L, 1><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \
-                                                                       grad, pot, energies);                           \
+                                                                       grad, pot, energies, rows);                     \
   else                                                                                                                 \
     k_pair_full<T, false, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
-                                                                        grad, pot, energies)
+                                                                        grad, pot, energies, rows)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
 
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                       const ScaleTab<T>& tab, T kappa, T* fld) {
+                       const ScaleTab<T>& tab, T kappa, T* fld, const int* rows) {
   const int lpr = pair_lanes_per_row();
-#define CALL(L) k_pair_field<T, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, fld)
+#define CALL(L) k_pair_field<T, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, fld, rows)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
@@ -213,9 +218,9 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
 
 #define INST(T)                                                                                                     \
   template void launch_pair_full<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,               \
-                                    const ScaleTab<T>&, T, int, T*, T*, double*);                                   \
+                                    const ScaleTab<T>&, T, int, T*, T*, double*, const int*);                       \
   template void launch_pair_field<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
-                                     const ScaleTab<T>&, T, T*);                                                    \
+                                     const ScaleTab<T>&, T, T*, const int*);                                        \
   template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,           \
                                     const ScaleTab<T>&, T, int, T*, double*);                                       \
   template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,             \

@@ -69,12 +69,14 @@ __device__ __forceinline__ int wave_agg_add(int* __restrict__ counter, int key, 
 // mode 0: count the (atom, brick) entries per brick; mode 1: write them (counter = running offsets)
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__ sites, RecipGeom<T> g, BrickGrid bg,
-                                             int* __restrict__ counter, int* __restrict__ entries) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+                                             int* __restrict__ counter, int* __restrict__ entries,
+                                             const int* __restrict__ list) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  const int i = slot < na ? (list ? list[slot] : slot) : 0;
   int b[3][2] = {{0, 0}, {0, 0}, {0, 0}}, n[3] = {0, 0, 0};
-  if (i < na) {
+  if (slot < na) {
     T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
-    for (int d = 0; d < 3; ++d) { int base; grid_ref(g, r, d, base); n[d] = bricks_on_axis(base, bg.nb[d], g.K[d], b[d]); }
+    for (int d = 0; d < 3; ++d) { int base; grid_ref(g, r, d, base); n[d] = bricks_on_axis(base, bg.nb[d], g.dim(d), b[d]); }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {      // wave-uniform trip count: every lane takes part in the ballots
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   const int bb[3] = {bx, by, bz};
   int lo[3], n[3];
   for (int d = 0; d < 3; ++d) {
-    lo[d] = (bb[d] * g.K[d]) / bg.nb[d];
-    n[d] = ((bb[d] + 1) * g.K[d]) / bg.nb[d] - lo[d];
+    lo[d] = (bb[d] * g.dim(d)) / bg.nb[d];
+    n[d] = ((bb[d] + 1) * g.dim(d)) / bg.nb[d] - lo[d];
   }
   for (int t = threadIdx.x; t < 4096; t += 256) tile[t] = 0.0;
   __syncthreads();
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     const T q = Q[0];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const int ja = wrap_add(st.base[0], a, g.K[0]) - lo[0];
+      const int ja = wrap_add(st.base[0], a, g.wrap0) - lo[0];
       if ((unsigned)ja >= (unsigned)n[0]) continue;
       const T m0 = st.M[0][a], d0 = st.D1[0][a], e0 = st.D2[0][a];
 #pragma unroll
@@ -151,10 +153,12 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
 // atomics, 8-lane groups, lanes 0..5 each spread one x-plane (36 points) of the atom's stencil.
 template <class T>
 __global__ __launch_bounds__(256) void k_spread_planes(int na, const Site<T>* __restrict__ sites, int lpol,
-                                                       RecipGeom<T> g, T* __restrict__ mesh) {
+                                                       RecipGeom<T> g, T* __restrict__ mesh,
+                                                       const int* __restrict__ list) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const int i = t >> 3, a = t & 7;
-  if (i >= na || a >= 6) return;
+  const int slot = t >> 3, a = t & 7;
+  if (slot >= na || a >= 6) return;
+  const int i = list ? list[slot] : slot;
   T r[3], Q[9];
   site_qtot(sites[i], lpol, r, Q);
   Stencil<T> st;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void k_spread_planes(int na, const Site<T>* __
 #pragma unroll
   for (int k = 0; k < 6; ++k)
     if (k == a) { m0 = st.M[0][k]; d0 = st.D1[0][k]; e0 = st.D2[0][k]; }
-  const int ia = wrap_add(st.base[0], a, g.K[0]);
+  const int ia = wrap_add(st.base[0], a, g.wrap0);
   const T q = Q[0];
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
@@ -198,14 +202,14 @@ __global__ __launch_bounds__(kRecipBlock) void k_spread_scalar(int na, const T* 
 // frequencies of mesh axes (1,0,2) into k-columns (0,1,2), which is the same thing whenever
 // K1 = K2 and |a| = |b| (orthorhombic) -- the only regime in which the reference is self-consistent.
 template <class T>
-__global__ void k_gtab(int K0, int K1, int K2, const double* __restrict__ binv, double volume, double kappa,
-                       int which, T* __restrict__ gtab) {
+__global__ void k_gtab(int K0, int K1, int K2, int y0, int ny, const double* __restrict__ binv, double volume,
+                       double kappa, int which, T* __restrict__ gtab) {
   const int nh = K2 / 2 + 1;
-  const long n = (long)K0 * K1 * nh;
+  const long n = (long)K0 * ny * nh;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
     const int i2 = (int)(t % nh);
-    const int i1 = (int)((t / nh) % K1);
-    const int i0 = (int)(t / ((long)nh * K1));
+    const int i1 = y0 + (int)((t / nh) % ny);
+    const int i0 = (int)(t / ((long)nh * ny));
     const int m0 = signed_freq(i0, K0), m1 = signed_freq(i1, K1), m2 = signed_freq(i2, K2);
     const double tp = 6.283185307179586;
     double kx = tp * (m0 * binv[0] + m1 * binv[3] + m2 * binv[6]);
@@ -215,7 +219,7 @@ __global__ void k_gtab(int K0, int K1, int K2, const double* __restrict__ binv, 
     double th = theta_k_1d(m0, K0) * theta_k_1d(m1, K1) * theta_k_1d(m2, K2);
     double G;
     if (which == 1) {   // Ck_1 (recip.py:434-435), gamma point excluded (recip.py:413-415), x DIELECTRIC (:424)
-      G = (t == 0) ? 0.0
+      G = (i0 == 0 && i1 == 0 && i2 == 0) ? 0.0
                    : 2.0 * kDielectric * (tp / volume / ksq) * exp(-ksq / (4.0 * kappa * kappa)) / (th * th);
     } else {            // dispersion: gamma point included, no DIELECTRIC (recip.py:416-426)
       G = 2.0 * disp_ck(which, ksq, kappa, volume) / (th * th);
@@ -226,10 +230,10 @@ __global__ void k_gtab(int K0, int K1, int K2, const double* __restrict__ binv, 
 
 // spec <- G * spec, E += sum over the FULL spectrum of (G/2)|S|^2 (interior half-spectrum planes count twice)
 template <class T>
-__global__ __launch_bounds__(256) void k_kspace(int K0, int K1, int K2, const T* __restrict__ gtab,
+__global__ __launch_bounds__(256) void k_kspace(int K0, int ny, int K2, const T* __restrict__ gtab,
                                                 T* __restrict__ spec, double* energies, int slot) {
   const int nh = K2 / 2 + 1;
-  const long n = (long)K0 * K1 * nh;
+  const long n = (long)K0 * ny * nh;
   double e = 0.0;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
     const int i2 = (int)(t % nh);
@@ -268,26 +272,28 @@ __device__ __forceinline__ void plane_weights(const Stencil<T>& st, int a, T w[4
 template <class T>
 __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* __restrict__ sites, int lpol,
                                                          RecipGeom<T> g, const T* __restrict__ phi,
-                                                         T* __restrict__ pot, T* __restrict__ grad) {
+                                                         T* __restrict__ pot, T* __restrict__ grad,
+                                                         const int* __restrict__ list) {
   const int t = blockIdx.x * kGatherBlock + threadIdx.x;
-  const int i = t >> 3, a = t & 7;
+  const int slot = t >> 3, a = t & 7;
+  const int i = slot < na ? (list ? list[slot] : slot) : na;
   T F[NF];
 #pragma unroll
   for (int k = 0; k < NF; ++k) F[k] = T(0);
   T r[3] = {0, 0, 0}, Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < na) {
+  if (slot < na) {
     site_qtot(sites[i], lpol, r, Q);
     if (a < 6) {
       Stencil<T> st;
       st.init(g, r);
       T w[4];
       plane_weights(st, a, w);
-      gather_plane(g, st, wrap_add(st.base[0], a, g.K[0]), w, [&](long idx) { return phi[idx]; }, F);
+      gather_plane(g, st, wrap_add(st.base[0], a, g.wrap0), w, [&](long idx) { return phi[idx]; }, F);
     }
   }
 #pragma unroll
   for (int k = 0; k < NF; ++k) F[k] = group8_sum(F[k]);
-  if (i < na && a == 0) {
+  if (slot < na && a == 0) {
     T P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gr[3] = {0, 0, 0};
     unfold_potential(g, Q, F, P, gr);
 #pragma unroll
@@ -301,20 +307,21 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* 
 template <class T>
 __global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Site<T>* __restrict__ sites,
                                                                RecipGeom<T> g, const T* __restrict__ phi,
-                                                               T* __restrict__ fld) {
+                                                               T* __restrict__ fld, const int* __restrict__ list) {
   const int t = blockIdx.x * kGatherBlock + threadIdx.x;
-  const int i = t >> 3, a = t & 7;
+  const int slot = t >> 3, a = t & 7;
+  const int i = slot < na ? (list ? list[slot] : slot) : na;
   T f[3] = {0, 0, 0};
-  if (i < na && a < 6) {
+  if (slot < na && a < 6) {
     T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
     Stencil<T> st;
     st.init(g, r);
     T w[4];
     plane_weights(st, a, w);
-    gather_plane_field(g, st, wrap_add(st.base[0], a, g.K[0]), w[0], w[1], [&](long idx) { return phi[idx]; }, f);
+    gather_plane_field(g, st, wrap_add(st.base[0], a, g.wrap0), w[0], w[1], [&](long idx) { return phi[idx]; }, f);
   }
   f[0] = group8_sum(f[0]); f[1] = group8_sum(f[1]); f[2] = group8_sum(f[2]);
-  if (i < na && a == 0) {
+  if (slot < na && a == 0) {
     const T* A = g.Aop;
 #pragma unroll
     for (int k = 0; k < 3; ++k) fld[3 * i + k] = A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
@@ -345,19 +352,20 @@ void launch_spread_atomic(hipStream_t st, int na, const Site<T>* sites, int lpol
 #define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
-                  T* mesh) {
-  const BrickGrid bg = make_bricks(g.K);
+                  T* mesh, const int* list) {
+  const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
+  const BrickGrid bg = make_bricks(dims);
   if (na < spread_brick_min_atoms()) {
-    RC(hipMemsetAsync(mesh, 0, sizeof(T) * (size_t)g.K[0] * g.K[1] * g.K[2], st));
-    k_spread_planes<T><<<nblk(na * 8, 256), 256, 0, st>>>(na, sites, lpol, g, mesh);
+    RC(hipMemsetAsync(mesh, 0, sizeof(T) * (size_t)g.nloc0 * g.K[1] * g.K[2], st));
+    k_spread_planes<T><<<nblk(na * 8, 256), 256, 0, st>>>(na, sites, lpol, g, mesh, list);
     return 0;
   }
   RC(hipMemsetAsync(bs.cursor, 0, sizeof(int) * (bg.ncell + 1), st));
-  k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr);
+  k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list);
   size_t need = bs.scan_bytes;
   RC(hipcub::DeviceScan::ExclusiveSum(bs.scan_tmp, need, bs.cursor, bs.cell_start, bg.ncell + 1, st));
   RC(hipMemcpyAsync(bs.cursor, bs.cell_start, sizeof(int) * (bg.ncell + 1), hipMemcpyDeviceToDevice, st));
-  k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, bs.sorted);
+  k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, bs.sorted, list);
   k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh);
   return 0;
 }
@@ -386,27 +394,50 @@ void launch_spread_scalar(hipStream_t st, int na, const T* pos, const T* vals, i
   k_spread_scalar<T><<<nblk(na, kRecipBlock), kRecipBlock, 0, st>>>(na, pos, vals, stride, chan, g, mesh);
 }
 template <class T>
-void launch_gtab(hipStream_t st, const int K[3], const double* box_inv, double volume, double kappa, int which, T* gtab) {
-  const long n = (long)K[0] * K[1] * (K[2] / 2 + 1);
+void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* box_inv, double volume, double kappa,
+                 int which, T* gtab) {
+  const long n = (long)K[0] * ny * (K[2] / 2 + 1);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  k_gtab<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], box_inv, volume, kappa, which, gtab);
+  k_gtab<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], y0, ny, box_inv, volume, kappa, which, gtab);
 }
 template <class T>
-void launch_kspace(hipStream_t st, const int K[3], const T* gtab, T* spec, double* energies, int slot) {
-  const long n = (long)K[0] * K[1] * (K[2] / 2 + 1);
+void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec, double* energies, int slot) {
+  const long n = (long)K[0] * ny * (K[2] / 2 + 1);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  k_kspace<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], gtab, spec, energies, slot);
+  k_kspace<T><<<blocks, 256, 0, st>>>(K[0], ny, K[2], gtab, spec, energies, slot);
+}
+
+// home list of a slab rank: atoms whose local base plane index is below the slab width
+template <class T>
+__global__ __launch_bounds__(256) void k_home_list(int na, const Site<T>* __restrict__ sites, RecipGeom<T> g, int width,
+                                                   int* __restrict__ list, int* __restrict__ count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool mine = false;
+  if (i < na) {
+    T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
+    int base;
+    grid_ref(g, r, 0, base);
+    mine = base < width;
+  }
+  const int slot = wave_agg_add(count, 0, mine);
+  if (mine) list[slot] = i;
+}
+template <class T>
+void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
+                      int* count) {
+  k_home_list<T><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, width, list, count);
 }
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad) {
-  k_gather<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad);
+                   T* grad, const int* list) {
+  k_gather<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list);
 }
 template <class T>
-void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld) {
-  k_gather_field<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, g, phi, fld);
+void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
+                         const int* list) {
+  k_gather_field<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list);
 }
 template <class T>
 void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
@@ -419,12 +450,16 @@ void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, i
 
 #define INST(T)                                                                                                       \
   template void launch_spread_atomic<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, T*);              \
-  template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*);         \
+  template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
+                                const int*);                                                                          \
   template void launch_spread_scalar<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, T*);     \
-  template void launch_gtab<T>(hipStream_t, const int*, const double*, double, double, int, T*);                      \
-  template void launch_kspace<T>(hipStream_t, const int*, const T*, T*, double*, int);                                \
-  template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*);       \
-  template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*);          \
+  template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*);            \
+  template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
+  template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
+  template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
+                                 const int*);                                                                         \
+  template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
+                                       const int*);                                                                   \
   template void launch_gather_scalar<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, const T*, T*);
 INST(float)
 INST(double)

@@ -50,6 +50,11 @@ struct RecipGeom {
   T Aop[9];    // d/dx_i = sum_j Aop[i][j] d/du_j as the reference's operators use it:
                //   Aop = -(N * box^-1)^T indexed exactly as admp/recip.py:52,177,212
   T Jac[9];    // true Jacobian du_j/dx_i = Jac[i][j] (what autodiff follows through u0, recip.py:75-77)
+  // x-slab view of the mesh (multi-GPU): the local array holds planes xoff .. xoff+nloc0-1 (mod K[0]) of the
+  // global mesh; wrap0 = K[0] when the whole axis is local (periodic wrap inside the stencil), else "never".
+  int xoff, nloc0, wrap0;
+  ADMP_HD int dim(int d) const { return d == 0 ? nloc0 : K[d]; }
+  ADMP_HD void whole_mesh() { xoff = 0; nloc0 = K[0]; wrap0 = K[0]; }
 };
 
 // fractional grid coordinate of an atom along dimension d: returns f, writes the base index m_u0 - 3 (wrapped)
@@ -58,7 +63,7 @@ ADMP_HD T grid_ref(const RecipGeom<T>& g, const T r[3], int d, int& base) {
   T frac = r[0] * g.hinv[0 + d] + r[1] * g.hinv[3 + d] + r[2] * g.hinv[6 + d];
   T rm = frac * T(g.K[d]);
   T c = m_ceil(rm);
-  int m = (int)c - 3;
+  int m = (int)c - 3 - (d == 0 ? g.xoff : 0);
   m %= g.K[d];
   if (m < 0) m += g.K[d];
   base = m;
@@ -165,7 +170,7 @@ ADMP_HD void spread_atom(const RecipGeom<T>& g, const T r[3], const T Q[9], AddF
   fold_multipole(g, Q, c1, c2);
   const T q = Q[0];
   for (int a = 0; a < 6; ++a) {
-    const int ia = wrap_add(st.base[0], a, g.K[0]);
+    const int ia = wrap_add(st.base[0], a, g.wrap0);
     const T m0 = st.M[0][a], d0 = st.D1[0][a], e0 = st.D2[0][a];
     for (int b = 0; b < 6; ++b) {
       const int ib = wrap_add(st.base[1], b, g.K[1]);
@@ -190,7 +195,7 @@ ADMP_HD void gather_atom(const RecipGeom<T>& g, const T r[3], LoadF phi, T* F) {
   st.init(g, r);
   for (int k = 0; k < NF; ++k) F[k] = T(0);
   for (int a = 0; a < 6; ++a) {
-    const int ia = wrap_add(st.base[0], a, g.K[0]);
+    const int ia = wrap_add(st.base[0], a, g.wrap0);
     T s00 = 0, s10 = 0, s20 = 0, s30 = 0, s01 = 0, s11 = 0, s21 = 0, s02 = 0, s12 = 0, s03 = 0;
     for (int b = 0; b < 6; ++b) {
       const int ib = wrap_add(st.base[1], b, g.K[1]);
@@ -301,7 +306,7 @@ ADMP_HD void gather_atom_field(const RecipGeom<T>& g, const T r[3], LoadF phi, T
   st.init(g, r);
   T f0 = 0, f1 = 0, f2 = 0;
   for (int a = 0; a < 6; ++a) {
-    const int ia = wrap_add(st.base[0], a, g.K[0]);
+    const int ia = wrap_add(st.base[0], a, g.wrap0);
     T s00 = 0, s10 = 0, s01 = 0;
     for (int b = 0; b < 6; ++b) {
       const int ib = wrap_add(st.base[1], b, g.K[1]);

@@ -44,8 +44,11 @@ class ADMPDispPmeForce(HipForceBase):
         self.get_forces = self._generate_get_forces()
 
     def _evaluate(self, positions, box, pairs, c_list, mScales, want_grad):
+        with self._on_stream():
+            return self._evaluate_on_stream(positions, box, pairs, c_list, mScales, want_grad)
+
+    def _evaluate_on_stream(self, positions, box, pairs, c_list, mScales, want_grad):
         na = self.n_atoms
-        self._use_current_stream()
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
         if isinstance(c_list, torch.Tensor):

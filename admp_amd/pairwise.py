@@ -39,10 +39,13 @@ class _PairInteraction(HipForceBase):
         self.static_args = dict(static_args or {})
 
     def _evaluate(self, positions, box, pairs, mScales, atomic_params, want_grad):
+        with self._on_stream():
+            return self._evaluate_on_stream(positions, box, pairs, mScales, atomic_params, want_grad)
+
+    def _evaluate_on_stream(self, positions, box, pairs, mScales, atomic_params, want_grad):
         na = self.n_atoms
         if len(atomic_params) != self.kernel.n_params:
             raise TypeError('%s takes %d atomic parameter lists' % (self.kernel.name, self.kernel.n_params))
-        self._use_current_stream()
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
         par = torch.stack([self._real(p, (na,)) for p in atomic_params], dim=1).contiguous()

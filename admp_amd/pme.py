@@ -97,8 +97,13 @@ class ADMPPmeForce(HipForceBase):
 
     def _evaluate(self, positions, box, pairs, Q_local, mScales, pol=None, tholes=None, pScales=None, dScales=None,
                   U_init=None, want_grad=True, want_dQ=False, maxiter=None, thresh=None):
+        with self._on_stream():
+            return self._evaluate_on_stream(positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales,
+                                            U_init, want_grad, want_dQ, maxiter, thresh)
+
+    def _evaluate_on_stream(self, positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales, U_init,
+                            want_grad, want_dQ, maxiter, thresh):
         L, h, na = self._L, self._h, self.n_atoms
-        self._use_current_stream()
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
         Q = self._pad_Q(Q_local)

@@ -95,6 +95,40 @@ int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* b
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
                         const double* mScales, double* E_out, void* dE_dpos, int on_device);
 
+/* ---- multi-GPU: x-slab decomposition, staged evaluation ---------------------------------------------
+ * (no counterpart in the reference, which is single-device)  One process per GPU; every rank
+ * holds all atoms' inputs, owns the mesh planes [X0,X1) along x and works on its "home" atoms (lowest stencil
+ * plane inside the slab).  The caller (admp_amd/parallel.py) runs the stages of one evaluation and puts the
+ * RCCL collectives in between: ghost-plane exchange after SPREAD / before GATHER, the all-to-all transposes
+ * between FFT_YZ and FFT_X, sum all-reduce of dipoles / gradient / energies, max all-reduce of the SCF field.
+ * All pointers are DEVICE pointers.  With nranks = 1 the same stages reproduce admp_pme_energy_grad. */
+int admp_slab_configure(admp_handle* h, int rank, int nranks);
+/* out11 = {X0, X1, Y0, Y1, local planes (X1-X0+ghost), ghost, K1, K2, K3/2+1, rank, nranks} */
+int admp_slab_info(admp_handle* h, int64_t* out11);
+/* starts an evaluation: packs the sites of ALL atoms, builds this rank's home list; arguments as in
+ * admp_pme_energy_grad.  n_home receives the number of home atoms. */
+int admp_stage_begin(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                     const void* tholes, int n_scales, const double* mScales, const double* pScales, void* U,
+                     int* n_home);
+enum {
+  ADMP_ST_SET_U = 1,         /* a = U (Na,3), all atoms: refresh packed dipoles                                   */
+  ADMP_ST_PAIR_FIELD = 2,    /* real-space dE/dU of the home atoms                                                */
+  ADMP_ST_SPREAD = 3,        /* a = local real mesh [nloc][K2][K3] (fully overwritten)                             */
+  ADMP_ST_FFT_YZ = 4,        /* a = real mesh, b = spectrum [nx][K2][K3/2+1]; iarg 0: r2c, 1: c2r (b -> a); with one
+                                rank this is the complete 3-D transform                                           */
+  ADMP_ST_FFT_X = 5,         /* a = transposed spectrum [K1][ny][K3/2+1], in place; iarg 0 forward, 1 inverse     */
+  ADMP_ST_KSPACE = 6,        /* a = spectrum in k-space layout; multiplies by G, accumulates the reciprocal energy
+                                (iarg 1: into the SCF slot, 0: into the final slot)                               */
+  ADMP_ST_GATHER_FIELD = 7,  /* a = phi mesh (local, ghosts filled): reciprocal dE/dU of the home atoms            */
+  ADMP_ST_FIELD_FINISH = 8,  /* dout[0] = max |dE/dU| over this rank's polarizable home atoms                      */
+  ADMP_ST_JACOBI = 9,        /* a = U_new (Na,3): home entries <- U - field*pol/D (other entries untouched)         */
+  ADMP_ST_PAIR_FULL = 10,    /* a = gradient (Na,3): zeroed, home rows written; real-space energy accumulated      */
+  ADMP_ST_GATHER = 11,       /* a = phi mesh, b = gradient: adds reciprocal dE/dr, dE/dQ of the home atoms          */
+  ADMP_ST_FINISH = 12        /* a = gradient (or NULL), b = dE/dQ_local (or NULL), iarg = which reciprocal slot,
+                                dout[4] = this rank's (real, recip, self, penalty) energies                        */
+};
+int admp_stage(admp_handle* h, int what, void* a, void* b, int iarg, double* dout);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream. */
 int admp_profile_enable(admp_handle* h, int on);

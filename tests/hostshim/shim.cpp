@@ -141,6 +141,7 @@ static RecipGeom<T> make_geom(const double* boxh, const int* K) {
       g.Aop[3 * i + j] = (T)(-(double)K[i] * b.hinv[3 * j + i]);   // -Nstar[i][j], Nstar[a][b] = N[a] inv[b][a]
       g.Jac[3 * i + j] = (T)(-(double)K[j] * b.hinv[3 * i + j]);   // du_j/dx_i
     }
+  g.whole_mesh();
   return g;
 }
 

@@ -217,3 +217,73 @@ def test_invariances_at_scale():
         assert np.abs(G0.sum(axis=0)).max() < 1e-3 * np.abs(G0).sum(axis=0).max()
     finally:
         settings.PRECISION = settings_old
+
+
+def _run_slab_ranks(nranks, prec, lpol, n_mol=125, seed=5):
+    """N python threads, one SlabPme each (all on this GPU), exchanging through the in-process communicator."""
+    import threading
+    import torch
+    from admp_amd.parallel import SlabPme, ThreadComm
+    settings.PRECISION = prec
+    pos, box, at, ai, cov, par, pairs = water_system(n_mol, seed, lpol)
+    world = ThreadComm.World(nranks)
+    results, errors = [None] * nranks, []
+
+    def work(rank):
+        try:
+            f = SlabPme(ThreadComm(world, rank), box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+            if lpol:
+                E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
+                                    par['pScales'], par['dScales'])
+                results[rank] = (E, G, f.energy_parts, f.U_ind, f.n_cycle, f.lconverg, f.n_home)
+            else:
+                E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['mScales'])
+                results[rank] = (E, G, f.energy_parts, None, 0, True, f.n_home)
+        except Exception as e:      # noqa: BLE001
+            errors.append((rank, repr(e)))
+            try:
+                world.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    return (pos, box, at, ai, cov, par, pairs), results
+
+
+@pytest.mark.parametrize('nranks', [1, 2, 3])
+@pytest.mark.parametrize('lpol', [False, True])
+def test_slab_decomposition_matches_single_gpu(precision, nranks, lpol):
+    """x-slab decomposition (admp_amd/parallel.py): every rank must return the single-GPU result."""
+    from admp_amd.pme import ADMPPmeForce
+    system, results = _run_slab_ranks(nranks, 'double', lpol)
+    pos, box, at, ai, cov, par, pairs = system
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+    if lpol:
+        E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
+                            par['dScales'])
+    else:
+        E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['mScales'])
+    scale = max(abs(p) for p in f.energy_parts)
+    assert sum(r[6] for r in results) == len(pos)            # home lists partition the atoms
+    for (Er, Gr, parts, U, ncyc, conv, nhome) in results:
+        for a, b in zip(parts, f.energy_parts):
+            assert abs(a - b) < 1e-10 * scale
+        assert rel(Gr, G) < 1e-10
+        if lpol:
+            assert ncyc == f.n_cycle and conv == f.lconverg and rel(U, f.U_ind) < 1e-10
+
+
+def test_slab_decomposition_single_precision(precision):
+    from admp_amd.pme import ADMPPmeForce
+    system, results = _run_slab_ranks(2, 'single', True, n_mol=216, seed=11)
+    pos, box, at, ai, cov, par, pairs = system
+    ref = oracle_es(pos, box, at, ai, cov, par, pairs, *(lambda f: (f.kappa, (f.K1, f.K2, f.K3)))(
+        ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)), True)
+    scale = max(abs(p) for p in ref['parts'])
+    for (Er, Gr, parts, U, ncyc, conv, nhome) in results:
+        assert abs(Er - ref['E']) < 5e-4 * scale and rel(Gr, ref['grad']) < 5e-4 and ncyc == ref['n_cycle']
