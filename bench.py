@@ -61,12 +61,16 @@ def make_workload(name):
                 pairs=pairs)
 
 
-def make_force(w):
+def make_force(w, comm=None):
     import torch
     from admp_amd import settings
     from admp_amd.pme import ADMPPmeForce
     settings.PRECISION = w['prec']
-    f = ADMPPmeForce(w['box'], w['at'], w['ai'], w['cov'], 4.0, 1e-4, 2, lpol=True)
+    if comm is None:
+        f = ADMPPmeForce(w['box'], w['at'], w['ai'], w['cov'], 4.0, 1e-4, 2, lpol=True)
+    else:
+        from admp_amd.parallel import SlabPme
+        f = SlabPme(comm, w['box'], w['at'], w['ai'], w['cov'], 4.0, 1e-4, 2, lpol=True)
     if w['K'] is not None:
         for k in ('K1', 'K2', 'K3'):
             f.update_env(k, w['K'])
@@ -183,12 +187,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # rehearsal on one GPU: several ranks share it (gloo backend only)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('ADMP_BENCH_BACKEND', 'nccl')        # 'gloo' = host-staged rehearsal on one GPU
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
 
     w = make_workload(opt.workload)
     f, a = make_force(w)
@@ -199,9 +210,31 @@ def main():
             dist.barrier()
 
     dt, rep, cyc = run_timed(f, a, opt.steps, opt.warmup, barrier if dist is not None else None)
-    dt = reduce_max_seconds(dt, dist, 'cuda')
+    rdev = 'cuda' if (dist is None or dist.get_backend() == 'nccl') else 'cpu'
+    dt = reduce_max_seconds(dt, dist, rdev)
     t_step = dt / opt.steps
     value = aggregate_ns_per_day(t_step, world)
+    head = dict(n_pairs=int(f.n_pairs), grid=[f.K1, f.K2, f.K3], kappa=round(float(f.kappa), 6),
+                roofline=roofline_of(rep, w, f.n_pairs))
+
+    # strong-scaling leg of the real multi-GPU path: the 1M-atom box, x-slab decomposed over all ranks
+    slab_scale = None
+    if world > 1 and not opt.no_scale and opt.workload == 'S1':
+        try:
+            from admp_amd.parallel import TorchComm
+            f = None
+            w3 = make_workload(os.environ.get('ADMP_BENCH_SCALE', 'S3'))
+            f3, a3 = make_force(w3, TorchComm())
+            dt3, rep3, cyc3 = run_timed(f3, a3, 5, 2, barrier)
+            dt3 = reduce_max_seconds(dt3, dist, rdev)
+            slab_scale = {'workload': w3['desc'], 'decomposition': 'x-slab over %d GPUs (RCCL all-to-all transposes, '
+                          'ghost-plane shifts, sum all-reduce of dipoles/gradient)' % world, 'scaling': 'strong',
+                          'n_atoms': 3 * w3['n_mol'], 'n_pairs': int(f3.n_pairs), 'home_atoms_rank0': int(f3.n_home),
+                          'ms_per_step': round(dt3 / 5 * 1e3, 3), 'ns_per_day': round(0.0864 / (dt3 / 5), 3),
+                          'scf_cycles_per_step': round(cyc3, 2), 'dtype': 'f32',
+                          'rank0_kernel_ms_per_step': {k: round(v[0] / 5, 4) for k, v in sorted(rep3.items())}}
+        except Exception as e:      # the headline line must still be printed
+            slab_scale = {'error': repr(e)}
 
     if rank == 0:
         out = {
@@ -209,13 +242,15 @@ def main():
             'value': round(value, 4), 'unit': 'ns/day', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
             'ms_per_step': round(t_step * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64' if w['prec'] == 'double' else 'f32', 'data': 'synthetic',
-            'config': {'workload': w['desc'], 'n_atoms': n_atoms, 'n_pairs': int(f.n_pairs),
-                       'pme_grid': [f.K1, f.K2, f.K3], 'kappa': round(float(f.kappa), 6), 'dt_fs': DT_FS,
+            'config': {'workload': w['desc'], 'n_atoms': n_atoms, 'n_pairs': head['n_pairs'],
+                       'pme_grid': head['grid'], 'kappa': head['kappa'], 'dt_fs': DT_FS,
                        'scf_cycles_per_step': round(cyc, 2),
                        'parallelism': 'single GPU' if world == 1 else 'replicas only (%d independent boxes)' % world},
-            'roofline': roofline_of(rep, w, f.n_pairs),
+            'roofline': head['roofline'],
             'kernel_ms_per_step': {k: round(v[0] / opt.steps, 5) for k, v in sorted(rep.items())},
         }
+        if slab_scale is not None:
+            out['at_scale'] = slab_scale
         if world == 1 and not opt.no_cpu:
             cb, ref = cpu_baseline(w) if opt.workload == 'S1' else (None, None)
             if cb is not None:
@@ -226,7 +261,7 @@ def main():
                 out['energy_rel_vs_oracle'] = float(abs(E - ref['E']) / abs(ref['E']))
         if world == 1 and not opt.no_scale and opt.workload == 'S1':
             try:
-                del f
+                f = None
                 w3 = make_workload('S3')
                 f3, a3 = make_force(w3)
                 dt3, rep3, cyc3 = run_timed(f3, a3, 5, 2)
@@ -239,8 +274,11 @@ def main():
                 out['at_scale'] = {'error': repr(e)}
         print(json.dumps(out))
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:      # a failed collective in the optional at_scale leg must not turn the run into an error
+            pass
 
 
 if __name__ == '__main__':

@@ -287,3 +287,46 @@ def test_slab_decomposition_single_precision(precision):
     scale = max(abs(p) for p in ref['parts'])
     for (Er, Gr, parts, U, ncyc, conv, nhome) in results:
         assert abs(Er - ref['E']) < 5e-4 * scale and rel(Gr, ref['grad']) < 5e-4 and ncyc == ref['n_cycle']
+
+
+SLAB_PROC_WORKER = '''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+dist.init_process_group('gloo')
+torch.cuda.set_device(0)
+from admp_amd import systems as S
+from admp_amd.parallel import SlabPme, TorchComm
+from admp_amd.pme import ADMPPmeForce
+pos, box = S.synthetic_water_box(125, seed=5)
+at, ai, cov = S.water_topology(125)
+par = S.water_parameters(125, True)
+pairs = S.build_pairs(pos, box, 4.0)
+args = (pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+f = SlabPme(TorchComm(), box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+E, G = f.get_forces(*args)
+E2, G2 = f.get_forces(*args, U_init=f.U_ind)          # second call: cached pair table, warm start
+ref = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+Er, Gr = ref.get_forces(*args)
+err = np.linalg.norm(G - Gr) / np.linalg.norm(Gr)
+assert abs(E - Er) < 1e-9 * max(abs(p) for p in ref.energy_parts) and err < 1e-10, (E, Er, err)
+assert f.n_cycle <= ref.n_cycle and abs(E2 - E) < 1e-3
+dist.barrier()
+if dist.get_rank() == 0:
+    print('SLAB-PROC-OK', dist.get_world_size(), f.n_home)
+dist.destroy_process_group()
+'''
+
+
+def test_slab_decomposition_two_processes_gloo(tmp_path):
+    """Two PROCESSES sharing this GPU, torch.distributed gloo backend (host-staged collectives): the production
+    driver (SlabPme + TorchComm) end to end; on a multi-GPU node the only difference is backend nccl (= RCCL)."""
+    import subprocess
+    import sys
+    script = tmp_path / 'slab_worker.py'
+    script.write_text(SLAB_PROC_WORKER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29541', str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'SLAB-PROC-OK 2' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
