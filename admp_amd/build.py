@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libadmp_hip.so')
-SOURCES = ['engine.hip', 'pair_kernels.hip', 'recip_kernels.hip', 'atom_kernels.hip', 'nbr_kernels.hip']
+SOURCES = ['engine.hip', 'pair_kernels.hip', 'recip_kernels.hip', 'atom_kernels.hip', 'nbr_kernels.hip', 'cell_kernels.hip']
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
 
@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if force or _stale(LIB, objs):
         rocm = os.environ.get('ROCM_PATH', '/opt/rocm')

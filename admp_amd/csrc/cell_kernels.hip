@@ -1,0 +1,195 @@
+// Cell-list neighbour search on the GPU: positions -> half pair list (i < j, minimum-image r < rc).
+// Stands in for jax_md.partition.neighbor_list(..., format=OrderedSparse) of the reference's drivers
+// (examples/water_1024/run_admp.py:109-112) -- the producer of the `pairs` array the PME path consumes.
+//
+//   cells in fractional coordinates, n_d = floor(height_d / rc) cells along lattice direction d (perpendicular
+//   height, so a sphere of radius rc around any point stays within the 27 neighbouring cells; directions with
+//   fewer than 3 cells visit every cell once);  counting sort of the atoms by cell (wave-aggregated atomics),
+//   cells sorted by atom index;  one thread per atom counts, then writes, its partners j > i.
+// The minimum-image distance uses the same arithmetic as the pair kernel (min_image, admp/spatial.py:13-32).
+#include <hipcub/hipcub.hpp>
+
+#include "launch.h"
+
+namespace admp {
+
+struct CellGrid {
+  int n[3];
+  int ncell;
+};
+
+template <class T>
+__device__ __forceinline__ int cell_of(const Box<T>& b, const CellGrid& cg, const T* r, int c[3]) {
+  T s[3];
+  s[0] = r[0] * b.hinv[0] + r[1] * b.hinv[3] + r[2] * b.hinv[6];
+  s[1] = r[0] * b.hinv[1] + r[1] * b.hinv[4] + r[2] * b.hinv[7];
+  s[2] = r[0] * b.hinv[2] + r[1] * b.hinv[5] + r[2] * b.hinv[8];
+  for (int d = 0; d < 3; ++d) {
+    T f = s[d] - m_floor(s[d]);
+    int k = (int)(f * T(cg.n[d]));
+    c[d] = k >= cg.n[d] ? cg.n[d] - 1 : (k < 0 ? 0 : k);
+  }
+  return (c[0] * cg.n[1] + c[1]) * cg.n[2] + c[2];
+}
+
+__device__ __forceinline__ int wave_agg_add_i(int* __restrict__ counter, int key, bool pred) {
+  const int lane = threadIdx.x & 63;
+  int slot = -1;
+  unsigned long long remaining = __ballot(pred);
+  while (remaining) {
+    const int leader = __ffsll((long long)remaining) - 1;
+    const int k = __shfl(key, leader, 64);
+    const unsigned long long same = __ballot(pred && key == k);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counter[k], __popcll(same));
+    base = __shfl(base, leader, 64);
+    if (pred && key == k) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+    remaining &= ~same;
+  }
+  return slot;
+}
+
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_cell_bin(int na, const T* __restrict__ pos, Box<T> box, CellGrid cg,
+                                                  int* __restrict__ counter, int* __restrict__ sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int cid = 0;
+  if (i < na) {
+    int c[3];
+    T r[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+    cid = cell_of(box, cg, r, c);
+  }
+  const int slot = wave_agg_add_i(counter, cid, i < na);
+  if (MODE == 1 && i < na) sorted[slot] = i;
+}
+
+__global__ void k_cell_sort(int ncell, const int* __restrict__ start, int* __restrict__ sorted) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  int b = start[c], e = start[c + 1];
+  for (int a = b + 1; a < e; ++a) {
+    int v = sorted[a], k = a - 1;
+    while (k >= b && sorted[k] > v) { sorted[k + 1] = sorted[k]; --k; }
+    sorted[k + 1] = v;
+  }
+}
+
+// MODE 0: count[i] = number of partners j > i within rc ; MODE 1: write them at offs[i]
+template <class T, int MODE>
+__global__ __launch_bounds__(128) void k_cell_pairs(int na, const T* __restrict__ pos, Box<T> box, CellGrid cg, T rc2,
+                                                    const int* __restrict__ start, const int* __restrict__ sorted,
+                                                    long long* __restrict__ count, const long long* __restrict__ offs,
+                                                    int* __restrict__ pairs) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= na) return;
+  T ri[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  int c[3];
+  cell_of(box, cg, ri, c);
+  long long n = 0, w = MODE ? offs[i] : 0;
+  int lo[3], cnt[3];
+  for (int d = 0; d < 3; ++d) {
+    if (cg.n[d] >= 3) { lo[d] = c[d] - 1; cnt[d] = 3; } else { lo[d] = 0; cnt[d] = cg.n[d]; }
+  }
+  for (int a = 0; a < cnt[0]; ++a)
+    for (int b = 0; b < cnt[1]; ++b)
+      for (int e = 0; e < cnt[2]; ++e) {
+        int cx = (lo[0] + a + cg.n[0]) % cg.n[0], cy = (lo[1] + b + cg.n[1]) % cg.n[1], cz = (lo[2] + e + cg.n[2]) % cg.n[2];
+        int cid = (cx * cg.n[1] + cy) * cg.n[2] + cz;
+        for (int k = start[cid]; k < start[cid + 1]; ++k) {
+          int j = sorted[k];
+          if (j <= i) continue;
+          T d[3] = {ri[0] - pos[3 * j], ri[1] - pos[3 * j + 1], ri[2] - pos[3 * j + 2]};
+          min_image(box, d);
+          if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2) {
+            if (MODE) { pairs[2 * w] = i; pairs[2 * w + 1] = j; ++w; }
+            else ++n;
+          }
+        }
+      }
+  if (!MODE) count[i] = n;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// Phase 1: bins the atoms and counts the pairs.  scratch layout is owned by the engine (see CellScratch).
+template <class T>
+int cell_count_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, const double* heights, double rc,
+                     CellScratch& cs, long long* n_pairs) {
+  CellGrid cg;
+  for (int d = 0; d < 3; ++d) {
+    int n = (int)(heights[d] / rc);
+    cg.n[d] = n < 1 ? 1 : (n > 1024 ? 1024 : n);
+  }
+  // keep the cell table bounded for huge dilute boxes
+  while ((long)cg.n[0] * cg.n[1] * cg.n[2] > 64L * 1024 * 1024) { for (int d = 0; d < 3; ++d) cg.n[d] = (cg.n[d] + 1) / 2; }
+  cg.ncell = cg.n[0] * cg.n[1] * cg.n[2];
+  cs.n[0] = cg.n[0]; cs.n[1] = cg.n[1]; cs.n[2] = cg.n[2];
+  if (cs.ensure(na, cg.ncell) != 0) return (int)hipErrorOutOfMemory;
+  const int blocks = (na + 255) / 256;
+  CK(hipMemsetAsync(cs.cursor, 0, sizeof(int) * (cg.ncell + 1), st));
+  k_cell_bin<T, 0><<<blocks, 256, 0, st>>>(na, pos, box, cg, cs.cursor, nullptr);
+  size_t need = cs.scan_bytes;
+  CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, cs.cursor, cs.start, cg.ncell + 1, st));
+  CK(hipMemcpyAsync(cs.cursor, cs.start, sizeof(int) * (cg.ncell + 1), hipMemcpyDeviceToDevice, st));
+  k_cell_bin<T, 1><<<blocks, 256, 0, st>>>(na, pos, box, cg, cs.cursor, cs.sorted);
+  k_cell_sort<<<(cg.ncell + 127) / 128, 128, 0, st>>>(cg.ncell, cs.start, cs.sorted);
+  k_cell_pairs<T, 0><<<(na + 127) / 128, 128, 0, st>>>(na, pos, box, cg, (T)(rc * rc), cs.start, cs.sorted, cs.count, nullptr, nullptr);
+  need = cs.scan_bytes;
+  CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, cs.count, cs.offs, na + 1, st));
+  CK(hipMemcpyAsync(n_pairs, cs.offs + na, sizeof(long long), hipMemcpyDeviceToHost, st));
+  CK(hipStreamSynchronize(st));
+  return 0;
+}
+
+template <class T>
+int cell_fill_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, double rc, CellScratch& cs, int* pairs) {
+  CellGrid cg;
+  cg.n[0] = cs.n[0]; cg.n[1] = cs.n[1]; cg.n[2] = cs.n[2];
+  cg.ncell = cg.n[0] * cg.n[1] * cg.n[2];
+  k_cell_pairs<T, 1><<<(na + 127) / 128, 128, 0, st>>>(na, pos, box, cg, (T)(rc * rc), cs.start, cs.sorted, nullptr, cs.offs, pairs);
+  CK(hipStreamSynchronize(st));
+  return 0;
+}
+
+int CellScratch::ensure(int na, int ncell) {
+  size_t scan = 0;
+  long long* pl = nullptr;
+  int* pi = nullptr;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, pl, pl, na + 1, (hipStream_t)0);
+  size_t scan2 = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan2, pi, pi, ncell + 1, (hipStream_t)0);
+  if (scan2 > scan) scan = scan2;
+  scan += 256;
+  if (na > cap_atoms || ncell > cap_cells || scan > scan_bytes) {
+    release();
+    cap_atoms = na; cap_cells = ncell; scan_bytes = scan;
+    if (hipMalloc(&start, sizeof(int) * (ncell + 1)) != hipSuccess) return -1;
+    if (hipMalloc(&cursor, sizeof(int) * (ncell + 1)) != hipSuccess) return -1;
+    if (hipMalloc(&sorted, sizeof(int) * (size_t)na) != hipSuccess) return -1;
+    if (hipMalloc(&count, sizeof(long long) * ((size_t)na + 1)) != hipSuccess) return -1;
+    if (hipMalloc(&offs, sizeof(long long) * ((size_t)na + 1)) != hipSuccess) return -1;
+    if (hipMalloc(&scan_tmp, scan) != hipSuccess) return -1;
+  }
+  (void)hipMemset(count, 0, sizeof(long long) * ((size_t)na + 1));
+  return 0;
+}
+
+void CellScratch::release() {
+  for (void* p : {(void*)start, (void*)cursor, (void*)sorted, (void*)count, (void*)offs, scan_tmp})
+    if (p) (void)hipFree(p);
+  start = cursor = sorted = nullptr;
+  count = offs = nullptr;
+  scan_tmp = nullptr;
+  cap_atoms = cap_cells = 0;
+  scan_bytes = 0;
+}
+
+#define INST(T)                                                                                                   \
+  template int cell_count_pairs<T>(hipStream_t, int, const T*, const Box<T>&, const double*, double, CellScratch&, \
+                                   long long*);                                                                   \
+  template int cell_fill_pairs<T>(hipStream_t, int, const T*, const Box<T>&, double, CellScratch&, int*);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace admp

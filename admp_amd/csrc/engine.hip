@@ -163,6 +163,8 @@ struct EngineBase {
   virtual void tt(const void* pos, const double* box, const void* abqc, int ns, const double* mS, double* E, void* dpos,
                   int on_device) = 0;
   // staged evaluation (device pointers only)
+  virtual void nbr_count(int na, const void* pos, const double* box, double rc, int64_t* n_pairs) = 0;
+  virtual void nbr_fill(int32_t* pairs) = 0;
   virtual void slab_info(int64_t* out) = 0;
   virtual int v_stage_begin(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole,
                             int ns, const double* mS, const double* pS, void* U) = 0;
@@ -258,6 +260,7 @@ struct Engine : EngineBase {
                       &bin_sorted, &bin_scan, &home_list})
       b->release();
     free_topology();
+    cells.release();
     prof.destroy();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -648,6 +651,32 @@ struct Engine : EngineBase {
     if (conv) *conv = flag;
   }
 
+  // ---- neighbour search (cell list) ------------------------------------------------------------------
+  CellScratch cells;
+  int nb_na = 0; const T* nb_pos = nullptr; Box<T> nb_box; double nb_rc = 0;
+  void nbr_count(int na, const void* pos, const double* box, double rc, int64_t* n_pairs) override {
+    ARG_CHECK(na > 0 && pos && box && rc > 0 && n_pairs, "bad argument");
+    double inv[9], vol;
+    nb_box = make_box(box, inv, &vol);
+    double heights[3];
+    for (int d = 0; d < 3; ++d)   // perpendicular height along lattice direction d = 1 / |column d of box^-1|
+      heights[d] = 1.0 / std::sqrt(inv[0 + d] * inv[0 + d] + inv[3 + d] * inv[3 + d] + inv[6 + d] * inv[6 + d]);
+    for (int d = 0; d < 3; ++d) ARG_CHECK(rc <= 0.5 * heights[d] * (1 + 1e-12), "rc exceeds half the box height (minimum image)");
+    nb_na = na; nb_pos = reinterpret_cast<const T*>(pos); nb_rc = rc;
+    long long n = 0;
+    TIMED("neighbor_count");
+    int r = cell_count_pairs<T>(stream, na, nb_pos, nb_box, heights, rc, cells, &n);
+    if (r != 0) throw Err{ADMP_E_HIP, std::string("cell_count_pairs: ") + hipGetErrorString((hipError_t)r)};
+    *n_pairs = (int64_t)n;
+  }
+  void nbr_fill(int32_t* pairs) override {
+    ARG_CHECK(nb_pos && pairs, "admp_neighbor_count must precede admp_neighbor_fill");
+    TIMED("neighbor_fill");
+    int r = cell_fill_pairs<T>(stream, nb_na, nb_pos, nb_box, nb_rc, cells, pairs);
+    if (r != 0) throw Err{ADMP_E_HIP, std::string("cell_fill_pairs: ") + hipGetErrorString((hipError_t)r)};
+    nb_pos = nullptr;
+  }
+
   void slab_info(int64_t* o) override {
     ARG_CHECK(have_ewald, "admp_set_ewald first");
     update_slab();
@@ -860,6 +889,13 @@ int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* b
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
                         const double* mScales, double* E_out, void* dE_dpos, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.tt(positions, box, abqc, n_scales, mScales, E_out, dE_dpos, on_device); });
+}
+
+int admp_neighbor_count(admp_handle* h, int n_atoms, const void* positions, const double* box, double rc, int64_t* n_pairs) {
+  return guarded(h, [&](EngineBase& e) { e.nbr_count(n_atoms, positions, box, rc, n_pairs); });
+}
+int admp_neighbor_fill(admp_handle* h, int32_t* pairs_out) {
+  return guarded(h, [&](EngineBase& e) { e.nbr_fill(pairs_out); });
 }
 
 int admp_slab_configure(admp_handle* h, int rank, int nranks) {

@@ -142,6 +142,22 @@ template <class T>
 void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
                           const RecipGeom<T>& g, const T* phi, T* grad);
 
+// ---- cell_kernels.hip: positions -> half pair list (cell list), two phases so that the caller can size `pairs`
+struct CellScratch {
+  int n[3] = {0, 0, 0};
+  int* start = nullptr; int* cursor = nullptr; int* sorted = nullptr;
+  long long* count = nullptr; long long* offs = nullptr;
+  void* scan_tmp = nullptr; size_t scan_bytes = 0;
+  int cap_atoms = 0, cap_cells = 0;
+  int ensure(int na, int ncell);
+  void release();
+};
+template <class T>
+int cell_count_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, const double* heights, double rc,
+                     CellScratch& cs, long long* n_pairs);
+template <class T>
+int cell_fill_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, double rc, CellScratch& cs, int* pairs);
+
 // ---- nbr_kernels.hip
 // builds nb from (n_rows, 2) device pairs; scratch (deg/cursor) is managed inside. Returns hipError_t as int.
 int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, const int* pairs_dev, NbrTable& nb,

@@ -153,12 +153,15 @@ int pair_lanes_per_row() {
 }
 
 // minimum waves per SIMD requested from the register allocator for the polarizable kernel
-// (env ADMP_PAIR_MINW: 1 = no constraint, 2 = at most 256 registers)
+// (env ADMP_PAIR_MINW: 1 = no constraint, 2 = at most 256 registers).  Defaults from measurement:
+//   f32: 2 (242 VGPRs, no spill; S2 0.110 ms vs 0.161 ms at 1 wave/SIMD)
+//   f64: 1 (the 256-register cap costs 184 B/lane of scratch: S1 30 us vs 20 us unconstrained)
+template <class T>
 static int pair_min_waves() {
   static int v = -1;
   if (v < 0) {
     const char* s = getenv("ADMP_PAIR_MINW");
-    v = s ? atoi(s) : 2;   // measured on S2: 0.125 ms vs 0.161 ms unconstrained (1 wave/SIMD)
+    v = s ? atoi(s) : (sizeof(T) == 4 ? 2 : 1);
   }
   return v;
 }
@@ -179,7 +182,7 @@ template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows) {
   const int lpr = pair_lanes_per_row();
-  const int minw = pair_min_waves();
+  const int minw = pair_min_waves<T>();
 #define CALL(L)                                                                                                        \
   if (lpol && minw >= 2)                                                                                               \
     k_pair_full<T, true, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \

@@ -95,6 +95,16 @@ int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* b
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
                         const double* mScales, double* E_out, void* dE_dpos, int on_device);
 
+/* ---- neighbour search ("next" row of SURVEY.md 8f) --------------------------------------------------------
+ * replaces: jax_md.partition.neighbor_list(displacement_fn, box, rc, 0, format=OrderedSparse).allocate(positions)
+ * of the reference's drivers (examples/water_1024/run_admp.py:109-112): the producer of `pairs`.
+ * Cell list on the GPU, any lattice with rc <= half of every box height.  Two phases so the caller can size
+ * the output: count -> allocate (n_pairs, 2) int32 on the device -> fill (rows i < j, grouped by i, j ascending
+ * within a cell sweep).  positions is a DEVICE pointer to (n_atoms, 3) reals and must stay valid until fill. */
+int admp_neighbor_count(admp_handle* h, int n_atoms, const void* positions, const double* box, double rc,
+                        int64_t* n_pairs);
+int admp_neighbor_fill(admp_handle* h, int32_t* pairs_out);
+
 /* ---- multi-GPU: x-slab decomposition, staged evaluation ---------------------------------------------
  * (no counterpart in the reference, which is single-device)  One process per GPU; every rank
  * holds all atoms' inputs, owns the mesh planes [X0,X1) along x and works on its "home" atoms (lowest stencil

@@ -330,3 +330,36 @@ def test_slab_decomposition_two_processes_gloo(tmp_path):
                         '--master-addr', '127.0.0.1', '--master-port', '29541', str(script)],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and 'SLAB-PROC-OK 2' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize('prec', ['double', 'single'])
+def test_gpu_neighbour_list_matches_kdtree(precision, prec):
+    """Cell-list search (admp_amd.neighbor) against the host cKDTree builder, cubic and triclinic cells,
+    atoms outside the cell, and a box too small for 3 cells per side."""
+    import torch
+    from admp_amd.neighbor import NeighborList
+    settings.PRECISION = prec
+    for n_mol, rc in ((27, 4.0), (512, 4.0), (512, 6.5)):
+        pos, box = S.synthetic_water_box(n_mol, seed=3)
+        shifted = pos + np.array([37.0, -11.0, 5.0])
+        got = NeighborList(box, rc).allocate(shifted).cpu().numpy()
+        want = S.build_pairs(pos, box, rc)
+        assert (got[:, 0] < got[:, 1]).all()
+        a = set(map(tuple, got.tolist()))
+        b = set(map(tuple, want.tolist()))
+        if prec == 'double':
+            assert a == b and len(got) == len(want)
+        else:   # pairs within rounding of rc may differ in single precision
+            assert len(a ^ b) <= max(2, len(b) // 20000)
+    # triclinic: brute-force minimum image with the reference's rounding rule (admp/spatial.py:13-32)
+    rng = np.random.default_rng(1)
+    box = np.array([[14.0, 0, 0], [2.5, 13.0, 0], [-1.5, 2.0, 15.0]])
+    pos = rng.uniform(-5, 20, (400, 3))
+    if prec == 'double':
+        got = set(map(tuple, NeighborList(box, 5.0).allocate(pos).cpu().numpy().tolist()))
+        i, j = np.triu_indices(len(pos), 1)
+        d = pos[i] - pos[j]
+        s = d @ np.linalg.inv(box)
+        d = (s - np.floor(s + 0.5)) @ box
+        m = np.linalg.norm(d, axis=1) < 5.0
+        assert got == set(zip(i[m].tolist(), j[m].tolist()))
