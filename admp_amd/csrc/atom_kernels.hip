@@ -192,6 +192,94 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish(Topology top, const T* __
   }
 }
 
+// Single-GPU closing kernel without atomics: every atom PULLS the frame-adjoint contributions of the frames it
+// takes part in (itself and the sites that use it as z/x/y axis atom, inverse map built by admp_set_topology);
+// each frame is re-evaluated by its <= 4 member atoms, which is far cheaper than scattered global float atomics
+// (k_finish: 0.27 ms per 1M atoms, this kernel: see profiles/).  pot is read-only here.
+template <class T>
+__device__ __forceinline__ void total_potential(const Site<T>& s, const T* __restrict__ pot_i, int lpol, const T f[3],
+                                                T P[9], double* eself) {
+  double es = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    T q = s.Q[k];
+    if (lpol && k >= 1 && k <= 3) q += s.U[k - 1];
+    const T fl = k == 0 ? f[0] : (k < 4 ? f[1] : f[2]);
+    es += (double)(fl * q * q);
+    P[k] = pot_i[k] - T(2.0 * kDielectric) * fl * q;
+  }
+  if (eself) *eself = -kDielectric * es;
+}
+
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const T* __restrict__ pos, Box<T> box,
+                                                            const Site<T>* __restrict__ sites,
+                                                            const T* __restrict__ pol, const T* __restrict__ Ucart,
+                                                            int lpol, T kappa, const T* __restrict__ pot,
+                                                            T* __restrict__ grad, T* __restrict__ dQlocal,
+                                                            double* energies) {
+  const int a = blockIdx.x * kAtomBlock + threadIdx.x;
+  double eself = 0.0, epen = 0.0;
+  if (a < top.na) {
+    T f[3];
+    self_factors(kappa, f);
+    T P[9];
+    total_potential(sites[a], pot + 9 * (size_t)a, lpol, f, P, &eself);
+    if (lpol) {
+      T al = pol[a];
+      al = al < T(1e-8) ? T(1e-8) : al;
+      double u2 = (double)Ucart[3 * a] * Ucart[3 * a] + (double)Ucart[3 * a + 1] * Ucart[3 * a + 1] +
+                  (double)Ucart[3 * a + 2] * Ucart[3 * a + 2];
+      epen = kDielectric * 0.5 * u2 / (double)al;
+    }
+    if (grad) {
+      T g[3] = {0, 0, 0};
+      for (int k = top.inv_ptr[a]; k < top.inv_ptr[a + 1]; ++k) {
+        const int i = top.inv_idx[k];
+        int type, iz, ix, iy;
+        FrameWork<T> w;
+        frame_of(top, pos, box, i, type, iz, ix, iy, w);
+        if (type == NoAxisType) continue;
+        T Pi[9];
+        if (i == a) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) Pi[q] = P[q];
+        } else {
+          total_potential(sites[i], pot + 9 * (size_t)i, lpol, f, Pi, nullptr);
+        }
+        T tau[3], gp[3], gz[3], gx[3], gy[3];
+        multipole_torque(Pi, sites[i].Q, tau);
+        local_frame_bwd(type, w, tau, gp, gz, gx, gy);
+        const bool usex = type != Zonly, usey = (type == ZBisect || type == ThreeFold);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if (i == a) g[q] += gp[q];
+          if (iz == a) g[q] += gz[q];
+          if (usex && ix == a) g[q] += gx[q];
+          if (usey && iy == a) g[q] += gy[q];
+        }
+        if (i == a && dQlocal) {
+          T dl[9];
+          rot_harm(Pi, w.X, w.Y, w.Z, dl);
+#pragma unroll
+          for (int q = 0; q < 9; ++q) dQlocal[9 * a + q] = dl[q];
+        }
+      }
+      if (dQlocal && top.axis_type[a] == NoAxisType) {   // identity frame
+#pragma unroll
+        for (int q = 0; q < 9; ++q) dQlocal[9 * a + q] = P[q];
+      }
+      grad[3 * a] += g[0]; grad[3 * a + 1] += g[1]; grad[3 * a + 2] += g[2];
+    }
+  }
+  eself = block_reduce_sum<kAtomBlock>(eself);
+  epen = block_reduce_sum<kAtomBlock>(epen);
+  if (threadIdx.x == 0) {
+    atomicAdd(&energies[E_SELF], eself);
+    if (lpol) atomicAdd(&energies[E_PEN], epen);
+  }
+}
+
 static inline int nblk(int n) { return (n + kAtomBlock - 1) / kAtomBlock; }
 
 template <class T>
@@ -217,8 +305,12 @@ template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
                    const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
                    const int* list, int nlist) {
-  k_finish<T><<<nblk(nlist), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
-                                                  energies, list, nlist);
+  if (!list && top.inv_ptr)   // single GPU: pull formulation, no atomics
+    k_finish_pull<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
+                                                          dQlocal, energies);
+  else
+    k_finish<T><<<nblk(nlist), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
+                                                    energies, list, nlist);
 }
 
 #define INST(T)                                                                                                        \

@@ -176,6 +176,8 @@ struct EngineBase {
     if (top.excl_ptr) (void)hipFree(top.excl_ptr);
     if (top.excl_col) (void)hipFree(top.excl_col);
     if (top.excl_nb) (void)hipFree(top.excl_nb);
+    if (top.inv_ptr) (void)hipFree(top.inv_ptr);
+    if (top.inv_idx) (void)hipFree(top.inv_idx);
     top = Topology();
     if (nbr.rowptr) (void)hipFree(nbr.rowptr);
     if (nbr.col) (void)hipFree(nbr.col);
@@ -211,6 +213,26 @@ struct EngineBase {
         HIP_TRY(hipMemcpy(top.excl_col, ecol, sizeof(int) * nnz, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(top.excl_nb, enb, sizeof(int) * nnz, hipMemcpyHostToDevice));
       }
+    }
+    {   // inverse frame map for the atomics-free closing kernel
+      std::vector<std::vector<int>> inv(na);
+      for (int i = 0; i < na; ++i) {
+        if (at[i] == NoAxisType || ai[3 * i] < 0) { inv[i].push_back(i); continue; }
+        int mem[4] = {i, ai[3 * i], at[i] != Zonly ? ai[3 * i + 1] : -1,
+                      (at[i] == ZBisect || at[i] == ThreeFold) ? ai[3 * i + 2] : -1};
+        for (int m = 0; m < 4; ++m) {
+          if (mem[m] < 0) continue;
+          bool dup = false;
+          for (int q = 0; q < m; ++q) dup = dup || mem[q] == mem[m];
+          if (!dup) inv[mem[m]].push_back(i);
+        }
+      }
+      std::vector<int> ptr(na + 1, 0), idx;
+      for (int a = 0; a < na; ++a) { ptr[a + 1] = ptr[a] + (int)inv[a].size(); idx.insert(idx.end(), inv[a].begin(), inv[a].end()); }
+      HIP_TRY(hipMalloc(&top.inv_ptr, sizeof(int) * (na + 1)));
+      HIP_TRY(hipMalloc(&top.inv_idx, sizeof(int) * (idx.empty() ? 1 : idx.size())));
+      HIP_TRY(hipMemcpy(top.inv_ptr, ptr.data(), sizeof(int) * (na + 1), hipMemcpyHostToDevice));
+      if (!idx.empty()) HIP_TRY(hipMemcpy(top.inv_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
     }
     have_top = true;
   }
@@ -252,6 +274,7 @@ struct Engine : EngineBase {
   // validity of the cached G table
   double tab_box[9] = {0}, tab_kappa = -1;
   int tab_which = 0, tabK[3] = {0, 0, 0}, tabY0 = 0;
+  bool warm_regime = false;   // previous polarizable call converged at its first SCF check
 
   ~Engine() override {
     destroy_plans();
@@ -547,7 +570,7 @@ struct Engine : EngineBase {
     TIMED("jacobi_update");
     launch_jacobi_update<T>(stream, ev.n_home, ev.pol, field.as<T>(), ev.U, Unew, sites.as<Site<T>>(), ev.home);
   }
-  void stage_pair_full(T* grad_p) {
+  void stage_pair_full(T* grad_p, T* fld_out = nullptr) {
     need_eval();
     if (ev.home) {   // rows of other ranks stay zero so that a sum all-reduce assembles the gradient
       HIP_TRY(hipMemsetAsync(grad_p, 0, 3 * (size_t)top.na * sizeof(T), stream));
@@ -555,12 +578,12 @@ struct Engine : EngineBase {
     }
     TIMED("pair_full");
     launch_pair_full<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, lpol, grad_p, pot.as<T>(),
-                        energies_d.as<double>(), ev.home);
+                        energies_d.as<double>(), ev.home, fld_out);
   }
-  void stage_gather(const T* mesh_p, T* grad_p) {
+  void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr) {
     need_eval();
     TIMED("gather");
-    launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home);
+    launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out);
   }
   // closes the evaluation: E_out = (real, recip[slot], self, penalty) of THIS rank's share
   void stage_finish(T* grad_p, T* dQl, int recip_slot, double* E) {
@@ -618,12 +641,29 @@ struct Engine : EngineBase {
 
     // phi_valid: the mesh holds phi = c2r(G S) of the CURRENT dipoles (last SCF field evaluation, no update since):
     // the closing gather can then reuse it instead of spreading and transforming again.
-    bool phi_valid = false;
+    bool phi_valid = false, done = false;
     int cyc = 0, flag = 1;
     if (lpol) {
       ARG_CHECK(max_cycle >= 1, "max_cycle must be >= 1");
       int i = 0;
-      for (i = 0; i < max_cycle; ++i) {     // admp/pme.py:132-138
+      if (warm_regime) {
+        // Steady-state MD regime (the previous call converged at its first check): evaluate the FIRST SCF cycle
+        // with the full kernels -- they produce dE/dU alongside the gradient -- so that, when the check passes
+        // again, the step is already finished (no separate field kernels, no second pass).  Same arithmetic and
+        // same (U, flag, i) as the plain loop; a failed check only costs the difference between the kernels.
+        stage_pair_full(gbuf, fld_pair.as<T>());
+        recip_pass(E_SCF_RECIP);
+        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>());
+        const double fmax = stage_field_finish();
+        if (fmax < thresh) {
+          phi_valid = done = true;
+        } else {
+          HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_REAL, 0, sizeof(double), stream));
+          stage_jacobi(U);
+          i = 1;
+        }
+      }
+      for (; !done && i < max_cycle; ++i) {     // admp/pme.py:132-138
         stage_pair_field();
         recip_pass(E_SCF_RECIP);
         stage_gather_field(mesh.as<T>());
@@ -634,11 +674,14 @@ struct Engine : EngineBase {
       if (i == max_cycle) i = max_cycle - 1;   // python's loop variable after exhaustion
       cyc = i;
       flag = (i != max_cycle - 1);             // admp/pme.py:139-143
+      warm_regime = (cyc == 0);
     }
 
-    stage_pair_full(gbuf);
-    if (!phi_valid) recip_pass(E_RECIP);
-    stage_gather(mesh.as<T>(), gbuf);
+    if (!done) {
+      stage_pair_full(gbuf);
+      if (!phi_valid) recip_pass(E_RECIP);
+      stage_gather(mesh.as<T>(), gbuf);
+    }
     stage_finish(dpos ? gbuf : nullptr, dQl, phi_valid ? E_SCF_RECIP : E_RECIP, E);
 
     if (!on_device) {

@@ -36,6 +36,9 @@ struct Topology {
   int* excl_ptr = nullptr;    // na + 1
   int* excl_col = nullptr;
   int* excl_nb = nullptr;
+  // inverse frame map: inv_idx[inv_ptr[a] .. inv_ptr[a+1]) = sites whose local frame involves atom a
+  int* inv_ptr = nullptr;     // na + 1
+  int* inv_idx = nullptr;
 };
 
 // energies[] slots on the device
@@ -71,7 +74,8 @@ void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipG
 // ---- pair_kernels.hip
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows);
+                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows,
+                      T* fld /* optional: also write the real-space dE/dU (speculative SCF pass) */);
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                        const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows);
@@ -134,7 +138,7 @@ void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spe
                    double* energies, int slot);
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad, const int* list);
+                   T* grad, const int* list, T* fld_recip /* optional: cartesian reciprocal dE/dU */);
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
                          T* fld_recip, const int* list);

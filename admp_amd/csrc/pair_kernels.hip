@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
                                                           const Site<T>* __restrict__ sites, Box<T> box,
                                                           ScaleTab<T> tab, T kappa, T* __restrict__ grad,
                                                           T* __restrict__ pot, double* energies,
-                                                          const int* __restrict__ rows) {
+                                                          const int* __restrict__ rows, T* __restrict__ fld) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
@@ -58,18 +58,23 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
       const int nb = (c >> 28) & 15;
       const Site<T> J = sites[c & kColMask];
       const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
-      e += (double)pair_energy_grad<T, LPOL, false>(box, I, J, sc, kappa, g, P, F, nullptr, nullptr);
+      e += (double)pair_energy_grad<T, LPOL, false>(box, I, J, sc, kappa, g, P, (LPOL && fld) ? F : nullptr, nullptr, nullptr);
     }
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) g[k] = row_reduce<T, LPR>(g[k]);
 #pragma unroll
   for (int k = 0; k < 9; ++k) P[k] = row_reduce<T, LPR>(P[k]);
+  if (LPOL && fld) {   // speculative SCF pass: the real-space dE/dU comes out of the same evaluation
+#pragma unroll
+    for (int k = 0; k < 3; ++k) F[k] = row_reduce<T, LPR>(F[k]);
+  }
   if (slot < na && sub == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) grad[3 * row + k] = g[k];
 #pragma unroll
     for (int k = 0; k < 9; ++k) pot[9 * row + k] = P[k];
+    if (LPOL && fld) { fld[3 * row] = F[0]; fld[3 * row + 1] = F[1]; fld[3 * row + 2] = F[2]; }
   }
   e = block_reduce_sum<kPairBlock>(e);
   if (threadIdx.x == 0) atomicAdd(&energies[E_REAL], 0.5 * e);
@@ -180,19 +185,20 @@ static inline unsigned grid_for(int na, int lpr) { return (unsigned)(((long)na *
 
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows) {
+                      const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows,
+                      T* fld) {
   const int lpr = pair_lanes_per_row();
   const int minw = pair_min_waves<T>();
 #define CALL(L)                                                                                                        \
   if (lpol && minw >= 2)                                                                                               \
     k_pair_full<T, true, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \
-                                                                       grad, pot, energies, rows);                     \
+                                                                       grad, pot, energies, rows, fld);                \
   else if (lpol)                                                                                                       \
     k_pair_full<T, true, L, 1><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \
-                                                                       grad, pot, energies, rows);                     \
+                                                                       grad, pot, energies, rows, fld);                \
   else                                                                                                                 \
     k_pair_full<T, false, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
-                                                                        grad, pot, energies, rows)
+                                                                        grad, pot, energies, rows, fld)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
@@ -221,7 +227,7 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
 
 #define INST(T)                                                                                                     \
   template void launch_pair_full<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,               \
-                                    const ScaleTab<T>&, T, int, T*, T*, double*, const int*);                       \
+                                    const ScaleTab<T>&, T, int, T*, T*, double*, const int*, T*);                   \
   template void launch_pair_field<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
                                      const ScaleTab<T>&, T, T*, const int*);                                        \
   template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,           \

@@ -273,7 +273,7 @@ template <class T>
 __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* __restrict__ sites, int lpol,
                                                          RecipGeom<T> g, const T* __restrict__ phi,
                                                          T* __restrict__ pot, T* __restrict__ grad,
-                                                         const int* __restrict__ list) {
+                                                         const int* __restrict__ list, T* __restrict__ fld) {
   const int t = blockIdx.x * kGatherBlock + threadIdx.x;
   const int slot = t >> 3, a = t & 7;
   const int i = slot < na ? (list ? list[slot] : slot) : na;
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* 
     unfold_potential(g, Q, F, P, gr);
 #pragma unroll
     for (int k = 0; k < 9; ++k) pot[9 * i + k] += P[k];
+    if (fld) { fld[3 * i] = P[2]; fld[3 * i + 1] = P[3]; fld[3 * i + 2] = P[1]; }   // harmonic (z,x,y) -> cartesian
     if (grad) {
       grad[3 * i] += gr[0]; grad[3 * i + 1] += gr[1]; grad[3 * i + 2] += gr[2];
     }
@@ -431,8 +432,8 @@ void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipG
 }
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad, const int* list) {
-  k_gather<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list);
+                   T* grad, const int* list, T* fld) {
+  k_gather<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld);
 }
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
@@ -457,7 +458,7 @@ void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, i
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
-                                 const int*);                                                                         \
+                                 const int*, T*);                                                                       \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
                                        const int*);                                                                   \
   template void launch_gather_scalar<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, const T*, T*);

@@ -363,3 +363,28 @@ def test_gpu_neighbour_list_matches_kdtree(precision, prec):
         d = (s - np.floor(s + 0.5)) @ box
         m = np.linalg.norm(d, axis=1) < 5.0
         assert got == set(zip(i[m].tolist(), j[m].tolist()))
+
+
+def test_warm_regime_fast_path_is_equivalent(precision):
+    """After a call that converged at its first SCF check the next call evaluates the first cycle with the full
+    kernels (engine.hip `warm_regime`); results must be those of the plain loop, whether the check then passes
+    (step finished in one pass) or fails (falls back to the Jacobi loop)."""
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    pos, box, at, ai, cov, par, pairs = water_system(125, 5, True)
+    args = (pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    E0, G0 = f.get_forces(*args)                       # cold: Jacobi loop from zero
+    U = f.U_ind.copy()
+    E1, G1 = f.get_forces(*args, U_init=U)             # plain loop, converges at the first check
+    assert f.n_cycle == 0
+    E2, G2 = f.get_forces(*args, U_init=U)             # fast path, check passes
+    assert f.n_cycle == 0 and f.lconverg
+    scale = max(abs(p) for p in f.energy_parts)
+    assert abs(E2 - E1) < 1e-12 * scale and rel(G2, G1) < 1e-12
+    assert abs(E1 - E0) < 1e-3 * abs(E0)               # same fixed point up to the loose SCF threshold
+    E3, G3 = f.get_forces(*args)                       # fast path armed, but U_init = 0: the check fails
+    fresh = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    E4, G4 = fresh.get_forces(*args)
+    assert f.n_cycle == fresh.n_cycle and abs(E3 - E4) < 1e-12 * scale and rel(G3, G4) < 1e-12
+    assert rel(f.U_ind, fresh.U_ind) < 1e-12
