@@ -79,7 +79,7 @@ void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>*
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                        const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows);
-int pair_lanes_per_row();            // tuning knob (env ADMP_PAIR_LPR), default chosen per precision
+int pair_lanes_per_row(int n_rows);   // 2/4/8 by row count; env ADMP_PAIR_LPR overrides
 template <class T>
 void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies);

@@ -147,14 +147,18 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
   if (threadIdx.x == 0) atomicAdd(&energies[E_REAL], 0.5 * e);
 }
 
-int pair_lanes_per_row() {
-  static int v = -1;
-  if (v < 0) {
+// lanes of a wavefront that share one row.  Few lanes = fewer idle lanes at the row tail and less shuffle
+// folding; many lanes = enough wavefronts to fill the chip when there are few rows.  Measured (f32, polarizable):
+// 1M rows LPR 2/4/8/16 -> 0.958/1.018/1.056/1.128 ms; 98k rows 2/4/8 -> 0.125/0.121/0.125 ms.
+int pair_lanes_per_row(int n_rows) {
+  static int forced = -2;
+  if (forced == -2) {
     const char* s = getenv("ADMP_PAIR_LPR");
-    int x = s ? atoi(s) : 8;
-    v = (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32) ? x : 8;
+    int x = s ? atoi(s) : -1;
+    forced = (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32) ? x : -1;
   }
-  return v;
+  if (forced > 0) return forced;
+  return n_rows >= 262144 ? 2 : (n_rows >= 32768 ? 4 : 8);
 }
 
 // minimum waves per SIMD requested from the register allocator for the polarizable kernel
@@ -187,7 +191,7 @@ template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows,
                       T* fld) {
-  const int lpr = pair_lanes_per_row();
+  const int lpr = pair_lanes_per_row(na);
   const int minw = pair_min_waves<T>();
 #define CALL(L)                                                                                                        \
   if (lpol && minw >= 2)                                                                                               \
@@ -206,7 +210,7 @@ void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>*
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                        const ScaleTab<T>& tab, T kappa, T* fld, const int* rows) {
-  const int lpr = pair_lanes_per_row();
+  const int lpr = pair_lanes_per_row(na);
 #define CALL(L) k_pair_field<T, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, fld, rows)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL

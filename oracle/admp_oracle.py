@@ -376,6 +376,8 @@ def pme_real_pair_energies(norm_dr, QI, QJ, UI, UJ, th1, th2, dmp, m, p, kappa, 
 def pair_nbonds(covalent_map, pairs):
     """covalent_map[i, j] for every pair; dense ndarray or scipy sparse accepted."""
     i, j = pairs[:, 0], pairs[:, 1]
+    if len(i) == 0:
+        return np.zeros(0, dtype=np.int64)
     if hasattr(covalent_map, 'tocsr'):
         return np.asarray(covalent_map.tocsr()[i, j]).ravel().astype(np.int64)
     return np.asarray(covalent_map)[i, j].astype(np.int64)

@@ -438,6 +438,198 @@ def test_parameter_gradient_of_fluctuating_multipoles(precision, lpol):
     else:
         Eo = O.energy_pme(sysm, po, T(box), pairs, Qo, None, None, None, T(par['mScales']), None)
     Eo.backward()
-    assert abs(float(E) - float(Eo)) < 1e-9 * max(abs(x) for x in f.energy_parts)
+    assert abs(float(E.detach()) - float(Eo.detach())) < 1e-9 * max(abs(x) for x in f.energy_parts)
     assert rel(p.grad.cpu().numpy(), po.grad.numpy()) < 1e-8
     assert rel(kv.grad.cpu().numpy(), ko.grad.numpy()) < 1e-8
+
+
+def _mixed_axis_system(seed=2):
+    """8 'molecules' of 4 atoms exercising every axis rule (ZThenX, Bisector, ZBisect, ThreeFold, Zonly, none)."""
+    rng = np.random.default_rng(seed)
+    n_mol, L = 8, 14.0
+    centres = np.array([[x, y, z] for x in (3.5, 10.5) for y in (3.5, 10.5) for z in (3.5, 10.5)], dtype=float)
+    pos, at, ai = [], [], []
+    local = np.array([[0, 0, 0], [1.0, 0.1, 0.0], [-0.3, 0.95, 0.1], [-0.2, -0.4, 0.9]])
+    types = [(0, 1, 2, -1), (1, 0, 2, -1), (2, 0, 1, 3), (3, 1, 2, 0)]   # per atom: (type, z, x, y) within the molecule
+    for m in range(n_mol):
+        rot = S._random_rotations(rng, 1)[0]
+        base = 4 * m
+        for k in range(4):
+            pos.append(centres[m] + rot @ local[k] + rng.normal(scale=0.05, size=3))
+        for k, (t, z, x, y) in enumerate(types):
+            if m % 4 == 3 and k == 3:
+                at.append(5); ai.append([-1, -1, -1])                 # NoAxisType site (charge only)
+            elif m % 4 == 2 and k == 0:
+                at.append(4); ai.append([base + 1, -1, -1])            # Zonly
+            else:
+                at.append(t); ai.append([base + z, base + x, base + y if y >= 0 else -1])
+    pos = np.array(pos)
+    at, ai = np.array(at, dtype=np.int32), np.array(ai, dtype=np.int32)
+    na = len(pos)
+    Q = rng.normal(size=(na, 9)) * np.array([0.6, .3, .3, .3, .2, .2, .2, .2, .2])
+    Q[at == 5, 1:] = 0.0
+    Q[:, 0] -= Q[:, 0].mean()
+    cov = np.zeros((na, na), dtype=np.int32)
+    for m in range(n_mol):
+        for a in range(4):
+            for b in range(4):
+                if a != b:
+                    cov[4 * m + a, 4 * m + b] = 1 if 0 in (a, b) else 2
+    pol = rng.uniform(0.4, 1.2, na) * (rng.random(na) < 0.6)
+    thole = rng.uniform(2.0, 8.0, na)
+    return pos, np.eye(3) * L, at, ai, cov, Q, pol, thole
+
+
+@pytest.mark.parametrize('lpol', [False, True])
+@pytest.mark.parametrize('tric', [False, True])
+def test_all_axis_rules_and_triclinic_cell(precision, lpol, tric):
+    """Every local-axis rule, general scale tables, dense covalent map; orthorhombic and triclinic cells.
+    For the triclinic cell the oracle is evaluated with the consistent k-vector assignment."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    settings.PRECISION = 'double'
+    pos, box, at, ai, cov, Q, pol, thole = _mixed_axis_system()
+    if tric:
+        box = np.array([[14.0, 0, 0], [1.5, 14.0, 0], [-1.0, 0.8, 14.0]])
+    pairs = np.array([(i, j) for i in range(len(pos)) for j in range(i + 1, len(pos))], dtype=np.int32)
+    d = pos[pairs[:, 0]] - pos[pairs[:, 1]]
+    s = d @ np.linalg.inv(box)
+    d = (s - np.floor(s + 0.5)) @ box
+    pairs = pairs[np.linalg.norm(d, axis=1) < 6.0]
+    mS = np.array([0.0, 0.4, 0.8, 1.0, 1.0])
+    pS = np.array([0.0, 0.0, 1.0, 1.0, 1.0])
+    f = ADMPPmeForce(box, at, ai, cov, 6.0, 1e-5, 2, lpol=lpol)
+    K = (f.K1, f.K1, f.K1)
+    for k in ('K1', 'K2', 'K3'):
+        f.update_env(k, K[0])
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, K, 2, lpol)
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+    p = T(pos).requires_grad_(True)
+    if lpol:
+        E, G = f.get_forces(pos, box, pairs, Q, pol, thole, mS, pS, pS)
+        # oracle with the consistent k assignment needs the SCF done through the same energy function
+        U = T(np.zeros_like(pos))
+        for i in range(30):
+            Ug = U.clone().requires_grad_(True)
+            e = _oracle_energy(O, sysm, T(pos), T(box), pairs, T(Q), Ug, T(pol), T(thole), T(mS), T(pS), quirk=not tric)
+            fld, = torch.autograd.grad(e, Ug)
+            if float(fld[T(pol) > 0.001].abs().max()) < 10.0:
+                break
+            U = U - fld * T(pol)[:, None] / O.DIELECTRIC
+        assert f.n_cycle == i
+        e = _oracle_energy(O, sysm, p, T(box), pairs, T(Q), U, T(pol), T(thole), T(mS), T(pS), quirk=not tric)
+        assert rel(f.U_ind, U.numpy()) < 1e-8
+    else:
+        E, G = f.get_forces(pos, box, pairs, Q, mS)
+        e = _oracle_energy(O, sysm, p, T(box), pairs, T(Q), None, None, None, T(mS), None, quirk=not tric)
+    g, = torch.autograd.grad(e, p)
+    scale = max(abs(x) for x in f.energy_parts)
+    assert abs(E - float(e.detach())) < 1e-9 * scale
+    assert rel(G, g.numpy()) < 1e-8
+
+
+def _oracle_energy(O, sysm, pos, box, pairs, Q, U, pol, thole, mS, pS, quirk):
+    """energy_pme of the oracle with a switch for the k-column quirk of the reference."""
+    import torch
+    frames = O.construct_local_frames(pos, box, sysm.axis_type, sysm.axis_indices)
+    Qg = O.rot_local2global(Q, frames, 2)
+    if U is not None:
+        Uh = U @ O._C1_C2H.T
+        Qt = torch.cat([Qg[:, 0:1], Qg[:, 1:4] + Uh, Qg[:, 4:]], dim=1)
+        e = O.pme_real(pos, box, pairs, Qg, Uh, pol, thole, mS, pS, sysm.covalent_map, sysm.kappa, 2, True) + \
+            O.pol_penalty(Uh, pol)
+    else:
+        Qt = Qg
+        e = O.pme_real(pos, box, pairs, Qg, None, None, None, mS, None, sysm.covalent_map, sysm.kappa, 2, False)
+    return e + O.pme_recip(pos, box, Qt, sysm.kappa, sysm.K, 2, quirk=quirk) + O.pme_self(Qt, sysm.kappa, 2)
+
+
+@pytest.mark.parametrize('lmax', [0, 1])
+def test_lower_multipole_orders(precision, lmax):
+    """lmax = 0 (no frames at all) and lmax = 1: Q_local has (lmax+1)^2 columns."""
+    from admp_amd.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    settings.PRECISION = 'double'
+    pos, box, at, ai, cov, par, pairs = water_system(64, 9, False)
+    nh = (lmax + 1) ** 2
+    Q = par['Q_local'][:, :nh].copy()
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, lmax)
+    E, G = f.get_forces(pos, box, pairs, Q, par['mScales'])
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), lmax, False)
+    ref = O.pme_energy_and_grad(sysm, pos, box, pairs, Q, par['mScales'])
+    assert abs(E - ref['E']) < 1e-9 * max(abs(p) for p in ref['parts']) and rel(G, ref['grad']) < 1e-8
+    with pytest.raises(NotImplementedError):
+        ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 3)
+
+
+def test_empty_pair_list_and_isolated_atoms(precision):
+    """No pairs at all: the energy is reciprocal + self only; padding-only lists behave the same."""
+    from admp_amd.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    settings.PRECISION = 'double'
+    pos, box, at, ai, cov, par, pairs = water_system(27, 4, False)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    E, G = f.get_forces(pos, box, np.zeros((0, 2), dtype=np.int32), par['Q_local'], par['mScales'])
+    assert f.n_pairs == 0 and f.energy_parts[0] == 0.0
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, False)
+    ref = O.pme_energy_and_grad(sysm, pos, box, np.zeros((0, 2), dtype=np.int64), par['Q_local'], par['mScales'])
+    assert abs(E - ref['E']) < 1e-9 * abs(ref['parts'][2]) and rel(G, ref['grad']) < 1e-8
+    pad = np.full((13, 2), len(pos), dtype=np.int32)
+    E2, _ = f.get_forces(pos, box, pad, par['Q_local'], par['mScales'])
+    assert E2 == E
+
+
+def test_c_abi_with_host_pointers(precision):
+    """The C ABI called the way INTEGRATION.md's stub does: plain ctypes, HOST numpy buffers (on_device = 0)."""
+    import ctypes
+    from admp_amd import _lib
+    from admp_amd._device import covalent_to_csr
+    from admp_amd.pme import setup_ewald_parameters
+    from oracle import admp_oracle as O
+    L = _lib.load()
+    pos, box, at, ai, cov, par, pairs = water_system(64, 6, True)
+    na = len(pos)
+    kappa, K1, K2, K3 = setup_ewald_parameters(4.0, 1e-4, box)
+    h = ctypes.c_void_p()
+    assert L.admp_create(ctypes.byref(h), 0, 8) == 0
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    ptr, col, nb = covalent_to_csr(cov, na)
+    at32, ai32 = np.ascontiguousarray(at, dtype=np.int32), np.ascontiguousarray(ai, dtype=np.int32)
+    assert L.admp_set_topology(h, na, vp(at32), vp(ai32), vp(ptr), vp(col), vp(nb)) == 0
+    assert L.admp_set_ewald(h, kappa, K1, K2, K3, 2, 1) == 0
+    p32 = np.ascontiguousarray(pairs, dtype=np.int32)
+    assert L.admp_set_pairs(h, len(p32), vp(p32), 0) == 0
+    assert L.admp_num_pairs(h) == len(pairs)
+    posc, Qc = np.ascontiguousarray(pos), np.ascontiguousarray(par['Q_local'])
+    polc, thc = np.ascontiguousarray(par['pol']), np.ascontiguousarray(par['tholes'])
+    U = np.zeros((na, 3)); grad = np.empty((na, 3)); dQ = np.empty((na, 9))
+    E = (ctypes.c_double * 4)(); ncyc = ctypes.c_int(); conv = ctypes.c_int()
+    d = _lib.darr
+    rc = L.admp_pme_energy_grad(h, vp(posc), d(box.ravel()), vp(Qc), vp(polc), vp(thc), 5, d(par['mScales']),
+                                d(par['pScales']), d(par['dScales']), vp(U), 30, 10.0, E, vp(grad), vp(dQ),
+                                ctypes.byref(ncyc), ctypes.byref(conv), 0)
+    assert rc == 0, L.admp_last_error(h)
+    sysm = O.PmeSystem(at, ai, cov, kappa, (K1, K2, K3), 2, True)
+    ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], par['pol'], par['tholes'],
+                                par['pScales'], want_dQ=True)
+    scale = max(abs(p) for p in ref['parts'])
+    assert abs(sum(E) - ref['E']) < 1e-9 * scale and rel(grad, ref['grad']) < 1e-8 and rel(dQ, ref['dQ_local']) < 1e-8
+    assert rel(U, ref['U_ind']) < 1e-8 and ncyc.value == ref['n_cycle'] and bool(conv.value) == ref['lconverg']
+    # error behaviour: negative code + message, never an abort
+    assert L.admp_set_ewald(h, -1.0, K1, K2, K3, 2, 1) < 0 and b'kappa' in L.admp_last_error(h)
+    assert L.admp_set_ewald(h, kappa, K1, K2, K3, 3, 1) < 0
+    assert L.admp_destroy(h) == 0
+
+
+@pytest.mark.parametrize('pmax', [6, 8])
+def test_dispersion_lower_orders_and_single_precision(precision, pmax):
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from oracle import admp_oracle as O
+    pos, box, at, ai, cov, par, pairs = water_system(125, 12, False)
+    for prec, tol in (('double', 1e-9), ('single', 5e-4)):
+        settings.PRECISION = prec
+        d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, pmax)
+        E, G = d.get_forces(pos, box, pairs, par['c_list'][:, :(pmax - 4) // 2], par['mScales'])
+        ref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d.kappa, (d.K1, d.K2, d.K3), pmax)
+        assert abs(E - ref['E']) < tol * max(abs(p) for p in ref['parts']) and rel(G, ref['grad']) < max(tol, 1e-8)
