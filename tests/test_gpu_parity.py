@@ -633,3 +633,45 @@ def test_dispersion_lower_orders_and_single_precision(precision, pmax):
         E, G = d.get_forces(pos, box, pairs, par['c_list'][:, :(pmax - 4) // 2], par['mScales'])
         ref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d.kappa, (d.K1, d.K2, d.K3), pmax)
         assert abs(E - ref['E']) < tol * max(abs(p) for p in ref['parts']) and rel(G, ref['grad']) < max(tol, 1e-8)
+
+
+def test_full_size_directional_derivative(precision):
+    """BASELINE's full size (1 048 575 polarizable atoms, K = 256), double precision: the gradient returned by the
+    HIP adjoint must be the derivative of the returned energy.  Central difference along a random direction at
+    FIXED induced dipoles (the SCF is warm-started from its own result and passes its first check, so U does not
+    move -- which is exactly what the Hellmann-Feynman gradient of the reference differentiates)."""
+    import torch
+    from admp_amd.neighbor import NeighborList
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    nm = 349525
+    pos, box = S.synthetic_water_box(nm, seed=20240)
+    at, ai, cov = S.water_topology(nm)
+    par = S.water_parameters(nm, True)
+    pairs = NeighborList(box, 4.0).allocate(pos)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    for k in ('K1', 'K2', 'K3'):
+        f.update_env(k, 256)
+    dev = 'cuda'
+    p0 = torch.as_tensor(pos, device=dev)
+    rest = [torch.as_tensor(par[k], device=dev) for k in ('Q_local', 'pol', 'tholes')] + \
+           [par['mScales'], par['pScales'], par['dScales']]
+    E0, G = f.get_forces(p0, box, pairs, *rest)
+    U = torch.as_tensor(f.U_ind, device=dev).clone()
+    E0, G = f.get_forces(p0, box, pairs, *rest, U_init=U)
+    assert f.n_cycle == 0 and f.n_pairs == len(pairs)
+    # direction: the gradient itself blended with noise (a purely random direction in 3M dimensions has a
+    # derivative of O(1) kJ/mol/A, below the round-off of energies whose Ewald parts are O(1e8))
+    g = torch.Generator(device=dev).manual_seed(1)
+    v = G / G.norm() + 0.5 * torch.randn(p0.shape, generator=g, device=dev, dtype=p0.dtype) / (3 * nm * 3) ** 0.5
+    v /= v.norm()
+    h = 0.05                                   # ~5e-5 A per atom
+    Ep = f.get_energy(p0 + h * v, box, pairs, *rest, U_init=U)
+    assert f.n_cycle == 0
+    Em = f.get_energy(p0 - h * v, box, pairs, *rest, U_init=U)
+    assert f.n_cycle == 0
+    fd = (Ep - Em) / (2 * h)
+    an = float((G * v).sum())
+    assert abs(fd - an) < 2e-6 * abs(an) + 1e-4, (fd, an)
+    # and the gradient is translation invariant in sum up to the PME mesh error
+    assert float(G.sum(dim=0).abs().max()) < 1e-4 * float(G.abs().sum(dim=0).max())
