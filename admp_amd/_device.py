@@ -140,6 +140,10 @@ class HipForceBase:
     def set_pairs(self, pairs):
         """Compile the (Np, 2) pair list into the device neighbour table (rows with i >= j are dropped,
         reference admp/pme.py:671).  Called automatically by get_energy/get_forces when `pairs` changes."""
+        if pairs is None:
+            if self._pairs_key is None:
+                raise ValueError('pairs=None needs a previous set_pairs / update_neighbors')
+            return
         key = self._pairs_fingerprint(pairs)
         if key == self._pairs_key:
             return
@@ -159,6 +163,18 @@ class HipForceBase:
         _lib.check(self._h, self._L.admp_set_pairs(self._h, t.shape[0], self._ptr(t), 1), 'admp_set_pairs')
         self._pairs_key = key
         self._pairs_keep = pairs      # keeps id() unique while cached
+
+    def update_neighbors(self, positions, box, rc=None):
+        """Neighbour search + table compile in one GPU pass (cell list): afterwards pass `pairs=None` to
+        get_energy / get_forces.  The MD-loop counterpart of re-running jax_md's neighbour list in the reference's
+        drivers; equivalent to `set_pairs(NeighborList(box, rc).allocate(positions))`."""
+        rc = float(self.rc if rc is None else rc)
+        with self._on_stream():
+            pos = self._real(positions, (self.n_atoms, 3))
+            _lib.check(self._h, self._L.admp_set_pairs_from_positions(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), rc),
+                       'admp_set_pairs_from_positions')
+        self._pairs_key = ('from_positions',)
+        self._pairs_keep = None
 
     @property
     def n_pairs(self):

@@ -32,6 +32,7 @@ PROTOTYPES = {
     'admp_tt_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _dp, _vp, _i32]),
     'admp_neighbor_count': (_i32, [_vp, _i32, _vp, _dp, _dbl, _c.POINTER(_i64)]),
     'admp_neighbor_fill': (_i32, [_vp, _vp]),
+    'admp_set_pairs_from_positions': (_i32, [_vp, _vp, _dp, _dbl]),
     'admp_slab_configure': (_i32, [_vp, _i32, _i32]),
     'admp_slab_info': (_i32, [_vp, _c.POINTER(_i64)]),
     'admp_stage_begin': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _ip]),

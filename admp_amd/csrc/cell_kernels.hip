@@ -109,6 +109,49 @@ __global__ __launch_bounds__(128) void k_cell_pairs(int na, const T* __restrict_
   if (!MODE) count[i] = n;
 }
 
+// Full (both directions) neighbour rows straight from the cell list: row i = every j != i within rc, in the
+// deterministic cell-sweep order; entry = j | nbonds << 28 (covalent map looked up in CSR form).  MODE 0 counts.
+__device__ __forceinline__ int cell_lookup_nbonds(const Topology& top, int i, int j) {
+  if (!top.excl_ptr) return 0;
+  for (int k = top.excl_ptr[i]; k < top.excl_ptr[i + 1]; ++k)
+    if (top.excl_col[k] == j) return top.excl_nb[k] & 15;
+  return 0;
+}
+
+template <class T, int MODE>
+__global__ __launch_bounds__(128) void k_cell_rows(Topology top, const T* __restrict__ pos, Box<T> box, CellGrid cg, T rc2,
+                                                   const int* __restrict__ start, const int* __restrict__ sorted,
+                                                   int* __restrict__ deg, const int* __restrict__ rowptr,
+                                                   int* __restrict__ col) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= top.na) return;
+  T ri[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  int c[3];
+  cell_of(box, cg, ri, c);
+  int n = 0, w = MODE ? rowptr[i] : 0;
+  int lo[3], cnt[3];
+  for (int d = 0; d < 3; ++d) {
+    if (cg.n[d] >= 3) { lo[d] = c[d] - 1; cnt[d] = 3; } else { lo[d] = 0; cnt[d] = cg.n[d]; }
+  }
+  for (int a = 0; a < cnt[0]; ++a)
+    for (int b = 0; b < cnt[1]; ++b)
+      for (int e = 0; e < cnt[2]; ++e) {
+        int cx = (lo[0] + a + cg.n[0]) % cg.n[0], cy = (lo[1] + b + cg.n[1]) % cg.n[1], cz = (lo[2] + e + cg.n[2]) % cg.n[2];
+        int cid = (cx * cg.n[1] + cy) * cg.n[2] + cz;
+        for (int k = start[cid]; k < start[cid + 1]; ++k) {
+          int j = sorted[k];
+          if (j == i) continue;
+          T d[3] = {ri[0] - pos[3 * j], ri[1] - pos[3 * j + 1], ri[2] - pos[3 * j + 2]};
+          min_image(box, d);
+          if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2) {
+            if (MODE) col[w++] = j | (cell_lookup_nbonds(top, i, j) << 28);
+            else ++n;
+          }
+        }
+      }
+  if (!MODE) deg[i] = n;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // Phase 1: bins the atoms and counts the pairs.  scratch layout is owned by the engine (see CellScratch).
@@ -151,6 +194,50 @@ int cell_fill_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, dou
   return 0;
 }
 
+// positions -> i-grouped neighbour table of the pair kernels in one go (no pair array, no atomics, no sort)
+template <class T>
+int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const double* heights,
+                     double rc, CellScratch& cs, NbrTable& nb) {
+  const int na = top.na;
+  long long dummy = 0;
+  (void)dummy;
+  CellGrid cg;
+  for (int d = 0; d < 3; ++d) {
+    int n = (int)(heights[d] / rc);
+    cg.n[d] = n < 1 ? 1 : (n > 1024 ? 1024 : n);
+  }
+  while ((long)cg.n[0] * cg.n[1] * cg.n[2] > 64L * 1024 * 1024) { for (int d = 0; d < 3; ++d) cg.n[d] = (cg.n[d] + 1) / 2; }
+  cg.ncell = cg.n[0] * cg.n[1] * cg.n[2];
+  cs.n[0] = cg.n[0]; cs.n[1] = cg.n[1]; cs.n[2] = cg.n[2];
+  if (cs.ensure(na, cg.ncell) != 0) return (int)hipErrorOutOfMemory;
+  const int blocks = (na + 255) / 256;
+  CK(hipMemsetAsync(cs.cursor, 0, sizeof(int) * (cg.ncell + 1), st));
+  k_cell_bin<T, 0><<<blocks, 256, 0, st>>>(na, pos, box, cg, cs.cursor, nullptr);
+  size_t need = cs.scan_bytes;
+  CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, cs.cursor, cs.start, cg.ncell + 1, st));
+  CK(hipMemcpyAsync(cs.cursor, cs.start, sizeof(int) * (cg.ncell + 1), hipMemcpyDeviceToDevice, st));
+  k_cell_bin<T, 1><<<blocks, 256, 0, st>>>(na, pos, box, cg, cs.cursor, cs.sorted);
+  k_cell_sort<<<(cg.ncell + 127) / 128, 128, 0, st>>>(cg.ncell, cs.start, cs.sorted);
+  if (!nb.rowptr) CK(hipMalloc(&nb.rowptr, sizeof(int) * (na + 1)));
+  int* deg = reinterpret_cast<int*>(cs.count);        // na + 1 ints fit in the (na + 1) long long scratch
+  CK(hipMemsetAsync(deg, 0, sizeof(int) * (na + 1), st));
+  k_cell_rows<T, 0><<<(na + 127) / 128, 128, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, cs.sorted, deg, nullptr, nullptr);
+  need = cs.scan_bytes;
+  CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, deg, nb.rowptr, na + 1, st));
+  int total = 0;
+  CK(hipMemcpyAsync(&total, nb.rowptr + na, sizeof(int), hipMemcpyDeviceToHost, st));
+  CK(hipStreamSynchronize(st));
+  if (total > nb.cap) {
+    if (nb.col) CK(hipFree(nb.col));
+    nb.cap = (int64_t)total + 1024;
+    CK(hipMalloc(&nb.col, sizeof(int) * nb.cap));
+  }
+  nb.n_half = total / 2;
+  k_cell_rows<T, 1><<<(na + 127) / 128, 128, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, cs.sorted, nullptr, nb.rowptr, nb.col);
+  CK(hipStreamSynchronize(st));
+  return 0;
+}
+
 int CellScratch::ensure(int na, int ncell) {
   size_t scan = 0;
   long long* pl = nullptr;
@@ -187,7 +274,9 @@ void CellScratch::release() {
 #define INST(T)                                                                                                   \
   template int cell_count_pairs<T>(hipStream_t, int, const T*, const Box<T>&, const double*, double, CellScratch&, \
                                    long long*);                                                                   \
-  template int cell_fill_pairs<T>(hipStream_t, int, const T*, const Box<T>&, double, CellScratch&, int*);
+  template int cell_fill_pairs<T>(hipStream_t, int, const T*, const Box<T>&, double, CellScratch&, int*);                \
+  template int cell_build_table<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const double*, double,   \
+                                   CellScratch&, NbrTable&);
 INST(float)
 INST(double)
 #undef INST

@@ -165,6 +165,7 @@ struct EngineBase {
   // staged evaluation (device pointers only)
   virtual void nbr_count(int na, const void* pos, const double* box, double rc, int64_t* n_pairs) = 0;
   virtual void nbr_fill(int32_t* pairs) = 0;
+  virtual void nbr_table(const void* pos, const double* box, double rc) = 0;
   virtual void slab_info(int64_t* out) = 0;
   virtual int v_stage_begin(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole,
                             int ns, const double* mS, const double* pS, void* U) = 0;
@@ -720,6 +721,21 @@ struct Engine : EngineBase {
     nb_pos = nullptr;
   }
 
+  void nbr_table(const void* pos, const double* box, double rc) override {
+    ARG_CHECK(have_top, "admp_set_topology must precede admp_set_pairs_from_positions");
+    ARG_CHECK(pos && box && rc > 0, "bad argument");
+    double inv[9], vol;
+    Box<T> b = make_box(box, inv, &vol);
+    double heights[3];
+    for (int d = 0; d < 3; ++d)
+      heights[d] = 1.0 / std::sqrt(inv[0 + d] * inv[0 + d] + inv[3 + d] * inv[3 + d] + inv[6 + d] * inv[6 + d]);
+    for (int d = 0; d < 3; ++d) ARG_CHECK(rc <= 0.5 * heights[d] * (1 + 1e-12), "rc exceeds half the box height (minimum image)");
+    TIMED("neighbor_table");
+    int r = cell_build_table<T>(stream, top, reinterpret_cast<const T*>(pos), b, heights, rc, cells, nbr);
+    if (r != 0) throw Err{ADMP_E_HIP, std::string("cell_build_table: ") + hipGetErrorString((hipError_t)r)};
+    have_pairs = true;
+  }
+
   void slab_info(int64_t* o) override {
     ARG_CHECK(have_ewald, "admp_set_ewald first");
     update_slab();
@@ -939,6 +955,10 @@ int admp_neighbor_count(admp_handle* h, int n_atoms, const void* positions, cons
 }
 int admp_neighbor_fill(admp_handle* h, int32_t* pairs_out) {
   return guarded(h, [&](EngineBase& e) { e.nbr_fill(pairs_out); });
+}
+
+int admp_set_pairs_from_positions(admp_handle* h, const void* positions, const double* box, double rc) {
+  return guarded(h, [&](EngineBase& e) { e.nbr_table(positions, box, rc); });
 }
 
 int admp_slab_configure(admp_handle* h, int rank, int nranks) {

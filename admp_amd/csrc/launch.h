@@ -114,9 +114,6 @@ struct BinScratch {
 };
 
 // ---- recip_kernels.hip
-// v1 spread (one thread per atom, global float atomics); mesh must be zeroed first
-template <class T>
-void launch_spread_atomic(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, T* mesh);
 // LDS-brick spread: bins the atoms, accumulates every brick in LDS, writes each mesh point exactly once
 // (no memset, no global atomics).  Returns a hipError_t as int.
 template <class T>
@@ -161,6 +158,10 @@ int cell_count_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, co
                      CellScratch& cs, long long* n_pairs);
 template <class T>
 int cell_fill_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, double rc, CellScratch& cs, int* pairs);
+// positions -> the pair kernels' neighbour table directly (both directions, nbonds packed), no pair array in between
+template <class T>
+int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const double* heights,
+                     double rc, CellScratch& cs, NbrTable& nb);
 
 // ---- nbr_kernels.hip
 // builds nb from (n_rows, 2) device pairs; scratch (deg/cursor) is managed inside. Returns hipError_t as int.

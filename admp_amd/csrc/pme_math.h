@@ -250,22 +250,8 @@ struct Radial {
   }
 };
 
-// ten permanent coefficients (admp/pme.py:303-324); mm = mscale - 1
+// coefficient slots (the ten permanent ones of admp/pme.py:303-324 are streamed inside pair_energy_grad)
 enum { CC, CD, DD0, DD1, CQ, DQ0, DQ1, QQ0, QQ1, QQ2, CUD, DUD0, DUD1, UDQ0, UDQ1, UDUD0, UDUD1, NCOEF };
-
-template <class S, class T>
-ADMP_HD void perm_coefs(const Radial<S, T>& a, T mm, S* c) {
-  c[CC] = a.R1 * (mm + a.B2 - a.xX);
-  c[CD] = a.R2 * (mm + a.B2);
-  c[DD0] = a.R3 * ((mm + a.B3) * T(3) + a.x3X) * T(-2.0 / 3.0);
-  c[DD1] = a.R3 * (mm + a.B3 - a.x3X * T(2.0 / 3.0));
-  c[CQ] = a.R3 * (mm + a.B3);
-  c[DQ0] = a.R4 * ((mm + a.B3) * T(3) + a.x5X * T(4.0 / 3.0));
-  c[DQ1] = a.R4 * (mm + a.B3) * T(-kSqrt3);
-  c[QQ0] = a.R5 * ((mm + a.B4) * T(6) + (a.x2 * T(10) - T(3)) * a.x5X * T(4.0 / 45.0));
-  c[QQ1] = a.R5 * ((mm + a.B4) * T(15) + a.x5X) * T(-4.0 / 15.0);
-  c[QQ2] = a.R5 * (mm + a.B4 - a.x5X * T(4.0 / 15.0));
-}
 
 // seven induced coefficients (admp/pme.py:408-475).
 //   aw   : Thole width after the Fermi switch on pscale (pme.py:411; r-independent)

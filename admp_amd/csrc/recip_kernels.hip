@@ -21,17 +21,6 @@ __device__ __forceinline__ void site_qtot(const Site<T>& s, int lpol, T r[3], T 
   if (lpol) { Q[1] += s.U[0]; Q[2] += s.U[1]; Q[3] += s.U[2]; }   // Q_global_tot, admp/pme.py:236
 }
 
-// Spread, first version: one thread per atom, 216 hardware float atomics each (Q_mesh.at[].add, recip.py:324-328).
-template <class T>
-__global__ __launch_bounds__(kRecipBlock) void k_spread(int na, const Site<T>* __restrict__ sites, int lpol,
-                                                        RecipGeom<T> g, T* __restrict__ mesh) {
-  int i = blockIdx.x * kRecipBlock + threadIdx.x;
-  if (i >= na) return;
-  T r[3], Q[9];
-  site_qtot(sites[i], lpol, r, Q);
-  spread_atom(g, r, Q, [&](long idx, T v) { atomicAdd(&mesh[idx], v); });
-}
-
 // ---- LDS-brick spread -------------------------------------------------------------------------------
 // brick index of mesh index i on an axis of K points cut into nb bricks [b*K/nb, (b+1)*K/nb)
 __device__ __forceinline__ int brick_of(int i, int nb, int K) { return ((i + 1) * nb - 1) / K; }
@@ -345,11 +334,6 @@ __global__ __launch_bounds__(kRecipBlock) void k_gather_scalar(int na, const T* 
 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 
-template <class T>
-void launch_spread_atomic(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, T* mesh) {
-  k_spread<T><<<nblk(na, kRecipBlock), kRecipBlock, 0, st>>>(na, sites, lpol, g, mesh);
-}
-
 #define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
@@ -450,7 +434,6 @@ void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, i
 }
 
 #define INST(T)                                                                                                       \
-  template void launch_spread_atomic<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, T*);              \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
                                 const int*);                                                                          \
   template void launch_spread_scalar<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, T*);     \

@@ -125,17 +125,14 @@ def run_timed(f, a, steps, warmup, barrier=None):
 def time_list_rebuild(f, w, reps=3):
     """Neighbour search + compilation of the pair table (the step either side of the path), ms per rebuild."""
     import torch
-    from admp_amd.neighbor import NeighborList
     dt = torch.float32 if w['prec'] == 'single' else torch.float64
     p = torch.as_tensor(w['pos'], dtype=dt, device='cuda')
-    nl = NeighborList(w['box'], 4.0)
-    nl.allocate(p)
+    f.update_neighbors(p, w['box'])
     best = float('inf')
     for _ in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pairs = nl.allocate(p)
-        f.set_pairs(pairs)
+        f.update_neighbors(p, w['box'])          # cell-list search fused with the table build
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
     return best * 1e3

@@ -104,6 +104,9 @@ int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box
 int admp_neighbor_count(admp_handle* h, int n_atoms, const void* positions, const double* box, double rc,
                         int64_t* n_pairs);
 int admp_neighbor_fill(admp_handle* h, int32_t* pairs_out);
+/* search + admp_set_pairs fused: builds the handle's neighbour table (all pairs with minimum-image r < rc) straight
+ * from DEVICE positions (n_atoms of admp_set_topology), without materialising the pair array. */
+int admp_set_pairs_from_positions(admp_handle* h, const void* positions, const double* box, double rc);
 
 /* ---- multi-GPU: x-slab decomposition, staged evaluation ---------------------------------------------
  * (no counterpart in the reference, which is single-device)  One process per GPU; every rank

@@ -675,3 +675,21 @@ def test_full_size_directional_derivative(precision):
     assert abs(fd - an) < 2e-6 * abs(an) + 1e-4, (fd, an)
     # and the gradient is translation invariant in sum up to the PME mesh error
     assert float(G.sum(dim=0).abs().max()) < 1e-4 * float(G.abs().sum(dim=0).max())
+
+
+def test_update_neighbors_equals_explicit_pair_list(precision):
+    """Fused GPU neighbour search + table build (update_neighbors, pairs=None) against the explicit pair list."""
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    pos, box, at, ai, cov, par, pairs = water_system(216, 13, True)
+    rest = (par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    E0, G0 = f.get_forces(pos, box, pairs, *rest)
+    g = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    with pytest.raises(ValueError):
+        g.get_forces(pos, box, None, *rest)
+    g.update_neighbors(pos + 3 * box[1], box)               # positions outside the cell
+    assert g.n_pairs == len(pairs)
+    E1, G1 = g.get_forces(pos, box, None, *rest)
+    scale = max(abs(p) for p in f.energy_parts)
+    assert abs(E1 - E0) < 1e-11 * scale and rel(G1, G0) < 1e-11 and g.n_cycle == f.n_cycle
