@@ -330,130 +330,150 @@ ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J
   ADMP_FENCE9(A); ADMP_FENCE9(B);
   if (LPOL) { ADMP_FENCE3(UA); ADMP_FENCE3(UB); }
 
-  // ---- phase 2: permanent coefficients (admp/pme.py:303-324), streamed: each coefficient (value, d/dr) is
-  // consumed at once into the energy, dE/dr and the frame-component gradients PA = dE/dA, PB = dE/dB
-  typedef Dual<T> S;
-  Radial<S, T> rad;
-  rad.init(S(r, T(1)), kappa);
-  rad.fence();
+  // ---- phase 2: permanent coefficients (admp/pme.py:283-324) with hand-derived radial derivatives.
+  // Every coefficient is c = R_n f with R_n = D r^-n and f a linear form in  mm + B_k  and  x^m X
+  // (x = kappa r, X = 2 exp(-x^2)/sqrt(pi), B_1 = erfc x, B_k = B_{k-1} + 2^{k-2} x^{2k-3} X / (2k-3)!!).
+  // With g = r df/dr one has  dc/dr = R_n (g - n f) / r, and the building blocks obey
+  //   r d(x^m X)/dr = x^m X (m - 2 x^2),  r dB_1/dr = -xX,  r dB_2/dr = -2 x^2 xX,
+  //   r dB_3/dr = -(4/3) x^2 x^3X,        r dB_4/dr = -(8/15) x^2 x^5X
+  // -- the same numbers reverse-mode AD of the reference's formulas produces (checked against the oracle).
+  const T R1 = T(kDielectric) * rinv, R2 = R1 * rinv, R3 = R2 * rinv, R4 = R3 * rinv, R5 = R4 * rinv;
+  const T xk = kappa * r, x2 = xk * xk;
+  const T X = T(kTwoOverSqrtPi) * m_exp(-x2);
+  const T xX = xk * X, x3X = x2 * xX, x5X = x2 * x3X;
+  const T B1 = m_erfc(xk);
+  const T B2 = B1 + xX, B3 = B2 + T(2.0 / 3.0) * x3X, B4 = B3 + T(4.0 / 15.0) * x5X;
+  const T b2p = T(-2) * x2 * xX, b3p = T(-4.0 / 3.0) * x2 * x3X, b4p = T(-8.0 / 15.0) * x2 * x5X;
+  const T x3Xp = x3X * (T(3) - T(2) * x2), x5Xp = x5X * (T(5) - T(2) * x2);
   T e = T(0), dedr = T(0);
   T PA[9], PB[9], FA[3] = {T(0), T(0), T(0)}, FB[3] = {T(0), T(0), T(0)};
   const T mm = sc.mm;
-#define ADMP_TERM(c, shape) { const T s_ = (shape); e += (c).v * s_; dedr += (c).d * s_; }
-  {  // cc
-    const S c = rad.R1 * (mm + rad.B2 - rad.xX);
-    ADMP_TERM(c, A[0] * B[0])
-    PA[0] = c.v * B[0]; PB[0] = c.v * A[0];
+  // cv = coefficient value, accumulates energy and dE/dr for the bilinear shape s
+#define ADMP_COEF(Rn, n, f, g, shape)                                          \
+  const T cv = (Rn) * (f);                                                     \
+  { const T s_ = (shape); e += cv * s_; dedr += (Rn) * rinv * ((g) - T(n) * (f)) * s_; }
+  {  // cc : f = mm + B2 - xX = mm + erfc(x)
+    const T f = mm + B1, g = -xX;
+    ADMP_COEF(R1, 1, f, g, A[0] * B[0])
+    PA[0] = cv * B[0]; PB[0] = cv * A[0];
   }
   {  // cd
-    const S c = rad.R2 * (mm + rad.B2);
-    ADMP_TERM(c, A[0] * B[1] - A[1] * B[0])
-    PA[0] += c.v * B[1]; PA[1] = -c.v * B[0]; PB[0] -= c.v * A[1]; PB[1] = c.v * A[0];
+    const T f = mm + B2;
+    ADMP_COEF(R2, 2, f, b2p, A[0] * B[1] - A[1] * B[0])
+    PA[0] += cv * B[1]; PA[1] = -cv * B[0]; PB[0] -= cv * A[1]; PB[1] = cv * A[0];
   }
-  const S mB3 = mm + rad.B3;
+  const T f3 = mm + B3, f4 = mm + B4;
   {  // cq
-    const S c = rad.R3 * mB3;
-    ADMP_TERM(c, A[0] * B[4] + A[4] * B[0])
-    PA[0] += c.v * B[4]; PA[4] = c.v * B[0]; PB[0] += c.v * A[4]; PB[4] = c.v * A[0];
+    ADMP_COEF(R3, 3, f3, b3p, A[0] * B[4] + A[4] * B[0])
+    PA[0] += cv * B[4]; PA[4] = cv * B[0]; PB[0] += cv * A[4]; PB[4] = cv * A[0];
   }
   {  // dd_m0
-    const S c = rad.R3 * (mB3 * T(3) + rad.x3X) * T(-2.0 / 3.0);
-    ADMP_TERM(c, A[1] * B[1])
-    PA[1] += c.v * B[1]; PB[1] += c.v * A[1];
+    const T f = T(-2) * f3 - T(2.0 / 3.0) * x3X, g = T(-2) * b3p - T(2.0 / 3.0) * x3Xp;
+    ADMP_COEF(R3, 3, f, g, A[1] * B[1])
+    PA[1] += cv * B[1]; PB[1] += cv * A[1];
   }
   {  // dd_m1
-    const S c = rad.R3 * (mB3 - rad.x3X * T(2.0 / 3.0));
-    ADMP_TERM(c, A[2] * B[2] + A[3] * B[3])
-    PA[2] = c.v * B[2]; PA[3] = c.v * B[3]; PB[2] = c.v * A[2]; PB[3] = c.v * A[3];
+    const T f = f3 - T(2.0 / 3.0) * x3X, g = b3p - T(2.0 / 3.0) * x3Xp;
+    ADMP_COEF(R3, 3, f, g, A[2] * B[2] + A[3] * B[3])
+    PA[2] = cv * B[2]; PA[3] = cv * B[3]; PB[2] = cv * A[2]; PB[3] = cv * A[3];
   }
   {  // dq_m0
-    const S c = rad.R4 * (mB3 * T(3) + rad.x5X * T(4.0 / 3.0));
-    ADMP_TERM(c, A[4] * B[1] - A[1] * B[4])
-    PA[1] -= c.v * B[4]; PA[4] += c.v * B[1]; PB[1] += c.v * A[4]; PB[4] -= c.v * A[1];
+    const T f = T(3) * f3 + T(4.0 / 3.0) * x5X, g = T(3) * b3p + T(4.0 / 3.0) * x5Xp;
+    ADMP_COEF(R4, 4, f, g, A[4] * B[1] - A[1] * B[4])
+    PA[1] -= cv * B[4]; PA[4] += cv * B[1]; PB[1] += cv * A[4]; PB[4] -= cv * A[1];
   }
   {  // dq_m1
-    const S c = rad.R4 * mB3 * T(-kSqrt3);
-    ADMP_TERM(c, A[5] * B[2] + A[6] * B[3] - A[2] * B[5] - A[3] * B[6])
-    PA[2] -= c.v * B[5]; PA[3] -= c.v * B[6]; PA[5] = c.v * B[2]; PA[6] = c.v * B[3];
-    PB[2] += c.v * A[5]; PB[3] += c.v * A[6]; PB[5] = -c.v * A[2]; PB[6] = -c.v * A[3];
+    const T f = T(-kSqrt3) * f3, g = T(-kSqrt3) * b3p;
+    ADMP_COEF(R4, 4, f, g, A[5] * B[2] + A[6] * B[3] - A[2] * B[5] - A[3] * B[6])
+    PA[2] -= cv * B[5]; PA[3] -= cv * B[6]; PA[5] = cv * B[2]; PA[6] = cv * B[3];
+    PB[2] += cv * A[5]; PB[3] += cv * A[6]; PB[5] = -cv * A[2]; PB[6] = -cv * A[3];
   }
-  const S mB4 = mm + rad.B4;
-  {  // qq_m0
-    const S c = rad.R5 * (mB4 * T(6) + (rad.x2 * T(10) - T(3)) * rad.x5X * T(4.0 / 45.0));
-    ADMP_TERM(c, A[4] * B[4])
-    PA[4] += c.v * B[4]; PB[4] += c.v * A[4];
+  {  // qq_m0 : (4/45)(10 x^2 - 3) x^5X, r d/dr of it = (4/45)[(10 x^2 - 3) x^5X' + 20 x^2 x^5X]
+    const T w = T(10) * x2 - T(3);
+    const T f = T(6) * f4 + T(4.0 / 45.0) * w * x5X;
+    const T g = T(6) * b4p + T(4.0 / 45.0) * (w * x5Xp + T(20) * x2 * x5X);
+    ADMP_COEF(R5, 5, f, g, A[4] * B[4])
+    PA[4] += cv * B[4]; PB[4] += cv * A[4];
   }
   {  // qq_m1
-    const S c = rad.R5 * (mB4 * T(15) + rad.x5X) * T(-4.0 / 15.0);
-    ADMP_TERM(c, A[5] * B[5] + A[6] * B[6])
-    PA[5] += c.v * B[5]; PA[6] += c.v * B[6]; PB[5] += c.v * A[5]; PB[6] += c.v * A[6];
+    const T f = T(-4) * f4 - T(4.0 / 15.0) * x5X, g = T(-4) * b4p - T(4.0 / 15.0) * x5Xp;
+    ADMP_COEF(R5, 5, f, g, A[5] * B[5] + A[6] * B[6])
+    PA[5] += cv * B[5]; PA[6] += cv * B[6]; PB[5] += cv * A[5]; PB[6] += cv * A[6];
   }
   {  // qq_m2
-    const S c = rad.R5 * (mB4 - rad.x5X * T(4.0 / 15.0));
-    ADMP_TERM(c, A[7] * B[7] + A[8] * B[8])
-    PA[7] = c.v * B[7]; PA[8] = c.v * B[8]; PB[7] = c.v * A[7]; PB[8] = c.v * A[8];
+    const T f = f4 - T(4.0 / 15.0) * x5X, g = b4p - T(4.0 / 15.0) * x5Xp;
+    ADMP_COEF(R5, 5, f, g, A[7] * B[7] + A[8] * B[8])
+    PA[7] = cv * B[7]; PA[8] = cv * B[8]; PB[7] = cv * A[7]; PB[8] = cv * A[8];
   }
   ADMP_FENCE9(PA); ADMP_FENCE9(PB); ADMP_FENCE2(e, dedr);
 
-  // ---- phase 3: induced coefficients (admp/pme.py:408-475), Thole factors as duals in r
+  // ---- phase 3: induced coefficients (admp/pme.py:408-475).  Thole factors th = 1 - exp(-au) poly(au) with
+  // au = a r / dmp: r d(th)/dr = au d(th)/d(au) (zero where the reference's clamps are active: au >= 50 kills
+  // the exponential, a clamped u = r/dmp has no r dependence).
   if (LPOL) {
-    const S u = trim_inf(S(r, T(1)) * m_rcp(dmp), T(1e8));
-    const S au = u * aw;
-    const S expau = (val(au) < T(50)) ? m_exp(-au) : S(T(0));
-    const S au2 = trim_inf(au * au, T(1e8));
-    const S au3 = trim_inf(au2 * au, T(1e8));
-    const S au4 = trim_inf(au3 * au, T(1e8));
-    const S base = au + T(1) + au2 * T(0.5);
-    const S th_c = T(1) - expau * base;                       // == thole_d1 (pme.py:430)
-    const S th_d0 = T(1) - expau * (base + au3 * T(0.25));
-    const S th_q1 = T(1) - expau * (base + au3 * T(1.0 / 6.0));
-    const S th_q0 = T(1) - expau * (base + au3 * T(1.0 / 6.0) + au4 * T(1.0 / 18.0));
+    const T uraw = r * m_rcp(dmp);
+    const bool ucap = !(uraw < T(1e8));
+    const T au = (ucap ? T(1e8) : uraw) * aw;
+    const bool live = au < T(50);
+    const T Ex = live ? m_exp(-au) : T(0);
+    const T au2 = au * au, au3 = au2 * au, au4 = au3 * au;      // only used where Ex != 0, i.e. au < 50: no clamp active
+    const T base = T(1) + au + T(0.5) * au2;
+    const T th_c = T(1) - Ex * base;                            // == thole_d1 (pme.py:430)
+    const T th_d0 = T(1) - Ex * (base + T(0.25) * au3);
+    const T th_q1 = T(1) - Ex * (base + T(1.0 / 6.0) * au3);
+    const T th_q0 = T(1) - Ex * (base + T(1.0 / 6.0) * au3 + T(1.0 / 18.0) * au4);
+    const T Ed = ucap ? T(0) : Ex;
+    const T tcp = T(0.5) * Ed * au3;                            // r d(th_c)/dr
+    const T td0p = T(0.25) * Ed * au3 * (au - T(1));
+    const T tq1p = T(1.0 / 6.0) * Ed * au4;
+    const T tq0p = T(1.0 / 18.0) * Ed * au4 * (au - T(1));
     const T p = sc.p, hf = T(0.5);
     {  // cud
-      const S c = rad.R2 * (th_c * p - T(1) + rad.B2) * T(2);
-      ADMP_TERM(c, hf * (A[0] * UB[0] - B[0] * UA[0]))
-      const T h = hf * c.v;
+      const T f = T(2) * (p * th_c - T(1) + B2), g = T(2) * (p * tcp + b2p);
+      ADMP_COEF(R2, 2, f, g, hf * (A[0] * UB[0] - B[0] * UA[0]))
+      const T h = hf * cv;
       PA[0] += h * UB[0]; PB[0] -= h * UA[0]; FA[0] = -h * B[0]; FB[0] = h * A[0];
     }
     {  // dud_m0
-      const S c = rad.R3 * ((th_d0 * p - T(1) + rad.B3) * T(3) + rad.x3X) * T(-4.0 / 3.0);
-      ADMP_TERM(c, hf * (B[1] * UA[0] + A[1] * UB[0]))
-      const T h = hf * c.v;
+      const T f = T(-4.0 / 3.0) * (T(3) * (p * th_d0 - T(1) + B3) + x3X), g = T(-4.0 / 3.0) * (T(3) * (p * td0p + b3p) + x3Xp);
+      ADMP_COEF(R3, 3, f, g, hf * (B[1] * UA[0] + A[1] * UB[0]))
+      const T h = hf * cv;
       PA[1] += h * UB[0]; PB[1] += h * UA[0]; FA[0] += h * B[1]; FB[0] += h * A[1];
     }
     {  // dud_m1
-      const S c = rad.R3 * (th_c * p - T(1) + rad.B3 - rad.x3X * T(2.0 / 3.0)) * T(2);
-      ADMP_TERM(c, hf * (B[2] * UA[1] + B[3] * UA[2] + A[2] * UB[1] + A[3] * UB[2]))
-      const T h = hf * c.v;
+      const T f = T(2) * (p * th_c - T(1) + B3 - T(2.0 / 3.0) * x3X), g = T(2) * (p * tcp + b3p - T(2.0 / 3.0) * x3Xp);
+      ADMP_COEF(R3, 3, f, g, hf * (B[2] * UA[1] + B[3] * UA[2] + A[2] * UB[1] + A[3] * UB[2]))
+      const T h = hf * cv;
       PA[2] += h * UB[1]; PA[3] += h * UB[2]; PB[2] += h * UA[1]; PB[3] += h * UA[2];
       FA[1] = h * B[2]; FA[2] = h * B[3]; FB[1] = h * A[2]; FB[2] = h * A[3];
     }
     {  // udq_m0
-      const S c = rad.R4 * ((th_q0 * p - T(1) + rad.B3) * T(3) + rad.x5X * T(4.0 / 3.0)) * T(2);
-      ADMP_TERM(c, hf * (A[4] * UB[0] - B[4] * UA[0]))
-      const T h = hf * c.v;
+      const T f = T(2) * (T(3) * (p * th_q0 - T(1) + B3) + T(4.0 / 3.0) * x5X);
+      const T g = T(2) * (T(3) * (p * tq0p + b3p) + T(4.0 / 3.0) * x5Xp);
+      ADMP_COEF(R4, 4, f, g, hf * (A[4] * UB[0] - B[4] * UA[0]))
+      const T h = hf * cv;
       PA[4] += h * UB[0]; PB[4] -= h * UA[0]; FA[0] -= h * B[4]; FB[0] += h * A[4];
     }
     {  // udq_m1
-      const S c = rad.R4 * (th_q1 * p - T(1) + rad.B3) * T(-2.0 * kSqrt3);
-      ADMP_TERM(c, hf * (A[5] * UB[1] + A[6] * UB[2] - B[5] * UA[1] - B[6] * UA[2]))
-      const T h = hf * c.v;
+      const T f = T(-2.0 * kSqrt3) * (p * th_q1 - T(1) + B3), g = T(-2.0 * kSqrt3) * (p * tq1p + b3p);
+      ADMP_COEF(R4, 4, f, g, hf * (A[5] * UB[1] + A[6] * UB[2] - B[5] * UA[1] - B[6] * UA[2]))
+      const T h = hf * cv;
       PA[5] += h * UB[1]; PA[6] += h * UB[2]; PB[5] -= h * UA[1]; PB[6] -= h * UA[2];
       FA[1] -= h * B[5]; FA[2] -= h * B[6]; FB[1] += h * A[5]; FB[2] += h * A[6];
     }
     {  // udud_m0 (uscales = 1, pme.py:472)
-      const S c = rad.R3 * ((th_d0 - T(1) + rad.B3) * T(3) + rad.x3X) * T(-2.0 / 3.0);
-      ADMP_TERM(c, UA[0] * UB[0])
-      FA[0] += c.v * UB[0]; FB[0] += c.v * UA[0];
+      const T f = T(-2.0 / 3.0) * (T(3) * (th_d0 - T(1) + B3) + x3X), g = T(-2.0 / 3.0) * (T(3) * (td0p + b3p) + x3Xp);
+      ADMP_COEF(R3, 3, f, g, UA[0] * UB[0])
+      FA[0] += cv * UB[0]; FB[0] += cv * UA[0];
     }
     {  // udud_m1
-      const S c = rad.R3 * (th_c - T(1) + rad.B3 - rad.x3X * T(2.0 / 3.0));
-      ADMP_TERM(c, UA[1] * UB[1] + UA[2] * UB[2])
-      FA[1] += c.v * UB[1]; FA[2] += c.v * UB[2]; FB[1] += c.v * UA[1]; FB[2] += c.v * UA[2];
+      const T f = th_c - T(1) + B3 - T(2.0 / 3.0) * x3X, g = tcp + b3p - T(2.0 / 3.0) * x3Xp;
+      ADMP_COEF(R3, 3, f, g, UA[1] * UB[1] + UA[2] * UB[2])
+      FA[1] += cv * UB[1]; FA[2] += cv * UB[2]; FB[1] += cv * UA[1]; FB[2] += cv * UA[2];
     }
     ADMP_FENCE9(PA); ADMP_FENCE9(PB); ADMP_FENCE3(FA); ADMP_FENCE3(FB); ADMP_FENCE2(e, dedr);
   }
-#undef ADMP_TERM
+#undef ADMP_COEF
 
   // ---- phase 4: transverse gradient from rotational invariance, back to the global frame
   T gx = gen_toward_x(PA, A) + gen_toward_x(PB, B);
