@@ -262,7 +262,8 @@ struct EngineBase {
 template <class T>
 struct Engine : EngineBase {
   // per-atom
-  DevBuf sites, grad, pot, fld_pair, fld_recip, field, energies_d, fmax_d;
+  DevBuf sites, grad, pot, fld_pair, fld_recip, field, energies_d;
+  bool fmax_clean = false, slot_clean[E_SLOTS] = {false};
   // staging for host-pointer calls
   DevBuf s_pos, s_Q, s_pol, s_thole, s_U, s_out, s_dQ, s_par;
   // mesh
@@ -279,7 +280,7 @@ struct Engine : EngineBase {
 
   ~Engine() override {
     destroy_plans();
-    for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &fmax_d, &s_pos, &s_Q, &s_pol,
+    for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtab, &fft_work, &binv_d, &scan_scratch, &bin_cells,
                       &bin_sorted, &bin_scan, &home_list})
       b->release();
@@ -495,14 +496,15 @@ struct Engine : EngineBase {
     sites.need(sizeof(Site<T>) * (size_t)na);
     pot.need(9 * (size_t)na * sizeof(T));
     energies_d.need(E_SLOTS * sizeof(double));
-    fmax_d.need(sizeof(unsigned long long));
     if (lpol) {
       fld_pair.need(3 * (size_t)na * sizeof(T));
       fld_recip.need(3 * (size_t)na * sizeof(T));
       field.need(3 * (size_t)na * sizeof(T));
     }
     ensure_bins(na);
-    HIP_TRY(hipMemsetAsync(energies_d.p, 0, E_SLOTS * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(energies_d.p, 0, E_SLOTS * sizeof(double), stream));   // energies and the max|field| word
+    fmax_clean = true;
+    for (bool& c : slot_clean) c = true;
     { TIMED("prepare_sites"); launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, ev.U, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>()); }
     if (snranks > 1) {
       home_list.need(sizeof(int) * (size_t)na + sizeof(int));
@@ -544,7 +546,8 @@ struct Engine : EngineBase {
   // spectrum buffer in the k-space layout [K0][ny][K2/2+1]: energy into `slot`, multiply by G
   void stage_kspace(T* spec_p, int slot) {
     need_eval();
-    HIP_TRY(hipMemsetAsync(energies_d.as<double>() + slot, 0, sizeof(double), stream));
+    if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + slot, 0, sizeof(double), stream));
+    slot_clean[slot] = false;
     TIMED("kspace");
     launch_kspace<T>(stream, K, nyown(), gtab.as<T>(), spec_p, energies_d.as<double>(), slot);
   }
@@ -553,14 +556,21 @@ struct Engine : EngineBase {
     TIMED("gather_field");
     launch_gather_field<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.g, mesh_p, fld_recip.as<T>(), ev.home);
   }
-  double stage_field_finish() {
+  // max|field| lives in the last word of the energies buffer (bit pattern of a non-negative double), so that one
+  // device->host copy can fetch it together with the energies
+  unsigned long long* fmax_word() { return reinterpret_cast<unsigned long long*>(energies_d.as<double>() + E_FMAX); }
+  void launch_field_finish_only() {
     need_eval();
-    HIP_TRY(hipMemsetAsync(fmax_d.p, 0, sizeof(unsigned long long), stream));
-    { TIMED("field_finish");
-      launch_field_finish<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
-                             (T)kappa, field.as<T>(), fmax_d.as<unsigned long long>(), ev.home); }
+    if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
+    fmax_clean = false;
+    TIMED("field_finish");
+    launch_field_finish<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
+                           (T)kappa, field.as<T>(), fmax_word(), ev.home);
+  }
+  double stage_field_finish() {
+    launch_field_finish_only();
     unsigned long long bits = 0;
-    HIP_TRY(hipMemcpyAsync(&bits, fmax_d.p, sizeof(bits), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&bits, fmax_word(), sizeof(bits), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     double fmax;
     std::memcpy(&fmax, &bits, sizeof(fmax));
@@ -587,15 +597,23 @@ struct Engine : EngineBase {
     launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out);
   }
   // closes the evaluation: E_out = (real, recip[slot], self, penalty) of THIS rank's share
-  void stage_finish(T* grad_p, T* dQl, int recip_slot, double* E) {
+  void launch_finish_only(T* grad_p, T* dQl) {
     need_eval();
-    { TIMED("finish");
-      launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
-                       dQl, energies_d.as<double>(), ev.home, ev.n_home); }
+    TIMED("finish");
+    launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
+                     dQl, energies_d.as<double>(), ev.home, ev.n_home);
+  }
+  // one device->host copy + sync: energies (and the max|field| word, returned)
+  double read_energies(int recip_slot, double* E) {
     double Eh[E_SLOTS];
     HIP_TRY(hipMemcpyAsync(Eh, energies_d.p, sizeof(Eh), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     E[0] = Eh[E_REAL]; E[1] = Eh[recip_slot]; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
+    return Eh[E_FMAX];   // same bits as the device word
+  }
+  void stage_finish(T* grad_p, T* dQl, int recip_slot, double* E) {
+    launch_finish_only(grad_p, dQl);
+    read_energies(recip_slot, E);
     ev.active = false;
   }
 
@@ -642,7 +660,7 @@ struct Engine : EngineBase {
 
     // phi_valid: the mesh holds phi = c2r(G S) of the CURRENT dipoles (last SCF field evaluation, no update since):
     // the closing gather can then reuse it instead of spreading and transforming again.
-    bool phi_valid = false, done = false;
+    bool phi_valid = false, done = false, finished = false;
     int cyc = 0, flag = 1;
     if (lpol) {
       ARG_CHECK(max_cycle >= 1, "max_cycle must be >= 1");
@@ -652,14 +670,19 @@ struct Engine : EngineBase {
         // with the full kernels -- they produce dE/dU alongside the gradient -- so that, when the check passes
         // again, the step is already finished (no separate field kernels, no second pass).  Same arithmetic and
         // same (U, flag, i) as the plain loop; a failed check only costs the difference between the kernels.
+        // The closing kernel is enqueued speculatively as well, so the step has ONE host synchronisation.
         stage_pair_full(gbuf, fld_pair.as<T>());
         recip_pass(E_SCF_RECIP);
         stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>());
-        const double fmax = stage_field_finish();
+        launch_field_finish_only();
+        launch_finish_only(dpos ? gbuf : nullptr, dQl);
+        const double fmax = read_energies(E_SCF_RECIP, E);
         if (fmax < thresh) {
-          phi_valid = done = true;
-        } else {
+          phi_valid = done = finished = true;
+          ev.active = false;
+        } else {   // undo the speculative energy sums; gradient / dQ are rewritten by the regular closing pass
           HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_REAL, 0, sizeof(double), stream));
+          HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_SELF, 0, 2 * sizeof(double), stream));
           stage_jacobi(U);
           i = 1;
         }
@@ -683,7 +706,7 @@ struct Engine : EngineBase {
       if (!phi_valid) recip_pass(E_RECIP);
       stage_gather(mesh.as<T>(), gbuf);
     }
-    stage_finish(dpos ? gbuf : nullptr, dQl, phi_valid ? E_SCF_RECIP : E_RECIP, E);
+    if (!finished) stage_finish(dpos ? gbuf : nullptr, dQl, phi_valid ? E_SCF_RECIP : E_RECIP, E);
 
     if (!on_device) {
       if (dpos_) HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));

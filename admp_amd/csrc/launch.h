@@ -42,7 +42,7 @@ struct Topology {
 };
 
 // energies[] slots on the device
-enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SCF_RECIP = 6, E_SLOTS = 8 };
+enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SCF_RECIP = 6, E_FMAX = 7 /* bit pattern */, E_SLOTS = 8 };
 
 // ---- atom_kernels.hip
 template <class T>

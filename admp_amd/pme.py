@@ -91,6 +91,8 @@ class ADMPPmeForce(HipForceBase):
             q = torch.as_tensor(np.asarray(Q_local, dtype=np.float64), dtype=self._dtype).to(self._device)
         if q.dim() != 2 or q.shape[0] != self.n_atoms or q.shape[1] < nh:
             raise ValueError('Q_local must be (Na, >= (lmax+1)^2)')
+        if q.shape[1] == 9 and nh == 9 and q.is_contiguous():
+            return q                       # already in the library's layout: no copy
         out = torch.zeros((self.n_atoms, 9), dtype=self._dtype, device=self._device)
         out[:, :nh] = q[:, :nh]
         return out
