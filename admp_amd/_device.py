@@ -181,7 +181,9 @@ class HipForceBase:
         return int(self._L.admp_num_pairs(self._h))
 
     # ---- measurement ---------------------------------------------------------------------------------------
-    def profile(self, on=True):
+    def profile(self, on=True, only=None):
+        """Bracket kernel launches with HIP events; `only` restricts it to one label (e.g. 'pair_full')."""
+        _lib.check(self._h, self._L.admp_profile_filter(self._h, only.encode() if only else None), 'admp_profile_filter')
         _lib.check(self._h, self._L.admp_profile_enable(self._h, 1 if on else 0), 'admp_profile_enable')
 
     def profile_reset(self):

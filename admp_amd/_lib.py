@@ -38,6 +38,7 @@ PROTOTYPES = {
     'admp_stage_begin': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _ip]),
     'admp_stage': (_i32, [_vp, _i32, _vp, _vp, _i32, _dp]),
     'admp_profile_enable': (_i32, [_vp, _i32]),
+    'admp_profile_filter': (_i32, [_vp, _c.c_char_p]),
     'admp_profile_reset': (_i32, [_vp]),
     'admp_profile_count': (_i32, [_vp]),
     'admp_profile_entry': (_i32, [_vp, _i32, _c.POINTER(_c.c_char_p), _dp, _c.POINTER(_i64)]),

@@ -71,6 +71,7 @@ struct DevBuf {
 // per-label launch timing with HIP events on the engine's stream
 struct Profiler {
   bool on = false;
+  std::string only;   // when non-empty, only sections with exactly this label are bracketed
   struct Rec { int label; hipEvent_t a, b; };
   std::vector<std::string> labels;
   std::map<std::string, int> index;
@@ -124,7 +125,9 @@ struct Profiler {
 
 struct Scoped {
   Profiler& p; hipStream_t st; Profiler::Rec r; bool active;
-  Scoped(Profiler& p_, const char* name, hipStream_t st_) : p(p_), st(st_), active(p_.on) { if (active) p.begin(name, st, r); }
+  Scoped(Profiler& p_, const char* name, hipStream_t st_) : p(p_), st(st_), active(p_.on && (p_.only.empty() || p_.only == name)) {
+    if (active) p.begin(name, st, r);
+  }
   ~Scoped() { if (active) p.end(st, r); }
 };
 #define TIMED(name) Scoped scoped_timer_(prof, name, stream)
@@ -1007,6 +1010,9 @@ int admp_stage(admp_handle* h, int what, void* a, void* b, int iarg, double* dou
 
 int admp_profile_enable(admp_handle* h, int on) {
   return guarded(h, [&](EngineBase& e) { e.prof.collect(e.stream); e.prof.on = on != 0; });
+}
+int admp_profile_filter(admp_handle* h, const char* label) {
+  return guarded(h, [&](EngineBase& e) { e.prof.only = label ? label : ""; });
 }
 int admp_profile_reset(admp_handle* h) {
   return guarded(h, [&](EngineBase& e) { e.prof.reset(e.stream); });

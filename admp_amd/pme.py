@@ -74,9 +74,6 @@ class ADMPPmeForce(HipForceBase):
     def refresh_calculators(self):
         _lib.check(self._h, self._L.admp_set_ewald(self._h, float(self.kappa), int(self.K1), int(self.K2), int(self.K3),
                                                    int(self.lmax), 1 if self.lpol else 0), 'admp_set_ewald')
-        if not (self.K1 == self.K2):
-            warnings.warn('K1 != K2: the reference swaps the x/y k-columns (admp/recip.py:339-340) and is not '
-                          'self-consistent here; this implementation uses the physically consistent assignment')
         self.get_energy = self.generate_get_energy()
         self.get_forces = self._generate_get_forces()
         if self.lpol:
@@ -106,6 +103,10 @@ class ADMPPmeForce(HipForceBase):
     def _evaluate_on_stream(self, positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales, U_init,
                             want_grad, want_dQ, maxiter, thresh):
         L, h, na = self._L, self._h, self.n_atoms
+        if self.K1 != self.K2 and not getattr(self, '_warned_k', False):
+            self._warned_k = True
+            warnings.warn('K1 != K2: the reference swaps the x/y k-columns (admp/recip.py:339-340) and is not '
+                          'self-consistent here; this implementation uses the physically consistent assignment')
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
         Q = self._pad_Q(Q_local)

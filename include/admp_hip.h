@@ -145,6 +145,8 @@ int admp_stage(admp_handle* h, int what, void* a, void* b, int iarg, double* dou
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream. */
 int admp_profile_enable(admp_handle* h, int on);
+/* restrict the bracketing to one kernel label (e.g. "pair_full"); NULL or "" = every kernel */
+int admp_profile_filter(admp_handle* h, const char* label);
 int admp_profile_reset(admp_handle* h);
 /* number of distinct kernel labels seen; label / accumulated ms / launch count of entry idx */
 int admp_profile_count(admp_handle* h);
