@@ -15,7 +15,7 @@ if '--' in args:
     args = args[:k]
 src = args[0]
 flt = args[1] if len(args) > 1 else ''
-cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
+cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-fno-slp-vectorize',
        '-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', '/dev/null'] + extra
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
