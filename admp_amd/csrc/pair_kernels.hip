@@ -149,7 +149,8 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
 
 // lanes of a wavefront that share one row.  Few lanes = fewer idle lanes at the row tail and less shuffle
 // folding; many lanes = enough wavefronts to fill the chip when there are few rows.  Measured (f32, polarizable):
-// 1M rows LPR 2/4/8/16 -> 0.958/1.018/1.056/1.128 ms; 98k rows 2/4/8 -> 0.125/0.121/0.125 ms.
+// 1M rows LPR 1/2/4/8 -> 0.749/0.493/0.502/0.534 ms; 98k rows 2/4/8 -> 0.068/0.064/0.065 ms; 3k rows 4/8/16/32 ->
+// 38/23/18/24 us.
 int pair_lanes_per_row(int n_rows) {
   static int forced = -2;
   if (forced == -2) {
@@ -158,7 +159,7 @@ int pair_lanes_per_row(int n_rows) {
     forced = (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32) ? x : -1;
   }
   if (forced > 0) return forced;
-  return n_rows >= 262144 ? 2 : (n_rows >= 32768 ? 4 : 8);
+  return n_rows >= 262144 ? 2 : (n_rows >= 32768 ? 4 : (n_rows >= 8192 ? 8 : 16));
 }
 
 // minimum waves per SIMD requested from the register allocator for the polarizable kernel
