@@ -17,6 +17,16 @@ namespace admp {
 
 constexpr int kPairBlock = 256;
 
+// XCD-aware block order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with
+// its own L2; remapping block b -> (b % 8) * ceil(n/8) + b / 8 gives every XCD one contiguous range of rows, so the
+// partner rows gathered by neighbouring workgroups are shared in that XCD's L2 instead of being fetched by all eight.
+__device__ __forceinline__ long xcd_block(unsigned b, unsigned n) {
+  const unsigned per = (n + 7u) / 8u;
+  const unsigned m = (b & 7u) * per + (b >> 3);
+  return m < n ? (long)m : -1;
+}
+static inline unsigned xcd_grid(unsigned n) { return ((n + 7u) / 8u) * 8u; }
+
 template <class T, int LPR>
 __device__ __forceinline__ T row_reduce(T v) {
 #pragma unroll
@@ -40,10 +50,12 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
                                                           const Site<T>* __restrict__ sites, Box<T> box,
                                                           ScaleTab<T> tab, T kappa, T* __restrict__ grad,
                                                           T* __restrict__ pot, double* energies,
-                                                          const int* __restrict__ rows, T* __restrict__ fld) {
+                                                          const int* __restrict__ rows, T* __restrict__ fld,
+                                                          unsigned nblocks) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
-  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const long blk = xcd_block(blockIdx.x, nblocks);
+  const long t = (blk < 0 ? (long)na * LPR : blk * kPairBlock) + threadIdx.x;
   const int slot = (int)(t / LPR), sub = (int)(t % LPR);
   // `na` counts the rows this launch owns; with a row list (multi-GPU: the rank's home atoms) slot -> atom
   const int row = slot < na ? (rows ? rows[slot] : slot) : na;
@@ -85,10 +97,11 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __
                                                            const int* __restrict__ col,
                                                            const Site<T>* __restrict__ sites, Box<T> box,
                                                            ScaleTab<T> tab, T kappa, T* __restrict__ fld,
-                                                           const int* __restrict__ rows) {
+                                                           const int* __restrict__ rows, unsigned nblocks) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
-  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const long blk = xcd_block(blockIdx.x, nblocks);
+  const long t = (blk < 0 ? (long)na * LPR : blk * kPairBlock) + threadIdx.x;
   const int slot = (int)(t / LPR), sub = (int)(t % LPR);
   const int row = slot < na ? (rows ? rows[slot] : slot) : na;
   T F[3] = {0, 0, 0};
@@ -196,14 +209,14 @@ void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>*
   const int minw = pair_min_waves<T>();
 #define CALL(L)                                                                                                        \
   if (lpol && minw >= 2)                                                                                               \
-    k_pair_full<T, true, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \
-                                                                       grad, pot, energies, rows, fld);                \
+    k_pair_full<T, true, L, 2><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                      \
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L));               \
   else if (lpol)                                                                                                       \
-    k_pair_full<T, true, L, 1><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa,  \
-                                                                       grad, pot, energies, rows, fld);                \
+    k_pair_full<T, true, L, 1><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                      \
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L));               \
   else                                                                                                                 \
-    k_pair_full<T, false, L, 2><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
-                                                                        grad, pot, energies, rows, fld)
+    k_pair_full<T, false, L, 2><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                     \
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L))
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
@@ -212,7 +225,9 @@ template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                        const ScaleTab<T>& tab, T kappa, T* fld, const int* rows) {
   const int lpr = pair_lanes_per_row(na);
-#define CALL(L) k_pair_field<T, L><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, fld, rows)
+#define CALL(L)                                                                                              \
+  k_pair_field<T, L><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
+                                                                       fld, rows, grid_for(na, L))
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
