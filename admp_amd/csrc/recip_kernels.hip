@@ -389,8 +389,10 @@ void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* b
 template <class T>
 void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec, double* energies, int slot) {
   const long n = (long)K[0] * ny * (K[2] / 2 + 1);
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  // few, fat workgroups: every workgroup ends in one f64 atomic on the same energy word
+  int blocks = (int)((n + 2047) / 2048);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
   k_kspace<T><<<blocks, 256, 0, st>>>(K[0], ny, K[2], gtab, spec, energies, slot);
 }
 
