@@ -208,7 +208,42 @@ def aggregate_ns_per_day(t_step_s, world):
     return world * 0.0864 * DT_FS / t_step_s
 
 
+def slab_child(outpath):
+    """One rank of the slab-decomposed strong-scaling leg (spawned by main(), own process group)."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from admp_amd.parallel import TorchComm
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    backend = os.environ.get('ADMP_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(seconds=150))
+    else:
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=150))
+    rdev = 'cuda' if backend == 'nccl' else 'cpu'
+    w3 = make_workload(os.environ.get('ADMP_BENCH_SCALE', 'S3'))
+    f3, a3 = make_force(w3, TorchComm())
+    dt3, rep3, cyc3 = run_timed(f3, a3, 5, 2, dist.barrier, only=None)
+    dt3 = reduce_max_seconds(dt3, dist, rdev)
+    if rank == 0:
+        res = {'workload': w3['desc'], 'decomposition': 'x-slab over %d GPUs (RCCL all-to-all transposes, ghost-plane '
+               'shifts, sum all-reduce of dipoles/gradient)' % world, 'scaling': 'strong',
+               'n_atoms': 3 * w3['n_mol'], 'n_pairs': int(f3.n_pairs), 'home_atoms_rank0': int(f3.n_home),
+               'ms_per_step': round(dt3 / 5 * 1e3, 3), 'ns_per_day': round(0.0864 / (dt3 / 5), 3),
+               'scf_cycles_per_step': round(cyc3, 2), 'dtype': 'f32',
+               'rank0_kernel_ms_per_step': {k: round(v[0] / 5, 4) for k, v in sorted(rep3.items())}}
+        with open(outpath, 'w') as fh:
+            json.dump(res, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == '--slab-child':
+        return slab_child(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -254,24 +289,38 @@ def main():
     if world == 1:
         head['rebuild_ms'] = time_list_rebuild(f, w)
 
-    # strong-scaling leg of the real multi-GPU path: the 1M-atom box, x-slab decomposed over all ranks
+    # Strong-scaling leg of the real multi-GPU path (1M-atom box, x-slab decomposed over all ranks).  It runs in CHILD
+    # processes (one per rank, own process group on MASTER_PORT + 17) so that a failing or hanging collective can
+    # never take the headline line down: the parents only wait, with a time limit, and merge the child's JSON.
     slab_scale = None
     if world > 1 and not opt.no_scale and opt.workload == 'S1':
+        import subprocess
+        import tempfile
+        f = None
+        torch.cuda.empty_cache()
+        outpath = os.path.join(tempfile.gettempdir(), 'admp_slab_%s_%d.json' % (os.environ.get('MASTER_PORT', '0'), world))
+        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get('MASTER_PORT', '29500')) + 17))
+        for k in list(env):                      # the children rendezvous on their own store, not on torchrun's agent store
+            if k.startswith('TORCHELASTIC') or k.startswith('TORCH_NCCL') or k == 'GROUP_RANK':
+                env.pop(k)
+        env['TORCHELASTIC_USE_AGENT_STORE'] = 'False'
+        if rank == 0 and os.path.exists(outpath):
+            os.remove(outpath)
+        barrier()
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--slab-child', outpath], env=env,
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
         try:
-            from admp_amd.parallel import TorchComm
-            f = None
-            w3 = make_workload(os.environ.get('ADMP_BENCH_SCALE', 'S3'))
-            f3, a3 = make_force(w3, TorchComm())
-            dt3, rep3, cyc3 = run_timed(f3, a3, 5, 2, barrier)
-            dt3 = reduce_max_seconds(dt3, dist, rdev)
-            slab_scale = {'workload': w3['desc'], 'decomposition': 'x-slab over %d GPUs (RCCL all-to-all transposes, '
-                          'ghost-plane shifts, sum all-reduce of dipoles/gradient)' % world, 'scaling': 'strong',
-                          'n_atoms': 3 * w3['n_mol'], 'n_pairs': int(f3.n_pairs), 'home_atoms_rank0': int(f3.n_home),
-                          'ms_per_step': round(dt3 / 5 * 1e3, 3), 'ns_per_day': round(0.0864 / (dt3 / 5), 3),
-                          'scf_cycles_per_step': round(cyc3, 2), 'dtype': 'f32',
-                          'rank0_kernel_ms_per_step': {k: round(v[0] / 5, 4) for k, v in sorted(rep3.items())}}
-        except Exception as e:      # the headline line must still be printed
-            slab_scale = {'error': repr(e)}
+            _, err = child.communicate(timeout=360)
+            ok = child.returncode == 0
+        except subprocess.TimeoutExpired:
+            child.kill()
+            _, err = child.communicate()
+            ok = False
+        if rank == 0:
+            if ok and os.path.exists(outpath):
+                slab_scale = json.load(open(outpath))
+            else:
+                slab_scale = {'error': 'slab leg failed or timed out: ' + (err or b'').decode(errors='replace')[-400:]}
 
     if rank == 0:
         out = {
