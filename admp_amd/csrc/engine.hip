@@ -590,6 +590,8 @@ struct Engine : EngineBase {
       HIP_TRY(hipMemsetAsync(grad_p, 0, 3 * (size_t)top.na * sizeof(T), stream));
       HIP_TRY(hipMemsetAsync(pot.p, 0, 9 * (size_t)top.na * sizeof(T), stream));
     }
+    if (!slot_clean[E_REAL]) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_REAL, 0, sizeof(double), stream));
+    slot_clean[E_REAL] = false;
     TIMED("pair_full");
     launch_pair_full<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, lpol, grad_p, pot.as<T>(),
                         energies_d.as<double>(), ev.home, fld_out);
@@ -684,7 +686,6 @@ struct Engine : EngineBase {
           phi_valid = done = finished = true;
           ev.active = false;
         } else {   // undo the speculative energy sums; gradient / dQ are rewritten by the regular closing pass
-          HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_REAL, 0, sizeof(double), stream));
           HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_SELF, 0, 2 * sizeof(double), stream));
           stage_jacobi(U);
           i = 1;
@@ -783,8 +784,8 @@ struct Engine : EngineBase {
       case ADMP_ST_GATHER_FIELD: stage_gather_field((const T*)a); break;
       case ADMP_ST_FIELD_FINISH: ARG_CHECK(dout, "null"); dout[0] = stage_field_finish(); break;
       case ADMP_ST_JACOBI: stage_jacobi((T*)a); break;
-      case ADMP_ST_PAIR_FULL: stage_pair_full((T*)a); break;
-      case ADMP_ST_GATHER: stage_gather((const T*)a, (T*)b); break;
+      case ADMP_ST_PAIR_FULL: stage_pair_full((T*)a, (iarg && lpol) ? fld_pair.as<T>() : nullptr); break;
+      case ADMP_ST_GATHER: stage_gather((const T*)a, (T*)b, (iarg && lpol) ? fld_recip.as<T>() : nullptr); break;
       case ADMP_ST_FINISH: ARG_CHECK(dout, "null"); stage_finish((T*)a, (T*)b, iarg ? E_SCF_RECIP : E_RECIP, dout); break;
       default: throw Err{ADMP_E_ARG, "unknown stage"};
     }

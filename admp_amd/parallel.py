@@ -233,11 +233,36 @@ class SlabPme(ADMPPmeForce):
         self.n_home = int(nhome.value)
         B = self._buffers()
         mesh = B['mesh']
-        phi_valid, cyc, flag = False, 0, True
+        phi_valid, cyc, flag, done = False, 0, True, False
+        grad = torch.empty((na, 3), dtype=self._dtype, device=self._device)
+
+        def jacobi(U):
+            if c.size > 1:
+                Unew = torch.zeros_like(U)
+                self._stage(_lib.ST_JACOBI, Unew)
+                c.all_reduce_sum(Unew)
+                self._stage(_lib.ST_SET_U, Unew)
+                return Unew
+            self._stage(_lib.ST_JACOBI, U)
+            return U
+
         if self.lpol:
             fm = (ctypes.c_double * 1)()
-            i = 0
-            for i in range(maxiter):                       # admp/pme.py:132-138
+            start = 0
+            if getattr(self, '_warm_regime', False):
+                # steady-state regime (previous call passed its first check): first cycle with the full kernels, which
+                # also deliver dE/dU -- if the check passes again the step is finished (engine.hip, `warm_regime`)
+                self._stage(_lib.ST_PAIR_FULL, grad, None, 1)
+                self._recip(scf=True)
+                self._stage(_lib.ST_GATHER, mesh, grad, 1)
+                self._stage(_lib.ST_FIELD_FINISH, dout=fm)
+                if c.all_reduce_max(fm[0]) < thresh:
+                    phi_valid = done = True
+                else:
+                    U = jacobi(U)
+                    start = 1
+            i = 0 if done else start
+            for i in ([] if done else range(start, maxiter)):       # admp/pme.py:132-138
                 self._stage(_lib.ST_PAIR_FIELD)
                 self._recip(scf=True)
                 self._stage(_lib.ST_GATHER_FIELD, mesh)
@@ -245,21 +270,15 @@ class SlabPme(ADMPPmeForce):
                 if c.all_reduce_max(fm[0]) < thresh:
                     phi_valid = True
                     break
-                if c.size > 1:
-                    Unew = torch.zeros_like(U)
-                    self._stage(_lib.ST_JACOBI, Unew)
-                    c.all_reduce_sum(Unew)
-                    U = Unew
-                    self._stage(_lib.ST_SET_U, U)
-                else:
-                    self._stage(_lib.ST_JACOBI, U)
-            cyc = i
-            flag = (i != maxiter - 1)                      # admp/pme.py:139-143
-        grad = torch.empty((na, 3), dtype=self._dtype, device=self._device)
-        self._stage(_lib.ST_PAIR_FULL, grad)
-        if not phi_valid:
-            self._recip(scf=False)
-        self._stage(_lib.ST_GATHER, mesh, grad)
+                U = jacobi(U)
+            cyc = min(i, maxiter - 1)
+            flag = (cyc != maxiter - 1)                    # admp/pme.py:139-143
+            self._warm_regime = (cyc == 0)
+        if not done:
+            self._stage(_lib.ST_PAIR_FULL, grad)
+            if not phi_valid:
+                self._recip(scf=False)
+            self._stage(_lib.ST_GATHER, mesh, grad)
         E = (ctypes.c_double * 4)()
         self._stage(_lib.ST_FINISH, grad if want_grad else None, None, 1 if phi_valid else 0, E)
         Et = torch.tensor(list(E), dtype=torch.float64, device=self._device)

@@ -135,8 +135,10 @@ enum {
   ADMP_ST_GATHER_FIELD = 7,  /* a = phi mesh (local, ghosts filled): reciprocal dE/dU of the home atoms            */
   ADMP_ST_FIELD_FINISH = 8,  /* dout[0] = max |dE/dU| over this rank's polarizable home atoms                      */
   ADMP_ST_JACOBI = 9,        /* a = U_new (Na,3): home entries <- U - field*pol/D (other entries untouched)         */
-  ADMP_ST_PAIR_FULL = 10,    /* a = gradient (Na,3): zeroed, home rows written; real-space energy accumulated      */
-  ADMP_ST_GATHER = 11,       /* a = phi mesh, b = gradient: adds reciprocal dE/dr, dE/dQ of the home atoms          */
+  ADMP_ST_PAIR_FULL = 10,    /* a = gradient (Na,3): zeroed, home rows written; real-space energy accumulated;
+                                iarg 1: the real-space dE/dU is produced as well (speculative first SCF cycle)      */
+  ADMP_ST_GATHER = 11,       /* a = phi mesh, b = gradient: adds reciprocal dE/dr, dE/dQ of the home atoms;
+                                iarg 1: the reciprocal dE/dU is produced as well                                   */
   ADMP_ST_FINISH = 12        /* a = gradient (or NULL), b = dE/dQ_local (or NULL), iarg = which reciprocal slot,
                                 dout[4] = this rank's (real, recip, self, penalty) energies                        */
 };

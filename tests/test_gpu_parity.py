@@ -693,3 +693,44 @@ def test_update_neighbors_equals_explicit_pair_list(precision):
     E1, G1 = g.get_forces(pos, box, None, *rest)
     scale = max(abs(p) for p in f.energy_parts)
     assert abs(E1 - E0) < 1e-11 * scale and rel(G1, G0) < 1e-11 and g.n_cycle == f.n_cycle
+
+
+def test_slab_warm_regime_matches_fused_path(precision):
+    """Staged driver (1 and 2 ranks), repeated warm-started calls: the speculative first cycle must give the fused
+    single-GPU result both when the check passes and when it fails."""
+    import threading
+    from admp_amd.parallel import SlabPme, ThreadComm
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    pos, box, at, ai, cov, par, pairs = water_system(125, 5, True)
+    args = (pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    ref = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    E0, G0 = ref.get_forces(*args)
+    U0 = ref.U_ind.copy()
+    E1, G1 = ref.get_forces(*args, U_init=U0)
+    for nranks in (1, 2):
+        world = ThreadComm.World(nranks)
+        out, errors = [None] * nranks, []
+
+        def work(rank):
+            try:
+                f = SlabPme(ThreadComm(world, rank), box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+                a = f.get_forces(*args)                       # cold
+                b = f.get_forces(*args, U_init=U0)            # plain loop, passes at once -> arms the warm regime
+                c = f.get_forces(*args, U_init=U0)            # speculative cycle, passes
+                n_c = f.n_cycle
+                d = f.get_forces(*args)                       # speculative cycle fails (U_init = 0), falls back
+                out[rank] = (a, b, c, n_c, d, f.n_cycle, f.U_ind)
+            except Exception as e:      # noqa: BLE001
+                errors.append(repr(e))
+                world.barrier.abort()
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        [t.start() for t in ts]
+        [t.join(timeout=300) for t in ts]
+        assert not errors, errors
+        scale = max(abs(p) for p in ref.energy_parts)
+        for (a, b, c, n_c, d, n_d, U) in out:
+            assert abs(a[0] - E0) < 1e-10 * scale and rel(a[1], G0) < 1e-10
+            assert abs(b[0] - E1) < 1e-10 * scale and rel(b[1], G1) < 1e-10
+            assert n_c == 0 and abs(c[0] - E1) < 1e-10 * scale and rel(c[1], G1) < 1e-10
+            assert n_d == 2 and abs(d[0] - E0) < 1e-10 * scale and rel(d[1], G0) < 1e-10 and rel(U, U0) < 1e-10
