@@ -280,6 +280,38 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const 
   }
 }
 
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_scalar_sites(int na, const T* __restrict__ pos, const T* __restrict__ vals,
+                                                             int stride, int chan, double self_coef,
+                                                             Site<T>* __restrict__ sites, double* energies) {
+  const int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  double s2 = 0.0;
+  if (i < na) {
+    Site<T> s;
+    load3(pos, i, s.r);
+    const T c = vals[(long)stride * i + chan];
+    s.Q[0] = c;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) s.Q[k] = T(0);
+    s.U[0] = s.U[1] = s.U[2] = T(0);
+    s.p6 = s.thole = T(0);
+    s.pad[0] = s.pad[1] = s.pad[2] = T(0);
+    sites[i] = s;
+    s2 = (double)c * (double)c;
+  }
+  s2 = block_reduce_sum<kAtomBlock>(s2);
+  if (threadIdx.x == 0) atomicAdd(&energies[E_SELF], self_coef * s2);
+}
+
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_scale_add(int na, const T* __restrict__ vals, int stride, int chan,
+                                                          const T* __restrict__ v, T* __restrict__ grad) {
+  const int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (i >= na) return;
+  const T c = vals[(long)stride * i + chan];
+  grad[3 * i] += c * v[3 * i]; grad[3 * i + 1] += c * v[3 * i + 1]; grad[3 * i + 2] += c * v[3 * i + 2];
+}
+
 static inline int nblk(int n) { return (n + kAtomBlock - 1) / kAtomBlock; }
 
 template <class T>
@@ -313,7 +345,19 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
                                                     energies, list, nlist);
 }
 
+template <class T>
+void launch_scalar_sites(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, double self_coef,
+                         Site<T>* sites, double* energies) {
+  k_scalar_sites<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pos, vals, stride, chan, self_coef, sites, energies);
+}
+template <class T>
+void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int chan, const T* v, T* grad) {
+  k_scale_add<T><<<nblk(na), kAtomBlock, 0, st>>>(na, vals, stride, chan, v, grad);
+}
+
 #define INST(T)                                                                                                        \
+  template void launch_scalar_sites<T>(hipStream_t, int, const T*, const T*, int, int, double, Site<T>*, double*);      \
+  template void launch_scale_add<T>(hipStream_t, int, const T*, int, int, const T*, T*);                                \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
                                         const Box<T>&, Site<T>*);                                                       \
   template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \

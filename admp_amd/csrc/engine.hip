@@ -270,21 +270,22 @@ struct Engine : EngineBase {
   // staging for host-pointer calls
   DevBuf s_pos, s_Q, s_pol, s_thole, s_U, s_out, s_dQ, s_par;
   // mesh
-  DevBuf mesh, spec, gtab, fft_work, binv_d, bin_cells, bin_sorted, bin_scan;
+  DevBuf mesh, spec, gtabs[4], fft_work, binv_d, bin_cells, bin_sorted, bin_scan;   // gtabs: Ck_1, Ck_6, Ck_8, Ck_10
+  T* gtab_cur = nullptr;
   BinScratch bins;
   rocfft_plan plan_f = nullptr, plan_b = nullptr, plan_xf = nullptr, plan_xb = nullptr;
   rocfft_execution_info info_f = nullptr;
   int planK[3] = {0, 0, 0}, planR = 0, planRank = 0;
   DevBuf home_list;
   // validity of the cached G table
-  double tab_box[9] = {0}, tab_kappa = -1;
-  int tab_which = 0, tabK[3] = {0, 0, 0}, tabY0 = 0;
+  struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0; } tabkey[4];
+  static int tab_slot(int which) { return which == 1 ? 0 : (which == 6 ? 1 : (which == 8 ? 2 : 3)); }
   bool warm_regime = false;   // previous polarizable call converged at its first SCF check
 
   ~Engine() override {
     destroy_plans();
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
-                      &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtab, &fft_work, &binv_d, &scan_scratch, &bin_cells,
+                      &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
                       &bin_sorted, &bin_scan, &home_list})
       b->release();
     free_topology();
@@ -342,7 +343,6 @@ struct Engine : EngineBase {
     if (nspec_t > nspec) nspec = nspec_t;
     mesh.need(nreal * sizeof(T));
     spec.need(nspec * 2 * sizeof(T));
-    gtab.need(nspec_t * sizeof(T));
     binv_d.need(9 * sizeof(double));
     if (planK[0] == K[0] && planK[1] == K[1] && planK[2] == K[2] && planR == snranks && planRank == srank && plan_f) return;
     destroy_plans();
@@ -382,7 +382,7 @@ struct Engine : EngineBase {
     FFT_TRY(rocfft_execution_info_create(&info_f));
     if (wmax) FFT_TRY(rocfft_execution_info_set_work_buffer(info_f, fft_work.p, wmax));
     planK[0] = K[0]; planK[1] = K[1]; planK[2] = K[2]; planR = snranks; planRank = srank;
-    tab_kappa = -1;   // mesh changed: table stale
+    for (auto& k : tabkey) k.kappa = -1;   // mesh changed: tables stale
   }
 
   void run_plan(const char* label, rocfft_plan plan, void* in, void* out) {
@@ -420,18 +420,24 @@ struct Engine : EngineBase {
   }
 
   void ensure_gtab(const double* box, const double* inv, double vol, int which) {
-    bool same = tab_kappa == kappa && tab_which == which && tabK[0] == K[0] && tabK[1] == K[1] && tabK[2] == K[2] &&
-                tabY0 == (snranks > 1 ? Y0 : 0);
-    for (int k = 0; k < 9 && same; ++k) same = tab_box[k] == box[k];
+    const int slot = tab_slot(which);
+    TabKey& key = tabkey[slot];
+    DevBuf& buf = gtabs[slot];
+    const size_t nspec_t = (size_t)K[0] * nyown() * (K[2] / 2 + 1);
+    buf.need(nspec_t * sizeof(T));
+    gtab_cur = buf.template as<T>();
+    bool same = key.kappa == kappa && key.K[0] == K[0] && key.K[1] == K[1] && key.K[2] == K[2] &&
+                key.Y0 == (snranks > 1 ? Y0 : 0);
+    for (int k = 0; k < 9 && same; ++k) same = key.box[k] == box[k];
     if (same) return;
     HIP_TRY(hipMemcpyAsync(binv_d.p, inv, 9 * sizeof(double), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));   // `inv` is a caller stack array
     {
       TIMED("gtab");
-      launch_gtab<T>(stream, K, snranks > 1 ? Y0 : 0, nyown(), binv_d.as<double>(), std::fabs(vol), kappa, which, gtab.as<T>());
+      launch_gtab<T>(stream, K, snranks > 1 ? Y0 : 0, nyown(), binv_d.as<double>(), std::fabs(vol), kappa, which, gtab_cur);
     }
-    std::memcpy(tab_box, box, sizeof(tab_box));
-    tab_kappa = kappa; tab_which = which; tabK[0] = K[0]; tabK[1] = K[1]; tabK[2] = K[2]; tabY0 = snranks > 1 ? Y0 : 0;
+    std::memcpy(key.box, box, sizeof(key.box));
+    key.kappa = kappa; key.K[0] = K[0]; key.K[1] = K[1]; key.K[2] = K[2]; key.Y0 = snranks > 1 ? Y0 : 0;
   }
 
   ScaleTab<T> make_tab(int ns, const double* mS, const double* pS) {
@@ -552,7 +558,7 @@ struct Engine : EngineBase {
     if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + slot, 0, sizeof(double), stream));
     slot_clean[slot] = false;
     TIMED("kspace");
-    launch_kspace<T>(stream, K, nyown(), gtab.as<T>(), spec_p, energies_d.as<double>(), slot);
+    launch_kspace<T>(stream, K, nyown(), gtab_cur, spec_p, energies_d.as<double>(), slot);
   }
   void stage_gather_field(const T* mesh_p) {
     need_eval();
@@ -815,30 +821,33 @@ struct Engine : EngineBase {
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, dpos, Ed); }
-    const size_t nreal = (size_t)K[0] * K[1] * K[2];
-    double eself = 0.0;
-    // self term (disp_pme.py:254-279) needs sum c_p^2: folded into the spread pass via a tiny host reduction
-    std::vector<T> ch(3 * (size_t)na);
-    HIP_TRY(hipMemcpyAsync(ch.data(), cl, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    const double kp[3] = {std::pow(kappa, 6) / 12.0, std::pow(kappa, 8) / 48.0, std::pow(kappa, 10) / 240.0};
+    // one scalar reciprocal pass per power through the same brick spread / lane-group gather as the electrostatics:
+    // the channel is packed into charge-only site rows (which also accumulates the self term, disp_pme.py:254-279)
+    sites.need(sizeof(Site<T>) * (size_t)na);
+    fld_recip.need(3 * (size_t)na * sizeof(T));
+    ensure_bins(na);
+    RecipGeom<T> gj = g;                       // scalar sites: dE/dr = c * Jac . F1 (gather_field applies g.Aop)
+    for (int k = 0; k < 9; ++k) gj.Aop[k] = g.Jac[k];
+    const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
     for (int c = 0; c < (pmax - 4) / 2; ++c) {
-      double s2 = 0.0;
-      for (int i = 0; i < na; ++i) s2 += (double)ch[3 * (size_t)i + c] * (double)ch[3 * (size_t)i + c];
-      eself -= kp[c] * s2;
       ensure_gtab(box, inv, vol, 6 + 2 * c);
-      HIP_TRY(hipMemsetAsync(mesh.p, 0, nreal * sizeof(T), stream));
-      { TIMED("spread_scalar"); launch_spread_scalar<T>(stream, na, pos, cl, 3, c, g, mesh.as<T>()); }
+      { TIMED("scalar_sites"); launch_scalar_sites<T>(stream, na, pos, cl, 3, c, kp[c], sites.as<Site<T>>(), Ed); }
+      {
+        TIMED("spread");
+        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr);
+        if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+      }
       fft_forward(mesh.as<T>(), spec.as<T>());
-      { TIMED("kspace"); launch_kspace<T>(stream, K, K[1], gtab.as<T>(), spec.as<T>(), Ed, E_RECIP); }
+      { TIMED("kspace"); launch_kspace<T>(stream, K, K[1], gtab_cur, spec.as<T>(), Ed, E_RECIP); }
       fft_inverse(spec.as<T>(), mesh.as<T>());
-      { TIMED("gather_scalar"); launch_gather_scalar<T>(stream, na, pos, cl, 3, c, g, mesh.as<T>(), dpos); }
+      { TIMED("gather_field"); launch_gather_field<T>(stream, na, sites.as<Site<T>>(), gj, mesh.as<T>(), fld_recip.as<T>(), nullptr); }
+      { TIMED("scale_add"); launch_scale_add<T>(stream, na, cl, 3, c, fld_recip.as<T>(), dpos); }
     }
     double Eh[E_SLOTS];
     HIP_TRY(hipMemcpyAsync(Eh, Ed, sizeof(Eh), hipMemcpyDeviceToHost, stream));
     if (dpos_ && !on_device) HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    E[0] = Eh[E_REAL]; E[1] = Eh[E_RECIP]; E[2] = eself;
+    E[0] = Eh[E_REAL]; E[1] = Eh[E_RECIP]; E[2] = Eh[E_SELF];
   }
 
   void tt(const void* pos_, const double* box, const void* abqc_, int ns, const double* mS, double* E, void* dpos_,

@@ -66,6 +66,14 @@ template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
                    const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
                    const int* list, int nlist);
+// dispersion: site rows carrying one scalar channel (Q[0] = vals[i*stride+chan], no dipoles/quadrupoles); also
+// accumulates coef * sum_i vals^2 into energies[E_SELF] (the self term of admp/disp_pme.py:254-279)
+template <class T>
+void launch_scalar_sites(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, double self_coef,
+                         Site<T>* sites, double* energies);
+// grad[i] += vals[i*stride+chan] * v[i]   (scalar site: dE/dr = c * Jac . F1)
+template <class T>
+void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int chan, const T* v, T* grad);
 // atoms whose lowest stencil plane lies in the local slab (local base index < width): appended to `list`
 template <class T>
 void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
@@ -120,10 +128,6 @@ template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
                   T* mesh, const int* list);
 size_t spread_scan_bytes(int ncell);
-// scalar (lmax = 0) channel of the dispersion path: value column `chan` of a (na, stride) array
-template <class T>
-void launch_spread_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
-                          const RecipGeom<T>& g, T* mesh);
 // k-space layout [K0][ny][K2/2+1] holding mesh rows y0 .. y0+ny-1 (ny = K1, y0 = 0 on one rank).
 // which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels
 template <class T>
@@ -139,10 +143,6 @@ void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
                          T* fld_recip, const int* list);
-template <class T>
-void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
-                          const RecipGeom<T>& g, const T* phi, T* grad);
-
 // ---- cell_kernels.hip: positions -> half pair list (cell list), two phases so that the caller can size `pairs`
 struct CellScratch {
   int n[3] = {0, 0, 0};

@@ -175,17 +175,6 @@ __global__ __launch_bounds__(256) void k_spread_planes(int na, const Site<T>* __
   }
 }
 
-template <class T>
-__global__ __launch_bounds__(kRecipBlock) void k_spread_scalar(int na, const T* __restrict__ pos,
-                                                               const T* __restrict__ vals, int stride, int chan,
-                                                               RecipGeom<T> g, T* __restrict__ mesh) {
-  int i = blockIdx.x * kRecipBlock + threadIdx.x;
-  if (i >= na) return;
-  T r[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-  T Q[9] = {vals[(long)stride * i + chan], 0, 0, 0, 0, 0, 0, 0, 0};
-  spread_atom(g, r, Q, [&](long idx, T v) { atomicAdd(&mesh[idx], v); });
-}
-
 // G table over the r2c half spectrum [K1][K2][K3/2+1].  Frequencies are assigned axis by axis
 // (k_d <- mesh axis d); the reference's meshgrid(kz, kx, ky) (recip.py:339-340) instead puts the
 // frequencies of mesh axes (1,0,2) into k-columns (0,1,2), which is the same thing whenever
@@ -318,20 +307,6 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Sit
   }
 }
 
-template <class T>
-__global__ __launch_bounds__(kRecipBlock) void k_gather_scalar(int na, const T* __restrict__ pos,
-                                                               const T* __restrict__ vals, int stride, int chan,
-                                                               RecipGeom<T> g, const T* __restrict__ phi,
-                                                               T* __restrict__ grad) {
-  int i = blockIdx.x * kRecipBlock + threadIdx.x;
-  if (i >= na) return;
-  T r[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]}, gx[3];
-  // g.Aop holds the true Jacobian here (see launch_gather_scalar): gx = Jac . F1, dE/dx = q gx
-  gather_atom_field(g, r, [&](long idx) { return phi[idx]; }, gx);
-  const T q = vals[(long)stride * i + chan];
-  grad[3 * i] += q * gx[0]; grad[3 * i + 1] += q * gx[1]; grad[3 * i + 2] += q * gx[2];
-}
-
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 
 #define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -372,11 +347,6 @@ size_t spread_scan_bytes(int ncell) {
   int* p = nullptr;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need, p, p, ncell + 1, (hipStream_t)0);
   return need + 256;
-}
-template <class T>
-void launch_spread_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
-                          const RecipGeom<T>& g, T* mesh) {
-  k_spread_scalar<T><<<nblk(na, kRecipBlock), kRecipBlock, 0, st>>>(na, pos, vals, stride, chan, g, mesh);
 }
 template <class T>
 void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* box_inv, double volume, double kappa,
@@ -426,27 +396,16 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
                          const int* list) {
   k_gather_field<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list);
 }
-template <class T>
-void launch_gather_scalar(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan,
-                          const RecipGeom<T>& g, const T* phi, T* grad) {
-  // a scalar site's position gradient is q * Jac . F1: reuse the first-derivative gather with Aop := Jac
-  RecipGeom<T> gj = g;
-  for (int k = 0; k < 9; ++k) gj.Aop[k] = g.Jac[k];
-  k_gather_scalar<T><<<nblk(na, kRecipBlock), kRecipBlock, 0, st>>>(na, pos, vals, stride, chan, gj, phi, grad);
-}
-
 #define INST(T)                                                                                                       \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
                                 const int*);                                                                          \
-  template void launch_spread_scalar<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, T*);     \
   template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*);            \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
                                  const int*, T*);                                                                       \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
-                                       const int*);                                                                   \
-  template void launch_gather_scalar<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, const T*, T*);
+                                       const int*);
 INST(float)
 INST(double)
 #undef INST
