@@ -1,0 +1,244 @@
+// Direct-DFT mesh convolution for "hard" PME mesh sizes (see dft_math.h): five kernels replace
+// rocFFT r2c (Bluestein) -> k_kspace -> rocFFT c2r on one GPU:
+//     z lines r2c  ->  y lines forward  ->  x lines forward * G (+ reciprocal energy) x lines inverse  ->  y lines inverse  ->  z lines c2r
+// Every block stages a tile of lines in LDS as j <-> N-j pair sums, then one thread produces one output pair.
+// At 97^3 (f64) the whole chain is ~0.9 GFLOP of f64 FMAs; the lines come out of L2 / Infinity Cache (7 MB spectrum).
+#include "dft_math.h"
+#include "launch.h"
+#include "reduce.h"
+
+namespace admp {
+
+constexpr int kDftBlock = 256;
+
+int dft_tile_cols(int N) {
+  int nc = kDftBlock / (N / 2 + 1);
+  if (nc < 1) nc = 1;
+  if (nc > 8) nc = 8;
+  return nc;
+}
+
+extern __shared__ __align__(32) unsigned char dft_smem[];
+
+// ---- z lines (contiguous): real mesh [nlines][N] -> half spectrum [nlines][N/2+1]
+template <class T>
+__global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int NL, const T* __restrict__ mesh,
+                                                        Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg) {
+  const int H = (N - 1) / 2, Kh = N / 2 + 1;
+  Cx<T>* tw = reinterpret_cast<Cx<T>*>(dft_smem);
+  Cx<T>* p = tw + N;                              // [H][NL]
+  T* x0 = reinterpret_cast<T*>(p + H * NL);       // [NL]
+  T* xn = x0 + NL;                                // [NL]
+  const int line0 = blockIdx.x * NL;
+  const int nl = min(NL, nlines - line0);
+  for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
+  for (int t = threadIdx.x; t < H * nl; t += kDftBlock) {
+    const int l = t / H, jj = t - l * H;
+    const T* x = mesh + (long)(line0 + l) * N;
+    const T a = x[1 + jj], b = x[N - 1 - jj];
+    p[jj * NL + l] = Cx<T>{a + b, a - b};
+  }
+  if (threadIdx.x < nl) {
+    const T* x = mesh + (long)(line0 + threadIdx.x) * N;
+    x0[threadIdx.x] = x[0];
+    xn[threadIdx.x] = (N & 1) ? T(0) : x[N / 2];
+  }
+  __syncthreads();
+  const int l = threadIdx.x / Kh, k = threadIdx.x - l * Kh;
+  if (l < nl) spec[(long)(line0 + l) * Kh + k] = rdft_output<T>(N, k, NL, p + l, x0[l], xn[l], tw);
+}
+
+// ---- z lines back: half spectrum -> real mesh
+template <class T>
+__global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int NL, const Cx<T>* __restrict__ spec,
+                                                        T* __restrict__ mesh, const Cx<T>* __restrict__ twg) {
+  const int H = (N - 1) / 2, Kh = N / 2 + 1;
+  Cx<T>* tw = reinterpret_cast<Cx<T>*>(dft_smem);
+  Cx<T>* p = tw + N;
+  T* X0 = reinterpret_cast<T*>(p + H * NL);
+  T* Xn = X0 + NL;
+  const int line0 = blockIdx.x * NL;
+  const int nl = min(NL, nlines - line0);
+  for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
+  for (int t = threadIdx.x; t < Kh * nl; t += kDftBlock) {
+    const int l = t / Kh, k = t - l * Kh;
+    const Cx<T> v = spec[(long)(line0 + l) * Kh + k];
+    if (k == 0) X0[l] = v.re;
+    else if (2 * k == N) Xn[l] = v.re;
+    else p[(k - 1) * NL + l] = v;
+  }
+  if ((N & 1) && threadIdx.x < nl) Xn[threadIdx.x] = T(0);
+  __syncthreads();
+  const int l = threadIdx.x / Kh, j = threadIdx.x - l * Kh;
+  if (l < nl) {
+    T xj, xnj;
+    irdft_pair_outputs<T>(N, j, NL, p + l, X0[l], Xn[l], tw, xj, xnj);
+    T* x = mesh + (long)(line0 + l) * N;
+    x[j] = xj;
+    if (j != 0 && 2 * j != N) x[N - j] = xnj;
+  }
+}
+
+// stage a tile of NC strided complex lines as pair sums: element (j, c) at spec[base + j * jstride + c]
+template <class T>
+__device__ __forceinline__ void load_pairs(int N, int NC, int nca, const Cx<T>* __restrict__ spec, long base, long jstride,
+                                           PairCx<T>* ab, Cx<T>* x0, Cx<T>* xn) {
+  const int H = (N - 1) / 2;
+  for (int t = threadIdx.x; t < H * NC; t += kDftBlock) {
+    const int jj = t / NC, c = t - jj * NC;
+    PairCx<T> v{T(0), T(0), T(0), T(0)};
+    if (c < nca) {
+      const Cx<T> a = spec[base + (long)(1 + jj) * jstride + c], b = spec[base + (long)(N - 1 - jj) * jstride + c];
+      v = PairCx<T>{a.re + b.re, a.im + b.im, a.re - b.re, a.im - b.im};
+    }
+    ab[t] = v;
+  }
+  if (threadIdx.x < NC) {
+    const int c = threadIdx.x;
+    Cx<T> a{T(0), T(0)}, b{T(0), T(0)};
+    if (c < nca) {
+      a = spec[base + c];
+      if ((N & 1) == 0) b = spec[base + (long)(N / 2) * jstride + c];
+    }
+    x0[c] = a;
+    xn[c] = b;
+  }
+}
+
+// ---- strided complex lines, in place (y lines: fix = x plane; x lines: fix = y row)
+template <class T, int SIGN>
+__global__ __launch_bounds__(kDftBlock) void k_dft_strided(int N, int ncols, int NC, long jstride, long fixstride,
+                                                          Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg) {
+  const int H = (N - 1) / 2;
+  PairCx<T>* ab = reinterpret_cast<PairCx<T>*>(dft_smem);   // [H][NC]
+  Cx<T>* tw = reinterpret_cast<Cx<T>*>(ab + H * NC);          // [N]
+  Cx<T>* x0 = tw + N;                                         // [NC]
+  Cx<T>* xn = x0 + NC;                                        // [NC]
+  const int col0 = blockIdx.x * NC;
+  const int nca = min(NC, ncols - col0);
+  const long base = (long)blockIdx.y * fixstride + col0;
+  for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
+  load_pairs<T>(N, NC, nca, spec, base, jstride, ab, x0, xn);
+  __syncthreads();
+  const int k = threadIdx.x / NC, c = threadIdx.x - k * NC;
+  if (k <= N / 2 && c < nca) {
+    Cx<T> Xk, Xnk;
+    dft_pair_outputs<T, SIGN>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+    spec[base + (long)k * jstride + c] = Xk;
+    if (k != 0 && 2 * k != N) spec[base + (long)(N - k) * jstride + c] = Xnk;
+  }
+}
+
+// ---- x lines: forward, multiply by G (accumulating sum w G |S|^2, recip.py:400-414 / pme.py:240), inverse; in place
+template <class T>
+__global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int NC, long jstride, long fixstride, int K3,
+                                                         Cx<T>* __restrict__ spec, const T* __restrict__ gtab,
+                                                         const Cx<T>* __restrict__ twg, double* energies, int slot) {
+  const int H = (N - 1) / 2;
+  PairCx<T>* ab = reinterpret_cast<PairCx<T>*>(dft_smem);   // [H][NC]
+  Cx<T>* tw = reinterpret_cast<Cx<T>*>(ab + H * NC);          // [N]
+  Cx<T>* x0 = tw + N;                                         // [NC]
+  Cx<T>* xn = x0 + NC;                                        // [NC]
+  Cx<T>* S = xn + NC;                                         // [N][NC]
+  const int col0 = blockIdx.x * NC;
+  const int nca = min(NC, ncols - col0);
+  const long base = (long)blockIdx.y * fixstride + col0;
+  for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
+  load_pairs<T>(N, NC, nca, spec, base, jstride, ab, x0, xn);
+  __syncthreads();
+  const int k = threadIdx.x / NC, c = threadIdx.x - k * NC;
+  const bool task = k <= N / 2 && c < nca;
+  if (task) {
+    Cx<T> Xk, Xnk;
+    dft_pair_outputs<T, -1>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+    S[k * NC + c] = Xk;
+    if (k != 0 && 2 * k != N) S[(N - k) * NC + c] = Xnk;
+  }
+  __syncthreads();
+  double e = 0.0;
+  for (int t = threadIdx.x; t < H * NC; t += kDftBlock) {
+    const int jj = t / NC, cc = t - jj * NC;
+    PairCx<T> v{T(0), T(0), T(0), T(0)};
+    if (cc < nca) {
+      const int k1 = 1 + jj, k2 = N - 1 - jj, kz = col0 + cc;
+      const T G1 = gtab[base + (long)k1 * jstride + cc], G2 = gtab[base + (long)k2 * jstride + cc];
+      const Cx<T> s1 = S[k1 * NC + cc], s2 = S[k2 * NC + cc];
+      const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
+      e += w * ((double)G1 * ((double)s1.re * s1.re + (double)s1.im * s1.im) +
+                (double)G2 * ((double)s2.re * s2.re + (double)s2.im * s2.im));
+      const T ar = G1 * s1.re, ai = G1 * s1.im, br = G2 * s2.re, bi = G2 * s2.im;
+      v = PairCx<T>{ar + br, ai + bi, ar - br, ai - bi};
+    }
+    ab[t] = v;
+  }
+  if (threadIdx.x < NC) {
+    const int cc = threadIdx.x;
+    Cx<T> a{T(0), T(0)}, b{T(0), T(0)};
+    if (cc < nca) {
+      const int kz = col0 + cc;
+      const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
+      const T G0 = gtab[base + cc];
+      const Cx<T> s0 = S[cc];
+      e += w * (double)G0 * ((double)s0.re * s0.re + (double)s0.im * s0.im);
+      a = Cx<T>{G0 * s0.re, G0 * s0.im};
+      if ((N & 1) == 0) {
+        const T Gn = gtab[base + (long)(N / 2) * jstride + cc];
+        const Cx<T> sn = S[(N / 2) * NC + cc];
+        e += w * (double)Gn * ((double)sn.re * sn.re + (double)sn.im * sn.im);
+        b = Cx<T>{Gn * sn.re, Gn * sn.im};
+      }
+    }
+    x0[cc] = a;
+    xn[cc] = b;
+  }
+  __syncthreads();
+  if (task) {
+    Cx<T> Xk, Xnk;
+    dft_pair_outputs<T, +1>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+    spec[base + (long)k * jstride + c] = Xk;
+    if (k != 0 && 2 * k != N) spec[base + (long)(N - k) * jstride + c] = Xnk;
+  }
+  e = block_reduce_sum<kDftBlock>(e);
+  if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
+}
+
+// ---- launchers.  K = mesh dimensions, tw = (cos, sin) tables of K[0], K[1], K[2] back to back.
+template <class T>
+void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse) {
+  const int N = K[2], NL = dft_tile_cols(N), nlines = K[0] * K[1], H = (N - 1) / 2;
+  const size_t sh = sizeof(Cx<T>) * (size_t)(N + H * NL) + sizeof(T) * 2 * (size_t)NL;
+  const Cx<T>* t2 = reinterpret_cast<const Cx<T>*>(tw) + K[0] + K[1];
+  const int blocks = (nlines + NL - 1) / NL;
+  if (inverse)
+    k_dft_z_c2r<T><<<blocks, kDftBlock, sh, st>>>(N, nlines, NL, reinterpret_cast<const Cx<T>*>(spec), mesh, t2);
+  else
+    k_dft_z_r2c<T><<<blocks, kDftBlock, sh, st>>>(N, nlines, NL, mesh, reinterpret_cast<Cx<T>*>(spec), t2);
+}
+template <class T>
+void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse) {
+  const int N = K[1], NC = dft_tile_cols(N), Kh = K[2] / 2 + 1, H = (N - 1) / 2;
+  const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC);
+  const Cx<T>* t1 = reinterpret_cast<const Cx<T>*>(tw) + K[0];
+  const dim3 grid((Kh + NC - 1) / NC, K[0]);
+  if (inverse)
+    k_dft_strided<T, +1><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, (long)Kh, (long)K[1] * Kh, reinterpret_cast<Cx<T>*>(spec), t1);
+  else
+    k_dft_strided<T, -1><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, (long)Kh, (long)K[1] * Kh, reinterpret_cast<Cx<T>*>(spec), t1);
+}
+template <class T>
+void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot) {
+  const int N = K[0], NC = dft_tile_cols(N), Kh = K[2] / 2 + 1, H = (N - 1) / 2;
+  const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC + N * NC);
+  const dim3 grid((Kh + NC - 1) / NC, K[1]);
+  k_dft_x_conv<T><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, (long)K[1] * Kh, (long)Kh, K[2], reinterpret_cast<Cx<T>*>(spec), gtab,
+                                               reinterpret_cast<const Cx<T>*>(tw), energies, slot);
+}
+#define INST(T)                                                                                   \
+  template void launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int);                  \
+  template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int);                      \
+  template void launch_dft_x_conv<T>(hipStream_t, const int*, const T*, T*, const T*, double*, int);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace admp

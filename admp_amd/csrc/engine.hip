@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/admp_hip.h"
+#include "dft_math.h"
 #include "launch.h"
 
 using namespace admp;
@@ -277,6 +278,8 @@ struct Engine : EngineBase {
   rocfft_execution_info info_f = nullptr;
   int planK[3] = {0, 0, 0}, planR = 0, planRank = 0;
   DevBuf home_list;
+  DevBuf dft_tw;          // twiddle tables of the direct-DFT path
+  bool use_dft = false;   // mesh convolution through dft_kernels.hip instead of rocFFT (single rank, a Bluestein dimension)
   // validity of the cached G table
   struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0; } tabkey[4];
   static int tab_slot(int which) { return which == 1 ? 0 : (which == 6 ? 1 : (which == 8 ? 2 : 3)); }
@@ -286,7 +289,7 @@ struct Engine : EngineBase {
     destroy_plans();
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
-                      &bin_sorted, &bin_scan, &home_list})
+                      &bin_sorted, &bin_scan, &home_list, &dft_tw})
       b->release();
     free_topology();
     cells.release();
@@ -383,6 +386,51 @@ struct Engine : EngineBase {
     if (wmax) FFT_TRY(rocfft_execution_info_set_work_buffer(info_f, fft_work.p, wmax));
     planK[0] = K[0]; planK[1] = K[1]; planK[2] = K[2]; planR = snranks; planRank = srank;
     for (auto& k : tabkey) k.kappa = -1;   // mesh changed: tables stale
+    setup_dft();
+  }
+
+  // Direct-DFT convolution (dft_kernels.hip) when rocFFT would need Bluestein for some dimension (largest prime factor
+  // above 13) and the mesh is small enough for O(N^2) lines.  ADMP_DFT=0 disables it, ADMP_DFT=1 forces it for any mesh
+  // with all dimensions <= 160 (tests).
+  void setup_dft() {
+    use_dft = false;
+    if (snranks != 1) return;
+    const char* e = getenv("ADMP_DFT");
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 0) return;
+    bool small = true, hard = false;
+    for (int d = 0; d < 3; ++d) {
+      small = small && K[d] >= 2 && K[d] <= 160;
+      hard = hard || largest_prime_factor(K[d]) > 13;
+    }
+    if (!small || !(hard || mode == 1)) return;
+    std::vector<T> tw(2 * (size_t)(K[0] + K[1] + K[2]));
+    size_t o = 0;
+    for (int d = 0; d < 3; ++d)
+      for (int m = 0; m < K[d]; ++m) {
+        const double th = 2.0 * M_PI * (double)m / (double)K[d];
+        tw[o++] = (T)std::cos(th);
+        tw[o++] = (T)std::sin(th);
+      }
+    dft_tw.need(tw.size() * sizeof(T));
+    HIP_TRY(hipMemcpy(dft_tw.p, tw.data(), tw.size() * sizeof(T), hipMemcpyHostToDevice));
+    use_dft = true;
+  }
+  // mesh <- IFFT( G * FFT(mesh) ), energies[slot] += sum w G |S|^2 : the whole k-space leg of one reciprocal pass
+  void convolve(T* mesh_p, T* spec_p, const T* gtab, int slot) {
+    double* Ed = energies_d.as<double>();
+    if (use_dft) {
+      const T* tw = dft_tw.as<T>();
+      { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 0); }
+      { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec_p, 0); }
+      { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec_p, gtab, Ed, slot); }
+      { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec_p, 1); }
+      { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 1); }
+      return;
+    }
+    fft_forward(mesh_p, spec_p);
+    { TIMED("kspace"); launch_kspace<T>(stream, K, nyown(), gtab, spec_p, Ed, slot); }
+    fft_inverse(spec_p, mesh_p);
   }
 
   void run_plan(const char* label, rocfft_plan plan, void* in, void* out) {
@@ -631,9 +679,10 @@ struct Engine : EngineBase {
   // full reciprocal pass on one rank: spread -> r2c -> G multiply (+energy) -> c2r ; mesh then holds phi
   void recip_pass(int slot) {
     stage_spread(mesh.as<T>());
-    fft_forward(mesh.as<T>(), spec.as<T>());
-    stage_kspace(spec.as<T>(), slot);
-    fft_inverse(spec.as<T>(), mesh.as<T>());
+    need_eval();
+    if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + slot, 0, sizeof(double), stream));
+    slot_clean[slot] = false;
+    convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, slot);
   }
 
   void pme(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
@@ -837,9 +886,7 @@ struct Engine : EngineBase {
         int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr);
         if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
       }
-      fft_forward(mesh.as<T>(), spec.as<T>());
-      { TIMED("kspace"); launch_kspace<T>(stream, K, K[1], gtab_cur, spec.as<T>(), Ed, E_RECIP); }
-      fft_inverse(spec.as<T>(), mesh.as<T>());
+      convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, E_RECIP);
       { TIMED("gather_field"); launch_gather_field<T>(stream, na, sites.as<Site<T>>(), gj, mesh.as<T>(), fld_recip.as<T>(), nullptr); }
       { TIMED("scale_add"); launch_scale_add<T>(stream, na, cl, 3, c, fld_recip.as<T>(), dpos); }
     }

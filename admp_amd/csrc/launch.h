@@ -79,6 +79,17 @@ template <class T>
 void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
                       int* count);
 
+// ---- dft_kernels.hip: direct-DFT mesh convolution for mesh sizes rocFFT only does with Bluestein (dft_math.h)
+// tw = (cos, sin)(2 pi m / K[d]) tables of the three dimensions back to back (K[0] + K[1] + K[2] complex numbers)
+int dft_tile_cols(int N);
+template <class T>
+void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse);   // r2c / c2r along z
+template <class T>
+void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse);            // in place along y
+// along x: forward, spec *= gtab with energies[slot] += sum w G |S|^2, inverse -- one kernel, in place
+template <class T>
+void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot);
+
 // ---- pair_kernels.hip
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,

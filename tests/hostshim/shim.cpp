@@ -10,6 +10,7 @@
 #include "../../admp_amd/csrc/pme_math.h"
 #include "../../admp_amd/csrc/spline_math.h"
 #include "../../admp_amd/csrc/disp_math.h"
+#include "../../admp_amd/csrc/dft_math.h"
 
 using namespace admp;
 
@@ -207,6 +208,51 @@ static double tt_real(int na, const double* pos, const double* abqc, const doubl
   return e;
 }
 
+// ---- direct DFT lines (dft_math.h), driven exactly like dft_kernels.hip drives them
+template <class T>
+static void dft_line(int N, int sign, const double* in, double* out) {
+  const int H = (N - 1) / 2;
+  std::vector<Cx<T>> tw(N);
+  for (int m = 0; m < N; ++m) tw[m] = Cx<T>{(T)std::cos(2.0 * M_PI * m / N), (T)std::sin(2.0 * M_PI * m / N)};
+  std::vector<PairCx<T>> ab(H > 0 ? H : 1);
+  for (int j = 1; j <= H; ++j)
+    ab[j - 1] = PairCx<T>{(T)(in[2 * j] + in[2 * (N - j)]), (T)(in[2 * j + 1] + in[2 * (N - j) + 1]),
+                          (T)(in[2 * j] - in[2 * (N - j)]), (T)(in[2 * j + 1] - in[2 * (N - j) + 1])};
+  Cx<T> x0{(T)in[0], (T)in[1]}, xn{T(0), T(0)};
+  if (N % 2 == 0) xn = Cx<T>{(T)in[N], (T)in[N + 1]};
+  for (int k = 0; k <= N / 2; ++k) {
+    Cx<T> a, b;
+    if (sign < 0) dft_pair_outputs<T, -1>(N, k, 1, ab.data(), x0, xn, tw.data(), a, b);
+    else dft_pair_outputs<T, +1>(N, k, 1, ab.data(), x0, xn, tw.data(), a, b);
+    out[2 * k] = a.re; out[2 * k + 1] = a.im;
+    if (k != 0 && 2 * k != N) { out[2 * (N - k)] = b.re; out[2 * (N - k) + 1] = b.im; }
+  }
+}
+template <class T>
+static void rdft_line(int N, const double* in, double* out) {
+  const int H = (N - 1) / 2;
+  std::vector<Cx<T>> tw(N), p(H > 0 ? H : 1);
+  for (int m = 0; m < N; ++m) tw[m] = Cx<T>{(T)std::cos(2.0 * M_PI * m / N), (T)std::sin(2.0 * M_PI * m / N)};
+  for (int j = 1; j <= H; ++j) p[j - 1] = Cx<T>{(T)(in[j] + in[N - j]), (T)(in[j] - in[N - j])};
+  for (int k = 0; k <= N / 2; ++k) {
+    Cx<T> X = rdft_output<T>(N, k, 1, p.data(), (T)in[0], (N % 2 == 0) ? (T)in[N / 2] : T(0), tw.data());
+    out[2 * k] = X.re; out[2 * k + 1] = X.im;
+  }
+}
+template <class T>
+static void irdft_line(int N, const double* in, double* out) {
+  const int H = (N - 1) / 2;
+  std::vector<Cx<T>> tw(N), p(H > 0 ? H : 1);
+  for (int m = 0; m < N; ++m) tw[m] = Cx<T>{(T)std::cos(2.0 * M_PI * m / N), (T)std::sin(2.0 * M_PI * m / N)};
+  for (int k = 1; k <= H; ++k) p[k - 1] = Cx<T>{(T)in[2 * k], (T)in[2 * k + 1]};
+  for (int j = 0; j <= N / 2; ++j) {
+    T a, b;
+    irdft_pair_outputs<T>(N, j, 1, p.data(), (T)in[0], (N % 2 == 0) ? (T)in[N] : T(0), tw.data(), a, b);
+    out[j] = a;
+    if (j != 0 && 2 * j != N) out[N - j] = b;
+  }
+}
+
 extern "C" {
 double shim_pair_real(int prec, int na, const double* pos, const double* Q, const double* U, const double* p6,
                       const double* th, const double* boxh, long np, const int32_t* pairs, const int32_t* nb,
@@ -250,4 +296,11 @@ double shim_tt_real(int prec, int na, const double* pos, const double* abqc, con
                    : tt_real<double>(na, pos, abqc, boxh, np, pairs, nb, mtab, grad);
 }
 double shim_disp_ck(int which, double ksq, double kappa, double V) { return disp_ck(which, ksq, kappa, V); }
+// kind 0: complex line (sign -1 / +1), 1: r2c line, 2: c2r line of a half spectrum
+void shim_dft_line(int prec, int kind, int N, int sign, const double* in, double* out) {
+  if (kind == 0) { if (prec == 4) dft_line<float>(N, sign, in, out); else dft_line<double>(N, sign, in, out); }
+  else if (kind == 1) { if (prec == 4) rdft_line<float>(N, in, out); else rdft_line<double>(N, in, out); }
+  else { if (prec == 4) irdft_line<float>(N, in, out); else irdft_line<double>(N, in, out); }
+}
+int shim_largest_prime_factor(int n) { return largest_prime_factor(n); }
 }

@@ -175,6 +175,53 @@ print('BRICK-OK')
     assert r.returncode == 0 and 'BRICK-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_direct_dft_convolution_vs_rocfft(tmp_path):
+    """Meshes with a Bluestein dimension go through dft_kernels.hip instead of rocFFT (engine.hip setup_dft).  The two
+    k-space legs must agree to round-off: polarizable PME and dispersion PME, even / odd / prime dimensions, both
+    precisions; ADMP_DFT is read per handle, the child processes only keep the runs independent."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_parity import water_system
+from admp_amd import settings
+out = {}
+pos, box, at, ai, cov, par, pairs = water_system(216, 5, True)
+for prec in ('double', 'single'):
+    settings.PRECISION = prec
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    for K in ((0, 0, 0), (31, 34, 38), (96, 100, 45), (97, 64, 51)):
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+        d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+        if K[0]:
+            for o in (f, d):
+                o.K1, o.K2, o.K3 = K
+                o.refresh_calculators()
+        E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+        Ed, Gd = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+        key = '%%s_%%d_%%d_%%d' %% ((prec,) + (f.K1, f.K2, f.K3))
+        out[key + '_parts'] = np.asarray(f.energy_parts); out[key + '_G'] = np.asarray(G); out[key + '_U'] = np.asarray(f.U_ind)
+        out[key + '_dparts'] = np.asarray(d.energy_parts); out[key + '_Gd'] = np.asarray(Gd)
+np.savez(sys.argv[1], **out)
+print('DFT-RUN-OK')
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ('0', '1'):
+        path = str(tmp_path / ('dft%s.npz' % mode))
+        r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
+                           env=dict(os.environ, ADMP_DFT=mode), timeout=900)
+        assert r.returncode == 0 and 'DFT-RUN-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        res[mode] = dict(np.load(path))
+    assert len(res['0']) == 2 * 4 * 5
+    for key, a in res['0'].items():
+        b = res['1'][key]
+        tol = 1e-10 if key.startswith('double') else 2e-4
+        scale = np.abs(a).max()
+        assert np.abs(a - b).max() <= tol * scale, (key, np.abs(a - b).max(), scale)
+
+
 def test_pair_list_conventions():
     """Padding rows (i >= j) are dropped (admp/pme.py:671); order of rows is irrelevant; torch inputs work."""
     import torch
