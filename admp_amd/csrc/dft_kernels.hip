@@ -10,19 +10,33 @@
 namespace admp {
 
 constexpr int kDftBlock = 256;
+constexpr size_t kDftLdsBudget = 60 * 1024;
 
-int dft_tile_cols(int N) {
-  int nc = kDftBlock / (N / 2 + 1);
+// outputs per thread (KQ output pairs share one read of the pair sums); ADMP_DFT_KQ = 1 | 2 | 4 for tuning
+static int dft_kq() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("ADMP_DFT_KQ");
+    v = e ? atoi(e) : 4;
+    if (v != 1 && v != 2 && v != 4) v = 4;
+  }
+  return v;
+}
+// thread-tasks per line and lines (columns) per block
+static int dft_tasks(int N, int KQ) { return (N / 2 + 1 + KQ - 1) / KQ; }
+static int dft_cols(int N, int KQ, size_t bytes_per_col, size_t fixed_bytes) {
+  int nc = kDftBlock / dft_tasks(N, KQ);
   if (nc < 1) nc = 1;
-  if (nc > 8) nc = 8;
+  while (nc > 1 && fixed_bytes + bytes_per_col * nc > kDftLdsBudget) --nc;
   return nc;
 }
+int dft_tile_cols(int N) { return dft_cols(N, dft_kq(), 0, 0); }
 
 extern __shared__ __align__(32) unsigned char dft_smem[];
 
 // ---- z lines (contiguous): real mesh [nlines][N] -> half spectrum [nlines][N/2+1]
-template <class T>
-__global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int NL, const T* __restrict__ mesh,
+template <class T, int KQ>
+__global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int NL, int TK, const T* __restrict__ mesh,
                                                         Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg) {
   const int H = (N - 1) / 2, Kh = N / 2 + 1;
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(dft_smem);
@@ -44,13 +58,22 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int 
     xn[threadIdx.x] = (N & 1) ? T(0) : x[N / 2];
   }
   __syncthreads();
-  const int l = threadIdx.x / Kh, k = threadIdx.x - l * Kh;
-  if (l < nl) spec[(long)(line0 + l) * Kh + k] = rdft_output<T>(N, k, NL, p + l, x0[l], xn[l], tw);
+  const int l = threadIdx.x / TK, g = threadIdx.x - l * TK;
+  if (l < nl) {
+    int k[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
+    Cx<T> X[KQ];
+    rdft_outputs<T, KQ>(N, k, NL, p + l, x0[l], xn[l], tw, X);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+      if (g + q * TK < Kh) spec[(long)(line0 + l) * Kh + g + q * TK] = X[q];
+  }
 }
 
 // ---- z lines back: half spectrum -> real mesh
-template <class T>
-__global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int NL, const Cx<T>* __restrict__ spec,
+template <class T, int KQ>
+__global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int NL, int TK, const Cx<T>* __restrict__ spec,
                                                         T* __restrict__ mesh, const Cx<T>* __restrict__ twg) {
   const int H = (N - 1) / 2, Kh = N / 2 + 1;
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(dft_smem);
@@ -69,13 +92,22 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int 
   }
   if ((N & 1) && threadIdx.x < nl) Xn[threadIdx.x] = T(0);
   __syncthreads();
-  const int l = threadIdx.x / Kh, j = threadIdx.x - l * Kh;
+  const int l = threadIdx.x / TK, g = threadIdx.x - l * TK;
   if (l < nl) {
-    T xj, xnj;
-    irdft_pair_outputs<T>(N, j, NL, p + l, X0[l], Xn[l], tw, xj, xnj);
+    int j[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) j[q] = (g + q * TK < Kh) ? g + q * TK : 0;
+    T xj[KQ], xnj[KQ];
+    irdft_pair_outputs<T, KQ>(N, j, NL, p + l, X0[l], Xn[l], tw, xj, xnj);
     T* x = mesh + (long)(line0 + l) * N;
-    x[j] = xj;
-    if (j != 0 && 2 * j != N) x[N - j] = xnj;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int jq = g + q * TK;
+      if (jq < Kh) {
+        x[jq] = xj[q];
+        if (jq != 0 && 2 * jq != N) x[N - jq] = xnj[q];
+      }
+    }
   }
 }
 
@@ -106,10 +138,10 @@ __device__ __forceinline__ void load_pairs(int N, int NC, int nca, const Cx<T>* 
 }
 
 // ---- strided complex lines, in place (y lines: fix = x plane; x lines: fix = y row)
-template <class T, int SIGN>
-__global__ __launch_bounds__(kDftBlock) void k_dft_strided(int N, int ncols, int NC, long jstride, long fixstride,
+template <class T, int SIGN, int KQ>
+__global__ __launch_bounds__(kDftBlock) void k_dft_strided(int N, int ncols, int NC, int TK, long jstride, long fixstride,
                                                           Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg) {
-  const int H = (N - 1) / 2;
+  const int H = (N - 1) / 2, Kh = N / 2 + 1;
   PairCx<T>* ab = reinterpret_cast<PairCx<T>*>(dft_smem);   // [H][NC]
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(ab + H * NC);          // [N]
   Cx<T>* x0 = tw + N;                                         // [NC]
@@ -120,21 +152,30 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_strided(int N, int ncols, int
   for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
   load_pairs<T>(N, NC, nca, spec, base, jstride, ab, x0, xn);
   __syncthreads();
-  const int k = threadIdx.x / NC, c = threadIdx.x - k * NC;
-  if (k <= N / 2 && c < nca) {
-    Cx<T> Xk, Xnk;
-    dft_pair_outputs<T, SIGN>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
-    spec[base + (long)k * jstride + c] = Xk;
-    if (k != 0 && 2 * k != N) spec[base + (long)(N - k) * jstride + c] = Xnk;
+  const int g = threadIdx.x / NC, c = threadIdx.x - g * NC;
+  if (g < TK && c < nca) {
+    int k[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
+    Cx<T> Xk[KQ], Xnk[KQ];
+    dft_pair_outputs<T, SIGN, KQ>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK;
+      if (kq < Kh) {
+        spec[base + (long)kq * jstride + c] = Xk[q];
+        if (kq != 0 && 2 * kq != N) spec[base + (long)(N - kq) * jstride + c] = Xnk[q];
+      }
+    }
   }
 }
 
 // ---- x lines: forward, multiply by G (accumulating sum w G |S|^2, recip.py:400-414 / pme.py:240), inverse; in place
-template <class T>
-__global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int NC, long jstride, long fixstride, int K3,
-                                                         Cx<T>* __restrict__ spec, const T* __restrict__ gtab,
+template <class T, int KQ>
+__global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int NC, int TK, long jstride, long fixstride,
+                                                         int K3, Cx<T>* __restrict__ spec, const T* __restrict__ gtab,
                                                          const Cx<T>* __restrict__ twg, double* energies, int slot) {
-  const int H = (N - 1) / 2;
+  const int H = (N - 1) / 2, Kh = N / 2 + 1;
   PairCx<T>* ab = reinterpret_cast<PairCx<T>*>(dft_smem);   // [H][NC]
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(ab + H * NC);          // [N]
   Cx<T>* x0 = tw + N;                                         // [NC]
@@ -146,13 +187,22 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
   load_pairs<T>(N, NC, nca, spec, base, jstride, ab, x0, xn);
   __syncthreads();
-  const int k = threadIdx.x / NC, c = threadIdx.x - k * NC;
-  const bool task = k <= N / 2 && c < nca;
+  const int g = threadIdx.x / NC, c = threadIdx.x - g * NC;
+  const bool task = g < TK && c < nca;
+  int k[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
   if (task) {
-    Cx<T> Xk, Xnk;
-    dft_pair_outputs<T, -1>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
-    S[k * NC + c] = Xk;
-    if (k != 0 && 2 * k != N) S[(N - k) * NC + c] = Xnk;
+    Cx<T> Xk[KQ], Xnk[KQ];
+    dft_pair_outputs<T, -1, KQ>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK;
+      if (kq < Kh) {
+        S[kq * NC + c] = Xk[q];
+        if (kq != 0 && 2 * kq != N) S[(N - kq) * NC + c] = Xnk[q];
+      }
+    }
   }
   __syncthreads();
   double e = 0.0;
@@ -193,46 +243,67 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   }
   __syncthreads();
   if (task) {
-    Cx<T> Xk, Xnk;
-    dft_pair_outputs<T, +1>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
-    spec[base + (long)k * jstride + c] = Xk;
-    if (k != 0 && 2 * k != N) spec[base + (long)(N - k) * jstride + c] = Xnk;
+    Cx<T> Xk[KQ], Xnk[KQ];
+    dft_pair_outputs<T, +1, KQ>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK;
+      if (kq < Kh) {
+        spec[base + (long)kq * jstride + c] = Xk[q];
+        if (kq != 0 && 2 * kq != N) spec[base + (long)(N - kq) * jstride + c] = Xnk[q];
+      }
+    }
   }
   e = block_reduce_sum<kDftBlock>(e);
   if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
 }
 
 // ---- launchers.  K = mesh dimensions, tw = (cos, sin) tables of K[0], K[1], K[2] back to back.
+#define KQ_SWITCH(CALL)            \
+  switch (dft_kq()) {              \
+    case 1: { constexpr int KQ = 1; CALL; } break; \
+    case 2: { constexpr int KQ = 2; CALL; } break; \
+    default: { constexpr int KQ = 4; CALL; } break; \
+  }
+
 template <class T>
 void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse) {
-  const int N = K[2], NL = dft_tile_cols(N), nlines = K[0] * K[1], H = (N - 1) / 2;
+  const int N = K[2], nlines = K[0] * K[1], H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
+  const int NL = dft_cols(N, dft_kq(), sizeof(Cx<T>) * (size_t)H + 2 * sizeof(T), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(Cx<T>) * (size_t)(N + H * NL) + sizeof(T) * 2 * (size_t)NL;
   const Cx<T>* t2 = reinterpret_cast<const Cx<T>*>(tw) + K[0] + K[1];
   const int blocks = (nlines + NL - 1) / NL;
-  if (inverse)
-    k_dft_z_c2r<T><<<blocks, kDftBlock, sh, st>>>(N, nlines, NL, reinterpret_cast<const Cx<T>*>(spec), mesh, t2);
-  else
-    k_dft_z_r2c<T><<<blocks, kDftBlock, sh, st>>>(N, nlines, NL, mesh, reinterpret_cast<Cx<T>*>(spec), t2);
+  if (inverse) {
+    KQ_SWITCH((k_dft_z_c2r<T, KQ><<<blocks, kDftBlock, sh, st>>>(N, nlines, NL, TK, reinterpret_cast<const Cx<T>*>(spec), mesh, t2)))
+  } else {
+    KQ_SWITCH((k_dft_z_r2c<T, KQ><<<blocks, kDftBlock, sh, st>>>(N, nlines, NL, TK, mesh, reinterpret_cast<Cx<T>*>(spec), t2)))
+  }
 }
 template <class T>
 void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse) {
-  const int N = K[1], NC = dft_tile_cols(N), Kh = K[2] / 2 + 1, H = (N - 1) / 2;
+  const int N = K[1], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
+  const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + 2 * sizeof(Cx<T>), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC);
   const Cx<T>* t1 = reinterpret_cast<const Cx<T>*>(tw) + K[0];
   const dim3 grid((Kh + NC - 1) / NC, K[0]);
-  if (inverse)
-    k_dft_strided<T, +1><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, (long)Kh, (long)K[1] * Kh, reinterpret_cast<Cx<T>*>(spec), t1);
-  else
-    k_dft_strided<T, -1><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, (long)Kh, (long)K[1] * Kh, reinterpret_cast<Cx<T>*>(spec), t1);
+  Cx<T>* sp = reinterpret_cast<Cx<T>*>(spec);
+  if (inverse) {
+    KQ_SWITCH((k_dft_strided<T, +1, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1)))
+  } else {
+    KQ_SWITCH((k_dft_strided<T, -1, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1)))
+  }
 }
 template <class T>
 void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot) {
-  const int N = K[0], NC = dft_tile_cols(N), Kh = K[2] / 2 + 1, H = (N - 1) / 2;
+  const int N = K[0], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
+  const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + sizeof(Cx<T>) * (size_t)(2 + N), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC + N * NC);
   const dim3 grid((Kh + NC - 1) / NC, K[1]);
-  k_dft_x_conv<T><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, (long)K[1] * Kh, (long)Kh, K[2], reinterpret_cast<Cx<T>*>(spec), gtab,
-                                               reinterpret_cast<const Cx<T>*>(tw), energies, slot);
+  KQ_SWITCH((k_dft_x_conv<T, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)K[1] * Kh, (long)Kh, K[2],
+                                                             reinterpret_cast<Cx<T>*>(spec), gtab,
+                                                             reinterpret_cast<const Cx<T>*>(tw), energies, slot)))
 }
+#undef KQ_SWITCH
 #define INST(T)                                                                                   \
   template void launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int);                  \
   template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int);                      \

@@ -6,6 +6,8 @@
 // Every line transform uses the j <-> N-j symmetry of the twiddles, w^(jk) = c_jk + i s_jk with c even and s odd in j:
 //     X[k], X[N-k] = x_0 + sum_{j=1..H} (x_j + x_{N-j}) c_jk  +-  sgn i sum_{j=1..H} (x_j - x_{N-j}) s_jk   (+ x_{N/2} (-1)^k, N even)
 // with H = (N-1)/2: one pass over the H pair sums yields two outputs, a quarter of the multiplications of the plain sum.
+// The kernels are bound by LDS reads, not by arithmetic, so one thread produces KQ output pairs from one read of the
+// pair sums and carries the twiddles by rotation instead of fetching them.
 // The functions here are the per-output-pair arithmetic, shared by dft_kernels.hip and the host-compiled test shim.
 #pragma once
 #include "pme_math.h"
@@ -22,77 +24,158 @@ struct alignas(4 * sizeof(T)) PairCx {
   T are, aim, bre, bim;
 };
 
+// Each call produces KQ output pairs of one line (k[0..KQ)): the pair sums are read once for all of them, and the
+// twiddle of output k is advanced by the rotation w^k from j to j+1, re-seeded from the exact table every kDftReseed
+// steps (so the recurrence never runs longer than that; entries of k outside 0..N/2 may be passed as 0 and ignored).
+constexpr int kDftReseed = 8;
+
+template <class T>
+ADMP_HD Cx<T> cx_mul(Cx<T> a, Cx<T> b) {
+  return Cx<T>{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
 // complex line, direction SIGN (-1 forward, +1 inverse): outputs X[k] and X[N-k] (k = 0 .. N/2)
 //   ab[(j-1)*stride], j = 1..H   pair sums;  x0 = x_0;  xn = x_{N/2} (used when N is even);  tw[m] = (cos, sin)(2 pi m / N)
-template <class T, int SIGN>
-ADMP_HD void dft_pair_outputs(int N, int k, int stride, const PairCx<T>* ab, Cx<T> x0, Cx<T> xn, const Cx<T>* tw,
-                              Cx<T>& Xk, Cx<T>& Xnk) {
+template <class T, int SIGN, int KQ>
+ADMP_HD void dft_pair_outputs(int N, const int* k, int stride, const PairCx<T>* ab, Cx<T> x0, Cx<T> xn, const Cx<T>* tw,
+                              Cx<T>* Xk, Cx<T>* Xnk) {
   const int H = (N - 1) / 2;
-  T Are = 0, Aim = 0, Bre = 0, Bim = 0;
-  int m = 0;
-  for (int j = 0; j < H; ++j) {
-    m += k;
-    if (m >= N) m -= N;
-    const Cx<T> w = tw[m];
-    const PairCx<T> p = ab[j * stride];
-    Are += p.are * w.re;
-    Aim += p.aim * w.re;
-    Bre += p.bre * w.im;
-    Bim += p.bim * w.im;
+  T Are[KQ], Aim[KQ], Bre[KQ], Bim[KQ];
+  Cx<T> rot[KQ], w[KQ];
+  int m[KQ], step[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    Are[q] = Aim[q] = Bre[q] = Bim[q] = T(0);
+    rot[q] = tw[k[q]];
+    m[q] = k[q];
+    step[q] = (kDftReseed * k[q]) % N;
   }
-  T bre = x0.re + Are, bim = x0.im + Aim;
-  if ((N & 1) == 0) {
-    const T s = (k & 1) ? T(-1) : T(1);
-    bre += s * xn.re;
-    bim += s * xn.im;
+  for (int jb = 0; jb < H; jb += kDftReseed) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) w[q] = tw[m[q]];
+    const int je = (H - jb) < kDftReseed ? (H - jb) : kDftReseed;
+    if (je == kDftReseed) {
+#pragma unroll
+      for (int jj = 0; jj < kDftReseed; ++jj) {
+        const PairCx<T> p = ab[(jb + jj) * stride];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          Are[q] += p.are * w[q].re;
+          Aim[q] += p.aim * w[q].re;
+          Bre[q] += p.bre * w[q].im;
+          Bim[q] += p.bim * w[q].im;
+          w[q] = cx_mul(w[q], rot[q]);
+        }
+      }
+    } else {
+      for (int jj = 0; jj < je; ++jj) {
+        const PairCx<T> p = ab[(jb + jj) * stride];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          Are[q] += p.are * w[q].re;
+          Aim[q] += p.aim * w[q].re;
+          Bre[q] += p.bre * w[q].im;
+          Bim[q] += p.bim * w[q].im;
+          w[q] = cx_mul(w[q], rot[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      m[q] += step[q];
+      if (m[q] >= N) m[q] -= N;
+    }
   }
-  // sgn * i * B = sgn * (-Bim, Bre)
-  Xk.re = bre - T(SIGN) * Bim;
-  Xk.im = bim + T(SIGN) * Bre;
-  Xnk.re = bre + T(SIGN) * Bim;
-  Xnk.im = bim - T(SIGN) * Bre;
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    T bre = x0.re + Are[q], bim = x0.im + Aim[q];
+    if ((N & 1) == 0) {
+      const T s = (k[q] & 1) ? T(-1) : T(1);
+      bre += s * xn.re;
+      bim += s * xn.im;
+    }
+    // sgn * i * B = sgn * (-Bim, Bre)
+    Xk[q].re = bre - T(SIGN) * Bim[q];
+    Xk[q].im = bim + T(SIGN) * Bre[q];
+    Xnk[q].re = bre + T(SIGN) * Bim[q];
+    Xnk[q].im = bim - T(SIGN) * Bre[q];
+  }
 }
 
 // real pair sums shared by the r2c and c2r lines: P = sum_j p_j.re c_jk, R = sum_j p_j.im s_jk
-template <class T>
-ADMP_HD void real_pair_sums(int N, int k, int stride, const Cx<T>* p, const Cx<T>* tw, T& P, T& R) {
+template <class T, int KQ>
+ADMP_HD void real_pair_sums(int N, const int* k, int stride, const Cx<T>* p, const Cx<T>* tw, T* P, T* R) {
   const int H = (N - 1) / 2;
-  T sp = 0, sr = 0;
-  int m = 0;
-  for (int j = 0; j < H; ++j) {
-    m += k;
-    if (m >= N) m -= N;
-    const Cx<T> w = tw[m];
-    const Cx<T> v = p[j * stride];
-    sp += v.re * w.re;
-    sr += v.im * w.im;
+  Cx<T> rot[KQ], w[KQ];
+  int m[KQ], step[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    P[q] = R[q] = T(0);
+    rot[q] = tw[k[q]];
+    m[q] = k[q];
+    step[q] = (kDftReseed * k[q]) % N;
   }
-  P = sp;
-  R = sr;
+  for (int jb = 0; jb < H; jb += kDftReseed) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) w[q] = tw[m[q]];
+    const int je = (H - jb) < kDftReseed ? (H - jb) : kDftReseed;
+    if (je == kDftReseed) {
+#pragma unroll
+      for (int jj = 0; jj < kDftReseed; ++jj) {
+        const Cx<T> v = p[(jb + jj) * stride];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          P[q] += v.re * w[q].re;
+          R[q] += v.im * w[q].im;
+          w[q] = cx_mul(w[q], rot[q]);
+        }
+      }
+    } else {
+      for (int jj = 0; jj < je; ++jj) {
+        const Cx<T> v = p[(jb + jj) * stride];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          P[q] += v.re * w[q].re;
+          R[q] += v.im * w[q].im;
+          w[q] = cx_mul(w[q], rot[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      m[q] += step[q];
+      if (m[q] >= N) m[q] -= N;
+    }
+  }
 }
 
 // r2c line: p_j = (x_j + x_{N-j}, x_j - x_{N-j}) real pair sums; X[k] = x0 + P - i R  (+ xn (-1)^k), k = 0 .. N/2
-template <class T>
-ADMP_HD Cx<T> rdft_output(int N, int k, int stride, const Cx<T>* p, T x0, T xn, const Cx<T>* tw) {
-  T P, R;
-  real_pair_sums(N, k, stride, p, tw, P, R);
-  Cx<T> X;
-  X.re = x0 + P;
-  if ((N & 1) == 0) X.re += (k & 1) ? -xn : xn;
-  X.im = -R;
-  return X;
+template <class T, int KQ>
+ADMP_HD void rdft_outputs(int N, const int* k, int stride, const Cx<T>* p, T x0, T xn, const Cx<T>* tw, Cx<T>* X) {
+  T P[KQ], R[KQ];
+  real_pair_sums<T, KQ>(N, k, stride, p, tw, P, R);
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    X[q].re = x0 + P[q];
+    if ((N & 1) == 0) X[q].re += (k[q] & 1) ? -xn : xn;
+    X[q].im = -R[q];
+  }
 }
 
 // c2r line of a Hermitian half spectrum: p_k = X[k], k = 1..H; x_j = X0.re + 2(P - R), x_{N-j} = X0.re + 2(P + R)
 // (+ X[N/2].re (-1)^j); the imaginary parts of X[0] and X[N/2] are ignored like rocFFT's c2r does.
-template <class T>
-ADMP_HD void irdft_pair_outputs(int N, int j, int stride, const Cx<T>* p, T X0re, T Xnre, const Cx<T>* tw, T& xj, T& xnj) {
-  T P, R;
-  real_pair_sums(N, j, stride, p, tw, P, R);
-  T base = X0re + T(2) * P;
-  if ((N & 1) == 0) base += (j & 1) ? -Xnre : Xnre;
-  xj = base - T(2) * R;
-  xnj = base + T(2) * R;
+template <class T, int KQ>
+ADMP_HD void irdft_pair_outputs(int N, const int* j, int stride, const Cx<T>* p, T X0re, T Xnre, const Cx<T>* tw, T* xj,
+                                T* xnj) {
+  T P[KQ], R[KQ];
+  real_pair_sums<T, KQ>(N, j, stride, p, tw, P, R);
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    T base = X0re + T(2) * P[q];
+    if ((N & 1) == 0) base += (j[q] & 1) ? -Xnre : Xnre;
+    xj[q] = base - T(2) * R[q];
+    xnj[q] = base + T(2) * R[q];
+  }
 }
 
 // largest prime factor (host): rocFFT has radix kernels for 2, 3, 5, 7, 11, 13 and falls back to Bluestein above

@@ -138,6 +138,106 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   }
 }
 
+// Small systems (a few thousand atoms): binning in separate launches costs more than it saves and global f64 atomics
+// run at ~20 G/s (the mesh is shared by the 8 XCDs), so each brick's workgroup scans ALL atoms itself, keeps the ones
+// whose stencil touches the brick, and spreads them through the LDS tile: thread <- (entry, x-plane, y-row) column of
+// six z points, with the entries' spline weights staged in LDS.  One launch, no memset, no global atomics.
+constexpr int kScanChunk = 2048;   // atoms scanned per round (bounds the LDS entry list)
+constexpr int kScanSub = 32;       // entries whose weights are staged at a time
+
+template <class T>
+__global__ __launch_bounds__(256) void k_spread_scan(int na, const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
+                                                     BrickGrid bg, T* __restrict__ mesh, const int* __restrict__ list) {
+  __shared__ double tile[16 * 16 * 16];
+  __shared__ int ents[kScanChunk];
+  __shared__ int nent;
+  __shared__ T wts[kScanSub][64];      // per entry: M,D1,D2 of the 3 axes (54), then q, c1[3], c2[6]
+  __shared__ int ebase[kScanSub][3];
+  const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
+  const int bb[3] = {bx, by, bz};
+  int lo[3], n[3];
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = (bb[d] * g.dim(d)) / bg.nb[d];
+    n[d] = ((bb[d] + 1) * g.dim(d)) / bg.nb[d] - lo[d];
+  }
+  for (int t = threadIdx.x; t < 4096; t += 256) tile[t] = 0.0;
+  for (int c0 = 0; c0 < na; c0 += kScanChunk) {
+    if (threadIdx.x == 0) nent = 0;
+    __syncthreads();
+    const int cend = min(na, c0 + kScanChunk);
+    for (int s = c0 + threadIdx.x; s < cend; s += 256) {
+      const int i = list ? list[s] : s;
+      T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
+      bool hit = true;
+      for (int d = 0; d < 3; ++d) {
+        int base, out[2] = {0, 0};
+        grid_ref(g, r, d, base);
+        const int nn = bricks_on_axis(base, bg.nb[d], g.dim(d), out);
+        hit = hit && (out[0] == bb[d] || (nn == 2 && out[1] == bb[d]));
+      }
+      if (hit) ents[atomicAdd(&nent, 1)] = i;
+    }
+    __syncthreads();
+    const int ne = nent;
+    for (int sub = 0; sub < ne; sub += kScanSub) {
+      const int cnt = min(kScanSub, ne - sub);
+      if (threadIdx.x < cnt) {
+        T r[3], Q[9];
+        site_qtot(sites[ents[sub + threadIdx.x]], lpol, r, Q);
+        Stencil<T> st;
+        st.init(g, r);
+        T c1[3], c2[6];
+        fold_multipole(g, Q, c1, c2);
+        T* w = wts[threadIdx.x];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          ebase[threadIdx.x][d] = st.base[d];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            w[d * 18 + k] = st.M[d][k];
+            w[d * 18 + 6 + k] = st.D1[d][k];
+            w[d * 18 + 12 + k] = st.D2[d][k];
+          }
+        }
+        w[54] = Q[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[55 + k] = c1[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w[58 + k] = c2[k];
+      }
+      __syncthreads();
+      for (int task = threadIdx.x; task < cnt * 36; task += 256) {
+        const int e = task / 36, ab = task - e * 36, a = ab / 6, b = ab - a * 6;
+        const int ja = wrap_add(ebase[e][0], a, g.wrap0) - lo[0];
+        const int jb = wrap_add(ebase[e][1], b, g.K[1]) - lo[1];
+        if ((unsigned)ja >= (unsigned)n[0] || (unsigned)jb >= (unsigned)n[1]) continue;
+        const T* w = wts[e];
+        const T m0 = w[a], d0 = w[6 + a], e0 = w[12 + a];
+        const T m1 = w[18 + b], d1 = w[24 + b], e1 = w[30 + b];
+        const T mm = m0 * m1;
+        const T P0 = w[54] * mm + w[55] * d0 * m1 + w[56] * m0 * d1 + w[58] * e0 * m1 + w[59] * m0 * e1 + w[61] * d0 * d1;
+        const T P1 = w[57] * mm + w[62] * d0 * m1 + w[63] * m0 * d1;
+        const T P2 = w[60] * mm;
+        double* row = tile + (ja * 16 + jb) * 16;
+        const int bc = ebase[e][2];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int jc = wrap_add(bc, c, g.K[2]) - lo[2];
+          if ((unsigned)jc < (unsigned)n[2])
+            atomicAdd(&row[jc], (double)(P0 * w[36 + c] + P1 * w[42 + c] + P2 * w[48 + c]));
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  const int nyz = n[1] * n[2], ntot = n[0] * nyz;
+  for (int t = threadIdx.x; t < ntot; t += 256) {
+    const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
+    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * 16 + jc];
+  }
+}
+
 // Small systems (too few atoms to fill the chip brick by brick, and launch-latency bound): global float
 // atomics, 8-lane groups, lanes 0..5 each spread one x-plane (36 points) of the atom's stencil.
 template <class T>
@@ -316,6 +416,11 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
   if (na < spread_brick_min_atoms()) {
+    static const int scan_max = [] { const char* e = getenv("ADMP_SPREAD_SCAN_MAX"); return e ? atoi(e) : 8192; }();
+    if (na <= scan_max) {
+      k_spread_scan<T><<<bg.ncell, 256, 0, st>>>(na, sites, lpol, g, bg, mesh, list);
+      return 0;
+    }
     RC(hipMemsetAsync(mesh, 0, sizeof(T) * (size_t)g.nloc0 * g.K[1] * g.K[2], st));
     k_spread_planes<T><<<nblk(na * 8, 256), 256, 0, st>>>(na, sites, lpol, g, mesh, list);
     return 0;

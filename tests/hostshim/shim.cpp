@@ -208,10 +208,10 @@ static double tt_real(int na, const double* pos, const double* abqc, const doubl
   return e;
 }
 
-// ---- direct DFT lines (dft_math.h), driven exactly like dft_kernels.hip drives them
-template <class T>
+// ---- direct DFT lines (dft_math.h), driven like dft_kernels.hip drives them: KQ outputs per call, k = g + q * TK
+template <class T, int KQ>
 static void dft_line(int N, int sign, const double* in, double* out) {
-  const int H = (N - 1) / 2;
+  const int H = (N - 1) / 2, Kh = N / 2 + 1, TK = (Kh + KQ - 1) / KQ;
   std::vector<Cx<T>> tw(N);
   for (int m = 0; m < N; ++m) tw[m] = Cx<T>{(T)std::cos(2.0 * M_PI * m / N), (T)std::sin(2.0 * M_PI * m / N)};
   std::vector<PairCx<T>> ab(H > 0 ? H : 1);
@@ -220,37 +220,59 @@ static void dft_line(int N, int sign, const double* in, double* out) {
                           (T)(in[2 * j] - in[2 * (N - j)]), (T)(in[2 * j + 1] - in[2 * (N - j) + 1])};
   Cx<T> x0{(T)in[0], (T)in[1]}, xn{T(0), T(0)};
   if (N % 2 == 0) xn = Cx<T>{(T)in[N], (T)in[N + 1]};
-  for (int k = 0; k <= N / 2; ++k) {
-    Cx<T> a, b;
-    if (sign < 0) dft_pair_outputs<T, -1>(N, k, 1, ab.data(), x0, xn, tw.data(), a, b);
-    else dft_pair_outputs<T, +1>(N, k, 1, ab.data(), x0, xn, tw.data(), a, b);
-    out[2 * k] = a.re; out[2 * k + 1] = a.im;
-    if (k != 0 && 2 * k != N) { out[2 * (N - k)] = b.re; out[2 * (N - k) + 1] = b.im; }
+  for (int g = 0; g < TK; ++g) {
+    int k[KQ];
+    for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
+    Cx<T> a[KQ], b[KQ];
+    if (sign < 0) dft_pair_outputs<T, -1, KQ>(N, k, 1, ab.data(), x0, xn, tw.data(), a, b);
+    else dft_pair_outputs<T, +1, KQ>(N, k, 1, ab.data(), x0, xn, tw.data(), a, b);
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK;
+      if (kq >= Kh) continue;
+      out[2 * kq] = a[q].re; out[2 * kq + 1] = a[q].im;
+      if (kq != 0 && 2 * kq != N) { out[2 * (N - kq)] = b[q].re; out[2 * (N - kq) + 1] = b[q].im; }
+    }
   }
 }
-template <class T>
+template <class T, int KQ>
 static void rdft_line(int N, const double* in, double* out) {
-  const int H = (N - 1) / 2;
+  const int H = (N - 1) / 2, Kh = N / 2 + 1, TK = (Kh + KQ - 1) / KQ;
   std::vector<Cx<T>> tw(N), p(H > 0 ? H : 1);
   for (int m = 0; m < N; ++m) tw[m] = Cx<T>{(T)std::cos(2.0 * M_PI * m / N), (T)std::sin(2.0 * M_PI * m / N)};
   for (int j = 1; j <= H; ++j) p[j - 1] = Cx<T>{(T)(in[j] + in[N - j]), (T)(in[j] - in[N - j])};
-  for (int k = 0; k <= N / 2; ++k) {
-    Cx<T> X = rdft_output<T>(N, k, 1, p.data(), (T)in[0], (N % 2 == 0) ? (T)in[N / 2] : T(0), tw.data());
-    out[2 * k] = X.re; out[2 * k + 1] = X.im;
+  for (int g = 0; g < TK; ++g) {
+    int k[KQ];
+    for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
+    Cx<T> X[KQ];
+    rdft_outputs<T, KQ>(N, k, 1, p.data(), (T)in[0], (N % 2 == 0) ? (T)in[N / 2] : T(0), tw.data(), X);
+    for (int q = 0; q < KQ; ++q)
+      if (g + q * TK < Kh) { out[2 * (g + q * TK)] = X[q].re; out[2 * (g + q * TK) + 1] = X[q].im; }
   }
 }
-template <class T>
+template <class T, int KQ>
 static void irdft_line(int N, const double* in, double* out) {
-  const int H = (N - 1) / 2;
+  const int H = (N - 1) / 2, Kh = N / 2 + 1, TK = (Kh + KQ - 1) / KQ;
   std::vector<Cx<T>> tw(N), p(H > 0 ? H : 1);
   for (int m = 0; m < N; ++m) tw[m] = Cx<T>{(T)std::cos(2.0 * M_PI * m / N), (T)std::sin(2.0 * M_PI * m / N)};
   for (int k = 1; k <= H; ++k) p[k - 1] = Cx<T>{(T)in[2 * k], (T)in[2 * k + 1]};
-  for (int j = 0; j <= N / 2; ++j) {
-    T a, b;
-    irdft_pair_outputs<T>(N, j, 1, p.data(), (T)in[0], (N % 2 == 0) ? (T)in[N] : T(0), tw.data(), a, b);
-    out[j] = a;
-    if (j != 0 && 2 * j != N) out[N - j] = b;
+  for (int g = 0; g < TK; ++g) {
+    int j[KQ];
+    for (int q = 0; q < KQ; ++q) j[q] = (g + q * TK < Kh) ? g + q * TK : 0;
+    T a[KQ], b[KQ];
+    irdft_pair_outputs<T, KQ>(N, j, 1, p.data(), (T)in[0], (N % 2 == 0) ? (T)in[N] : T(0), tw.data(), a, b);
+    for (int q = 0; q < KQ; ++q) {
+      const int jq = g + q * TK;
+      if (jq >= Kh) continue;
+      out[jq] = a[q];
+      if (jq != 0 && 2 * jq != N) out[N - jq] = b[q];
+    }
   }
+}
+template <class T, int KQ>
+static void dft_any(int kind, int N, int sign, const double* in, double* out) {
+  if (kind == 0) dft_line<T, KQ>(N, sign, in, out);
+  else if (kind == 1) rdft_line<T, KQ>(N, in, out);
+  else irdft_line<T, KQ>(N, in, out);
 }
 
 extern "C" {
@@ -296,11 +318,17 @@ double shim_tt_real(int prec, int na, const double* pos, const double* abqc, con
                    : tt_real<double>(na, pos, abqc, boxh, np, pairs, nb, mtab, grad);
 }
 double shim_disp_ck(int which, double ksq, double kappa, double V) { return disp_ck(which, ksq, kappa, V); }
-// kind 0: complex line (sign -1 / +1), 1: r2c line, 2: c2r line of a half spectrum
-void shim_dft_line(int prec, int kind, int N, int sign, const double* in, double* out) {
-  if (kind == 0) { if (prec == 4) dft_line<float>(N, sign, in, out); else dft_line<double>(N, sign, in, out); }
-  else if (kind == 1) { if (prec == 4) rdft_line<float>(N, in, out); else rdft_line<double>(N, in, out); }
-  else { if (prec == 4) irdft_line<float>(N, in, out); else irdft_line<double>(N, in, out); }
+// kind 0: complex line (sign -1 / +1), 1: r2c line, 2: c2r line of a half spectrum; kq = outputs per call (1, 2, 4)
+void shim_dft_line(int prec, int kq, int kind, int N, int sign, const double* in, double* out) {
+  if (prec == 4) {
+    if (kq == 1) dft_any<float, 1>(kind, N, sign, in, out);
+    else if (kq == 2) dft_any<float, 2>(kind, N, sign, in, out);
+    else dft_any<float, 4>(kind, N, sign, in, out);
+  } else {
+    if (kq == 1) dft_any<double, 1>(kind, N, sign, in, out);
+    else if (kq == 2) dft_any<double, 2>(kind, N, sign, in, out);
+    else dft_any<double, 4>(kind, N, sign, in, out);
+  }
 }
 int shim_largest_prime_factor(int n) { return largest_prime_factor(n); }
 }
