@@ -36,8 +36,9 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
                                                               const T* __restrict__ Qlocal,
                                                               const T* __restrict__ Ucart, const T* __restrict__ pol,
                                                               const T* __restrict__ thole, Box<T> box,
-                                                              Site<T>* __restrict__ sites) {
+                                                              Site<T>* __restrict__ sites, double* zero_next) {
   int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (zero_next && i < E_SLOTS) zero_next[i] = 0.0;   // the NEXT evaluation's energy words (engine.hip: Ed_cur)
   if (i >= top.na) return;
   int type, iz, ix, iy;
   FrameWork<T> w;
@@ -71,7 +72,6 @@ __global__ __launch_bounds__(kAtomBlock) void k_update_U(int na, const T* __rest
   sites[i].U[2] = Ucart[3 * i + 1];
 }
 
-__device__ __forceinline__ unsigned long long nonneg_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 
 template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_field_finish(int na, const Site<T>* __restrict__ sites,
@@ -84,19 +84,9 @@ __global__ __launch_bounds__(kAtomBlock) void k_field_finish(int na, const Site<
   double fm = 0.0;
   if (slot < na) {
     const int i = list ? list[slot] : slot;
-    T f[3];
-    self_factors(kappa, f);
-    const T twoDf1 = T(2.0 * kDielectric) * f[1];
-    const Site<T>& s = sites[i];
-    T a = pol[i];
-    T ainv = T(kDielectric) / (a < T(1e-8) ? T(1e-8) : a);   // d/dU of D U^2 / (2 max(pol, 1e-8))
-    // pair field is in harmonic order (z,x,y); recip field is cartesian already
-    T hz = fld_pair[3 * i] - twoDf1 * (s.Q[1] + s.U[0]);
-    T hx = fld_pair[3 * i + 1] - twoDf1 * (s.Q[2] + s.U[1]);
-    T hy = fld_pair[3 * i + 2] - twoDf1 * (s.Q[3] + s.U[2]);
-    T fx = hx + fld_recip[3 * i] + ainv * Ucart[3 * i];
-    T fy = hy + fld_recip[3 * i + 1] + ainv * Ucart[3 * i + 1];
-    T fz = hz + fld_recip[3 * i + 2] + ainv * Ucart[3 * i + 2];
+    const T a = pol[i];
+    T fx, fy, fz;
+    total_field(sites[i], a, Ucart + 3 * i, fld_pair + 3 * i, fld_recip + 3 * i, kappa, fx, fy, fz);
     field[3 * i] = fx; field[3 * i + 1] = fy; field[3 * i + 2] = fz;
     if (a > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
   }
@@ -316,8 +306,8 @@ static inline int nblk(int n) { return (n + kAtomBlock - 1) / kAtomBlock; }
 
 template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
-                          const T* pol, const T* thole, const Box<T>& box, Site<T>* sites) {
-  k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites);
+                          const T* pol, const T* thole, const Box<T>& box, Site<T>* sites, double* zero_next) {
+  k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites, zero_next);
 }
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites) {
@@ -359,7 +349,7 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
   template void launch_scalar_sites<T>(hipStream_t, int, const T*, const T*, int, int, double, Site<T>*, double*);      \
   template void launch_scale_add<T>(hipStream_t, int, const T*, int, int, const T*, T*);                                \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
-                                        const Box<T>&, Site<T>*);                                                       \
+                                        const Box<T>&, Site<T>*, double*);                                              \
   template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
                                        unsigned long long*, const int*);                                                \

@@ -17,8 +17,8 @@ static int dft_kq() {
   static int v = 0;
   if (!v) {
     const char* e = getenv("ADMP_DFT_KQ");
-    v = e ? atoi(e) : 4;
-    if (v != 1 && v != 2 && v != 4) v = 4;
+    v = e ? atoi(e) : 2;
+    if (v != 1 && v != 2 && v != 4) v = 2;
   }
   return v;
 }
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
 #define KQ_SWITCH(CALL)            \
   switch (dft_kq()) {              \
     case 1: { constexpr int KQ = 1; CALL; } break; \
-    case 2: { constexpr int KQ = 2; CALL; } break; \
-    default: { constexpr int KQ = 4; CALL; } break; \
+    case 4: { constexpr int KQ = 4; CALL; } break; \
+    default: { constexpr int KQ = 2; CALL; } break; \
   }
 
 template <class T>

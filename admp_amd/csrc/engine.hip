@@ -268,6 +268,14 @@ struct Engine : EngineBase {
   // per-atom
   DevBuf sites, grad, pot, fld_pair, fld_recip, field, energies_d;
   bool fmax_clean = false, slot_clean[E_SLOTS] = {false};
+  // The energy words are double-buffered: the evaluation of step n accumulates into half (n & 1) while its first
+  // kernel zeroes the other half for step n+1 -- no memset dispatch per step.  Eh is pinned host memory for the
+  // one device-to-host copy of a step.
+  int ehalf = 0;
+  bool other_clean = false;
+  void* energies_seen = nullptr;
+  double* Eh = nullptr;
+  double* Ed_cur() { return energies_d.as<double>() + (size_t)ehalf * E_SLOTS; }
   // staging for host-pointer calls
   DevBuf s_pos, s_Q, s_pol, s_thole, s_U, s_out, s_dQ, s_par;
   // mesh
@@ -293,6 +301,7 @@ struct Engine : EngineBase {
       b->release();
     free_topology();
     cells.release();
+    if (Eh) (void)hipHostFree(Eh);
     prof.destroy();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -418,7 +427,7 @@ struct Engine : EngineBase {
   }
   // mesh <- IFFT( G * FFT(mesh) ), energies[slot] += sum w G |S|^2 : the whole k-space leg of one reciprocal pass
   void convolve(T* mesh_p, T* spec_p, const T* gtab, int slot) {
-    double* Ed = energies_d.as<double>();
+    double* Ed = Ed_cur();
     if (use_dft) {
       const T* tw = dft_tw.as<T>();
       { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 0); }
@@ -552,17 +561,29 @@ struct Engine : EngineBase {
     ev.U = lpol ? reinterpret_cast<T*>(U_) : nullptr;
     sites.need(sizeof(Site<T>) * (size_t)na);
     pot.need(9 * (size_t)na * sizeof(T));
-    energies_d.need(E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_SLOTS * sizeof(double));
+    if (energies_d.p != energies_seen) { energies_seen = energies_d.p; other_clean = false; }
     if (lpol) {
       fld_pair.need(3 * (size_t)na * sizeof(T));
       fld_recip.need(3 * (size_t)na * sizeof(T));
       field.need(3 * (size_t)na * sizeof(T));
     }
     ensure_bins(na);
-    HIP_TRY(hipMemsetAsync(energies_d.p, 0, E_SLOTS * sizeof(double), stream));   // energies and the max|field| word
+    if (other_clean) {
+      ehalf ^= 1;                      // zeroed by the previous evaluation's first kernel
+    } else {
+      ehalf = 0;
+      HIP_TRY(hipMemsetAsync(energies_d.p, 0, E_SLOTS * sizeof(double), stream));   // energies and the max|field| word
+    }
+    other_clean = false;
     fmax_clean = true;
     for (bool& c : slot_clean) c = true;
-    { TIMED("prepare_sites"); launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, ev.U, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>()); }
+    {
+      TIMED("prepare_sites");
+      launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, ev.U, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>(),
+                              energies_d.as<double>() + (size_t)(ehalf ^ 1) * E_SLOTS);
+    }
+    other_clean = true;
     if (snranks > 1) {
       home_list.need(sizeof(int) * (size_t)na + sizeof(int));
       int* cnt = home_list.as<int>() + na;
@@ -603,10 +624,10 @@ struct Engine : EngineBase {
   // spectrum buffer in the k-space layout [K0][ny][K2/2+1]: energy into `slot`, multiply by G
   void stage_kspace(T* spec_p, int slot) {
     need_eval();
-    if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + slot, 0, sizeof(double), stream));
+    if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(Ed_cur() + slot, 0, sizeof(double), stream));
     slot_clean[slot] = false;
     TIMED("kspace");
-    launch_kspace<T>(stream, K, nyown(), gtab_cur, spec_p, energies_d.as<double>(), slot);
+    launch_kspace<T>(stream, K, nyown(), gtab_cur, spec_p, Ed_cur(), slot);
   }
   void stage_gather_field(const T* mesh_p) {
     need_eval();
@@ -615,7 +636,7 @@ struct Engine : EngineBase {
   }
   // max|field| lives in the last word of the energies buffer (bit pattern of a non-negative double), so that one
   // device->host copy can fetch it together with the energies
-  unsigned long long* fmax_word() { return reinterpret_cast<unsigned long long*>(energies_d.as<double>() + E_FMAX); }
+  unsigned long long* fmax_word() { return reinterpret_cast<unsigned long long*>(Ed_cur() + E_FMAX); }
   void launch_field_finish_only() {
     need_eval();
     if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
@@ -644,28 +665,36 @@ struct Engine : EngineBase {
       HIP_TRY(hipMemsetAsync(grad_p, 0, 3 * (size_t)top.na * sizeof(T), stream));
       HIP_TRY(hipMemsetAsync(pot.p, 0, 9 * (size_t)top.na * sizeof(T), stream));
     }
-    if (!slot_clean[E_REAL]) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_REAL, 0, sizeof(double), stream));
+    if (!slot_clean[E_REAL]) HIP_TRY(hipMemsetAsync(Ed_cur() + E_REAL, 0, sizeof(double), stream));
     slot_clean[E_REAL] = false;
     TIMED("pair_full");
     launch_pair_full<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, lpol, grad_p, pot.as<T>(),
-                        energies_d.as<double>(), ev.home, fld_out);
+                        Ed_cur(), ev.home, fld_out);
   }
-  void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr) {
+  // with_field_finish: the gather also forms the total dE/dU and its maximum (launch_field_finish's work, fused)
+  void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr, bool with_field_finish = false) {
     need_eval();
+    FieldFin<T> ff;
+    if (with_field_finish) {
+      if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
+      fmax_clean = false;
+      ff.pol = ev.pol; ff.Ucart = ev.U; ff.fld_pair = fld_pair.as<T>(); ff.kappa = (T)kappa;
+      ff.field = field.as<T>(); ff.fmax_bits = fmax_word();
+    }
     TIMED("gather");
-    launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out);
+    launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff);
   }
   // closes the evaluation: E_out = (real, recip[slot], self, penalty) of THIS rank's share
   void launch_finish_only(T* grad_p, T* dQl) {
     need_eval();
     TIMED("finish");
     launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
-                     dQl, energies_d.as<double>(), ev.home, ev.n_home);
+                     dQl, Ed_cur(), ev.home, ev.n_home);
   }
   // one device->host copy + sync: energies (and the max|field| word, returned)
   double read_energies(int recip_slot, double* E) {
-    double Eh[E_SLOTS];
-    HIP_TRY(hipMemcpyAsync(Eh, energies_d.p, sizeof(Eh), hipMemcpyDeviceToHost, stream));
+    if (!Eh) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&Eh), E_SLOTS * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(Eh, Ed_cur(), E_SLOTS * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     E[0] = Eh[E_REAL]; E[1] = Eh[recip_slot]; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
     return Eh[E_FMAX];   // same bits as the device word
@@ -680,7 +709,7 @@ struct Engine : EngineBase {
   void recip_pass(int slot) {
     stage_spread(mesh.as<T>());
     need_eval();
-    if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(energies_d.as<double>() + slot, 0, sizeof(double), stream));
+    if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(Ed_cur() + slot, 0, sizeof(double), stream));
     slot_clean[slot] = false;
     convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, slot);
   }
@@ -733,15 +762,14 @@ struct Engine : EngineBase {
         // The closing kernel is enqueued speculatively as well, so the step has ONE host synchronisation.
         stage_pair_full(gbuf, fld_pair.as<T>());
         recip_pass(E_SCF_RECIP);
-        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>());
-        launch_field_finish_only();
+        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), true);
         launch_finish_only(dpos ? gbuf : nullptr, dQl);
         const double fmax = read_energies(E_SCF_RECIP, E);
         if (fmax < thresh) {
           phi_valid = done = finished = true;
           ev.active = false;
         } else {   // undo the speculative energy sums; gradient / dQ are rewritten by the regular closing pass
-          HIP_TRY(hipMemsetAsync(energies_d.as<double>() + E_SELF, 0, 2 * sizeof(double), stream));
+          HIP_TRY(hipMemsetAsync(Ed_cur() + E_SELF, 0, 2 * sizeof(double), stream));
           stage_jacobi(U);
           i = 1;
         }
@@ -866,7 +894,8 @@ struct Engine : EngineBase {
     grad.need(3 * (size_t)na * sizeof(T));
     if (dpos_ && on_device) dpos = reinterpret_cast<T*>(dpos_);
     else dpos = grad.as<T>();
-    energies_d.need(E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_SLOTS * sizeof(double));
+    ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, dpos, Ed); }
@@ -910,7 +939,8 @@ struct Engine : EngineBase {
     const T* par = stage_in(s_par, abqc_, 4 * (size_t)na, on_device);
     grad.need(3 * (size_t)na * sizeof(T));
     T* dpos = (dpos_ && on_device) ? reinterpret_cast<T*>(dpos_) : grad.as<T>();
-    energies_d.need(E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_SLOTS * sizeof(double));
+    ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     { TIMED("tt_pair"); launch_tt_pair<T>(stream, na, nbr, pos, par, bx, tab, dpos, Ed); }

@@ -165,4 +165,21 @@ ADMP_HD void self_factors(T kappa, T f[3]) {
   f[2] = f[0] * k2 * k2 / T(15);
 }
 
+// Cartesian dE/dU of one atom (admp/pme.py:111-143: the SCF residual): real-space part (harmonic order z,x,y) + reciprocal
+// part (cartesian) + self term + polarization penalty D U / max(pol, 1e-8).
+template <class T>
+ADMP_HD void total_field(const Site<T>& s, T a, const T* U, const T* fld_pair, const T* fld_recip, T kappa, T& fx, T& fy,
+                         T& fz) {
+  T f[3];
+  self_factors(kappa, f);
+  const T twoDf1 = T(2.0 * kDielectric) * f[1];
+  const T ainv = T(kDielectric) / (a < T(1e-8) ? T(1e-8) : a);   // d/dU of D U^2 / (2 max(pol, 1e-8))
+  const T hz = fld_pair[0] - twoDf1 * (s.Q[1] + s.U[0]);
+  const T hx = fld_pair[1] - twoDf1 * (s.Q[2] + s.U[1]);
+  const T hy = fld_pair[2] - twoDf1 * (s.Q[3] + s.U[2]);
+  fx = hx + fld_recip[0] + ainv * U[0];
+  fy = hy + fld_recip[1] + ainv * U[1];
+  fz = hz + fld_recip[2] + ainv * U[2];
+}
+
 }  // namespace admp

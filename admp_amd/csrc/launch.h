@@ -47,7 +47,8 @@ enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SCF_RECIP = 6, E_FMAX =
 // ---- atom_kernels.hip
 template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
-                          const T* pol, const T* thole, const Box<T>& box, Site<T>* sites);
+                          const T* pol, const T* thole, const Box<T>& box, Site<T>* sites,
+                          double* zero_next /* E_SLOTS doubles cleared for the next evaluation, or nullptr */);
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites);
 // field (Cartesian dE/dU) = pair (harmonic order) + recip (cartesian) + self + penalty; also max |field| over
@@ -148,9 +149,21 @@ void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* b
 template <class T>
 void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec /* interleaved complex */,
                    double* energies, int slot);
+// optional epilogue of the gather (single rank, speculative first SCF cycle): total dE/dU and its maximum, exactly
+// what launch_field_finish computes, without a separate dispatch
+template <class T>
+struct FieldFin {
+  const T* pol = nullptr;
+  const T* Ucart = nullptr;
+  const T* fld_pair = nullptr;
+  T kappa = 0;
+  T* field = nullptr;
+  unsigned long long* fmax_bits = nullptr;   // nullptr = epilogue off
+};
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad, const int* list, T* fld_recip /* optional: cartesian reciprocal dE/dU */);
+                   T* grad, const int* list, T* fld_recip /* optional: cartesian reciprocal dE/dU */,
+                   const FieldFin<T>& ff = FieldFin<T>());
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
                          T* fld_recip, const int* list);

@@ -181,29 +181,33 @@ __global__ __launch_bounds__(256) void k_spread_scan(int na, const Site<T>* __re
     const int ne = nent;
     for (int sub = 0; sub < ne; sub += kScanSub) {
       const int cnt = min(kScanSub, ne - sub);
-      if (threadIdx.x < cnt) {
-        T r[3], Q[9];
-        site_qtot(sites[ents[sub + threadIdx.x]], lpol, r, Q);
-        Stencil<T> st;
-        st.init(g, r);
-        T c1[3], c2[6];
-        fold_multipole(g, Q, c1, c2);
-        T* w = wts[threadIdx.x];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          ebase[threadIdx.x][d] = st.base[d];
+      if (threadIdx.x < 4 * cnt) {      // 4 threads per entry: one spline axis each, the fourth folds the multipoles
+        const int e = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const Site<T>& site = sites[ents[sub + e]];
+        T* w = wts[e];
+        if (part < 3) {
+          T r[3] = {site.r[0], site.r[1], site.r[2]};
+          int base;
+          T M[6], D1[6], D2[6], D3[6];
+          const T f = grid_ref(g, r, part, base);
+          bspline6(f, M, D1, D2, D3);
+          ebase[e][part] = base;
 #pragma unroll
           for (int k = 0; k < 6; ++k) {
-            w[d * 18 + k] = st.M[d][k];
-            w[d * 18 + 6 + k] = st.D1[d][k];
-            w[d * 18 + 12 + k] = st.D2[d][k];
+            w[part * 18 + k] = M[k];
+            w[part * 18 + 6 + k] = D1[k];
+            w[part * 18 + 12 + k] = D2[k];
           }
+        } else {
+          T r[3], Q[9], c1[3], c2[6];
+          site_qtot(site, lpol, r, Q);
+          fold_multipole(g, Q, c1, c2);
+          w[54] = Q[0];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) w[55 + k] = c1[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) w[58 + k] = c2[k];
         }
-        w[54] = Q[0];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) w[55 + k] = c1[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) w[58 + k] = c2[k];
       }
       __syncthreads();
       for (int task = threadIdx.x; task < cnt * 36; task += 256) {
@@ -351,7 +355,8 @@ template <class T>
 __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* __restrict__ sites, int lpol,
                                                          RecipGeom<T> g, const T* __restrict__ phi,
                                                          T* __restrict__ pot, T* __restrict__ grad,
-                                                         const int* __restrict__ list, T* __restrict__ fld) {
+                                                         const int* __restrict__ list, T* __restrict__ fld,
+                                                         FieldFin<T> ff) {
   const int t = blockIdx.x * kGatherBlock + threadIdx.x;
   const int slot = t >> 3, a = t & 7;
   const int i = slot < na ? (list ? list[slot] : slot) : na;
@@ -380,6 +385,18 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* 
     if (grad) {
       grad[3 * i] += gr[0]; grad[3 * i + 1] += gr[1]; grad[3 * i + 2] += gr[2];
     }
+  }
+  if (ff.fmax_bits) {   // kernel-uniform
+    double fm = 0.0;
+    if (slot < na && a == 0) {
+      const T al = ff.pol[i];
+      T fx, fy, fz;
+      total_field(sites[i], al, ff.Ucart + 3 * i, ff.fld_pair + 3 * i, fld + 3 * i, ff.kappa, fx, fy, fz);
+      ff.field[3 * i] = fx; ff.field[3 * i + 1] = fy; ff.field[3 * i + 2] = fz;
+      if (al > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
+    }
+    fm = block_reduce_max<kGatherBlock>(fm);
+    if (threadIdx.x == 0 && fm > 0.0) atomicMax(ff.fmax_bits, nonneg_bits(fm));
   }
 }
 
@@ -493,8 +510,8 @@ void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipG
 }
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad, const int* list, T* fld) {
-  k_gather<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld);
+                   T* grad, const int* list, T* fld, const FieldFin<T>& ff) {
+  k_gather<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff);
 }
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
@@ -508,7 +525,7 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
-                                 const int*, T*);                                                                       \
+                                 const int*, T*, const FieldFin<T>&);                                                   \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
                                        const int*);
 INST(float)

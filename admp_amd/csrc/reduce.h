@@ -16,6 +16,9 @@ __device__ __forceinline__ double wave_reduce_max(double v) {
   return v;
 }
 
+// order-preserving bit pattern of a non-negative double (for atomicMax on an unsigned word)
+__device__ __forceinline__ unsigned long long nonneg_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+
 // result valid in thread 0
 template <int BLOCK>
 __device__ __forceinline__ double block_reduce_sum(double v) {
