@@ -36,7 +36,8 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
                                                               const T* __restrict__ Qlocal,
                                                               const T* __restrict__ Ucart, const T* __restrict__ pol,
                                                               const T* __restrict__ thole, Box<T> box,
-                                                              Site<T>* __restrict__ sites, double* zero_next) {
+                                                              Site<T>* __restrict__ sites, double* zero_next,
+                                                              RecipGeom<T> g, int4* __restrict__ bases) {
   int i = blockIdx.x * kAtomBlock + threadIdx.x;
   if (zero_next && i < E_SLOTS) zero_next[i] = 0.0;   // the NEXT evaluation's energy words (engine.hip: Ed_cur)
   if (i >= top.na) return;
@@ -60,6 +61,13 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
   s.thole = thole ? thole[i] : T(0);
   s.pad[0] = s.pad[1] = s.pad[2] = T(0);
   sites[i] = s;
+  if (bases) {   // lowest mesh index of the atom's stencil on every axis: what the spread's binning needs, 16 B per atom
+    int b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) grid_ref(g, s.r, d, b[d]);
+    const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
+    bases[i] = make_int4(b[0], b[1], b[2], brick_code(b, dims, make_bricks(dims)));
+  }
 }
 
 template <class T>
@@ -306,8 +314,10 @@ static inline int nblk(int n) { return (n + kAtomBlock - 1) / kAtomBlock; }
 
 template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
-                          const T* pol, const T* thole, const Box<T>& box, Site<T>* sites, double* zero_next) {
-  k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites, zero_next);
+                          const T* pol, const T* thole, const Box<T>& box, Site<T>* sites, double* zero_next,
+                          const RecipGeom<T>& g, int4* bases) {
+  k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites, zero_next, g,
+                                                          bases);
 }
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites) {
@@ -349,7 +359,7 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
   template void launch_scalar_sites<T>(hipStream_t, int, const T*, const T*, int, int, double, Site<T>*, double*);      \
   template void launch_scale_add<T>(hipStream_t, int, const T*, int, int, const T*, T*);                                \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
-                                        const Box<T>&, Site<T>*, double*);                                              \
+                                        const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*);                  \
   template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
                                        unsigned long long*, const int*);                                                \

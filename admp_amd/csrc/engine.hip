@@ -287,6 +287,7 @@ struct Engine : EngineBase {
   int planK[3] = {0, 0, 0}, planR = 0, planRank = 0;
   DevBuf home_list;
   DevBuf dft_tw;          // twiddle tables of the direct-DFT path
+  DevBuf bases_d;         // int4 per atom: lowest stencil index on each mesh axis
   bool use_dft = false;   // mesh convolution through dft_kernels.hip instead of rocFFT (single rank, a Bluestein dimension)
   // validity of the cached G table
   struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0; } tabkey[4];
@@ -297,7 +298,7 @@ struct Engine : EngineBase {
     destroy_plans();
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
-                      &bin_sorted, &bin_scan, &home_list, &dft_tw})
+                      &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d})
       b->release();
     free_topology();
     cells.release();
@@ -539,6 +540,7 @@ struct Engine : EngineBase {
     T* U = nullptr;
     Box<T> bx; RecipGeom<T> g; ScaleTab<T> tab;
     int n_home = 0; const int* home = nullptr;   // this rank's atoms (nullptr = all, in order)
+    const int4* bases = nullptr;                 // stencil base indices per atom (written by prepare_sites)
     bool active = false;
   } ev;
 
@@ -569,6 +571,7 @@ struct Engine : EngineBase {
       field.need(3 * (size_t)na * sizeof(T));
     }
     ensure_bins(na);
+    bases_d.need(sizeof(int4) * (size_t)na);
     if (other_clean) {
       ehalf ^= 1;                      // zeroed by the previous evaluation's first kernel
     } else {
@@ -581,7 +584,8 @@ struct Engine : EngineBase {
     {
       TIMED("prepare_sites");
       launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, ev.U, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>(),
-                              energies_d.as<double>() + (size_t)(ehalf ^ 1) * E_SLOTS);
+                              energies_d.as<double>() + (size_t)(ehalf ^ 1) * E_SLOTS, ev.g, bases_d.as<int4>());
+      ev.bases = bases_d.as<int4>();
     }
     other_clean = true;
     if (snranks > 1) {
@@ -618,7 +622,7 @@ struct Engine : EngineBase {
   void stage_spread(T* mesh_p) {
     need_eval();
     TIMED("spread");
-    int rc = launch_spread<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, bins, mesh_p, ev.home);
+    int rc = launch_spread<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, bins, mesh_p, ev.home, ev.bases);
     if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
   }
   // spectrum buffer in the k-space layout [K0][ny][K2/2+1]: energy into `slot`, multiply by G
@@ -762,7 +766,11 @@ struct Engine : EngineBase {
         // The closing kernel is enqueued speculatively as well, so the step has ONE host synchronisation.
         stage_pair_full(gbuf, fld_pair.as<T>());
         recip_pass(E_SCF_RECIP);
-        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), true);
+        // small systems are dispatch-bound: the field finish rides in the gather's epilogue; at 1M atoms the fused
+        // kernel costs more (0.40 vs 0.31 + 0.056 ms) and the two stay separate
+        const bool fuse_ff = top.na <= 65536;
+        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), fuse_ff);
+        if (!fuse_ff) launch_field_finish_only();
         launch_finish_only(dpos ? gbuf : nullptr, dQl);
         const double fmax = read_energies(E_SCF_RECIP, E);
         if (fmax < thresh) {

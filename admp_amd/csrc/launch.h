@@ -48,7 +48,8 @@ enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SCF_RECIP = 6, E_FMAX =
 template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
                           const T* pol, const T* thole, const Box<T>& box, Site<T>* sites,
-                          double* zero_next /* E_SLOTS doubles cleared for the next evaluation, or nullptr */);
+                          double* zero_next /* E_SLOTS doubles cleared for the next evaluation, or nullptr */,
+                          const RecipGeom<T>& g, int4* bases /* optional: stencil base indices per atom */);
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites);
 // field (Cartesian dE/dU) = pair (harmonic order) + recip (cartesian) + self + penalty; also max |field| over
@@ -114,11 +115,26 @@ struct BrickGrid {
   int nb[3];
   int ncell;
 };
-inline BrickGrid make_bricks(const int K[3]) {
+__host__ __device__ inline BrickGrid make_bricks(const int K[3]) {
   BrickGrid b;
   for (int d = 0; d < 3; ++d) b.nb[d] = (K[d] + 15) / 16;
   b.ncell = b.nb[0] * b.nb[1] * b.nb[2];
   return b;
+}
+// brick index of mesh index i on an axis of K points cut into nb bricks [b*K/nb, (b+1)*K/nb)
+__host__ __device__ inline int brick_of(int i, int nb, int K) { return ((i + 1) * nb - 1) / K; }
+// Packed brick code of a stencil with lowest indices base[3]: 9 bits per axis = brick of `base`, bits 27..29 = the
+// stencil (6 points) reaches into the next brick on that axis.  Computed once per atom (the integer divisions are the
+// expensive part of binning) by k_prepare_sites, stored in the .w of the atom's int4 base record.
+__host__ __device__ inline int brick_code(const int base[3], const int dims[3], const BrickGrid& bg) {
+  int code = 0;
+  for (int d = 0; d < 3; ++d) {
+    const int b = brick_of(base[d], bg.nb[d], dims[d]);
+    const int end = ((b + 1) * dims[d]) / bg.nb[d];          // first index past the brick of `base`
+    code |= b << (9 * d);
+    if (bg.nb[d] > 1 && base[d] + 5 >= end) code |= 1 << (27 + d);
+  }
+  return code;
 }
 // below this atom count the spread uses global atomics (8 lanes per atom) instead of binned LDS bricks
 // (default 20000; env ADMP_SPREAD_BRICK_MIN overrides, 0 forces the brick path -- used by the parity tests)
@@ -138,7 +154,7 @@ struct BinScratch {
 // (no memset, no global atomics).  Returns a hipError_t as int.
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
-                  T* mesh, const int* list);
+                  T* mesh, const int* list, const int4* bases = nullptr /* from launch_prepare_sites, or recomputed */);
 size_t spread_scan_bytes(int ncell);
 // k-space layout [K0][ny][K2/2+1] holding mesh rows y0 .. y0+ny-1 (ny = K1, y0 = 0 on one rank).
 // which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels

@@ -22,19 +22,6 @@ __device__ __forceinline__ void site_qtot(const Site<T>& s, int lpol, T r[3], T 
 }
 
 // ---- LDS-brick spread -------------------------------------------------------------------------------
-// brick index of mesh index i on an axis of K points cut into nb bricks [b*K/nb, (b+1)*K/nb)
-__device__ __forceinline__ int brick_of(int i, int nb, int K) { return ((i + 1) * nb - 1) / K; }
-
-// The bricks (at most 2 per axis) that the 6-point stencil starting at `base` touches on one axis.
-__device__ __forceinline__ int bricks_on_axis(int base, int nb, int K, int out[2]) {
-  out[0] = brick_of(base, nb, K);
-  if (nb == 1) return 1;
-  const int end = ((out[0] + 1) * K) / nb;          // first index past the brick of `base`
-  if (base + 5 < end) return 1;
-  out[1] = out[0] + 1 == nb ? 0 : out[0] + 1;       // periodic wrap
-  return 2;
-}
-
 // Wave-aggregated counter update: lanes of the wavefront that target the same counter are combined into one
 // global atomic (atoms arrive in a spatially coherent order, so a wave touches only a handful of bricks);
 // returns this lane's slot (counter value before the add + rank among the lanes sharing the key), -1 if !pred.
@@ -55,17 +42,34 @@ __device__ __forceinline__ int wave_agg_add(int* __restrict__ counter, int key, 
   return slot;
 }
 
+// stencil base indices + brick code of atom i: the compact record written by k_prepare_sites, or recomputed
+template <class T>
+__device__ __forceinline__ int4 atom_bases(const Site<T>* __restrict__ sites, const int4* __restrict__ bases,
+                                           const RecipGeom<T>& g, const BrickGrid& bg, int i) {
+  if (bases) return bases[i];
+  T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
+  int b[3];
+  for (int d = 0; d < 3; ++d) grid_ref(g, r, d, b[d]);
+  const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
+  return make_int4(b[0], b[1], b[2], brick_code(b, dims, bg));
+}
+
 // mode 0: count the (atom, brick) entries per brick; mode 1: write them (counter = running offsets)
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__ sites, RecipGeom<T> g, BrickGrid bg,
                                              int* __restrict__ counter, int* __restrict__ entries,
-                                             const int* __restrict__ list) {
+                                             const int* __restrict__ list, const int4* __restrict__ bases) {
   const int slot = blockIdx.x * 256 + threadIdx.x;
   const int i = slot < na ? (list ? list[slot] : slot) : 0;
   int b[3][2] = {{0, 0}, {0, 0}, {0, 0}}, n[3] = {0, 0, 0};
   if (slot < na) {
-    T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
-    for (int d = 0; d < 3; ++d) { int base; grid_ref(g, r, d, base); n[d] = bricks_on_axis(base, bg.nb[d], g.dim(d), b[d]); }
+    const int code = atom_bases(sites, bases, g, bg, i).w;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      b[d][0] = (code >> (9 * d)) & 511;
+      b[d][1] = b[d][0] + 1 == bg.nb[d] ? 0 : b[d][0] + 1;   // periodic wrap
+      n[d] = 1 + ((code >> (27 + d)) & 1);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {      // wave-uniform trip count: every lane takes part in the ballots
@@ -147,7 +151,8 @@ constexpr int kScanSub = 32;       // entries whose weights are staged at a time
 
 template <class T>
 __global__ __launch_bounds__(256) void k_spread_scan(int na, const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
-                                                     BrickGrid bg, T* __restrict__ mesh, const int* __restrict__ list) {
+                                                     BrickGrid bg, T* __restrict__ mesh, const int* __restrict__ list,
+                                                     const int4* __restrict__ bases) {
   __shared__ double tile[16 * 16 * 16];
   __shared__ int ents[kScanChunk];
   __shared__ int nent;
@@ -167,13 +172,16 @@ __global__ __launch_bounds__(256) void k_spread_scan(int na, const Site<T>* __re
     const int cend = min(na, c0 + kScanChunk);
     for (int s = c0 + threadIdx.x; s < cend; s += 256) {
       const int i = list ? list[s] : s;
-      T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
+      // the stencil [base, base+5] (periodic) meets this brick's [lo, lo+n) iff, with u = base - lo (mod dim),
+      // u < n or u + 5 >= dim -- no integer division in the scan
+      const int4 v = atom_bases(sites, bases, g, bg, i);
+      const int base[3] = {v.x, v.y, v.z};
       bool hit = true;
+#pragma unroll
       for (int d = 0; d < 3; ++d) {
-        int base, out[2] = {0, 0};
-        grid_ref(g, r, d, base);
-        const int nn = bricks_on_axis(base, bg.nb[d], g.dim(d), out);
-        hit = hit && (out[0] == bb[d] || (nn == 2 && out[1] == bb[d]));
+        int u = base[d] - lo[d];
+        if (u < 0) u += g.dim(d);
+        hit = hit && (u < n[d] || u + 5 >= g.dim(d));
       }
       if (hit) ents[atomicAdd(&nent, 1)] = i;
     }
@@ -429,13 +437,13 @@ static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 #define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
-                  T* mesh, const int* list) {
+                  T* mesh, const int* list, const int4* bases) {
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
   if (na < spread_brick_min_atoms()) {
     static const int scan_max = [] { const char* e = getenv("ADMP_SPREAD_SCAN_MAX"); return e ? atoi(e) : 8192; }();
     if (na <= scan_max) {
-      k_spread_scan<T><<<bg.ncell, 256, 0, st>>>(na, sites, lpol, g, bg, mesh, list);
+      k_spread_scan<T><<<bg.ncell, 256, 0, st>>>(na, sites, lpol, g, bg, mesh, list, bases);
       return 0;
     }
     RC(hipMemsetAsync(mesh, 0, sizeof(T) * (size_t)g.nloc0 * g.K[1] * g.K[2], st));
@@ -443,11 +451,11 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
     return 0;
   }
   RC(hipMemsetAsync(bs.cursor, 0, sizeof(int) * (bg.ncell + 1), st));
-  k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list);
+  k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list, bases);
   size_t need = bs.scan_bytes;
   RC(hipcub::DeviceScan::ExclusiveSum(bs.scan_tmp, need, bs.cursor, bs.cell_start, bg.ncell + 1, st));
   RC(hipMemcpyAsync(bs.cursor, bs.cell_start, sizeof(int) * (bg.ncell + 1), hipMemcpyDeviceToDevice, st));
-  k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, bs.sorted, list);
+  k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, bs.sorted, list, bases);
   k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh);
   return 0;
 }
@@ -520,7 +528,7 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
 }
 #define INST(T)                                                                                                       \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
-                                const int*);                                                                          \
+                                const int*, const int4*);                                                             \
   template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*);            \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
