@@ -186,8 +186,17 @@ struct EngineBase {
     top = Topology();
     if (nbr.rowptr) (void)hipFree(nbr.rowptr);
     if (nbr.col) (void)hipFree(nbr.col);
+    if (nbr.order) (void)hipFree(nbr.order);
     nbr = NbrTable();
     have_top = have_pairs = false;
+  }
+
+  // row order of the freshly built table (see launch_row_order); ADMP_PAIR_SORT=0 keeps the natural order
+  void order_rows() {
+    static const bool off = [] { const char* e = getenv("ADMP_PAIR_SORT"); return e && atoi(e) == 0; }();
+    if (off || snranks != 1) { if (nbr.order) { (void)hipFree(nbr.order); nbr.order = nullptr; } return; }
+    if (!nbr.order) HIP_TRY(hipMalloc(&nbr.order, sizeof(int) * (size_t)top.na));
+    launch_row_order(stream, top.na, nbr.rowptr, nbr.order);
   }
 
   void set_topology(int na, const int32_t* atype, const int32_t* aidx, const int32_t* eptr, const int32_t* ecol,
@@ -256,6 +265,7 @@ struct EngineBase {
       TIMED("nbr_build");
       int rc = build_neighbour_table(stream, top, n_rows, dev, nbr, &scan_scratch.p, &scan_bytes);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("build_neighbour_table: ") + hipGetErrorString((hipError_t)rc)};
+      order_rows();
     }
     HIP_TRY(hipStreamSynchronize(stream));
     staged.release();
@@ -617,7 +627,8 @@ struct Engine : EngineBase {
   void stage_pair_field() {
     need_eval();
     TIMED("pair_field");
-    launch_pair_field<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(), ev.home);
+    launch_pair_field<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
+                         ev.home ? ev.home : nbr.order);
   }
   void stage_spread(T* mesh_p) {
     need_eval();
@@ -673,7 +684,7 @@ struct Engine : EngineBase {
     slot_clean[E_REAL] = false;
     TIMED("pair_full");
     launch_pair_full<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, lpol, grad_p, pot.as<T>(),
-                        Ed_cur(), ev.home, fld_out);
+                        Ed_cur(), ev.home ? ev.home : nbr.order, fld_out);
   }
   // with_field_finish: the gather also forms the total dE/dU and its maximum (launch_field_finish's work, fused)
   void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr, bool with_field_finish = false) {
@@ -851,6 +862,7 @@ struct Engine : EngineBase {
     TIMED("neighbor_table");
     int r = cell_build_table<T>(stream, top, reinterpret_cast<const T*>(pos), b, heights, rc, cells, nbr);
     if (r != 0) throw Err{ADMP_E_HIP, std::string("cell_build_table: ") + hipGetErrorString((hipError_t)r)};
+    order_rows();
     have_pairs = true;
   }
 

@@ -26,7 +26,9 @@ struct NbrTable {
   int* col = nullptr;      // 2 * n_half
   int64_t n_half = 0;
   int64_t cap = 0;         // allocated entries of col
+  int* order = nullptr;    // na: rows sorted by length inside windows of kRowWindow rows (launch_row_order), or nullptr
 };
+constexpr int kRowWindow = 1024;
 constexpr int kColMask = 0x0fffffff;
 
 struct Topology {
@@ -204,6 +206,11 @@ int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Bo
                      double rc, CellScratch& cs, NbrTable& nb);
 
 // ---- nbr_kernels.hip
+// order[] <- the rows of every window of W <= kRowWindow consecutive rows sorted by neighbour count (ties by index).  The
+// pair kernels give each row a fixed group of lanes, so a wavefront runs as long as its longest row: with rows of
+// equal length side by side the lanes stay busy (water, rc 4 A: 85 % -> 99 % of the lane-iterations useful), while the
+// window keeps the rows' site / output accesses local.
+void launch_row_order(hipStream_t st, int na, const int* rowptr, int* order);
 // builds nb from (n_rows, 2) device pairs; scratch (deg/cursor) is managed inside. Returns hipError_t as int.
 int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, const int* pairs_dev, NbrTable& nb,
                           void** scratch, size_t* scratch_bytes);
