@@ -35,10 +35,10 @@ ADMP_HD Cx<T> cx_mul(Cx<T> a, Cx<T> b) {
 }
 
 // complex line, direction SIGN (-1 forward, +1 inverse): outputs X[k] and X[N-k] (k = 0 .. N/2)
-//   ab[(j-1)*stride], j = 1..H   pair sums;  x0 = x_0;  xn = x_{N/2} (used when N is even);  tw[m] = (cos, sin)(2 pi m / N)
-template <class T, int SIGN, int KQ>
-ADMP_HD void dft_pair_outputs(int N, const int* k, int stride, const PairCx<T>* ab, Cx<T> x0, Cx<T> xn, const Cx<T>* tw,
-                              Cx<T>* Xk, Cx<T>* Xnk) {
+//   load(j), j = 0..H-1, returns the pair sums of line positions j+1 / N-1-j;  x0 = x_0;  xn = x_{N/2} (used when N is
+//   even);  tw[m] = (cos, sin)(2 pi m / N)
+template <class T, int SIGN, int KQ, class LoadAB>
+ADMP_HD void dft_pair_core(int N, const int* k, LoadAB load, Cx<T> x0, Cx<T> xn, const Cx<T>* tw, Cx<T>* Xk, Cx<T>* Xnk) {
   const int H = (N - 1) / 2;
   T Are[KQ], Aim[KQ], Bre[KQ], Bim[KQ];
   Cx<T> rot[KQ], w[KQ];
@@ -57,7 +57,7 @@ ADMP_HD void dft_pair_outputs(int N, const int* k, int stride, const PairCx<T>* 
     if (je == kDftReseed) {
 #pragma unroll
       for (int jj = 0; jj < kDftReseed; ++jj) {
-        const PairCx<T> p = ab[(jb + jj) * stride];
+        const PairCx<T> p = load(jb + jj);
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           Are[q] += p.are * w[q].re;
@@ -69,7 +69,7 @@ ADMP_HD void dft_pair_outputs(int N, const int* k, int stride, const PairCx<T>* 
       }
     } else {
       for (int jj = 0; jj < je; ++jj) {
-        const PairCx<T> p = ab[(jb + jj) * stride];
+        const PairCx<T> p = load(jb + jj);
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           Are[q] += p.are * w[q].re;
@@ -100,6 +100,23 @@ ADMP_HD void dft_pair_outputs(int N, const int* k, int stride, const PairCx<T>* 
     Xnk[q].re = bre + T(SIGN) * Bim[q];
     Xnk[q].im = bim - T(SIGN) * Bre[q];
   }
+}
+// pair sums stored as one record per position: ab[(j-1)*stride], j = 1..H
+template <class T, int SIGN, int KQ>
+ADMP_HD void dft_pair_outputs(int N, const int* k, int stride, const PairCx<T>* ab, Cx<T> x0, Cx<T> xn, const Cx<T>* tw,
+                              Cx<T>* Xk, Cx<T>* Xnk) {
+  dft_pair_core<T, SIGN, KQ>(N, k, [=](int j) { return ab[j * stride]; }, x0, xn, tw, Xk, Xnk);
+}
+// pair sums formed in place in a [N][stride] array of line values: row j holds x_j + x_{N-j}, row N-j holds x_j - x_{N-j}
+template <class T, int SIGN, int KQ>
+ADMP_HD void dft_pair_outputs_rows(int N, const int* k, int stride, const Cx<T>* col, const Cx<T>* tw, Cx<T>* Xk,
+                                   Cx<T>* Xnk) {
+  const Cx<T> x0 = col[0];
+  const Cx<T> xn = (N & 1) ? Cx<T>{T(0), T(0)} : col[(N / 2) * stride];
+  dft_pair_core<T, SIGN, KQ>(N, k, [=](int j) {
+    const Cx<T> a = col[(1 + j) * stride], b = col[(N - 1 - j) * stride];
+    return PairCx<T>{a.re, a.im, b.re, b.im};
+  }, x0, xn, tw, Xk, Xnk);
 }
 
 // real pair sums shared by the r2c and c2r lines: P = sum_j p_j.re c_jk, R = sum_j p_j.im s_jk

@@ -208,18 +208,20 @@ np.savez(sys.argv[1], **out)
 print('DFT-RUN-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ('0', '1'):
-        path = str(tmp_path / ('dft%s.npz' % mode))
+    modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'dft_kq4': dict(ADMP_DFT='1', ADMP_DFT_KQ='4')}
+    for mode, extra in modes.items():
+        path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
-                           env=dict(os.environ, ADMP_DFT=mode), timeout=900)
+                           env=dict(os.environ, **extra), timeout=900)
         assert r.returncode == 0 and 'DFT-RUN-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
         res[mode] = dict(np.load(path))
-    assert len(res['0']) == 2 * 4 * 5
-    for key, a in res['0'].items():
-        b = res['1'][key]
-        tol = 1e-10 if key.startswith('double') else 2e-4
-        scale = np.abs(a).max()
-        assert np.abs(a - b).max() <= tol * scale, (key, np.abs(a - b).max(), scale)
+    assert len(res['rocfft']) == 2 * 4 * 5
+    for key, a in res['rocfft'].items():
+        for mode in ('dft', 'dft_kq4'):
+            b = res[mode][key]
+            tol = 1e-10 if key.startswith('double') else 2e-4
+            scale = np.abs(a).max()
+            assert np.abs(a - b).max() <= tol * scale, (mode, key, np.abs(a - b).max(), scale)
 
 
 def test_pair_list_conventions():
