@@ -17,9 +17,10 @@ import torch
 
 class _PmeEnergy(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, force, box, pairs, rest, positions, Q_local):
+    def forward(ctx, force, box, pairs, rest, U_init, positions, Q_local):
         with torch.no_grad():
-            E, G, dQ = force.get_forces_and_dQ(positions, box, pairs, Q_local, *rest)
+            kw = {} if U_init is None else {'U_init': U_init}
+            E, G, dQ = force.get_forces_and_dQ(positions, box, pairs, Q_local, *rest, **kw)
         G = torch.as_tensor(G, device=positions.device).to(positions.dtype)
         dQ = torch.as_tensor(dQ, device=Q_local.device).to(Q_local.dtype)
         ctx.save_for_backward(G, dQ)
@@ -28,10 +29,11 @@ class _PmeEnergy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         G, dQ = ctx.saved_tensors
-        return None, None, None, None, gout * G, gout * dQ
+        return None, None, None, None, None, gout * G, gout * dQ
 
 
-def pme_energy(force, positions, box, pairs, Q_local, *rest):
+def pme_energy(force, positions, box, pairs, Q_local, *rest, U_init=None):
     """Differentiable electrostatic energy.  `rest` = (mScales,) or (pol, tholes, mScales, pScales, dScales),
-    as in `ADMPPmeForce.get_energy`; positions and Q_local are torch tensors (either may require grad)."""
-    return _PmeEnergy.apply(force, box, pairs, tuple(rest), positions, Q_local)
+    as in `ADMPPmeForce.get_energy`; positions and Q_local are torch tensors (either may require grad); U_init is the
+    SCF start of a polarizable force (the reference's keyword of the same name)."""
+    return _PmeEnergy.apply(force, box, pairs, tuple(rest), U_init, positions, Q_local)

@@ -492,6 +492,77 @@ def test_parameter_gradient_of_fluctuating_multipoles(precision, lpol):
     assert rel(kv.grad.cpu().numpy(), ko.grad.numpy()) < 1e-8
 
 
+def test_parameter_gradient_at_config_size(precision):
+    """BASELINE configs[4] at its stated size: 98 304 atoms (32 768 waters, K = 128), geometry-dependent Q_local.
+    The oracle cannot run at this size in seconds, so the check is size-independent: dE/dk and the total
+    dE/dpositions (explicit + through Q(positions)) from the HIP adjoint chained by torch autograd must equal central
+    differences of the energy the same path returns (non-polarizable and polarizable at fixed converged dipoles)."""
+    import torch
+    from admp_amd.autograd import pme_energy
+    from admp_amd.neighbor import NeighborList
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    n_mol = 32768
+    pos, box = S.synthetic_water_box(n_mol, seed=7)
+    at, ai, cov = S.water_topology(n_mol)
+    rng = np.random.default_rng(3)
+    pos = pos + rng.normal(scale=0.02, size=pos.shape)
+    pairs = NeighborList(box, 4.0).allocate(pos)
+    dev = 'cuda'
+
+    def model(p, kv, Q0):
+        m = p.reshape(n_mol, 3, 3)
+        s = (m[:, 1] - m[:, 0]).norm(dim=1) + (m[:, 2] - m[:, 0]).norm(dim=1) - 2 * S.R_OH
+        Q = Q0.clone().reshape(n_mol, 3, 9)
+        dq = kv[0] * s
+        Q[:, 0, 0] = Q[:, 0, 0] + dq
+        Q[:, 1, 0] = Q[:, 1, 0] - 0.5 * dq
+        Q[:, 2, 0] = Q[:, 2, 0] - 0.5 * dq
+        Q[:, 0, 1] = Q[:, 0, 1] + kv[1] * s
+        return Q.reshape(3 * n_mol, 9)
+
+    for lpol in (False, True):
+        par = S.water_parameters(n_mol, lpol)
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+        for k in ('K1', 'K2', 'K3'):
+            f.update_env(k, 128)
+        Q0 = torch.tensor(par['Q_local'], device=dev)
+        rest = (par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales']) if lpol else (par['mScales'],)
+        p = torch.tensor(pos, device=dev, requires_grad=True)
+        kv = torch.tensor([0.3, -0.15], device=dev, dtype=torch.float64, requires_grad=True)
+        kw = {}
+        if lpol:     # converge the dipoles once; every later evaluation starts from them and passes its first check
+            f.get_energy(p.detach(), box, pairs, model(p, kv, Q0).detach(), *rest)
+            U = torch.as_tensor(f.U_ind, device=dev).clone()
+            f.get_energy(p.detach(), box, pairs, model(p, kv, Q0).detach(), *rest, U_init=U)
+            U = torch.as_tensor(f.U_ind, device=dev).clone()
+            kw = dict(U_init=U)
+        E = pme_energy(f, p, box, pairs, model(p, kv, Q0), *rest, **kw)
+        E.backward()
+
+        def energy(pp, kk):
+            with torch.no_grad():
+                e = f.get_energy(pp, box, pairs, model(pp, kk, Q0), *rest, **kw)
+            if lpol:
+                assert f.n_cycle == 0
+            return float(e)
+
+        for c, h in ((0, 1e-3), (1, 1e-3)):
+            d = torch.zeros(2, device=dev, dtype=torch.float64)
+            d[c] = h
+            fd = (energy(p.detach(), kv.detach() + d) - energy(p.detach(), kv.detach() - d)) / (2 * h)
+            an = float(kv.grad[c])
+            assert abs(fd - an) < 2e-6 * abs(an) + 2e-4, (lpol, c, fd, an)
+        G = p.grad
+        g = torch.Generator(device=dev).manual_seed(5)
+        v = G / G.norm() + 0.5 * torch.randn(p.shape, generator=g, device=dev, dtype=p.dtype) / (9 * n_mol) ** 0.5
+        v /= v.norm()
+        h = 0.02
+        fd = (energy(p.detach() + h * v, kv.detach()) - energy(p.detach() - h * v, kv.detach())) / (2 * h)
+        an = float((G * v).sum())
+        assert abs(fd - an) < 5e-6 * abs(an) + 2e-4, (lpol, fd, an)
+
+
 def _mixed_axis_system(seed=2):
     """8 'molecules' of 4 atoms exercising every axis rule (ZThenX, Bisector, ZBisect, ThreeFold, Zonly, none)."""
     rng = np.random.default_rng(seed)
