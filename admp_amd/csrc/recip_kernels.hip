@@ -142,10 +142,98 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   }
 }
 
+// ---- column-task spread of an entry list into the brick's LDS tile (scan kernel; the binned kernel of large systems
+// keeps one thread per entry: with ~580 entries per brick the column tasks' LDS reads cost more than the bank
+// conflicts they avoid -- measured at 1M atoms 0.59 vs 0.31 ms).
+// Entries are taken SUB at a time: 4 threads per entry stage its spline weights in LDS (one axis each, the fourth folds
+// the multipoles), then every thread takes (entry, x, y) columns and issues the six z adds.  Lanes of a wavefront then
+// hit runs of consecutive tile words instead of 64 unrelated atoms' points; the z-rows of the tile are padded to 17
+// words so that the 36 columns of an entry fall into different LDS banks.
+constexpr int kTileRow = 17;
+constexpr int kTileWords = 16 * 16 * kTileRow;
+
+template <class T, int SUB, class GetEntry>
+__device__ __forceinline__ void spread_entry_list(double* tile, T (*wts)[64], int (*ebase)[3], int ne, GetEntry entry,
+                                                  const Site<T>* __restrict__ sites, int lpol, const RecipGeom<T>& g,
+                                                  const int lo[3], const int n[3]) {
+  for (int sub = 0; sub < ne; sub += SUB) {
+    const int cnt = min(SUB, ne - sub);
+    if (threadIdx.x < 4 * cnt) {
+      const int e = threadIdx.x >> 2, part = threadIdx.x & 3;
+      const Site<T>& site = sites[entry(sub + e)];
+      T* w = wts[e];
+      if (part < 3) {
+        T r[3] = {site.r[0], site.r[1], site.r[2]};
+        int base;
+        T M[6], D1[6], D2[6], D3[6];
+        const T f = grid_ref(g, r, part, base);
+        bspline6(f, M, D1, D2, D3);
+        ebase[e][part] = base;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          w[part * 18 + k] = M[k];
+          w[part * 18 + 6 + k] = D1[k];
+          w[part * 18 + 12 + k] = D2[k];
+        }
+      } else {
+        T r[3], Q[9], c1[3], c2[6];
+        site_qtot(site, lpol, r, Q);
+        fold_multipole(g, Q, c1, c2);
+        w[54] = Q[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[55 + k] = c1[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w[58 + k] = c2[k];
+      }
+    }
+    __syncthreads();
+    for (int task = threadIdx.x; task < cnt * 36; task += 256) {
+      const int e = task / 36, ab = task - e * 36, a = ab / 6, b = ab - a * 6;
+      const int ja = wrap_add(ebase[e][0], a, g.wrap0) - lo[0];
+      const int jb = wrap_add(ebase[e][1], b, g.K[1]) - lo[1];
+      if ((unsigned)ja >= (unsigned)n[0] || (unsigned)jb >= (unsigned)n[1]) continue;
+      const T* w = wts[e];
+      const T m0 = w[a], d0 = w[6 + a], e0 = w[12 + a];
+      const T m1 = w[18 + b], d1 = w[24 + b], e1 = w[30 + b];
+      const T mm = m0 * m1;
+      const T P0 = w[54] * mm + w[55] * d0 * m1 + w[56] * m0 * d1 + w[58] * e0 * m1 + w[59] * m0 * e1 + w[61] * d0 * d1;
+      const T P1 = w[57] * mm + w[62] * d0 * m1 + w[63] * m0 * d1;
+      const T P2 = w[60] * mm;
+      double* row = tile + (ja * 16 + jb) * kTileRow;
+      const int bc = ebase[e][2];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int jc = wrap_add(bc, c, g.K[2]) - lo[2];
+        if ((unsigned)jc < (unsigned)n[2])
+          atomicAdd(&row[jc], (double)(P0 * w[36 + c] + P1 * w[42 + c] + P2 * w[48 + c]));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void brick_range(const BrickGrid& bg, int dim0, int dim1, int dim2, int lo[3], int n[3]) {
+  const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
+  const int bb[3] = {bx, by, bz}, dims[3] = {dim0, dim1, dim2};
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = (bb[d] * dims[d]) / bg.nb[d];
+    n[d] = ((bb[d] + 1) * dims[d]) / bg.nb[d] - lo[d];
+  }
+}
+template <class T>
+__device__ __forceinline__ void store_tile(const double* tile, const RecipGeom<T>& g, const int lo[3], const int n[3],
+                                           T* __restrict__ mesh) {
+  const int nyz = n[1] * n[2], ntot = n[0] * nyz;
+  for (int t = threadIdx.x; t < ntot; t += 256) {
+    const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
+    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * kTileRow + jc];
+  }
+}
+
 // Small systems (a few thousand atoms): binning in separate launches costs more than it saves and global f64 atomics
-// run at ~20 G/s (the mesh is shared by the 8 XCDs), so each brick's workgroup scans ALL atoms itself, keeps the ones
-// whose stencil touches the brick, and spreads them through the LDS tile: thread <- (entry, x-plane, y-row) column of
-// six z points, with the entries' spline weights staged in LDS.  One launch, no memset, no global atomics.
+// run at ~20 G/s (the mesh is shared by the 8 XCDs), so each brick's workgroup scans the stencil records of ALL atoms
+// itself, keeps the ones whose stencil touches the brick, and spreads them as above.  One launch, no memset, no
+// global atomics.
 constexpr int kScanChunk = 2048;   // atoms scanned per round (bounds the LDS entry list)
 constexpr int kScanSub = 32;       // entries whose weights are staged at a time
 
@@ -153,19 +241,14 @@ template <class T>
 __global__ __launch_bounds__(256) void k_spread_scan(int na, const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                      BrickGrid bg, T* __restrict__ mesh, const int* __restrict__ list,
                                                      const int4* __restrict__ bases) {
-  __shared__ double tile[16 * 16 * 16];
+  __shared__ double tile[kTileWords];
   __shared__ int ents[kScanChunk];
   __shared__ int nent;
-  __shared__ T wts[kScanSub][64];      // per entry: M,D1,D2 of the 3 axes (54), then q, c1[3], c2[6]
+  __shared__ T wts[kScanSub][64];
   __shared__ int ebase[kScanSub][3];
-  const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
-  const int bb[3] = {bx, by, bz};
   int lo[3], n[3];
-  for (int d = 0; d < 3; ++d) {
-    lo[d] = (bb[d] * g.dim(d)) / bg.nb[d];
-    n[d] = ((bb[d] + 1) * g.dim(d)) / bg.nb[d] - lo[d];
-  }
-  for (int t = threadIdx.x; t < 4096; t += 256) tile[t] = 0.0;
+  brick_range(bg, g.dim(0), g.dim(1), g.dim(2), lo, n);
+  for (int t = threadIdx.x; t < kTileWords; t += 256) tile[t] = 0.0;
   for (int c0 = 0; c0 < na; c0 += kScanChunk) {
     if (threadIdx.x == 0) nent = 0;
     __syncthreads();
@@ -186,68 +269,10 @@ __global__ __launch_bounds__(256) void k_spread_scan(int na, const Site<T>* __re
       if (hit) ents[atomicAdd(&nent, 1)] = i;
     }
     __syncthreads();
-    const int ne = nent;
-    for (int sub = 0; sub < ne; sub += kScanSub) {
-      const int cnt = min(kScanSub, ne - sub);
-      if (threadIdx.x < 4 * cnt) {      // 4 threads per entry: one spline axis each, the fourth folds the multipoles
-        const int e = threadIdx.x >> 2, part = threadIdx.x & 3;
-        const Site<T>& site = sites[ents[sub + e]];
-        T* w = wts[e];
-        if (part < 3) {
-          T r[3] = {site.r[0], site.r[1], site.r[2]};
-          int base;
-          T M[6], D1[6], D2[6], D3[6];
-          const T f = grid_ref(g, r, part, base);
-          bspline6(f, M, D1, D2, D3);
-          ebase[e][part] = base;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            w[part * 18 + k] = M[k];
-            w[part * 18 + 6 + k] = D1[k];
-            w[part * 18 + 12 + k] = D2[k];
-          }
-        } else {
-          T r[3], Q[9], c1[3], c2[6];
-          site_qtot(site, lpol, r, Q);
-          fold_multipole(g, Q, c1, c2);
-          w[54] = Q[0];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) w[55 + k] = c1[k];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) w[58 + k] = c2[k];
-        }
-      }
-      __syncthreads();
-      for (int task = threadIdx.x; task < cnt * 36; task += 256) {
-        const int e = task / 36, ab = task - e * 36, a = ab / 6, b = ab - a * 6;
-        const int ja = wrap_add(ebase[e][0], a, g.wrap0) - lo[0];
-        const int jb = wrap_add(ebase[e][1], b, g.K[1]) - lo[1];
-        if ((unsigned)ja >= (unsigned)n[0] || (unsigned)jb >= (unsigned)n[1]) continue;
-        const T* w = wts[e];
-        const T m0 = w[a], d0 = w[6 + a], e0 = w[12 + a];
-        const T m1 = w[18 + b], d1 = w[24 + b], e1 = w[30 + b];
-        const T mm = m0 * m1;
-        const T P0 = w[54] * mm + w[55] * d0 * m1 + w[56] * m0 * d1 + w[58] * e0 * m1 + w[59] * m0 * e1 + w[61] * d0 * d1;
-        const T P1 = w[57] * mm + w[62] * d0 * m1 + w[63] * m0 * d1;
-        const T P2 = w[60] * mm;
-        double* row = tile + (ja * 16 + jb) * 16;
-        const int bc = ebase[e][2];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const int jc = wrap_add(bc, c, g.K[2]) - lo[2];
-          if ((unsigned)jc < (unsigned)n[2])
-            atomicAdd(&row[jc], (double)(P0 * w[36 + c] + P1 * w[42 + c] + P2 * w[48 + c]));
-        }
-      }
-      __syncthreads();
-    }
+    spread_entry_list<T, kScanSub>(tile, wts, ebase, nent, [&](int k) { return ents[k]; }, sites, lpol, g, lo, n);
   }
   __syncthreads();
-  const int nyz = n[1] * n[2], ntot = n[0] * nyz;
-  for (int t = threadIdx.x; t < ntot; t += 256) {
-    const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
-    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * 16 + jc];
-  }
+  store_tile(tile, g, lo, n, mesh);
 }
 
 // Small systems (too few atoms to fill the chip brick by brick, and launch-latency bound): global float
