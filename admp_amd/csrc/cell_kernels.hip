@@ -34,19 +34,23 @@ __device__ __forceinline__ int cell_of(const Box<T>& b, const CellGrid& cg, cons
 
 __device__ __forceinline__ int wave_agg_add_i(int* __restrict__ counter, int key, bool pred) {
   const int lane = threadIdx.x & 63;
-  int slot = -1;
+  int leader_of_me = lane, rank = 0, cnt = 0;
   unsigned long long remaining = __ballot(pred);
-  while (remaining) {
+  while (remaining) {                       // one pass per distinct key: shuffles and ballots only
     const int leader = __ffsll((long long)remaining) - 1;
     const int k = __shfl(key, leader, 64);
     const unsigned long long same = __ballot(pred && key == k);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&counter[k], __popcll(same));
-    base = __shfl(base, leader, 64);
-    if (pred && key == k) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+    if (pred && key == k) {
+      leader_of_me = leader;
+      rank = __popcll(same & ((1ull << lane) - 1ull));
+      cnt = __popcll(same);
+    }
     remaining &= ~same;
   }
-  return slot;
+  int base = 0;
+  if (pred && lane == leader_of_me) base = atomicAdd(&counter[key], cnt);   // all leaders in ONE instruction:
+  base = __shfl(base, leader_of_me, 64);                                      // a single atomic round trip per call
+  return pred ? base + rank : -1;
 }
 
 template <class T, int MODE>

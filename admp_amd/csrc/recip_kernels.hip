@@ -27,19 +27,23 @@ __device__ __forceinline__ void site_qtot(const Site<T>& s, int lpol, T r[3], T 
 // returns this lane's slot (counter value before the add + rank among the lanes sharing the key), -1 if !pred.
 __device__ __forceinline__ int wave_agg_add(int* __restrict__ counter, int key, bool pred) {
   const int lane = threadIdx.x & 63;
-  int slot = -1;
+  int leader_of_me = lane, rank = 0, cnt = 0;
   unsigned long long remaining = __ballot(pred);
-  while (remaining) {
+  while (remaining) {                       // one pass per distinct key: shuffles and ballots only
     const int leader = __ffsll((long long)remaining) - 1;
     const int k = __shfl(key, leader, 64);
     const unsigned long long same = __ballot(pred && key == k);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&counter[k], __popcll(same));
-    base = __shfl(base, leader, 64);
-    if (pred && key == k) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+    if (pred && key == k) {
+      leader_of_me = leader;
+      rank = __popcll(same & ((1ull << lane) - 1ull));
+      cnt = __popcll(same);
+    }
     remaining &= ~same;
   }
-  return slot;
+  int base = 0;
+  if (pred && lane == leader_of_me) base = atomicAdd(&counter[key], cnt);   // all leaders in ONE instruction:
+  base = __shfl(base, leader_of_me, 64);                                      // a single atomic round trip per call
+  return pred ? base + rank : -1;
 }
 
 // stencil base indices + brick code of atom i: the compact record written by k_prepare_sites, or recomputed
@@ -87,11 +91,15 @@ __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__
 // The tile is DOUBLE in both precisions: measured on MI355X (tools/ubench/lds_atomics.hip) ds_add_f32 sustains
 // only 0.33 lane-adds/clk/CU whereas ds_add_f64 sustains 7.4 (ds_add_u32: 13.6) -- a 22x difference that made
 // the f32 tile the bottleneck of the whole step; the f64 tile also makes the mesh sums precision-independent.
+#ifndef ADMP_BRICK_ROW
+#define ADMP_BRICK_ROW 17
+#endif
+constexpr int kBrickRow = ADMP_BRICK_ROW;   // z-row pitch of the LDS tile in words (17: bank skew)
 template <class T>
 __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                        BrickGrid bg, const int* __restrict__ brick_start,
                                                        const int* __restrict__ entries, T* __restrict__ mesh) {
-  __shared__ double tile[16 * 16 * 16];
+  __shared__ double tile[16 * 16 * kBrickRow];
   const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
   const int bb[3] = {bx, by, bz};
   int lo[3], n[3];
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     lo[d] = (bb[d] * g.dim(d)) / bg.nb[d];
     n[d] = ((bb[d] + 1) * g.dim(d)) / bg.nb[d] - lo[d];
   }
-  for (int t = threadIdx.x; t < 4096; t += 256) tile[t] = 0.0;
+  for (int t = threadIdx.x; t < 16 * 16 * kBrickRow; t += 256) tile[t] = 0.0;
   __syncthreads();
   const int end = brick_start[blockIdx.x + 1];
   for (int k = brick_start[blockIdx.x] + threadIdx.x; k < end; k += 256) {
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
         const T P0 = q * mm + c1[0] * d0 * m1 + c1[1] * m0 * d1 + c2[0] * e0 * m1 + c2[1] * m0 * e1 + c2[3] * d0 * d1;
         const T P1 = c1[2] * mm + c2[4] * d0 * m1 + c2[5] * m0 * d1;
         const T P2 = c2[2] * mm;
-        double* row = tile + (ja * 16 + jb) * 16;
+        double* row = tile + (ja * 16 + jb) * kBrickRow;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           const int jc = wrap_add(st.base[2], c, g.K[2]) - lo[2];
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   const int nyz = n[1] * n[2], ntot = n[0] * nyz;
   for (int t = threadIdx.x; t < ntot; t += 256) {
     const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
-    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * 16 + jc];
+    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * kBrickRow + jc];
   }
 }
 

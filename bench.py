@@ -173,6 +173,29 @@ def roofline_of(rep, w, n_pairs):
             'avg_launch_us': round(avg_s * 1e6, 2), 'launches': int(cnt)}
 
 
+def recip_kernel_rooflines(kb, w, grid):
+    """Achieved algorithmic HBM rate of the spread / gather / transform legs (SURVEY.md 8d formulas, ms per step from the
+    HIP-event breakdown).  These kernels are NOT HBM bound (LDS atomics / L2-resident stencil reads / rocFFT passes); the
+    fractions are reported because the north star asks for them next to the pair kernel's."""
+    wb = 4 if w['prec'] == 'single' else 8
+    na = 3 * w['n_mol']
+    K3 = grid[0] * grid[1] * grid[2]
+    Kh = grid[0] * grid[1] * (grid[2] // 2 + 1)
+    out = {}
+
+    def add(name, label_list, nbytes):
+        ms = sum(kb.get(k, 0.0) for k in label_list)
+        if ms > 0:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            out[name] = {'algorithmic_bytes': int(nbytes), 'ms': round(ms, 5), 'achieved_GBs': round(gbs, 1),
+                         'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4)}
+    add('spread', ['spread'], na * 15 * wb + K3 * wb)
+    add('gather', ['gather'], K3 * wb + na * 24 * wb)
+    add('transforms+kspace', ['rocfft_r2c', 'rocfft_c2r', 'kspace', 'dft_z_r2c', 'dft_y_fwd', 'dft_x_kspace', 'dft_y_inv',
+                              'dft_z_c2r'], 12 * Kh * 2 * wb + Kh * 5 * wb)
+    return out
+
+
 def cpu_baseline(w):
     """The float64 oracle (CPU restatement of the reference's algorithm) on the same workload, one call."""
     import torch
@@ -338,6 +361,7 @@ def main():
                        'parallelism': 'single GPU' if world == 1 else 'replicas only (%d independent boxes)' % world},
             'roofline': head['roofline'],
             'kernel_ms_per_step': head['kernels'],
+            'recip_kernels': recip_kernel_rooflines(head['kernels'], w, head['grid']),
         }
         if slab_scale is not None:
             out['at_scale'] = slab_scale
@@ -363,7 +387,8 @@ def main():
                                    'list_rebuild_ms': round(rb3, 3),
                                    'ns_per_day_rebuild_every_10_steps': round(0.0864 / (dt3 / 5 + rb3 * 1e-4), 3),
                                    'roofline': roofline_of(rep3, w3, f3.n_pairs),
-                                   'kernel_ms_per_step': kb3}
+                                   'kernel_ms_per_step': kb3,
+                                   'recip_kernels': recip_kernel_rooflines(kb3, w3, [f3.K1, f3.K2, f3.K3])}
             except Exception as e:      # the headline line must still be printed
                 out['at_scale'] = {'error': repr(e)}
         print(json.dumps(out))
