@@ -209,21 +209,26 @@ __device__ __forceinline__ void total_potential(const Site<T>& s, const T* __res
   if (eself) *eself = -kDielectric * es;
 }
 
-template <class T>
+template <class T, int LANES>
 __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const T* __restrict__ pos, Box<T> box,
                                                             const Site<T>* __restrict__ sites,
                                                             const T* __restrict__ pol, const T* __restrict__ Ucart,
                                                             int lpol, T kappa, const T* __restrict__ pot,
                                                             T* __restrict__ grad, T* __restrict__ dQlocal,
                                                             double* energies) {
-  const int a = blockIdx.x * kAtomBlock + threadIdx.x;
+  // LANES = 4 (small systems, latency bound): lane m takes the frames m, m+4, ... of the atom's inverse map (water: 3
+  // frames per atom), the partial gradients are folded with two xor shuffles -- a quarter of the dependent chain
+  // (3072 atoms: 14.5 -> 9.6 us).  LANES = 1 (large systems, throughput bound: at 1M atoms the 4-lane form is 3x slower).
+  const long t = (long)blockIdx.x * kAtomBlock + threadIdx.x;
+  const int a = (int)(t / LANES), m = (int)(t % LANES);
   double eself = 0.0, epen = 0.0;
+  T g[3] = {0, 0, 0};
   if (a < top.na) {
     T f[3];
     self_factors(kappa, f);
     T P[9];
-    total_potential(sites[a], pot + 9 * (size_t)a, lpol, f, P, &eself);
-    if (lpol) {
+    total_potential(sites[a], pot + 9 * (size_t)a, lpol, f, P, m == 0 ? &eself : nullptr);
+    if (lpol && m == 0) {
       T al = pol[a];
       al = al < T(1e-8) ? T(1e-8) : al;
       double u2 = (double)Ucart[3 * a] * Ucart[3 * a] + (double)Ucart[3 * a + 1] * Ucart[3 * a + 1] +
@@ -231,8 +236,7 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const 
       epen = kDielectric * 0.5 * u2 / (double)al;
     }
     if (grad) {
-      T g[3] = {0, 0, 0};
-      for (int k = top.inv_ptr[a]; k < top.inv_ptr[a + 1]; ++k) {
+      for (int k = top.inv_ptr[a] + m; k < top.inv_ptr[a + 1]; k += LANES) {
         const int i = top.inv_idx[k];
         int type, iz, ix, iy;
         FrameWork<T> w;
@@ -263,12 +267,19 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const 
           for (int q = 0; q < 9; ++q) dQlocal[9 * a + q] = dl[q];
         }
       }
-      if (dQlocal && top.axis_type[a] == NoAxisType) {   // identity frame
+      if (m == 0 && dQlocal && top.axis_type[a] == NoAxisType) {   // identity frame
 #pragma unroll
         for (int q = 0; q < 9; ++q) dQlocal[9 * a + q] = P[q];
       }
-      grad[3 * a] += g[0]; grad[3 * a + 1] += g[1]; grad[3 * a + 2] += g[2];
     }
+  }
+  if (grad) {   // kernel-uniform
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (LANES > 1) g[q] += __shfl_xor(g[q], 1, 64);
+      if (LANES > 2) g[q] += __shfl_xor(g[q], 2, 64);
+    }
+    if (a < top.na && m == 0) { grad[3 * a] += g[0]; grad[3 * a + 1] += g[1]; grad[3 * a + 2] += g[2]; }
   }
   eself = block_reduce_sum<kAtomBlock>(eself);
   epen = block_reduce_sum<kAtomBlock>(epen);
@@ -338,8 +349,14 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
                    const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
                    const int* list, int nlist) {
   if (!list && top.inv_ptr)   // single GPU: pull formulation, no atomics
-    k_finish_pull<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
-                                                          dQlocal, energies);
+  {
+    if (top.na <= 65536)
+      k_finish_pull<T, 4><<<nblk(4 * top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
+                                                                   dQlocal, energies);
+    else
+      k_finish_pull<T, 1><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
+                                                               dQlocal, energies);
+  }
   else
     k_finish<T><<<nblk(nlist), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
                                                     energies, list, nlist);
