@@ -67,7 +67,17 @@ __global__ __launch_bounds__(256) void k_cell_bin(int na, const T* __restrict__ 
   if (MODE == 1 && i < na) sorted[slot] = i;
 }
 
-__global__ void k_cell_sort(int ncell, const int* __restrict__ start, int* __restrict__ sorted) {
+// cell-sorted record of one atom: the row sweep reads ONE 16-B (f32) / 32-B (f64) word per candidate instead of an index
+// and three scattered coordinates
+template <class T>
+struct alignas(4 * sizeof(T)) CellAtom {
+  T x, y, z;
+  int id;
+};
+
+template <class T>
+__global__ void k_cell_sort(int ncell, const int* __restrict__ start, int* __restrict__ sorted, const T* __restrict__ pos,
+                            CellAtom<T>* __restrict__ spos) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncell) return;
   int b = start[c], e = start[c + 1];
@@ -76,6 +86,11 @@ __global__ void k_cell_sort(int ncell, const int* __restrict__ start, int* __res
     while (k >= b && sorted[k] > v) { sorted[k + 1] = sorted[k]; --k; }
     sorted[k + 1] = v;
   }
+  if (spos)
+    for (int a = b; a < e; ++a) {
+      const int j = sorted[a];
+      spos[a] = CellAtom<T>{pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], j};
+    }
 }
 
 // MODE 0: count[i] = number of partners j > i within rc ; MODE 1: write them at offs[i]
@@ -122,38 +137,63 @@ __device__ __forceinline__ int cell_lookup_nbonds(const Topology& top, int i, in
   return 0;
 }
 
+// 4 lanes per row: lane l sweeps the neighbour cells l, l+4, ... (of <= 27) of the row atom's cell; MODE 0 stores the
+// four partial counts (deg4) and the row length, MODE 1 writes each lane's segment at rowptr[i] + the partial counts
+// before it (lane-major, candidates in cell order: a fixed, reproducible order).  Writes beyond `cap` are dropped (the
+// host re-runs the fill after growing the buffer).
 template <class T, int MODE>
-__global__ __launch_bounds__(128) void k_cell_rows(Topology top, const T* __restrict__ pos, Box<T> box, CellGrid cg, T rc2,
-                                                   const int* __restrict__ start, const int* __restrict__ sorted,
-                                                   int* __restrict__ deg, const int* __restrict__ rowptr,
-                                                   int* __restrict__ col) {
-  const int i = blockIdx.x * 128 + threadIdx.x;
-  if (i >= top.na) return;
-  T ri[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-  int c[3];
-  cell_of(box, cg, ri, c);
-  int n = 0, w = MODE ? rowptr[i] : 0;
-  int lo[3], cnt[3];
-  for (int d = 0; d < 3; ++d) {
-    if (cg.n[d] >= 3) { lo[d] = c[d] - 1; cnt[d] = 3; } else { lo[d] = 0; cnt[d] = cg.n[d]; }
-  }
-  for (int a = 0; a < cnt[0]; ++a)
-    for (int b = 0; b < cnt[1]; ++b)
-      for (int e = 0; e < cnt[2]; ++e) {
-        int cx = (lo[0] + a + cg.n[0]) % cg.n[0], cy = (lo[1] + b + cg.n[1]) % cg.n[1], cz = (lo[2] + e + cg.n[2]) % cg.n[2];
-        int cid = (cx * cg.n[1] + cy) * cg.n[2] + cz;
-        for (int k = start[cid]; k < start[cid + 1]; ++k) {
-          int j = sorted[k];
-          if (j == i) continue;
-          T d[3] = {ri[0] - pos[3 * j], ri[1] - pos[3 * j + 1], ri[2] - pos[3 * j + 2]};
-          min_image(box, d);
-          if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2) {
-            if (MODE) col[w++] = j | (cell_lookup_nbonds(top, i, j) << 28);
-            else ++n;
+__global__ __launch_bounds__(256) void k_cell_rows(Topology top, const T* __restrict__ pos, Box<T> box, CellGrid cg, T rc2,
+                                                   const int* __restrict__ start, const CellAtom<T>* __restrict__ spos,
+                                                   int* __restrict__ deg, int* __restrict__ deg4,
+                                                   const int* __restrict__ rowptr, int* __restrict__ col, long cap) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(t >> 2), l = (int)(t & 3);
+  int n = 0;
+  long w = 0;
+  const bool live = i < top.na;
+  if (live) {
+    T ri[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+    int c[3];
+    cell_of(box, cg, ri, c);
+    int lo[3], cnt[3];
+    for (int d = 0; d < 3; ++d) {
+      if (cg.n[d] >= 3) { lo[d] = c[d] - 1; cnt[d] = 3; } else { lo[d] = 0; cnt[d] = cg.n[d]; }
+    }
+    if (MODE) {
+      w = rowptr[i];
+      for (int q = 0; q < l; ++q) w += deg4[4 * i + q];
+    }
+    const int ncell = cnt[0] * cnt[1] * cnt[2];
+    for (int ci = l; ci < ncell; ci += 4) {
+      const int e = ci % cnt[2], ab = ci / cnt[2], b = ab % cnt[1], a = ab / cnt[1];
+      int cx = lo[0] + a, cy = lo[1] + b, cz = lo[2] + e;
+      cx = cx < 0 ? cx + cg.n[0] : (cx >= cg.n[0] ? cx - cg.n[0] : cx);
+      cy = cy < 0 ? cy + cg.n[1] : (cy >= cg.n[1] ? cy - cg.n[1] : cy);
+      cz = cz < 0 ? cz + cg.n[2] : (cz >= cg.n[2] ? cz - cg.n[2] : cz);
+      const int cid = (cx * cg.n[1] + cy) * cg.n[2] + cz;
+      const int kend = start[cid + 1];
+      for (int k = start[cid]; k < kend; ++k) {
+        const CellAtom<T> p = spos[k];
+        if (p.id == i) continue;
+        T d[3] = {ri[0] - p.x, ri[1] - p.y, ri[2] - p.z};
+        min_image(box, d);
+        if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2) {
+          if (MODE) {
+            if (w < cap) col[w] = p.id | (cell_lookup_nbonds(top, i, p.id) << 28);
+            ++w;
+          } else {
+            ++n;
           }
         }
       }
-  if (!MODE) deg[i] = n;
+    }
+  }
+  if (!MODE) {
+    if (live) deg4[4 * i + l] = n;
+    n += __shfl_xor(n, 1, 64);
+    n += __shfl_xor(n, 2, 64);
+    if (live && l == 0) deg[i] = n;
+  }
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -179,7 +219,7 @@ int cell_count_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, co
   CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, cs.cursor, cs.start, cg.ncell + 1, st));
   CK(hipMemcpyAsync(cs.cursor, cs.start, sizeof(int) * (cg.ncell + 1), hipMemcpyDeviceToDevice, st));
   k_cell_bin<T, 1><<<blocks, 256, 0, st>>>(na, pos, box, cg, cs.cursor, cs.sorted);
-  k_cell_sort<<<(cg.ncell + 127) / 128, 128, 0, st>>>(cg.ncell, cs.start, cs.sorted);
+  k_cell_sort<T><<<(cg.ncell + 127) / 128, 128, 0, st>>>(cg.ncell, cs.start, cs.sorted, pos, nullptr);
   k_cell_pairs<T, 0><<<(na + 127) / 128, 128, 0, st>>>(na, pos, box, cg, (T)(rc * rc), cs.start, cs.sorted, cs.count, nullptr, nullptr);
   need = cs.scan_bytes;
   CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, cs.count, cs.offs, na + 1, st));
@@ -221,24 +261,32 @@ int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Bo
   CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, cs.cursor, cs.start, cg.ncell + 1, st));
   CK(hipMemcpyAsync(cs.cursor, cs.start, sizeof(int) * (cg.ncell + 1), hipMemcpyDeviceToDevice, st));
   k_cell_bin<T, 1><<<blocks, 256, 0, st>>>(na, pos, box, cg, cs.cursor, cs.sorted);
-  k_cell_sort<<<(cg.ncell + 127) / 128, 128, 0, st>>>(cg.ncell, cs.start, cs.sorted);
+  CellAtom<T>* spos = reinterpret_cast<CellAtom<T>*>(cs.spos);
+  k_cell_sort<T><<<(cg.ncell + 127) / 128, 128, 0, st>>>(cg.ncell, cs.start, cs.sorted, pos, spos);
   if (!nb.rowptr) CK(hipMalloc(&nb.rowptr, sizeof(int) * (na + 1)));
   int* deg = reinterpret_cast<int*>(cs.count);        // na + 1 ints fit in the (na + 1) long long scratch
-  CK(hipMemsetAsync(deg, 0, sizeof(int) * (na + 1), st));
-  k_cell_rows<T, 0><<<(na + 127) / 128, 128, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, cs.sorted, deg, nullptr, nullptr);
+  CK(hipMemsetAsync(deg + na, 0, sizeof(int), st));   // the scan's last element (the total)
+  const int rblocks = (int)(((long)na * 4 + 255) / 256);
+  k_cell_rows<T, 0><<<rblocks, 256, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, spos, deg, cs.deg4, nullptr, nullptr, 0);
   need = cs.scan_bytes;
   CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, deg, nb.rowptr, na + 1, st));
+  // The fill is enqueued optimistically with the buffer of the previous build (entries beyond it are dropped) and the
+  // total is read afterwards: one host synchronisation per rebuild unless the list outgrew its buffer.
   int total = 0;
+  if (nb.cap > 0)
+    k_cell_rows<T, 1><<<rblocks, 256, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, spos, nullptr, cs.deg4, nb.rowptr,
+                                               nb.col, (long)nb.cap);
   CK(hipMemcpyAsync(&total, nb.rowptr + na, sizeof(int), hipMemcpyDeviceToHost, st));
   CK(hipStreamSynchronize(st));
   if (total > nb.cap) {
     if (nb.col) CK(hipFree(nb.col));
-    nb.cap = (int64_t)total + 1024;
+    nb.cap = (int64_t)total + total / 8 + 1024;
     CK(hipMalloc(&nb.col, sizeof(int) * nb.cap));
+    k_cell_rows<T, 1><<<rblocks, 256, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, spos, nullptr, cs.deg4, nb.rowptr,
+                                               nb.col, (long)nb.cap);
+    CK(hipStreamSynchronize(st));
   }
   nb.n_half = total / 2;
-  k_cell_rows<T, 1><<<(na + 127) / 128, 128, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, cs.sorted, nullptr, nb.rowptr, nb.col);
-  CK(hipStreamSynchronize(st));
   return 0;
 }
 
@@ -259,16 +307,19 @@ int CellScratch::ensure(int na, int ncell) {
     if (hipMalloc(&sorted, sizeof(int) * (size_t)na) != hipSuccess) return -1;
     if (hipMalloc(&count, sizeof(long long) * ((size_t)na + 1)) != hipSuccess) return -1;
     if (hipMalloc(&offs, sizeof(long long) * ((size_t)na + 1)) != hipSuccess) return -1;
+    if (hipMalloc(&spos, 32 * (size_t)na + 32) != hipSuccess) return -1;
+    if (hipMalloc(&deg4, sizeof(int) * 4 * ((size_t)na + 1)) != hipSuccess) return -1;
     if (hipMalloc(&scan_tmp, scan) != hipSuccess) return -1;
+    (void)hipMemset(count, 0, sizeof(long long) * ((size_t)na + 1));   // count[na] stays 0: the scans' total slot
   }
-  (void)hipMemset(count, 0, sizeof(long long) * ((size_t)na + 1));
   return 0;
 }
 
 void CellScratch::release() {
-  for (void* p : {(void*)start, (void*)cursor, (void*)sorted, (void*)count, (void*)offs, scan_tmp})
+  for (void* p : {(void*)start, (void*)cursor, (void*)sorted, (void*)count, (void*)offs, spos, (void*)deg4, scan_tmp})
     if (p) (void)hipFree(p);
   start = cursor = sorted = nullptr;
+  spos = nullptr; deg4 = nullptr;
   count = offs = nullptr;
   scan_tmp = nullptr;
   cap_atoms = cap_cells = 0;

@@ -190,6 +190,8 @@ struct CellScratch {
   int n[3] = {0, 0, 0};
   int* start = nullptr; int* cursor = nullptr; int* sorted = nullptr;
   long long* count = nullptr; long long* offs = nullptr;
+  void* spos = nullptr;        // cell-sorted packed records (x, y, z, atom id), 4 reals (<= 32 B) per atom
+  int* deg4 = nullptr;         // 4 partial row lengths per atom (one per lane of k_cell_rows)
   void* scan_tmp = nullptr; size_t scan_bytes = 0;
   int cap_atoms = 0, cap_cells = 0;
   int ensure(int na, int ncell);
