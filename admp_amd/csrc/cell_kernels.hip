@@ -146,15 +146,31 @@ __global__ __launch_bounds__(256) void k_cell_rows(Topology top, const T* __rest
                                                    const int* __restrict__ start, const CellAtom<T>* __restrict__ spos,
                                                    int* __restrict__ deg, int* __restrict__ deg4,
                                                    const int* __restrict__ rowptr, int* __restrict__ col, long cap) {
+  // rows are visited in cell-sorted order: the lanes of a wavefront then sweep the same few cells (L1-resident)
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const int i = (int)(t >> 2), l = (int)(t & 3);
+  const int slot = (int)(t >> 2), l = (int)(t & 3);
   int n = 0;
   long w = 0;
-  const bool live = i < top.na;
+  const bool live = slot < top.na;
+  int i = 0;
   if (live) {
-    T ri[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+    const CellAtom<T> me = spos[slot];
+    i = me.id;
+    T ri[3] = {me.x, me.y, me.z};
     int c[3];
     cell_of(box, cg, ri, c);
+    // the row atom's exclusions (covalent neighbours) in registers: the per-hit lookup is then compare-only
+    constexpr int kEx = 6;
+    int ex_col[kEx], ex_nb[kEx], nex = 0, ex_beg = 0, ex_end = 0;
+    if (MODE && top.excl_ptr) {
+      ex_beg = top.excl_ptr[i]; ex_end = top.excl_ptr[i + 1];
+      nex = ex_end - ex_beg < kEx ? ex_end - ex_beg : kEx;
+#pragma unroll
+      for (int q = 0; q < kEx; ++q) {
+        ex_col[q] = q < nex ? top.excl_col[ex_beg + q] : -1;
+        ex_nb[q] = q < nex ? (top.excl_nb[ex_beg + q] & 15) : 0;
+      }
+    }
     int lo[3], cnt[3];
     for (int d = 0; d < 3; ++d) {
       if (cg.n[d] >= 3) { lo[d] = c[d] - 1; cnt[d] = 3; } else { lo[d] = 0; cnt[d] = cg.n[d]; }
@@ -179,7 +195,12 @@ __global__ __launch_bounds__(256) void k_cell_rows(Topology top, const T* __rest
         min_image(box, d);
         if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2) {
           if (MODE) {
-            if (w < cap) col[w] = p.id | (cell_lookup_nbonds(top, i, p.id) << 28);
+            int nb = 0;
+#pragma unroll
+            for (int q = 0; q < kEx; ++q) nb = (ex_col[q] == p.id) ? ex_nb[q] : nb;
+            for (int q = ex_beg + kEx; q < ex_end; ++q)      // rows with more than kEx covalent neighbours
+              if (top.excl_col[q] == p.id) nb = top.excl_nb[q] & 15;
+            if (w < cap) col[w] = p.id | (nb << 28);
             ++w;
           } else {
             ++n;

@@ -99,31 +99,32 @@ int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, c
   return 0;
 }
 
-// one workgroup per window: bitonic sort of (length << 10 | local index) in LDS
+// one workgroup per kRowWindow rows = kRowWindow / W windows: bitonic network of (length << 10 | local index) in LDS,
+// stopped at span W so that every aligned W-chunk is sorted on its own (ascending)
 __global__ __launch_bounds__(256) void k_row_order(int na, const int* __restrict__ rowptr, int* __restrict__ order, int W) {
   __shared__ unsigned key[kRowWindow];
-  const int w0 = blockIdx.x * W;
+  const int w0 = blockIdx.x * kRowWindow;
   for (int t = threadIdx.x; t < kRowWindow; t += 256) {
     const int i = w0 + t;
     unsigned len = 0x1fffffu;                                   // padding sorts to the end
-    if (i < na && t < W) { len = (unsigned)(rowptr[i + 1] - rowptr[i]); if (len > 0x1ffffeu) len = 0x1ffffeu; }
+    if (i < na) { len = (unsigned)(rowptr[i + 1] - rowptr[i]); if (len > 0x1ffffeu) len = 0x1ffffeu; }
     key[t] = (len << 10) | (unsigned)t;
   }
   __syncthreads();
-  for (int k = 2; k <= kRowWindow; k <<= 1)
+  for (int k = 2; k <= W; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = threadIdx.x; t < kRowWindow; t += 256) {
         const int p = t ^ j;
         if (p > t) {
           const unsigned a = key[t], b = key[p];
-          const bool up = (t & k) == 0;
+          const bool up = k == W || (t & k) == 0;
           if ((a > b) == up) { key[t] = b; key[p] = a; }
         }
       }
       __syncthreads();
     }
   for (int t = threadIdx.x; t < kRowWindow; t += 256)
-    if (w0 + t < na && t < W) order[w0 + t] = w0 + (int)(key[t] & 1023u);
+    if (w0 + t < na) order[w0 + t] = w0 + (int)(key[t] & 1023u);
 }
 void launch_row_order(hipStream_t st, int na, const int* rowptr, int* order) {
   // window = the rows one workgroup of the pair kernel owns (256 lanes / lanes per row): measured at 1M atoms
@@ -132,7 +133,9 @@ void launch_row_order(hipStream_t st, int na, const int* rowptr, int* order) {
   int W = 256 / pair_lanes_per_row(na);
   if (W < 64) W = 64;
   if (Wenv >= 64 && Wenv <= kRowWindow) W = Wenv;
-  if (na > 0) k_row_order<<<(na + W - 1) / W, 256, 0, st>>>(na, rowptr, order, W);
+  int p2 = 64;
+  while (p2 * 2 <= W) p2 *= 2;                 // power of two (the bitonic network's span)
+  if (na > 0) k_row_order<<<(na + kRowWindow - 1) / kRowWindow, 256, 0, st>>>(na, rowptr, order, p2);
 }
 
 }  // namespace admp
