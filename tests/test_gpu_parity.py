@@ -797,6 +797,34 @@ def test_full_size_directional_derivative(precision):
     assert float(G.sum(dim=0).abs().max()) < 1e-4 * float(G.abs().sum(dim=0).max())
 
 
+@pytest.mark.parametrize('prec', ['double', 'single'])
+def test_repeated_evaluations_agree_to_roundoff(precision, prec):
+    """The real-space rows have a fixed summation order and nothing on the single-GPU path scatters per-atom results
+    with global atomics; the only order-dependent sums are the f64 LDS tiles of the spread and the four energy words
+    (block sums combined by double atomics).  Repeated evaluations therefore agree to round-off of the f64 mesh sums
+    -- also after the neighbour table has been rebuilt from the same positions (another row order)."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = prec
+    tol = 1e-12 if prec == 'double' else 2e-6
+    for n_mol in (216, 8192):                     # scan-spread / brick-spread regimes
+        pos, box, at, ai, cov, par, pairs = water_system(n_mol, 4, True)
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+        args = (par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+        runs = []
+        for rep in range(3):
+            if rep == 2:
+                f.update_neighbors(torch.as_tensor(pos, device='cuda', dtype=torch.float64 if prec == 'double' else torch.float32), box)
+                E, G = f.get_forces(pos, box, None, *args)
+            else:
+                E, G = f.get_forces(pos, box, pairs, *args)
+            runs.append((float(E), np.array(G), np.array(f.U_ind), f.n_cycle))
+        for E, G, U, cyc in runs[1:]:
+            assert cyc == runs[0][3]
+            assert abs(E - runs[0][0]) <= (1e-12 if prec == 'double' else 1e-7) * max(abs(x) for x in f.energy_parts)
+            assert rel(G, runs[0][1]) < tol and rel(U, runs[0][2]) < tol
+
+
 def test_update_neighbors_equals_explicit_pair_list(precision):
     """Fused GPU neighbour search + table build (update_neighbors, pairs=None) against the explicit pair list."""
     from admp_amd.pme import ADMPPmeForce
