@@ -371,8 +371,10 @@ __global__ __launch_bounds__(256) void k_kspace(int K0, int ny, int K2, const T*
   if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
 }
 
-// Gather: 8-lane groups, one atom per group, lanes 0..5 each take one x-plane of the 6^3 stencil (36 mesh
-// loads in flight per lane), the 20 (or 3) partial sums are folded across the group with xor shuffles and
+// Gather: 8-lane groups, one atom per group, lanes 0..5 each take one z-index of the 6^3 stencil (36 mesh
+// loads in flight per lane; the six lanes' loads of one (x, y) are neighbours in memory -- one or two cache lines
+// per group and instruction, where a per-x-plane split touches six: the L1 line rate was the bound, 0.30 -> see
+// DESIGN.md 6), the 20 (or 3) partial sums are folded across the group with xor shuffles and
 // lane 0 converts them to dE/dQ, dE/dr.
 constexpr int kGatherBlock = 256;
 
@@ -384,12 +386,13 @@ __device__ __forceinline__ T group8_sum(T v) {
   return v;
 }
 
+// the lane's own spline weights along the z axis (register arrays are indexed by compare-select, not dynamically)
 template <class T>
-__device__ __forceinline__ void plane_weights(const Stencil<T>& st, int a, T w[4]) {
+__device__ __forceinline__ void zcol_weights(const Stencil<T>& st, int c, T w[4]) {
   w[0] = w[1] = w[2] = w[3] = T(0);
 #pragma unroll
   for (int k = 0; k < 6; ++k)
-    if (k == a) { w[0] = st.M[0][k]; w[1] = st.D1[0][k]; w[2] = st.D2[0][k]; w[3] = st.D3[0][k]; }
+    if (k == c) { w[0] = st.M[2][k]; w[1] = st.D1[2][k]; w[2] = st.D2[2][k]; w[3] = st.D3[2][k]; }
 }
 
 template <class T>
@@ -411,8 +414,8 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* 
       Stencil<T> st;
       st.init(g, r);
       T w[4];
-      plane_weights(st, a, w);
-      gather_plane(g, st, wrap_add(st.base[0], a, g.wrap0), w, [&](long idx) { return phi[idx]; }, F);
+      zcol_weights(st, a, w);
+      gather_zcol(g, st, wrap_add(st.base[2], a, g.K[2]), w, [&](long idx) { return phi[idx]; }, F);
     }
   }
 #pragma unroll
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Sit
     Stencil<T> st;
     st.init(g, r);
     T w[4];
-    plane_weights(st, a, w);
-    gather_plane_field(g, st, wrap_add(st.base[0], a, g.wrap0), w[0], w[1], [&](long idx) { return phi[idx]; }, f);
+    zcol_weights(st, a, w);
+    gather_zcol_field(g, st, wrap_add(st.base[2], a, g.K[2]), w[0], w[1], [&](long idx) { return phi[idx]; }, f);
   }
   f[0] = group8_sum(f[0]); f[1] = group8_sum(f[1]); f[2] = group8_sum(f[2]);
   if (slot < na && a == 0) {

@@ -270,6 +270,75 @@ ADMP_HD void gather_plane(const RecipGeom<T>& g, const Stencil<T>& st, int ia, c
   F[F003] = m0 * s03;
 }
 
+// One z-index (stencil index c along dimension 2) of gather_atom: lane c of a 6-lane set reads, for every (a, b), the
+// mesh word next to its neighbours' -- the six loads of one (a, b) fall into one or two cache lines, where the
+// per-plane split above touches six.  wz[4] = the dimension-2 spline and its first three derivatives at that index.
+template <class T, class LoadF>
+ADMP_HD void gather_zcol(const RecipGeom<T>& g, const Stencil<T>& st, int ic, const T wz[4], LoadF phi, T* F) {
+  T u00 = 0, u10 = 0, u20 = 0, u30 = 0, u01 = 0, u11 = 0, u21 = 0, u02 = 0, u12 = 0, u03 = 0;   // u[i along x][j along y]
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int a = 0; a < 6; ++a) {
+    const int ia = wrap_add(st.base[0], a, g.wrap0);
+    T t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 6; ++b) {
+      const int ib = wrap_add(st.base[1], b, g.K[1]);
+      const T v = phi(((long)ia * g.K[1] + ib) * g.K[2] + ic);
+      t0 += v * st.M[1][b];
+      t1 += v * st.D1[1][b];
+      t2 += v * st.D2[1][b];
+      t3 += v * st.D3[1][b];
+    }
+    const T m0 = st.M[0][a], d0 = st.D1[0][a], e0 = st.D2[0][a], g0 = st.D3[0][a];
+    u00 += m0 * t0; u10 += d0 * t0; u20 += e0 * t0; u30 += g0 * t0;
+    u01 += m0 * t1; u11 += d0 * t1; u21 += e0 * t1;
+    u02 += m0 * t2; u12 += d0 * t2;
+    u03 += m0 * t3;
+  }
+  const T m2 = wz[0], d2 = wz[1], e2 = wz[2], g2 = wz[3];
+  F[F000] = m2 * u00; F[F100] = m2 * u10; F[F200] = m2 * u20; F[F300] = m2 * u30;
+  F[F010] = m2 * u01; F[F110] = m2 * u11; F[F210] = m2 * u21;
+  F[F020] = m2 * u02; F[F120] = m2 * u12;
+  F[F030] = m2 * u03;
+  F[F001] = d2 * u00; F[F101] = d2 * u10; F[F201] = d2 * u20;
+  F[F011] = d2 * u01; F[F111] = d2 * u11;
+  F[F021] = d2 * u02;
+  F[F002] = e2 * u00; F[F102] = e2 * u10;
+  F[F012] = e2 * u01;
+  F[F003] = g2 * u00;
+}
+// first-derivative part of one z-index: f[3] = (F100, F010, F001) contributions
+template <class T, class LoadF>
+ADMP_HD void gather_zcol_field(const RecipGeom<T>& g, const Stencil<T>& st, int ic, T m2, T d2, LoadF phi, T f[3]) {
+  T u00 = 0, u10 = 0, u01 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int a = 0; a < 6; ++a) {
+    const int ia = wrap_add(st.base[0], a, g.wrap0);
+    T t0 = 0, t1 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 6; ++b) {
+      const int ib = wrap_add(st.base[1], b, g.K[1]);
+      const T v = phi(((long)ia * g.K[1] + ib) * g.K[2] + ic);
+      t0 += v * st.M[1][b];
+      t1 += v * st.D1[1][b];
+    }
+    u00 += st.M[0][a] * t0;
+    u10 += st.D1[0][a] * t0;
+    u01 += st.M[0][a] * t1;
+  }
+  f[0] = m2 * u10;
+  f[1] = m2 * u01;
+  f[2] = d2 * u00;
+}
+
 // first-derivative part of one plane: f[3] = (F100, F010, F001) contributions
 template <class T, class LoadF>
 ADMP_HD void gather_plane_field(const RecipGeom<T>& g, const Stencil<T>& st, int ia, T m0, T d0, LoadF phi, T f[3]) {

@@ -196,6 +196,37 @@ def recip_kernel_rooflines(kb, w, grid):
     return out
 
 
+def other_terms_ms(w, reps=20):
+    """The other calculators of the path (admp/disp_pme.py, admp/pairwise.py) on the same workload: ms per get_forces.
+    Informational -- the headline metric is the electrostatics step."""
+    import torch
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
+    dt = torch.float32 if w['prec'] == 'single' else torch.float64
+    pos = torch.as_tensor(w['pos'], dtype=dt, device='cuda')
+    par = w['par']
+    cl = torch.as_tensor(par['c_list'], dtype=dt, device='cuda')
+    disp = ADMPDispPmeForce(w['box'], w['cov'], 4.0, 1e-4, 10)
+    if w['K'] is not None:
+        for k in ('K1', 'K2', 'K3'):
+            disp.update_env(k, w['K'])
+    tt = value_and_grad(generate_pairwise_interaction(TT_damping_qq_c6_kernel, w['cov'], static_args={}))
+    a_, b_, q_ = (torch.as_tensor(par[k], dtype=dt, device='cuda') for k in ('a_list', 'b_list', 'q_list'))
+    c6 = cl[:, 0].contiguous()
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / reps * 1e3, 4)
+    return {'dispersion_pme_pmax10_ms': timeit(lambda: disp.get_forces(pos, w['box'], w['pairs'], cl, par['mScales'])),
+            'tang_toennies_ms': timeit(lambda: tt(pos, w['box'], w['pairs'], par['mScales'], a_, b_, q_, c6))}
+
+
 def cpu_baseline(w):
     """The float64 oracle (CPU restatement of the reference's algorithm) on the same workload, one call."""
     import torch
@@ -373,6 +404,11 @@ def main():
                 Gh = G.cpu().numpy()
                 out['force_rel_l2_vs_oracle'] = float(np.linalg.norm(Gh - ref['grad']) / np.linalg.norm(ref['grad']))
                 out['energy_rel_vs_oracle'] = float(abs(E - ref['E']) / abs(ref['E']))
+        if world == 1:
+            try:
+                out['other_terms'] = other_terms_ms(w)
+            except Exception as e:
+                out['other_terms'] = {'error': repr(e)}
         if world == 1 and not opt.no_scale and opt.workload == 'S1':
             try:
                 f = None
