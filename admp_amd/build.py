@@ -23,6 +23,7 @@ FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-at
 # (2 waves/SIMD); without it: 928 VALU, 127 VGPRs (4 waves/SIMD), 0.874 -> 0.496 ms on 1M atoms.  The gather and the
 # closing kernel gain as well (152 -> 103, 136 -> 100 VGPRs).
 FLAGS.append('-fno-slp-vectorize')
+FLAGS += os.environ.get('ADMP_EXTRA_FLAGS', '').split()      # experiments: e.g. -DADMP_SITE_ALIGN=128
 EXTRA_FLAGS = {}
 
 def _headers():

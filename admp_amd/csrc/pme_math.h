@@ -284,8 +284,11 @@ ADMP_HD void ind_coefs(const Radial<S, T>& a, S r, T aw, T dmp, T p, S* c) {
 // ---------------------------------------------------------------- the pair
 // Per-site data as the kernels keep it (global frame).
 // 20 reals = five 16-byte (f32) / 32-byte (f64) vectors: one gathered row of the site table.
+#ifndef ADMP_SITE_ALIGN
+#define ADMP_SITE_ALIGN 16
+#endif
 template <class T>
-struct alignas(16) Site {
+struct alignas(ADMP_SITE_ALIGN) Site {
   T r[3];
   T Q[9];    // permanent multipoles, global harmonics
   T U[3];    // induced dipole, global harmonic order (z,x,y)  (admp/pme.py:235)
