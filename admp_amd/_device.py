@@ -97,10 +97,35 @@ class HipForceBase:
         self._use_current_stream()
         return torch.cuda.stream(self._tstream)
 
+    def _enter_stream(self):
+        """Lean form of `with self._on_stream()` for the per-step calls: returns the caller's stream to restore (or None
+        when it already is this object's stream).  Same semantics: order our stream after the caller's, make it current
+        so that torch allocations / copies of the call belong to it."""
+        prev = torch.cuda.current_stream(self._device)
+        if self._stream is None:
+            self._tstream = torch.cuda.Stream(device=self._device)
+            self._stream = self._tstream.cuda_stream
+            _lib.check(self._h, self._L.admp_set_stream(self._h, ctypes.c_void_p(self._stream)), 'admp_set_stream')
+        ts = self._tstream
+        if prev.cuda_stream == ts.cuda_stream:
+            return None
+        ts.wait_stream(prev)
+        torch.cuda.set_stream(ts)
+        return prev
+
+    @staticmethod
+    def _leave_stream(prev):
+        if prev is not None:
+            torch.cuda.set_stream(prev)
+
     def _real(self, x, shape=None):
         """array-like -> contiguous device tensor of the handle's precision."""
         if isinstance(x, torch.Tensor):
-            t = x.detach().to(device=self._device, dtype=self._dtype).contiguous()
+            if x.dtype == self._dtype and x.is_cuda and x.is_contiguous() and not x.requires_grad and \
+                    x.device.index == self._device.index:
+                t = x                                 # already what the library reads: no new tensor object
+            else:
+                t = x.detach().to(device=self._device, dtype=self._dtype).contiguous()
         else:
             t = torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float64)), dtype=self._dtype).to(self._device)
         if shape is not None and tuple(t.shape) != tuple(shape):
@@ -144,6 +169,9 @@ class HipForceBase:
             if self._pairs_key is None:
                 raise ValueError('pairs=None needs a previous set_pairs / update_neighbors')
             return
+        if pairs is self._pairs_keep and isinstance(pairs, torch.Tensor) and self._pairs_key is not None and \
+                pairs._version == self._pairs_key[-1]:
+            return                                   # same tensor object, not written since: the cached table holds
         key = self._pairs_fingerprint(pairs)
         if key == self._pairs_key:
             return

@@ -4,6 +4,8 @@ There is deliberately no fallback: if the HIP library is missing or cannot be lo
 import fails loudly -- the PME path exists only as MI355X kernels.
 """
 import ctypes
+
+import numpy as np
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -81,5 +83,5 @@ def check(handle, rc, what):
 
 def darr(values):
     """ctypes double array from a python/numpy sequence."""
-    vals = [float(v) for v in values]
-    return (ctypes.c_double * len(vals))(*vals)
+    a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+    return (ctypes.c_double * a.size).from_buffer_copy(a.tobytes())

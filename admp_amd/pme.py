@@ -83,6 +83,10 @@ class ADMPPmeForce(HipForceBase):
     def _pad_Q(self, Q_local):
         nh = (self.lmax + 1) ** 2
         if isinstance(Q_local, torch.Tensor):
+            if Q_local.dtype == self._dtype and Q_local.is_cuda and Q_local.dim() == 2 and Q_local.shape[1] == 9 and \
+                    nh == 9 and Q_local.shape[0] == self.n_atoms and Q_local.is_contiguous() and \
+                    not Q_local.requires_grad and Q_local.device.index == self._device.index:
+                return Q_local             # already the library's layout and precision
             q = Q_local.detach().to(device=self._device, dtype=self._dtype)
         else:
             q = torch.as_tensor(np.asarray(Q_local, dtype=np.float64), dtype=self._dtype).to(self._device)
@@ -96,9 +100,12 @@ class ADMPPmeForce(HipForceBase):
 
     def _evaluate(self, positions, box, pairs, Q_local, mScales, pol=None, tholes=None, pScales=None, dScales=None,
                   U_init=None, want_grad=True, want_dQ=False, maxiter=None, thresh=None):
-        with self._on_stream():
+        prev = self._enter_stream()
+        try:
             return self._evaluate_on_stream(positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales,
                                             U_init, want_grad, want_dQ, maxiter, thresh)
+        finally:
+            self._leave_stream(prev)
 
     def _evaluate_on_stream(self, positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales, U_init,
                             want_grad, want_dQ, maxiter, thresh):
