@@ -841,6 +841,15 @@ def test_update_neighbors_equals_explicit_pair_list(precision):
     E1, G1 = g.get_forces(pos, box, None, *rest)
     scale = max(abs(p) for p in f.energy_parts)
     assert abs(E1 - E0) < 1e-11 * scale and rel(G1, G0) < 1e-11 and g.n_cycle == f.n_cycle
+    # the table is rebuilt in place: a shorter list into the old buffer, then a longer one that outgrows it (the
+    # optimistic fill must be repeated after the buffer has grown), then back -- each against an explicit list
+    for rc in (3.0, 5.5, 4.0):
+        g.update_neighbors(pos, box, rc=rc)
+        ref_pairs = S.build_pairs(pos, box, rc)
+        assert g.n_pairs == len(ref_pairs)
+        Ea, Ga = g.get_forces(pos, box, None, *rest)
+        Eb, Gb = f.get_forces(pos, box, ref_pairs, *rest)
+        assert abs(Ea - Eb) < 1e-11 * scale and rel(Ga, Gb) < 1e-11, rc
 
 
 def test_slab_warm_regime_matches_fused_path(precision):
