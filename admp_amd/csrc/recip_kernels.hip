@@ -477,7 +477,9 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
   if (na < spread_brick_min_atoms()) {
-    static const int scan_max = [] { const char* e = getenv("ADMP_SPREAD_SCAN_MAX"); return e ? atoi(e) : 8192; }();
+    // measured (f32, reference K rule): 12 288 atoms scan 0.052 / bricks 0.066 / global atomics 0.130 ms; 18 000 atoms
+    // 0.070 / 0.083 / 0.189; 30 000 atoms 0.144 / 0.109 -- the scan kernel serves everything below the brick threshold
+    static const int scan_max = [] { const char* e = getenv("ADMP_SPREAD_SCAN_MAX"); return e ? atoi(e) : 20000; }();
     if (na <= scan_max) {
       k_spread_scan<T><<<bg.ncell, 256, 0, st>>>(na, sites, lpol, g, bg, mesh, list, bases);
       return 0;
