@@ -35,7 +35,22 @@ def setup_ewald_parameters(rc, ethresh, box):
     K1 = math.ceil(2 * kappa * box[0, 0] / 3 / ethresh ** 0.2)
     K2 = math.ceil(2 * kappa * box[1, 1] / 3 / ethresh ** 0.2)
     K3 = math.ceil(2 * kappa * box[2, 2] / 3 / ethresh ** 0.2)
+    if settings.FFT_FRIENDLY_MESH:
+        K1, K2, K3 = (next_smooth(int(k)) for k in (K1, K2, K3))
     return kappa, int(K1), int(K2), int(K3)
+
+
+def next_smooth(n):
+    """smallest m >= n whose prime factors are all <= 7 (settings.FFT_FRIENDLY_MESH)"""
+    m = max(int(n), 1)
+    while True:
+        k = m
+        for p in (2, 3, 5, 7):
+            while k % p == 0:
+                k //= p
+        if k == 1:
+            return m
+        m += 1
 
 
 class ADMPPmeForce(HipForceBase):

@@ -11,6 +11,12 @@ DO_JIT = True             # no-op here            (admp/settings.py:8)
 POL_CONV = 10.0           # gradient convergence threshold for the induced dipoles, kJ/mol/(e A)
 MAX_N_POL = 30            # maximum number of SCF cycles
 
+# Not in the reference (default off = the reference's mesh exactly): round K1..K3 of setup_ewald_parameters UP to the next
+# size with prime factors <= 7.  The reference's rule often lands on sizes rocFFT can only do with Bluestein (305 = 5*61
+# for a 99 A box: 2.5 ms per transform pair instead of ~0.3 ms); a finer mesh only lowers the PME error, but the numbers
+# then differ from the reference's at the level of ethresh -- hence opt-in.
+FFT_FRIENDLY_MESH = False
+
 
 def jit_condition(*args, **kwargs):
     def deco(func):

@@ -120,3 +120,17 @@ def test_bench_pair_kernel_bytes_formula():
     total, per_pair = bench.pair_kernel_bytes(13_826_823, 1_048_575, 4, True)
     assert abs(per_pair - (8 + 68 + 60 + 128 / (13_826_823 / 1_048_575))) < 1e-9     # 145.6 B/pair
     assert abs(per_pair - 145.7) < 0.1
+
+
+def test_fft_friendly_mesh_is_opt_in():
+    """settings.FFT_FRIENDLY_MESH rounds the reference's K up to a 7-smooth size; off by default (reference mesh)."""
+    from admp_amd import settings
+    from admp_amd.pme import setup_ewald_parameters, next_smooth
+    box = np.eye(3) * 31.289
+    assert setup_ewald_parameters(4.0, 1e-4, box)[1:] == (97, 97, 97)
+    assert [next_smooth(n) for n in (1, 97, 98, 154, 305, 128)] == [1, 98, 98, 160, 315, 128]
+    settings.FFT_FRIENDLY_MESH = True
+    try:
+        assert setup_ewald_parameters(4.0, 1e-4, box)[1:] == (98, 98, 98)
+    finally:
+        settings.FFT_FRIENDLY_MESH = False
