@@ -217,6 +217,72 @@ __global__ __launch_bounds__(256) void k_cell_rows(Topology top, const T* __rest
   }
 }
 
+// Tiny systems (<= kBruteMax atoms): no cells at all -- every row tests every atom, 16 lanes per row (lane l takes the
+// atoms j = l, l + 16, ...), positions staged through LDS.  Two launches (count, fill) replace the six of the cell
+// path, whose dispatch latency dominates the rebuild at this size (3072 atoms: 0.21 ms -> see DESIGN.md 6).
+// Row order: lane-major, j ascending within a lane -- fixed and reproducible.
+constexpr int kBruteMax = 4096;
+constexpr int kBruteTile = 1024;
+
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_brute_rows(Topology top, const T* __restrict__ pos, Box<T> box, T rc2,
+                                                    int* __restrict__ deg, int* __restrict__ deg16,
+                                                    const int* __restrict__ rowptr, int* __restrict__ col, long cap) {
+  __shared__ T tile[kBruteTile][3];
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  const bool live = i < top.na;
+  T ri[3] = {0, 0, 0};
+  if (live) { ri[0] = pos[3 * i]; ri[1] = pos[3 * i + 1]; ri[2] = pos[3 * i + 2]; }
+  constexpr int kEx = 6;
+  int ex_col[kEx], ex_nb[kEx], ex_beg = 0, ex_end = 0;
+#pragma unroll
+  for (int q = 0; q < kEx; ++q) { ex_col[q] = -1; ex_nb[q] = 0; }
+  long w = 0;
+  if (MODE && live) {
+    if (top.excl_ptr) {
+      ex_beg = top.excl_ptr[i]; ex_end = top.excl_ptr[i + 1];
+#pragma unroll
+      for (int q = 0; q < kEx; ++q)
+        if (ex_beg + q < ex_end) { ex_col[q] = top.excl_col[ex_beg + q]; ex_nb[q] = top.excl_nb[ex_beg + q] & 15; }
+    }
+    w = rowptr[i];
+    for (int q = 0; q < l; ++q) w += deg16[16 * i + q];
+  }
+  int n = 0;
+  for (int j0 = 0; j0 < top.na; j0 += kBruteTile) {
+    const int nt = min(kBruteTile, top.na - j0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * nt; t += 256) (&tile[0][0])[t] = pos[3 * (long)j0 + t];
+    __syncthreads();
+    if (live)
+      for (int jj = l; jj < nt; jj += 16) {
+        const int j = j0 + jj;
+        if (j == i) continue;
+        T d[3] = {ri[0] - tile[jj][0], ri[1] - tile[jj][1], ri[2] - tile[jj][2]};
+        min_image(box, d);
+        if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2) {
+          if (MODE) {
+            int nb = 0;
+#pragma unroll
+            for (int q = 0; q < kEx; ++q) nb = (ex_col[q] == j) ? ex_nb[q] : nb;
+            for (int q = ex_beg + kEx; q < ex_end; ++q)
+              if (top.excl_col[q] == j) nb = top.excl_nb[q] & 15;
+            if (w < cap) col[w] = j | (nb << 28);
+            ++w;
+          } else {
+            ++n;
+          }
+        }
+      }
+  }
+  if (!MODE) {
+    if (live) deg16[16 * i + l] = n;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) n += __shfl_xor(n, off, 64);
+    if (live && l == 0) deg[i] = n;
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // Phase 1: bins the atoms and counts the pairs.  scratch layout is owned by the engine (see CellScratch).
@@ -264,8 +330,30 @@ template <class T>
 int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const double* heights,
                      double rc, CellScratch& cs, NbrTable& nb) {
   const int na = top.na;
-  long long dummy = 0;
-  (void)dummy;
+  if (na <= kBruteMax) {
+    if (cs.ensure(na, 1) != 0) return (int)hipErrorOutOfMemory;
+    if (!nb.rowptr) CK(hipMalloc(&nb.rowptr, sizeof(int) * (na + 1)));
+    int* deg = reinterpret_cast<int*>(cs.count);
+    CK(hipMemsetAsync(deg + na, 0, sizeof(int), st));
+    const int rblocks = (na + 15) / 16;
+    k_brute_rows<T, 0><<<rblocks, 256, 0, st>>>(top, pos, box, (T)(rc * rc), deg, cs.deg4, nullptr, nullptr, 0);
+    size_t need = cs.scan_bytes;
+    CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, deg, nb.rowptr, na + 1, st));
+    int total = 0;
+    if (nb.cap > 0)
+      k_brute_rows<T, 1><<<rblocks, 256, 0, st>>>(top, pos, box, (T)(rc * rc), nullptr, cs.deg4, nb.rowptr, nb.col, (long)nb.cap);
+    CK(hipMemcpyAsync(&total, nb.rowptr + na, sizeof(int), hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    if (total > nb.cap) {
+      if (nb.col) CK(hipFree(nb.col));
+      nb.cap = (int64_t)total + total / 8 + 1024;
+      CK(hipMalloc(&nb.col, sizeof(int) * nb.cap));
+      k_brute_rows<T, 1><<<rblocks, 256, 0, st>>>(top, pos, box, (T)(rc * rc), nullptr, cs.deg4, nb.rowptr, nb.col, (long)nb.cap);
+      CK(hipStreamSynchronize(st));
+    }
+    nb.n_half = total / 2;
+    return 0;
+  }
   CellGrid cg;
   for (int d = 0; d < 3; ++d) {
     int n = (int)(heights[d] / rc);
@@ -329,7 +417,8 @@ int CellScratch::ensure(int na, int ncell) {
     if (hipMalloc(&count, sizeof(long long) * ((size_t)na + 1)) != hipSuccess) return -1;
     if (hipMalloc(&offs, sizeof(long long) * ((size_t)na + 1)) != hipSuccess) return -1;
     if (hipMalloc(&spos, 32 * (size_t)na + 32) != hipSuccess) return -1;
-    if (hipMalloc(&deg4, sizeof(int) * 4 * ((size_t)na + 1)) != hipSuccess) return -1;
+    // partial row lengths: 4 per row (cell sweep) or 16 per row (brute-force rows of tiny systems)
+    if (hipMalloc(&deg4, sizeof(int) * (na <= 4096 ? 16 : 4) * ((size_t)na + 1)) != hipSuccess) return -1;
     if (hipMalloc(&scan_tmp, scan) != hipSuccess) return -1;
     (void)hipMemset(count, 0, sizeof(long long) * ((size_t)na + 1));   // count[na] stays 0: the scans' total slot
   }
