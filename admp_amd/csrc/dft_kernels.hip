@@ -37,7 +37,10 @@ extern __shared__ __align__(32) unsigned char dft_smem[];
 // ---- z lines (contiguous): real mesh [nlines][N] -> half spectrum [nlines][N/2+1]
 template <class T, int KQ>
 __global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int NL, int TK, const T* __restrict__ mesh,
-                                                        Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg) {
+                                                        Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg,
+                                                        long mesh_stride, long spec_stride) {
+  mesh += blockIdx.y * mesh_stride;      // batch of independent meshes (dispersion: C6, C8, C10)
+  spec += blockIdx.y * spec_stride;
   const int H = (N - 1) / 2, Kh = N / 2 + 1;
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(dft_smem);
   Cx<T>* p = tw + N;                              // [H][NL]
@@ -74,7 +77,10 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int 
 // ---- z lines back: half spectrum -> real mesh
 template <class T, int KQ>
 __global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int NL, int TK, const Cx<T>* __restrict__ spec,
-                                                        T* __restrict__ mesh, const Cx<T>* __restrict__ twg) {
+                                                        T* __restrict__ mesh, const Cx<T>* __restrict__ twg,
+                                                        long mesh_stride, long spec_stride) {
+  mesh += blockIdx.y * mesh_stride;
+  spec += blockIdx.y * spec_stride;
   const int H = (N - 1) / 2, Kh = N / 2 + 1;
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(dft_smem);
   Cx<T>* p = tw + N;
@@ -140,7 +146,9 @@ __device__ __forceinline__ void load_pairs(int N, int NC, int nca, const Cx<T>* 
 // ---- strided complex lines, in place (y lines: fix = x plane; x lines: fix = y row)
 template <class T, int SIGN, int KQ>
 __global__ __launch_bounds__(kDftBlock) void k_dft_strided(int N, int ncols, int NC, int TK, long jstride, long fixstride,
-                                                          Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg) {
+                                                          Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg,
+                                                          long spec_stride) {
+  spec += blockIdx.z * spec_stride;
   const int H = (N - 1) / 2, Kh = N / 2 + 1;
   PairCx<T>* ab = reinterpret_cast<PairCx<T>*>(dft_smem);   // [H][NC]
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(ab + H * NC);          // [N]
@@ -173,8 +181,11 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_strided(int N, int ncols, int
 // ---- x lines: forward, multiply by G (accumulating sum w G |S|^2, recip.py:400-414 / pme.py:240), inverse; in place
 template <class T, int KQ>
 __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int NC, int TK, long jstride, long fixstride,
-                                                         int K3, Cx<T>* __restrict__ spec, const T* __restrict__ gtab,
-                                                         const Cx<T>* __restrict__ twg, double* energies, int slot) {
+                                                         int K3, Cx<T>* __restrict__ spec, DftTabs<T> tabs,
+                                                         const Cx<T>* __restrict__ twg, double* energies, int slot,
+                                                         long spec_stride) {
+  spec += blockIdx.z * spec_stride;
+  const T* __restrict__ gtab = tabs.p[blockIdx.z];
   const int H = (N - 1) / 2, Kh = N / 2 + 1;
   PairCx<T>* ab = reinterpret_cast<PairCx<T>*>(dft_smem);   // [H][NC]
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(ab + H * NC);          // [N]
@@ -267,47 +278,52 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   }
 
 template <class T>
-void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse) {
+void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb, long mesh_stride,
+                  long spec_stride) {
   const int N = K[2], nlines = K[0] * K[1], H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NL = dft_cols(N, dft_kq(), sizeof(Cx<T>) * (size_t)H + 2 * sizeof(T), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(Cx<T>) * (size_t)(N + H * NL) + sizeof(T) * 2 * (size_t)NL;
   const Cx<T>* t2 = reinterpret_cast<const Cx<T>*>(tw) + K[0] + K[1];
-  const int blocks = (nlines + NL - 1) / NL;
+  const dim3 grid((nlines + NL - 1) / NL, nb);
+  const long ss = spec_stride / 2;       // strides are given in reals; the kernels index complex numbers
   if (inverse) {
-    KQ_SWITCH((k_dft_z_c2r<T, KQ><<<blocks, kDftBlock, sh, st>>>(N, nlines, NL, TK, reinterpret_cast<const Cx<T>*>(spec), mesh, t2)))
+    KQ_SWITCH((k_dft_z_c2r<T, KQ><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, reinterpret_cast<const Cx<T>*>(spec), mesh, t2, mesh_stride, ss)))
   } else {
-    KQ_SWITCH((k_dft_z_r2c<T, KQ><<<blocks, kDftBlock, sh, st>>>(N, nlines, NL, TK, mesh, reinterpret_cast<Cx<T>*>(spec), t2)))
+    KQ_SWITCH((k_dft_z_r2c<T, KQ><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, mesh, reinterpret_cast<Cx<T>*>(spec), t2, mesh_stride, ss)))
   }
 }
 template <class T>
-void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse) {
+void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse, int nb, long spec_stride) {
   const int N = K[1], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + 2 * sizeof(Cx<T>), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC);
   const Cx<T>* t1 = reinterpret_cast<const Cx<T>*>(tw) + K[0];
-  const dim3 grid((Kh + NC - 1) / NC, K[0]);
+  const dim3 grid((Kh + NC - 1) / NC, K[0], nb);
   Cx<T>* sp = reinterpret_cast<Cx<T>*>(spec);
+  const long ss = spec_stride / 2;
   if (inverse) {
-    KQ_SWITCH((k_dft_strided<T, +1, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1)))
+    KQ_SWITCH((k_dft_strided<T, +1, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1, ss)))
   } else {
-    KQ_SWITCH((k_dft_strided<T, -1, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1)))
+    KQ_SWITCH((k_dft_strided<T, -1, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1, ss)))
   }
 }
 template <class T>
-void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot) {
+void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
+                       int slot, int nb, long spec_stride) {
   const int N = K[0], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + sizeof(Cx<T>) * (size_t)(2 + N), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC + N * NC);
-  const dim3 grid((Kh + NC - 1) / NC, K[1]);
+  const dim3 grid((Kh + NC - 1) / NC, K[1], nb);
   KQ_SWITCH((k_dft_x_conv<T, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)K[1] * Kh, (long)Kh, K[2],
-                                                             reinterpret_cast<Cx<T>*>(spec), gtab,
-                                                             reinterpret_cast<const Cx<T>*>(tw), energies, slot)))
+                                                             reinterpret_cast<Cx<T>*>(spec), tabs,
+                                                             reinterpret_cast<const Cx<T>*>(tw), energies, slot,
+                                                             spec_stride / 2)))
 }
 #undef KQ_SWITCH
 #define INST(T)                                                                                   \
-  template void launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int);                  \
-  template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int);                      \
-  template void launch_dft_x_conv<T>(hipStream_t, const int*, const T*, T*, const T*, double*, int);
+  template void launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long); \
+  template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int, int, long);           \
+  template void launch_dft_x_conv<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long);
 INST(float)
 INST(double)
 #undef INST

@@ -443,7 +443,9 @@ struct Engine : EngineBase {
       const T* tw = dft_tw.as<T>();
       { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 0); }
       { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec_p, 0); }
-      { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec_p, gtab, Ed, slot); }
+      DftTabs<T> tabs;
+      tabs.p[0] = gtab;
+      { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec_p, tabs, Ed, slot); }
       { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec_p, 1); }
       { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 1); }
       return;
@@ -927,7 +929,34 @@ struct Engine : EngineBase {
     RecipGeom<T> gj = g;                       // scalar sites: dE/dr = c * Jac . F1 (gather_field applies g.Aop)
     for (int k = 0; k < 9; ++k) gj.Aop[k] = g.Jac[k];
     const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
-    for (int c = 0; c < (pmax - 4) / 2; ++c) {
+    const int nch = (pmax - 4) / 2;
+    if (use_dft && nch > 1) {
+      // direct-DFT meshes are small and dispatch bound: the powers are spread into separate meshes and transformed
+      // as ONE batch (5 launches instead of 5 per power); gather per power from its own mesh
+      const size_t nreal = (size_t)K[0] * K[1] * K[2], nspec = 2 * (size_t)K[0] * K[1] * (K[2] / 2 + 1);
+      mesh.need(nch * nreal * sizeof(T));
+      spec.need(nch * nspec * sizeof(T));
+      DftTabs<T> tabs;
+      for (int c = 0; c < nch; ++c) {
+        ensure_gtab(box, inv, vol, 6 + 2 * c);
+        tabs.p[c] = gtab_cur;
+        { TIMED("scalar_sites"); launch_scalar_sites<T>(stream, na, pos, cl, 3, c, kp[c], sites.as<Site<T>>(), Ed); }
+        TIMED("spread");
+        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>() + c * nreal, nullptr);
+        if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+      }
+      const T* tw = dft_tw.as<T>();
+      { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 0, nch, (long)nreal, (long)nspec); }
+      { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 0, nch, (long)nspec); }
+      { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec.as<T>(), tabs, Ed, E_RECIP, nch, (long)nspec); }
+      { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 1, nch, (long)nspec); }
+      { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 1, nch, (long)nreal, (long)nspec); }
+      for (int c = 0; c < nch; ++c) {   // the site rows still hold the positions (only the charge slot differs per power)
+        { TIMED("gather_field"); launch_gather_field<T>(stream, na, sites.as<Site<T>>(), gj, mesh.as<T>() + c * nreal, fld_recip.as<T>(), nullptr); }
+        { TIMED("scale_add"); launch_scale_add<T>(stream, na, cl, 3, c, fld_recip.as<T>(), dpos); }
+      }
+    } else
+    for (int c = 0; c < nch; ++c) {
       ensure_gtab(box, inv, vol, 6 + 2 * c);
       { TIMED("scalar_sites"); launch_scalar_sites<T>(stream, na, pos, cl, 3, c, kp[c], sites.as<Site<T>>(), Ed); }
       {

@@ -86,13 +86,22 @@ void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipG
 // ---- dft_kernels.hip: direct-DFT mesh convolution for mesh sizes rocFFT only does with Bluestein (dft_math.h)
 // tw = (cos, sin)(2 pi m / K[d]) tables of the three dimensions back to back (K[0] + K[1] + K[2] complex numbers)
 int dft_tile_cols(int N);
+// nb independent meshes (batch) are transformed by one launch each: mesh b at mesh + b * mesh_stride, its half spectrum
+// at spec + b * spec_stride (strides in reals), its G table tabs.p[b] (dispersion PME: the C6 / C8 / C10 passes)
 template <class T>
-void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse);   // r2c / c2r along z
+struct DftTabs {
+  const T* p[3] = {nullptr, nullptr, nullptr};
+};
 template <class T>
-void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse);            // in place along y
+void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb = 1,
+                  long mesh_stride = 0, long spec_stride = 0);                                    // r2c / c2r along z
+template <class T>
+void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse, int nb = 1,
+                  long spec_stride = 0);                                                          // in place along y
 // along x: forward, spec *= gtab with energies[slot] += sum w G |S|^2, inverse -- one kernel, in place
 template <class T>
-void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot);
+void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
+                       int slot, int nb = 1, long spec_stride = 0);
 
 // ---- pair_kernels.hip
 template <class T>
