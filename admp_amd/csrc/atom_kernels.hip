@@ -291,8 +291,12 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const 
 
 template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_scalar_sites(int na, const T* __restrict__ pos, const T* __restrict__ vals,
-                                                             int stride, int chan, double self_coef,
+                                                             int stride, int chan, SelfCoefs self_coefs,
                                                              Site<T>* __restrict__ sites, double* energies) {
+  // blockIdx.y = channel of a batch (the site rows of channel b follow those of channel b-1)
+  chan += blockIdx.y;
+  sites += (size_t)blockIdx.y * na;
+  const double self_coef = self_coefs.c[blockIdx.y];
   const int i = blockIdx.x * kAtomBlock + threadIdx.x;
   double s2 = 0.0;
   if (i < na) {
@@ -314,11 +318,16 @@ __global__ __launch_bounds__(kAtomBlock) void k_scalar_sites(int na, const T* __
 
 template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_scale_add(int na, const T* __restrict__ vals, int stride, int chan,
-                                                          const T* __restrict__ v, T* __restrict__ grad) {
+                                                          const T* __restrict__ v, T* __restrict__ grad, int nch) {
   const int i = blockIdx.x * kAtomBlock + threadIdx.x;
   if (i >= na) return;
-  const T c = vals[(long)stride * i + chan];
-  grad[3 * i] += c * v[3 * i]; grad[3 * i + 1] += c * v[3 * i + 1]; grad[3 * i + 2] += c * v[3 * i + 2];
+  T gx = 0, gy = 0, gz = 0;
+  for (int b = 0; b < nch; ++b) {            // channel b's vectors follow channel b-1's
+    const T c = vals[(long)stride * i + chan + b];
+    const T* vb = v + (size_t)b * 3 * na;
+    gx += c * vb[3 * i]; gy += c * vb[3 * i + 1]; gz += c * vb[3 * i + 2];
+  }
+  grad[3 * i] += gx; grad[3 * i + 1] += gy; grad[3 * i + 2] += gz;
 }
 
 static inline int nblk(int n) { return (n + kAtomBlock - 1) / kAtomBlock; }
@@ -365,16 +374,27 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
 template <class T>
 void launch_scalar_sites(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, double self_coef,
                          Site<T>* sites, double* energies) {
-  k_scalar_sites<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pos, vals, stride, chan, self_coef, sites, energies);
+  SelfCoefs sc;
+  sc.c[0] = self_coef;
+  k_scalar_sites<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pos, vals, stride, chan, sc, sites, energies);
 }
 template <class T>
-void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int chan, const T* v, T* grad) {
-  k_scale_add<T><<<nblk(na), kAtomBlock, 0, st>>>(na, vals, stride, chan, v, grad);
+void launch_scalar_sites_batch(hipStream_t st, int na, const T* pos, const T* vals, int stride, int nch,
+                               const double* self_coefs, Site<T>* sites, double* energies) {
+  SelfCoefs sc;
+  for (int b = 0; b < nch && b < 3; ++b) sc.c[b] = self_coefs[b];
+  k_scalar_sites<T><<<dim3(nblk(na), nch), kAtomBlock, 0, st>>>(na, pos, vals, stride, 0, sc, sites, energies);
+}
+template <class T>
+void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int chan, const T* v, T* grad, int nch) {
+  k_scale_add<T><<<nblk(na), kAtomBlock, 0, st>>>(na, vals, stride, chan, v, grad, nch);
 }
 
 #define INST(T)                                                                                                        \
   template void launch_scalar_sites<T>(hipStream_t, int, const T*, const T*, int, int, double, Site<T>*, double*);      \
-  template void launch_scale_add<T>(hipStream_t, int, const T*, int, int, const T*, T*);                                \
+  template void launch_scale_add<T>(hipStream_t, int, const T*, int, int, const T*, T*, int);                           \
+  template void launch_scalar_sites_batch<T>(hipStream_t, int, const T*, const T*, int, int, const double*, Site<T>*,   \
+                                             double*);                                                                  \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
                                         const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*);                  \
   template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \

@@ -940,10 +940,22 @@ struct Engine : EngineBase {
       for (int c = 0; c < nch; ++c) {
         ensure_gtab(box, inv, vol, 6 + 2 * c);
         tabs.p[c] = gtab_cur;
-        { TIMED("scalar_sites"); launch_scalar_sites<T>(stream, na, pos, cl, 3, c, kp[c], sites.as<Site<T>>(), Ed); }
+      }
+      sites.need(sizeof(Site<T>) * (size_t)na * nch);
+      fld_recip.need(3 * (size_t)na * sizeof(T) * nch);
+      const bool batch_spread = na < spread_brick_min_atoms();     // the scan-spread regime takes the channels as a batch
+      if (batch_spread) {
+        { TIMED("scalar_sites"); launch_scalar_sites_batch<T>(stream, na, pos, cl, 3, nch, kp, sites.as<Site<T>>(), Ed); }
         TIMED("spread");
-        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>() + c * nreal, nullptr);
+        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr, nullptr, nch);
         if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+      } else {
+        for (int c = 0; c < nch; ++c) {
+          { TIMED("scalar_sites"); launch_scalar_sites<T>(stream, na, pos, cl, 3, c, kp[c], sites.as<Site<T>>(), Ed); }
+          TIMED("spread");
+          int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>() + c * nreal, nullptr);
+          if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+        }
       }
       const T* tw = dft_tw.as<T>();
       { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 0, nch, (long)nreal, (long)nspec); }
@@ -951,10 +963,9 @@ struct Engine : EngineBase {
       { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec.as<T>(), tabs, Ed, E_RECIP, nch, (long)nspec); }
       { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 1, nch, (long)nspec); }
       { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 1, nch, (long)nreal, (long)nspec); }
-      for (int c = 0; c < nch; ++c) {   // the site rows still hold the positions (only the charge slot differs per power)
-        { TIMED("gather_field"); launch_gather_field<T>(stream, na, sites.as<Site<T>>(), gj, mesh.as<T>() + c * nreal, fld_recip.as<T>(), nullptr); }
-        { TIMED("scale_add"); launch_scale_add<T>(stream, na, cl, 3, c, fld_recip.as<T>(), dpos); }
-      }
+      // the site rows hold the positions (only the charge slot differs per power): one gather over the batch of meshes
+      { TIMED("gather_field"); launch_gather_field<T>(stream, na, sites.as<Site<T>>(), gj, mesh.as<T>(), fld_recip.as<T>(), nullptr, nch); }
+      { TIMED("scale_add"); launch_scale_add<T>(stream, na, cl, 3, 0, fld_recip.as<T>(), dpos, nch); }
     } else
     for (int c = 0; c < nch; ++c) {
       ensure_gtab(box, inv, vol, 6 + 2 * c);

@@ -76,8 +76,16 @@ template <class T>
 void launch_scalar_sites(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, double self_coef,
                          Site<T>* sites, double* energies);
 // grad[i] += vals[i*stride+chan] * v[i]   (scalar site: dE/dr = c * Jac . F1)
+// nch > 1: grad[i] += sum_b vals[i*stride+chan+b] * v[b][i] with v[b] = v + b * 3 * na
 template <class T>
-void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int chan, const T* v, T* grad);
+void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int chan, const T* v, T* grad, int nch = 1);
+struct SelfCoefs {
+  double c[3] = {0, 0, 0};
+};
+// channels 0..nch-1 of vals at once: site rows of channel b at sites + b * na
+template <class T>
+void launch_scalar_sites_batch(hipStream_t st, int na, const T* pos, const T* vals, int stride, int nch,
+                               const double* self_coefs, Site<T>* sites, double* energies);
 // atoms whose lowest stencil plane lies in the local slab (local base index < width): appended to `list`
 template <class T>
 void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
@@ -165,7 +173,8 @@ struct BinScratch {
 // (no memset, no global atomics).  Returns a hipError_t as int.
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
-                  T* mesh, const int* list, const int4* bases = nullptr /* from launch_prepare_sites, or recomputed */);
+                  T* mesh, const int* list, const int4* bases = nullptr /* from launch_prepare_sites, or recomputed */,
+                  int nb = 1 /* batch (scan kernel only): site rows of b at sites + b * na, its mesh at mesh + b * mesh size */);
 size_t spread_scan_bytes(int ncell);
 // k-space layout [K0][ny][K2/2+1] holding mesh rows y0 .. y0+ny-1 (ny = K1, y0 = 0 on one rank).
 // which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels
@@ -193,7 +202,7 @@ void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const
                    const FieldFin<T>& ff = FieldFin<T>());
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
-                         T* fld_recip, const int* list);
+                         T* fld_recip, const int* list, int nb = 1 /* batch: phi of b at phi + b * mesh size, fld + b * 3 * na */);
 // ---- cell_kernels.hip: positions -> half pair list (cell list), two phases so that the caller can size `pairs`
 struct CellScratch {
   int n[3] = {0, 0, 0};

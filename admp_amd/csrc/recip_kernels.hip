@@ -249,6 +249,8 @@ template <class T>
 __global__ __launch_bounds__(256) void k_spread_scan(int na, const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                      BrickGrid bg, T* __restrict__ mesh, const int* __restrict__ list,
                                                      const int4* __restrict__ bases) {
+  sites += (size_t)blockIdx.y * na;                                            // batch of scalar channels (dispersion)
+  mesh += (size_t)blockIdx.y * ((size_t)g.nloc0 * g.K[1] * g.K[2]);
   __shared__ double tile[kTileWords];
   __shared__ int ents[kScanChunk];
   __shared__ int nent;
@@ -448,6 +450,8 @@ template <class T>
 __global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Site<T>* __restrict__ sites,
                                                                RecipGeom<T> g, const T* __restrict__ phi,
                                                                T* __restrict__ fld, const int* __restrict__ list) {
+  phi += (size_t)blockIdx.y * ((size_t)g.nloc0 * g.K[1] * g.K[2]);            // batch: same atoms, another mesh
+  fld += (size_t)blockIdx.y * 3 * na;
   const int t = blockIdx.x * kGatherBlock + threadIdx.x;
   const int slot = t >> 3, a = t & 7;
   const int i = slot < na ? (list ? list[slot] : slot) : na;
@@ -473,7 +477,7 @@ static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 #define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
-                  T* mesh, const int* list, const int4* bases) {
+                  T* mesh, const int* list, const int4* bases, int nb) {
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
   if (na < spread_brick_min_atoms()) {
@@ -481,13 +485,15 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
     // 0.070 / 0.083 / 0.189; 30 000 atoms 0.144 / 0.109 -- the scan kernel serves everything below the brick threshold
     static const int scan_max = [] { const char* e = getenv("ADMP_SPREAD_SCAN_MAX"); return e ? atoi(e) : 20000; }();
     if (na <= scan_max) {
-      k_spread_scan<T><<<bg.ncell, 256, 0, st>>>(na, sites, lpol, g, bg, mesh, list, bases);
+      k_spread_scan<T><<<dim3(bg.ncell, nb), 256, 0, st>>>(na, sites, lpol, g, bg, mesh, list, bases);
       return 0;
     }
+    if (nb != 1) return (int)hipErrorInvalidValue;
     RC(hipMemsetAsync(mesh, 0, sizeof(T) * (size_t)g.nloc0 * g.K[1] * g.K[2], st));
     k_spread_planes<T><<<nblk(na * 8, 256), 256, 0, st>>>(na, sites, lpol, g, mesh, list);
     return 0;
   }
+  if (nb != 1) return (int)hipErrorInvalidValue;      // batches exist for the scan kernel only
   RC(hipMemsetAsync(bs.cursor, 0, sizeof(int) * (bg.ncell + 1), st));
   k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list, bases);
   size_t need = bs.scan_bytes;
@@ -561,19 +567,19 @@ void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const
 }
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
-                         const int* list) {
-  k_gather_field<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list);
+                         const int* list, int nb) {
+  k_gather_field<T><<<dim3(nblk(na * 8, kGatherBlock), nb), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list);
 }
 #define INST(T)                                                                                                       \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
-                                const int*, const int4*);                                                             \
+                                const int*, const int4*, int);                                                        \
   template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*);            \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
                                  const int*, T*, const FieldFin<T>&);                                                   \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
-                                       const int*);
+                                       const int*, int);
 INST(float)
 INST(double)
 #undef INST
