@@ -953,7 +953,8 @@ struct Engine : EngineBase {
         for (int c = 0; c < nch; ++c) {
           { TIMED("scalar_sites"); launch_scalar_sites<T>(stream, na, pos, cl, 3, c, kp[c], sites.as<Site<T>>(), Ed); }
           TIMED("spread");
-          int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>() + c * nreal, nullptr);
+          int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>() + c * nreal, nullptr, nullptr, 1,
+                                    c > 0);
           if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
         }
       }
@@ -972,7 +973,7 @@ struct Engine : EngineBase {
       { TIMED("scalar_sites"); launch_scalar_sites<T>(stream, na, pos, cl, 3, c, kp[c], sites.as<Site<T>>(), Ed); }
       {
         TIMED("spread");
-        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr);
+        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr, nullptr, 1, c > 0);
         if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
       }
       convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, E_RECIP);

@@ -174,7 +174,8 @@ struct BinScratch {
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
                   T* mesh, const int* list, const int4* bases = nullptr /* from launch_prepare_sites, or recomputed */,
-                  int nb = 1 /* batch (scan kernel only): site rows of b at sites + b * na, its mesh at mesh + b * mesh size */);
+                  int nb = 1 /* batch (scan kernel only): site rows of b at sites + b * na, its mesh at mesh + b * mesh size */,
+                  int reuse_bins = 0 /* binned kernel: positions unchanged since the previous call, keep its brick lists */);
 size_t spread_scan_bytes(int ncell);
 // k-space layout [K0][ny][K2/2+1] holding mesh rows y0 .. y0+ny-1 (ny = K1, y0 = 0 on one rank).
 // which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels

@@ -477,7 +477,7 @@ static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 #define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
-                  T* mesh, const int* list, const int4* bases, int nb) {
+                  T* mesh, const int* list, const int4* bases, int nb, int reuse_bins) {
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
   if (na < spread_brick_min_atoms()) {
@@ -494,6 +494,10 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
     return 0;
   }
   if (nb != 1) return (int)hipErrorInvalidValue;      // batches exist for the scan kernel only
+  if (reuse_bins) {   // same positions as the previous call (next dispersion power): the brick lists are still valid
+    k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh);
+    return 0;
+  }
   RC(hipMemsetAsync(bs.cursor, 0, sizeof(int) * (bg.ncell + 1), st));
   k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list, bases);
   size_t need = bs.scan_bytes;
@@ -572,7 +576,7 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
 }
 #define INST(T)                                                                                                       \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
-                                const int*, const int4*, int);                                                        \
+                                const int*, const int4*, int, int);                                                   \
   template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*);            \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \

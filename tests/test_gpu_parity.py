@@ -168,6 +168,19 @@ for prec, tol in (('double', 1e-8), ('single', 5e-4)):
     scale = max(abs(p) for p in ref['parts'])
     assert abs(f.energy_parts[1] - ref['parts'][1]) < tol * scale, (prec, f.energy_parts, ref['parts'])
     assert rel(G, ref['grad']) < tol and rel(f.U_ind, ref['U_ind']) < tol and f.n_cycle == ref['n_cycle'], prec
+# dispersion PME through the binned bricks (the brick lists of the first power are reused by the next ones)
+from admp_amd.disp_pme import ADMPDispPmeForce
+from oracle import admp_oracle as O
+dref = None
+for prec, tol in (('double', 1e-9), ('single', 5e-4)):
+    settings.PRECISION = prec
+    d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+    for K in ((d.K1, d.K2, d.K3), (60, 60, 60)):          # direct-DFT mesh (58 = 2 * 29) and a rocFFT one
+        d.K1, d.K2, d.K3 = K
+        d.refresh_calculators()
+        E, G = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+        dref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d.kappa, K, 10)
+        assert abs(E - dref['E']) < tol * max(abs(p) for p in dref['parts']) and rel(G, dref['grad']) < max(tol, 1e-8), (prec, K)
 print('BRICK-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ADMP_SPREAD_BRICK_MIN='0')
