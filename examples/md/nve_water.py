@@ -51,7 +51,6 @@ def main():
     from admp_amd.pme import ADMPPmeForce
     from admp_amd.disp_pme import ADMPDispPmeForce
     from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
-    from admp_amd.neighbor import NeighborList
 
     n_mol = opt.waters
     pos0, box = S.synthetic_water_box(n_mol, seed=20240)
@@ -62,9 +61,18 @@ def main():
     rc, skin = 4.0, 1.0
     pme = ADMPPmeForce(box, at, ai, cov, rc, 1e-4, 2, lpol=opt.pol)
     disp = ADMPDispPmeForce(box, cov, rc, 1e-4, 10)
-    tt = value_and_grad(generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={}))
-    nbl = NeighborList(box, rc + skin)        # Verlet list with a skin: the pair kernels have no cutoff test of their
-    #                                           own (like the reference), so the list is rebuilt every --rebuild steps
+    tt_obj = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+    tt = value_and_grad(tt_obj)
+
+    class Lists:
+        """Verlet lists with a skin, rebuilt every --rebuild steps (the pair kernels have no cutoff test of their own,
+        like the reference).  Each calculator compiles its own neighbour table on the GPU straight from the positions
+        (`update_neighbors`, search fused with the table build) and is then called with pairs=None."""
+        def allocate(self, p):
+            for obj in (pme, disp, tt_obj):
+                obj.update_neighbors(p, box, rc=rc + skin)
+            return None
+    nbl = Lists()
     pos = torch.as_tensor(pos0, dtype=dt, device=dev)
     mass = torch.as_tensor(np.tile(MASS, n_mol), dtype=dt, device=dev)[:, None]
     T = lambda k: torch.as_tensor(par[k], dtype=dt, device=dev)      # noqa: E731
