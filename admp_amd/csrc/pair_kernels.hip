@@ -129,11 +129,13 @@ template <class T, int LPR, bool TT>
 __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* __restrict__ rowptr,
                                                             const int* __restrict__ col, const T* __restrict__ pos,
                                                             const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
-                                                            T kappa, int pmax, T* __restrict__ grad, double* energies) {
+                                                            T kappa, int pmax, T* __restrict__ grad, double* energies,
+                                                            const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
+  const int row = slot < na ? (rows ? rows[slot] : slot) : na;      // length-sorted row order (launch_row_order)
   constexpr int NP = TT ? 4 : 3;
   T g[3] = {0, 0, 0};
   double e = 0.0;
@@ -235,14 +237,22 @@ void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>
 template <class T>
 void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies) {
-  k_pair_scalar<T, 8, false><<<grid_for(na, 8), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, clist, box, tab, kappa,
-                                                                     pmax, grad, energies);
+  const int lpr = pair_lanes_per_row(na);
+#define CALL(L)                                                                                                        \
+  k_pair_scalar<T, L, false><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, clist, box, tab, kappa, \
+                                                                     pmax, grad, energies, nb.order)
+  ADMP_LPR_SWITCH(lpr, CALL)
+#undef CALL
 }
 template <class T>
 void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* abqc, const Box<T>& box,
                     const ScaleTab<T>& tab, T* grad, double* energies) {
-  k_pair_scalar<T, 8, true><<<grid_for(na, 8), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, abqc, box, tab, T(0), 0,
-                                                                    grad, energies);
+  const int lpr = pair_lanes_per_row(na);
+#define CALL(L)                                                                                                       \
+  k_pair_scalar<T, L, true><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, abqc, box, tab, T(0), 0, \
+                                                                    grad, energies, nb.order)
+  ADMP_LPR_SWITCH(lpr, CALL)
+#undef CALL
 }
 
 #define INST(T)                                                                                                     \
