@@ -9,7 +9,10 @@
 
 namespace admp {
 
-constexpr int kDftBlock = 256;
+#ifndef ADMP_DFT_BLOCK
+#define ADMP_DFT_BLOCK 256
+#endif
+constexpr int kDftBlock = ADMP_DFT_BLOCK;
 constexpr size_t kDftLdsBudget = 60 * 1024;
 
 // outputs per thread (KQ output pairs share one read of the pair sums); ADMP_DFT_KQ = 1 | 2 | 4 for tuning
@@ -196,6 +199,25 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   const int nca = min(NC, ncols - col0);
   const long base = (long)blockIdx.y * fixstride + col0;
   for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
+  // the G values this thread multiplies with after the forward transform: fetched now, so that their latency hides
+  // behind the transform instead of sitting between two barriers (H * NC < KQ * kDftBlock by construction of NC)
+  T Gp[KQ][2], G0 = T(0), Gn = T(0);
+#pragma unroll
+  for (int u = 0; u < KQ; ++u) {
+    Gp[u][0] = Gp[u][1] = T(0);
+    const int t = threadIdx.x + u * kDftBlock;
+    if (t < H * NC) {
+      const int jj = t / NC, cc = t - jj * NC;
+      if (cc < nca) {
+        Gp[u][0] = gtab[base + (long)(1 + jj) * jstride + cc];
+        Gp[u][1] = gtab[base + (long)(N - 1 - jj) * jstride + cc];
+      }
+    }
+  }
+  if (threadIdx.x < nca) {
+    G0 = gtab[base + threadIdx.x];
+    if ((N & 1) == 0) Gn = gtab[base + (long)(N / 2) * jstride + threadIdx.x];
+  }
   load_pairs<T>(N, NC, nca, spec, base, jstride, ab, x0, xn);
   __syncthreads();
   const int g = threadIdx.x / NC, c = threadIdx.x - g * NC;
@@ -217,12 +239,15 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   }
   __syncthreads();
   double e = 0.0;
-  for (int t = threadIdx.x; t < H * NC; t += kDftBlock) {
+#pragma unroll
+  for (int u = 0; u < KQ; ++u) {
+    const int t = threadIdx.x + u * kDftBlock;
+    if (t >= H * NC) continue;
     const int jj = t / NC, cc = t - jj * NC;
     PairCx<T> v{T(0), T(0), T(0), T(0)};
     if (cc < nca) {
       const int k1 = 1 + jj, k2 = N - 1 - jj, kz = col0 + cc;
-      const T G1 = gtab[base + (long)k1 * jstride + cc], G2 = gtab[base + (long)k2 * jstride + cc];
+      const T G1 = Gp[u][0], G2 = Gp[u][1];
       const Cx<T> s1 = S[k1 * NC + cc], s2 = S[k2 * NC + cc];
       const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
       e += w * ((double)G1 * ((double)s1.re * s1.re + (double)s1.im * s1.im) +
@@ -238,12 +263,10 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
     if (cc < nca) {
       const int kz = col0 + cc;
       const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
-      const T G0 = gtab[base + cc];
       const Cx<T> s0 = S[cc];
       e += w * (double)G0 * ((double)s0.re * s0.re + (double)s0.im * s0.im);
       a = Cx<T>{G0 * s0.re, G0 * s0.im};
       if ((N & 1) == 0) {
-        const T Gn = gtab[base + (long)(N / 2) * jstride + cc];
         const Cx<T> sn = S[(N / 2) * NC + cc];
         e += w * (double)Gn * ((double)sn.re * sn.re + (double)sn.im * sn.im);
         b = Cx<T>{Gn * sn.re, Gn * sn.im};
