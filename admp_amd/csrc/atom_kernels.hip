@@ -4,6 +4,8 @@
 // the polarization penalty (admp/pme.py:760-774) and the local-frame adjoint.
 //
 // One thread per atom; 20-real site rows are written as whole 16/32-byte vectors.
+#include <cstdlib>
+
 #include "launch.h"
 #include "reduce.h"
 
@@ -359,7 +361,8 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
                    const int* list, int nlist) {
   if (!list && top.inv_ptr)   // single GPU: pull formulation, no atomics
   {
-    if (top.na <= 65536)
+    static const int lanes4_max = [] { const char* e = getenv("ADMP_FINISH4_MAX"); return e ? atoi(e) : 8192; }();
+    if (top.na <= lanes4_max)   // 3072 atoms: 9.6 vs 14.5 us; 30k atoms: 19.9 vs 14.2 us; 98k: 47 vs 21 us
       k_finish_pull<T, 4><<<nblk(4 * top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
                                                                    dQlocal, energies);
     else
