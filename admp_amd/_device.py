@@ -192,6 +192,19 @@ class HipForceBase:
         self._pairs_key = key
         self._pairs_keep = pairs      # keeps id() unique while cached
 
+    def _mscale_gradient(self, kind, positions, box, pairs, params, n_params, n_scales, pmax=0):
+        """dE/dmScales (n_scales,) of this calculator: the gradient jax.grad(potential, argnums=3)(...)['mScales'] of the
+        reference's examples/openmm_api/run.py:41-46."""
+        with self._on_stream():
+            self.set_pairs(pairs)
+            pos = self._real(positions, (self.n_atoms, 3))
+            par = self._real(params, (self.n_atoms, n_params))
+            out = (ctypes.c_double * int(n_scales))()
+            rc = self._L.admp_mscale_grad(self._h, int(kind), self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(par),
+                                          int(pmax), int(n_scales), out, 1)
+            _lib.check(self._h, rc, 'admp_mscale_grad')
+        return np.array(out[:], dtype=np.float64)
+
     def update_neighbors(self, positions, box, rc=None):
         """Neighbour search + table compile in one GPU pass (cell list): afterwards pass `pairs=None` to
         get_energy / get_forces.  The MD-loop counterpart of re-running jax_md's neighbour list in the reference's

@@ -166,6 +166,8 @@ struct EngineBase {
                     void* dpos, int on_device) = 0;
   virtual void tt(const void* pos, const double* box, const void* abqc, int ns, const double* mS, double* E, void* dpos,
                   int on_device) = 0;
+  virtual void mscale_grad(int kind, const void* pos, const double* box, const void* par, int pmax, int ns, double* out,
+                           int on_device) = 0;
   // staged evaluation (device pointers only)
   virtual void nbr_count(int na, const void* pos, const double* box, double rc, int64_t* n_pairs) = 0;
   virtual void nbr_fill(int32_t* pairs) = 0;
@@ -1012,6 +1014,39 @@ struct Engine : EngineBase {
     HIP_TRY(hipStreamSynchronize(stream));
     E[0] = Eh[E_REAL];
   }
+
+  // dE/dmScales[k] = sum over the covalent classes nb that read mScales[k] (index (nb - 1) mod ns, with the reference's
+  // negative-index wrap for non-bonded pairs) of the class sums produced by launch_mscale_sums
+  void mscale_grad(int kind, const void* pos_, const double* box, const void* par_, int pmax, int ns, double* out,
+                   int on_device) override {
+    ARG_CHECK(have_top && have_pairs, "topology and pairs must be set first");
+    ARG_CHECK(pos_ && box && par_ && out && ns >= 1 && ns <= 16, "bad argument");
+    ARG_CHECK(kind >= 0 && kind <= 2, "kind must be 0 (multipolar PME), 1 (dispersion) or 2 (Tang-Toennies)");
+    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
+    const int na = top.na;
+    HIP_TRY(hipSetDevice(device));
+    double inv[9], vol;
+    Box<T> bx = make_box(box, inv, &vol);
+    const T* pos = stage_in(s_pos, pos_, 3 * (size_t)na, on_device);
+    const size_t npar = kind == 0 ? 9 : (kind == 1 ? 3 : 4);
+    const T* par = stage_in(kind == 0 ? s_Q : s_par, par_, npar * (size_t)na, on_device);
+    energies_d.need(2 * E_SLOTS * sizeof(double));
+    ehalf = 0; other_clean = false;
+    double* cls = energies_d.as<double>();          // 16 class sums
+    HIP_TRY(hipMemsetAsync(cls, 0, 16 * sizeof(double), stream));
+    if (kind == 0) {
+      ARG_CHECK(have_ewald, "ewald parameters must be set first");
+      sites.need(sizeof(Site<T>) * (size_t)na);
+      RecipGeom<T> g = make_geom(inv);
+      launch_prepare_sites<T>(stream, top, pos, par, nullptr, nullptr, nullptr, bx, sites.as<Site<T>>(), nullptr, g, nullptr);
+    }
+    { TIMED("mscale_grad"); launch_mscale_sums<T>(stream, kind, na, nbr, sites.as<Site<T>>(), pos, par, bx, pmax, cls); }
+    double h16[16];
+    HIP_TRY(hipMemcpyAsync(h16, cls, sizeof(h16), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < ns; ++k) out[k] = 0.0;
+    for (int nb = 0; nb < 16; ++nb) out[((nb - 1) % ns + ns) % ns] += h16[nb];
+  }
 };
 
 }  // namespace
@@ -1123,6 +1158,11 @@ int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* b
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
                         const double* mScales, double* E_out, void* dE_dpos, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.tt(positions, box, abqc, n_scales, mScales, E_out, dE_dpos, on_device); });
+}
+
+int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const double* box, const void* params, int pmax,
+                     int n_scales, double* dE_dmScales, int on_device) {
+  return guarded(h, [&](EngineBase& e) { e.mscale_grad(kind, positions, box, params, pmax, n_scales, dE_dmScales, on_device); });
 }
 
 int admp_neighbor_count(admp_handle* h, int n_atoms, const void* positions, const double* box, double rc, int64_t* n_pairs) {

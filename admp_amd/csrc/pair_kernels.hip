@@ -162,6 +162,66 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
   if (threadIdx.x == 0) atomicAdd(&energies[E_REAL], 0.5 * e);
 }
 
+// dE/dmScales (the parameter gradient the reference's examples/openmm_api/run.py:41-46 prints): per covalent class
+// nb = 0..15 the sum over its pairs of d(pair energy)/d(mscale).  KIND 0: multipolar PME (bare multipole interaction,
+// pair_bare_energy), 1: dispersion (sum_p c_p,i c_p,j / r^p), 2: Tang-Toennies (the kernel without its m factor).
+// Non-bonded pairs (class 0, almost all of them) accumulate in a register, the bonded classes through LDS atomics.
+template <class T, int KIND>
+__global__ __launch_bounds__(kPairBlock) void k_pair_mgrad(int na, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ col, const Site<T>* __restrict__ sites,
+                                                           const T* __restrict__ pos, const T* __restrict__ par, Box<T> box,
+                                                           int pmax, double* __restrict__ cls) {
+  __shared__ double s_cls[16];
+  if (threadIdx.x < 16) s_cls[threadIdx.x] = 0.0;
+  __syncthreads();
+  constexpr int LPR = 8;
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  double e0 = 0.0;
+  if (row < na) {
+    Site<T> I;
+    T ri[3] = {0, 0, 0}, pi[4] = {0, 0, 0, 0};
+    constexpr int NP = KIND == 2 ? 4 : 3;
+    if (KIND == 0) I = sites[row];
+    else {
+      ri[0] = pos[3 * row]; ri[1] = pos[3 * row + 1]; ri[2] = pos[3 * row + 2];
+      for (int k = 0; k < NP; ++k) pi[k] = par[NP * row + k];
+    }
+    const int end = rowptr[row + 1];
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = (c >> 28) & 15, j = c & kColMask;
+      T v;
+      if (KIND == 0) {
+        v = pair_bare_energy<T>(box, I, sites[j]);
+      } else {
+        T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]}, pj[4] = {0, 0, 0, 0}, g[3] = {0, 0, 0};
+        for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
+        if (KIND == 1) {   // disp_pair is linear in mm: E(mm = 1) - E(mm = 0)
+          v = disp_pair(box, ri, rj, pi, pj, T(1), T(0), pmax, g) - disp_pair(box, ri, rj, pi, pj, T(0), T(0), pmax, g);
+        } else {
+          v = tt_pair(box, ri, rj, pi, pj, T(1), g);
+        }
+      }
+      if (nb == 0) e0 += (double)v;
+      else atomicAdd(&s_cls[nb], (double)v);
+    }
+  }
+  e0 = block_reduce_sum<kPairBlock>(e0);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&cls[0], 0.5 * e0);
+  if (threadIdx.x >= 1 && threadIdx.x < 16 && s_cls[threadIdx.x] != 0.0) atomicAdd(&cls[threadIdx.x], 0.5 * s_cls[threadIdx.x]);
+}
+
+template <class T>
+void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, const Site<T>* sites, const T* pos,
+                        const T* par, const Box<T>& box, int pmax, double* cls16) {
+  const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
+  if (kind == 0) k_pair_mgrad<T, 0><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16);
+  else if (kind == 1) k_pair_mgrad<T, 1><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16);
+  else k_pair_mgrad<T, 2><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16);
+}
+
 // lanes of a wavefront that share one row.  Few lanes = fewer idle lanes at the row tail and less shuffle
 // folding; many lanes = enough wavefronts to fill the chip when there are few rows.  Measured (f32, polarizable):
 // 1M rows LPR 1/2/4/8 -> 0.749/0.493/0.502/0.534 ms; 98k rows 2/4/8 -> 0.068/0.064/0.065 ms; 3k rows 4/8/16/32 ->
@@ -263,7 +323,9 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
   template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,           \
                                     const ScaleTab<T>&, T, int, T*, double*);                                       \
   template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,             \
-                                  const ScaleTab<T>&, T*, double*);
+                                  const ScaleTab<T>&, T*, double*);                                                 \
+  template void launch_mscale_sums<T>(hipStream_t, int, int, const NbrTable&, const Site<T>*, const T*, const T*,   \
+                                      const Box<T>&, int, double*);
 INST(float)
 INST(double)
 #undef INST

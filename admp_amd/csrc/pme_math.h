@@ -250,6 +250,27 @@ struct Radial {
   }
 };
 
+// d(pair energy)/d(mscale): the real-space pair energy is linear in mm = mscale - 1 (every permanent coefficient is
+// R_n (mm + B_k) x const, admp/pme.py:303-324; the induced ones carry pscale instead), so the derivative is the bare
+// (undamped, unscaled) multipole interaction of the two sites in their quasi-internal frame.
+template <class T, class SiteT>
+ADMP_HD T pair_bare_energy(const Box<T>& box, const SiteT& I, const SiteT& J) {
+  T d[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+  min_image(box, d);
+  const T r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const T rinv = T(1) / m_sqrt(r2);
+  T z[3] = {d[0] * rinv, d[1] * rinv, d[2] * rinv}, x[3], y[3];
+  qi_frame(z, x, y);
+  T A[9], B[9];
+  rot_harm(I.Q, x, y, z, A);
+  rot_harm(J.Q, x, y, z, B);
+  const T R1 = T(kDielectric) * rinv, R2 = R1 * rinv, R3 = R2 * rinv, R4 = R3 * rinv, R5 = R4 * rinv;
+  return R1 * (A[0] * B[0]) + R2 * (A[0] * B[1] - A[1] * B[0]) +
+         R3 * ((A[0] * B[4] + A[4] * B[0]) - T(2) * A[1] * B[1] + (A[2] * B[2] + A[3] * B[3])) +
+         R4 * (T(3) * (A[4] * B[1] - A[1] * B[4]) - T(kSqrt3) * (A[5] * B[2] + A[6] * B[3] - A[2] * B[5] - A[3] * B[6])) +
+         R5 * (T(6) * A[4] * B[4] - T(4) * (A[5] * B[5] + A[6] * B[6]) + (A[7] * B[7] + A[8] * B[8]));
+}
+
 // coefficient slots (the ten permanent ones of admp/pme.py:303-324 are streamed inside pair_energy_grad)
 enum { CC, CD, DD0, DD1, CQ, DQ0, DQ1, QQ0, QQ1, QQ2, CUD, DUD0, DUD1, UDQ0, UDQ1, UDUD0, UDUD1, NCOEF };
 

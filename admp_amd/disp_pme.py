@@ -69,6 +69,18 @@ class ADMPDispPmeForce(HipForceBase):
         self.energy_parts = tuple(E)
         return np.float64(E[0] + E[1] + E[2]), grad
 
+    def get_mscale_gradient(self, positions, box, pairs, c_list, mScales):
+        """dE/dmScales (len(mScales),): `grad(pot_disp, argnums=3)(...)['mScales']` of the reference
+        (examples/openmm_api/run.py:41-43)."""
+        nc = (self.pmax - 4) // 2
+        c = np.zeros((self.n_atoms, 3)) if not isinstance(c_list, torch.Tensor) else None
+        if c is None:
+            c = torch.zeros((self.n_atoms, 3), dtype=self._dtype, device=self._device)
+            c[:, :nc] = c_list.detach().to(device=self._device, dtype=self._dtype)[:, :nc]
+        else:
+            c[:, :nc] = np.asarray(c_list, dtype=np.float64)[:, :nc]
+        return self._mscale_gradient(1, positions, box, pairs, c, 3, len(self._host64(mScales)), self.pmax)
+
     def generate_get_energy(self):
         def get_energy(positions, box, pairs, c_list, mScales):
             return self._evaluate(positions, box, pairs, c_list, mScales, False)[0]

@@ -57,6 +57,13 @@ class _PairInteraction(HipForceBase):
         _lib.check(self._h, rc, 'admp_tt_energy_grad')
         return np.float64(E[0]), grad
 
+    def get_mscale_gradient(self, positions, box, pairs, mScales, *atomic_params):
+        """dE/dmScales (len(mScales),) of this pair interaction."""
+        if len(atomic_params) != self.kernel.n_params:
+            raise TypeError('%s takes %d atomic parameter lists' % (self.kernel.name, self.kernel.n_params))
+        par = torch.stack([self._real(p, (self.n_atoms,)) for p in atomic_params], dim=1).contiguous()
+        return self._mscale_gradient(2, positions, box, pairs, par, self.kernel.n_params, len(self._host64(mScales)))
+
     def __call__(self, positions, box, pairs, mScales, *atomic_params):
         return self._evaluate(positions, box, pairs, mScales, atomic_params, False)[0]
 

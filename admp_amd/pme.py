@@ -214,6 +214,12 @@ class ADMPPmeForce(HipForceBase):
             r = self._evaluate(positions, box, pairs, Q_local, mScales, want_dQ=True)
         return r['E'], self._like(r['grad'], positions), self._like(r['dQ'], positions)
 
+    def get_mscale_gradient(self, positions, box, pairs, Q_local, mScales):
+        """dE/dmScales, shape (len(mScales),): what `grad(pot_pme, argnums=3)(...)['mScales']` gives in the reference
+        (examples/openmm_api/run.py:44-46).  The energy is linear in mScales and its induced part carries pScales, so neither
+        the values of mScales nor the induced dipoles enter."""
+        return self._mscale_gradient(0, positions, box, pairs, self._pad_Q(Q_local), 9, len(self._host64(mScales)))
+
     def optimize_Uind(self, positions, box, pairs, Q_local, pol, tholes, mScales, pScales, dScales, U_init=None,
                       maxiter=None, thresh=None):
         """Jacobi SCF of the induced dipoles; returns (U, converged, i) like admp/pme.py:111-143."""

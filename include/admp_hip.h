@@ -95,6 +95,16 @@ int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* b
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
                         const double* mScales, double* E_out, void* dE_dpos, int on_device);
 
+/* replaces: jax.grad(potential, argnums=3)(...)['mScales'] of the reference's parameter-gradient example
+ * (examples/openmm_api/run.py:41-46): dE/dmScales[k], k = 0..n_scales-1, of one calculator on the current pair list.
+ *   kind 0  multipolar PME         params = Q_local (Na,9) real   (admp/pme.py:681-683: mscales = mScales[nbonds-1])
+ *   kind 1  dispersion PME         params = c_list  (Na,3) real, pmax as in admp_disp_energy_grad
+ *   kind 2  Tang-Toennies damping  params = abqc    (Na,4) real
+ * The pair energy is linear in the scale factor, so the result does not depend on the current mScales values (nor, for a
+ * polarizable handle, on the induced dipoles: the induced terms carry pScales).  positions / params [dev|host]. */
+int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const double* box, const void* params, int pmax,
+                     int n_scales, double* dE_dmScales, int on_device);
+
 /* ---- neighbour search ("next" row of SURVEY.md 8f) --------------------------------------------------------
  * replaces: jax_md.partition.neighbor_list(displacement_fn, box, rc, 0, format=OrderedSparse).allocate(positions)
  * of the reference's drivers (examples/water_1024/run_admp.py:109-112): the producer of `pairs`.

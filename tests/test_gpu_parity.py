@@ -576,6 +576,45 @@ def test_parameter_gradient_at_config_size(precision):
         assert abs(fd - an) < 5e-6 * abs(an) + 2e-4, (lpol, fd, an)
 
 
+def test_mscale_gradients_vs_oracle_autograd(precision):
+    """dE/dmScales of the three calculators -- what the reference's examples/openmm_api/run.py:41-46 prints from
+    jax.grad(potential, argnums=3) -- against torch autograd through the oracle, f64 and f32, with a bonded model that
+    populates several covalent classes (water: 1-2 and 1-3 pairs plus the wrapped non-bonded class)."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel
+    from oracle import admp_oracle as O
+    pos, box, at, ai, cov, par, pairs = water_system(125, 21, True)
+    mS0 = np.array([0.3, 0.7, 0.0, 1.0, 0.9])
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+    for prec, tol in (('double', 1e-9), ('single', 2e-4)):
+        settings.PRECISION = prec
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+        g = f.get_mscale_gradient(pos, box, pairs, par['Q_local'], mS0)
+        sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, True)
+        m = T(mS0).clone().requires_grad_(True)
+        U, _, _ = O.optimize_Uind(sysm, T(pos), box, pairs, T(par['Q_local']), T(par['pol']), T(par['tholes']), T(mS0),
+                                  T(par['pScales']))
+        E = O.energy_pme(sysm, T(pos), T(box), pairs, T(par['Q_local']), U.detach(), T(par['pol']), T(par['tholes']), m,
+                         T(par['pScales']))
+        ref, = torch.autograd.grad(E, m)
+        assert np.abs(g - ref.numpy()).max() < tol * np.abs(ref.numpy()).max(), (prec, g, ref)
+        d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+        gd = d.get_mscale_gradient(pos, box, pairs, par['c_list'], mS0)
+        m = T(mS0).clone().requires_grad_(True)
+        Ed = sum(O.disp_pme_parts(T(pos), T(box), pairs, T(par['c_list']), m, cov, d.kappa, (d.K1, d.K2, d.K3), 10))
+        ref, = torch.autograd.grad(Ed, m)
+        assert np.abs(gd - ref.numpy()).max() < tol * np.abs(ref.numpy()).max(), (prec, gd, ref)
+        tt = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+        lists = [par[k] for k in ('a_list', 'b_list', 'q_list')] + [par['c_list'][:, 0]]
+        gt = tt.get_mscale_gradient(pos, box, pairs, mS0, *lists)
+        m = T(mS0).clone().requires_grad_(True)
+        Et = O.tt_damping_energy(T(pos), T(box), pairs, m, cov, *[T(x) for x in lists])
+        ref, = torch.autograd.grad(Et, m)
+        assert np.abs(gt - ref.numpy()).max() < tol * np.abs(ref.numpy()).max(), (prec, gt, ref)
+
+
 def _mixed_axis_system(seed=2):
     """8 'molecules' of 4 atoms exercising every axis rule (ZThenX, Bisector, ZBisect, ThreeFold, Zonly, none)."""
     rng = np.random.default_rng(seed)
