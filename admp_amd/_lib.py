@@ -32,6 +32,7 @@ PROTOTYPES = {
                                     _ip, _ip, _i32]),
     'admp_disp_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _i32, _dp, _dp, _vp, _i32]),
     'admp_tt_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _dp, _vp, _i32]),
+    'admp_thole_sums': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _vp, _vp]),
     'admp_mscale_grad': (_i32, [_vp, _i32, _vp, _dp, _vp, _i32, _i32, _dp, _i32]),
     'admp_neighbor_count': (_i32, [_vp, _i32, _vp, _dp, _dbl, _c.POINTER(_i64)]),
     'admp_neighbor_fill': (_i32, [_vp, _vp]),

@@ -166,6 +166,8 @@ struct EngineBase {
                     void* dpos, int on_device) = 0;
   virtual void tt(const void* pos, const double* box, const void* abqc, int ns, const double* mS, double* E, void* dpos,
                   int on_device) = 0;
+  virtual void thole_sums(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
+                          const double* mS, const double* pS, const void* U, void* sumX, void* sumXw) = 0;
   virtual void mscale_grad(int kind, const void* pos, const double* box, const void* par, int pmax, int ns, double* out,
                            int on_device) = 0;
   // staged evaluation (device pointers only)
@@ -1015,6 +1017,19 @@ struct Engine : EngineBase {
     E[0] = Eh[E_REAL];
   }
 
+  // raw per-atom sums behind dE/dpol and dE/dtholes (device pointers only); the caller finishes them (admp_amd/pme.py)
+  void thole_sums(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
+                  const double* mS, const double* pS, const void* U, void* sumX, void* sumXw) override {
+    ARG_CHECK(lpol, "polarizable handle required");
+    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
+    ARG_CHECK(sumX && sumXw && U, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, const_cast<void*>(U));
+    { TIMED("thole_sums"); launch_thole_sums<T>(stream, top.na, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T*)sumX, (T*)sumXw); }
+    ev.active = false;
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+
   // dE/dmScales[k] = sum over the covalent classes nb that read mScales[k] (index (nb - 1) mod ns, with the reference's
   // negative-index wrap for non-bonded pairs) of the class sums produced by launch_mscale_sums
   void mscale_grad(int kind, const void* pos_, const double* box, const void* par_, int pmax, int ns, double* out,
@@ -1163,6 +1178,12 @@ int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box
 int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const double* box, const void* params, int pmax,
                      int n_scales, double* dE_dmScales, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.mscale_grad(kind, positions, box, params, pmax, n_scales, dE_dmScales, on_device); });
+}
+
+int admp_thole_sums(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                    const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
+                    void* sumX, void* sumXw) {
+  return guarded(h, [&](EngineBase& e) { e.thole_sums(positions, box, Q_local, pol, tholes, n_scales, mScales, pScales, U, sumX, sumXw); });
 }
 
 int admp_neighbor_count(admp_handle* h, int n_atoms, const void* positions, const double* box, double rc, int64_t* n_pairs) {

@@ -120,6 +120,10 @@ template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                        const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows);
 int pair_lanes_per_row(int n_rows);   // 2/4/8 by row count; env ADMP_PAIR_LPR overrides
+// sumX[i] = sum_j dE_ij/d ln(au_ij), sumXw[i] = sum_j (same) * d ln(au_ij)/d thole_i  (pme_math.h pair_thole_logderiv)
+template <class T>
+void launch_thole_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                       const ScaleTab<T>& tab, T* sumX, T* sumXw);
 // cls16[nb] += sum over the pairs of covalent class nb of d(pair energy)/d(mscale); kind 0: multipolar PME (sites),
 // 1: dispersion (pos, par = c6/c8/c10 per atom, pmax), 2: Tang-Toennies (pos, par = a/b/q/c6 per atom)
 template <class T>

@@ -213,6 +213,42 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_mgrad(int na, const int* __
   if (threadIdx.x >= 1 && threadIdx.x < 16 && s_cls[threadIdx.x] != 0.0) atomicAdd(&cls[threadIdx.x], 0.5 * s_cls[threadIdx.x]);
 }
 
+// per-atom sums of d(pair energy)/d ln(au) (pair_thole_logderiv): sumX[i] = sum_j X_ij, sumXw[i] = sum_j X_ij wth_ij
+template <class T>
+__global__ __launch_bounds__(kPairBlock) void k_pair_tholegrad(int na, const int* __restrict__ rowptr,
+                                                               const int* __restrict__ col,
+                                                               const Site<T>* __restrict__ sites, Box<T> box,
+                                                               ScaleTab<T> tab, T* __restrict__ sumX, T* __restrict__ sumXw) {
+  __shared__ T s_tab[48];
+  stage_tab(tab, s_tab);
+  constexpr int LPR = 8;
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  T sx = 0, sw = 0;
+  if (row < na) {
+    const Site<T> I = sites[row];
+    const int end = rowptr[row + 1];
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = (c >> 28) & 15;
+      const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
+      T wth;
+      const T X = pair_thole_logderiv<T>(box, I, sites[c & kColMask], sc, &wth);
+      sx += X;
+      sw += X * wth;
+    }
+  }
+  sx = row_reduce<T, LPR>(sx);
+  sw = row_reduce<T, LPR>(sw);
+  if (row < na && sub == 0) { sumX[row] = sx; sumXw[row] = sw; }
+}
+template <class T>
+void launch_thole_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                       const ScaleTab<T>& tab, T* sumX, T* sumXw) {
+  const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
+  k_pair_tholegrad<T><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, sumX, sumXw);
+}
+
 template <class T>
 void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, const Site<T>* sites, const T* pos,
                         const T* par, const Box<T>& box, int pmax, double* cls16) {
@@ -325,7 +361,9 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
   template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,             \
                                   const ScaleTab<T>&, T*, double*);                                                 \
   template void launch_mscale_sums<T>(hipStream_t, int, int, const NbrTable&, const Site<T>*, const T*, const T*,   \
-                                      const Box<T>&, int, double*);
+                                      const Box<T>&, int, double*);                                                 \
+  template void launch_thole_sums<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
+                                     const ScaleTab<T>&, T*, T*);
 INST(float)
 INST(double)
 #undef INST

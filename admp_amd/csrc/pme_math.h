@@ -535,6 +535,53 @@ ADMP_HD T pair_energy_grad(const Box<T>& box, const Site<T>& I, const Site<T>& J
   return e;
 }
 
+// d(pair energy)/d ln(au), au = a_w r / dmp the Thole argument (admp/pme.py:408-432): the only way the polarizabilities
+// (dmp = (alpha_i alpha_j)^(1/6)) and the Thole parameters (a_w) enter the pair energy.  The Thole factors depend on au
+// alone, so this is the "au d(th)/d(au)" part of the induced coefficients' radial derivative in pair_energy_grad,
+// contracted with the same bilinear shapes.  Returns X; *wth receives d ln(au) / d(thole_i) = (1 - w0) / a_w.
+// dE/dalpha_i = -(1/(6 alpha_i)) sum_j X_ij (+ the penalty term), dE/dthole_i = sum_j X_ij wth_ij.
+template <class T>
+ADMP_HD T pair_thole_logderiv(const Box<T>& box, const Site<T>& I, const Site<T>& J, const PairScales<T>& sc, T* wth) {
+  T d[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+  min_image(box, d);
+  const T r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const T rinv = T(1) / m_sqrt(r2);
+  const T r = r2 * rinv;
+  T z[3] = {d[0] * rinv, d[1] * rinv, d[2] * rinv}, x[3], y[3];
+  qi_frame(z, x, y);
+  T A[9], B[9], UA[3], UB[3];
+  rot_harm(I.Q, x, y, z, A);
+  rot_harm(J.Q, x, y, z, B);
+  rot_dip(I.U, x, y, z, UA);
+  rot_dip(J.U, x, y, z, UB);
+  const T aw = sc.w0 * T(kDefaultTholeWidth) + (T(1) - sc.w0) * (I.thole + J.thole);
+  T dmp = I.p6 * J.p6;
+  const bool dmp_floor = dmp < T(1e-8);
+  dmp = dmp_floor ? T(1e-8) : dmp;
+  const T uraw = r / dmp;
+  *wth = aw > T(0) ? (T(1) - sc.w0) / aw : T(0);           // a_w = 0 (both tholes 0): X ~ au^3 vanishes with it
+  if (!(uraw < T(1e8))) return T(0);                      // u clamped: no dependence left
+  const T au = uraw * aw;
+  if (!(au < T(50))) return T(0);                         // exponential switched off
+  const T Ex = m_exp(-au);
+  const T au3 = au * au * au, au4 = au3 * au;
+  const T tcp = T(0.5) * Ex * au3;                        // au d(th_c)/d(au)
+  const T td0p = T(0.25) * Ex * au3 * (au - T(1));
+  const T tq1p = T(1.0 / 6.0) * Ex * au4;
+  const T tq0p = T(1.0 / 18.0) * Ex * au4 * (au - T(1));
+  const T R2 = T(kDielectric) * rinv * rinv, R3 = R2 * rinv, R4 = R3 * rinv;
+  const T p = sc.p, hf = T(0.5);
+  T X = R2 * (T(2) * p * tcp) * hf * (A[0] * UB[0] - B[0] * UA[0]);
+  X += R3 * (T(-4) * p * td0p) * hf * (B[1] * UA[0] + A[1] * UB[0]);
+  X += R3 * (T(2) * p * tcp) * hf * (B[2] * UA[1] + B[3] * UA[2] + A[2] * UB[1] + A[3] * UB[2]);
+  X += R4 * (T(6) * p * tq0p) * hf * (A[4] * UB[0] - B[4] * UA[0]);
+  X += R4 * (T(-2.0 * kSqrt3) * p * tq1p) * hf * (A[5] * UB[1] + A[6] * UB[2] - B[5] * UA[1] - B[6] * UA[2]);
+  X += R3 * (T(-2) * td0p) * (UA[0] * UB[0]);
+  X += R3 * tcp * (UA[1] * UB[1] + UA[2] * UB[2]);
+  if (dmp_floor) { /* dmp pinned at its floor: X still drives dE/dthole, the caller drops the alpha part via p6 == 0 */ }
+  return X;
+}
+
 // Field-only evaluation for the SCF (dE/dU_I of the real-space term, admp/pme.py:133):
 // only the seven induced coefficients, no radial derivative, no torque.
 template <class T>

@@ -214,6 +214,34 @@ class ADMPPmeForce(HipForceBase):
             r = self._evaluate(positions, box, pairs, Q_local, mScales, want_dQ=True)
         return r['E'], self._like(r['grad'], positions), self._like(r['dQ'], positions)
 
+    def get_pol_thole_gradients(self, positions, box, pairs, Q_local, pol, tholes, mScales, pScales, dScales, U_init=None):
+        """(dE/dpol, dE/dtholes), each (Na,): the 'pol' and 'tholes' entries of `grad(pot_pme, argnums=3)` in the reference.
+        The induced dipoles are converged first (like `get_energy`); at the SCF solution dE/dU = 0, so the parameter
+        gradient is the partial derivative at fixed dipoles: the Thole-damping part of every pair (admp_thole_sums) plus
+        the polarization penalty D |U|^2 / (2 alpha) (admp/pme.py:760-774).  Sites with pol <= 1e-8 get 0 for dE/dpol."""
+        if not self.lpol:
+            raise RuntimeError('get_pol_thole_gradients needs lpol=True')
+        self.get_energy(positions, box, pairs, Q_local, pol, tholes, mScales, pScales, dScales, U_init=U_init)
+        with self._on_stream():
+            na = self.n_atoms
+            pos = self._real(positions, (na, 3))
+            Q = self._pad_Q(Q_local)
+            pol_t, th_t = self._real(pol, (na,)), self._real(tholes, (na,))
+            U = self._real(self.U_ind, (na, 3))
+            mS = self._host64(mScales)
+            pS = self._host64(pScales, len(mS))
+            sx = torch.empty(na, dtype=self._dtype, device=self._device)
+            sw = torch.empty(na, dtype=self._dtype, device=self._device)
+            rc = self._L.admp_thole_sums(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(Q),
+                                         self._ptr(pol_t), self._ptr(th_t), len(mS), _lib.darr(mS), _lib.darr(pS),
+                                         self._ptr(U), self._ptr(sx), self._ptr(sw))
+            _lib.check(self._h, rc, 'admp_thole_sums')
+            live = pol_t > 1e-8
+            safe = torch.where(live, pol_t, torch.ones_like(pol_t))
+            dpol = torch.where(live, -sx / (6.0 * safe) - DIELECTRIC * (U * U).sum(dim=1) / (2.0 * safe * safe),
+                               torch.zeros_like(pol_t))
+        return self._like(dpol, positions), self._like(sw, positions)
+
     def get_mscale_gradient(self, positions, box, pairs, Q_local, mScales):
         """dE/dmScales, shape (len(mScales),): what `grad(pot_pme, argnums=3)(...)['mScales']` gives in the reference
         (examples/openmm_api/run.py:44-46).  The energy is linear in mScales and its induced part carries pScales, so neither

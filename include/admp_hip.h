@@ -105,6 +105,17 @@ int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box
 int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const double* box, const void* params, int pmax,
                      int n_scales, double* dE_dmScales, int on_device);
 
+/* replaces: the 'pol' / 'tholes' entries of jax.grad(pot_pme, argnums=3) (parameter gradients of the polarizable model).
+ * The polarizabilities and Thole parameters enter the pair energy only through the Thole argument
+ * au = a_w r / (alpha_i alpha_j)^(1/6) (admp/pme.py:408-414).  This call returns, for the induced dipoles U given
+ * (normally the converged ones), the per-atom sums
+ *   sumX[i]  = sum_j dE_ij / d ln(au_ij)            -> dE/dalpha_i = -sumX[i] / (6 alpha_i) - D |U_i|^2 / (2 alpha_i^2)
+ *   sumXw[i] = sum_j dE_ij / d ln(au_ij) (1 - w0_ij) / a_w,ij   -> dE/dthole_i = sumXw[i]
+ * (the closing formulas are applied by the caller, admp_amd/pme.py).  All array arguments are DEVICE pointers. */
+int admp_thole_sums(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                    const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
+                    void* sumX, void* sumXw);
+
 /* ---- neighbour search ("next" row of SURVEY.md 8f) --------------------------------------------------------
  * replaces: jax_md.partition.neighbor_list(displacement_fn, box, rc, 0, format=OrderedSparse).allocate(positions)
  * of the reference's drivers (examples/water_1024/run_admp.py:109-112): the producer of `pairs`.

@@ -615,6 +615,37 @@ def test_mscale_gradients_vs_oracle_autograd(precision):
         assert np.abs(gt - ref.numpy()).max() < tol * np.abs(ref.numpy()).max(), (prec, gt, ref)
 
 
+def test_pol_and_thole_gradients_vs_oracle_autograd(precision):
+    """dE/dpol and dE/dtholes at the converged dipoles against torch autograd through the oracle at the same (fixed)
+    dipoles -- the Hellmann-Feynman parameter gradient jax.grad(pot_pme, argnums=3) gives in the reference.  Every atom
+    polarizable here (with alpha = 0 the reference's own gradient is 0 * inf); the alpha = 0 convention (gradient 0) is
+    checked on the standard water parameters."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    pos, box, at, ai, cov, par, pairs = water_system(125, 31, True)
+    rng = np.random.default_rng(5)
+    pol = np.where(par['pol'] > 0, par['pol'], 0.25) * rng.uniform(0.8, 1.2, len(pos))
+    th = par['tholes'] + rng.uniform(0.5, 3.0, len(pos))
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+    for prec, tol in (('double', 1e-8), ('single', 5e-4)):
+        settings.PRECISION = prec
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+        dpol, dth = f.get_pol_thole_gradients(pos, box, pairs, par['Q_local'], pol, th, par['mScales'], par['pScales'],
+                                              par['dScales'])
+        sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, True)
+        pt, tt = T(pol).clone().requires_grad_(True), T(th).clone().requires_grad_(True)
+        U = T(np.asarray(f.U_ind, dtype=np.float64))
+        E = O.energy_pme(sysm, T(pos), T(box), pairs, T(par['Q_local']), U, pt, tt, T(par['mScales']), T(par['pScales']))
+        rp, rt = torch.autograd.grad(E, (pt, tt))
+        assert rel(dpol, rp.numpy()) < tol and rel(dth, rt.numpy()) < tol, (prec, rel(dpol, rp.numpy()), rel(dth, rt.numpy()))
+    settings.PRECISION = 'double'
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    dpol, dth = f.get_pol_thole_gradients(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
+                                          par['pScales'], par['dScales'])
+    assert np.all(dpol[par['pol'] == 0] == 0.0) and np.all(np.isfinite(dpol)) and np.all(np.isfinite(dth))
+
+
 def _mixed_axis_system(seed=2):
     """8 'molecules' of 4 atoms exercising every axis rule (ZThenX, Bisector, ZBisect, ThreeFold, Zonly, none)."""
     rng = np.random.default_rng(seed)
