@@ -538,11 +538,14 @@ struct Engine : EngineBase {
   void ensure_bins(int na) {
     const int dims[3] = {nloc0(), K[1], K[2]};
     const BrickGrid bg = make_bricks(dims);
-    bin_cells.need(sizeof(int) * 2 * (size_t)(bg.ncell + 1));
+    bin_cells.need(sizeof(int) * 3 * (size_t)(bg.ncell + 1));
     bin_sorted.need(sizeof(int) * 8 * (size_t)na);
     bin_scan.need(spread_scan_bytes(bg.ncell));
+    if (bins.cell_start != bin_cells.as<int>() || bins.cursor != bin_cells.as<int>() + (bg.ncell + 1))
+      bins.counters_zero = false;                  // fresh or re-laid-out storage
     bins.cell_start = bin_cells.as<int>();
     bins.cursor = bin_cells.as<int>() + (bg.ncell + 1);
+    bins.fillcur = bin_cells.as<int>() + 2 * (size_t)(bg.ncell + 1);
     bins.sorted = bin_sorted.as<int>();
     bins.scan_tmp = bin_scan.p;
     bins.scan_bytes = bin_scan.bytes;

@@ -171,7 +171,9 @@ int spread_brick_min_atoms();
 // (atom, brick) entry list sorted[<= 8 na] (a stencil touches at most 2 bricks per axis)
 struct BinScratch {
   int* cell_start = nullptr;   // ncell + 1
-  int* cursor = nullptr;       // ncell + 1
+  int* cursor = nullptr;       // ncell + 1: per-brick entry counts (input of the scan)
+  int* fillcur = nullptr;      // ncell + 1: per-brick fill cursors of the second binning pass
+  bool counters_zero = false;  // cursor / fillcur are all zero (the brick kernel clears its own words when it is done)
   int* sorted = nullptr;       // 8 * na
   void* scan_tmp = nullptr;
   size_t scan_bytes = 0;

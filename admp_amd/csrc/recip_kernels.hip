@@ -62,7 +62,8 @@ __device__ __forceinline__ int4 atom_bases(const Site<T>* __restrict__ sites, co
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__ sites, RecipGeom<T> g, BrickGrid bg,
                                              int* __restrict__ counter, int* __restrict__ entries,
-                                             const int* __restrict__ list, const int4* __restrict__ bases) {
+                                             const int* __restrict__ list, const int4* __restrict__ bases,
+                                             const int* __restrict__ start) {
   const int slot = blockIdx.x * 256 + threadIdx.x;
   const int i = slot < na ? (list ? list[slot] : slot) : 0;
   int b[3][2] = {{0, 0}, {0, 0}, {0, 0}}, n[3] = {0, 0, 0};
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__
     const bool pred = x < n[0] && y < n[1] && z < n[2];
     const int cid = (b[0][x] * bg.nb[1] + b[1][y]) * bg.nb[2] + b[2][z];
     const int slot = wave_agg_add(counter, cid, pred);
-    if (MODE == 1 && pred) entries[slot] = i;
+    if (MODE == 1 && pred) entries[start[cid] + slot] = i;
   }
 }
 
@@ -98,7 +99,8 @@ constexpr int kBrickRow = ADMP_BRICK_ROW;   // z-row pitch of the LDS tile in wo
 template <class T>
 __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                        BrickGrid bg, const int* __restrict__ brick_start,
-                                                       const int* __restrict__ entries, T* __restrict__ mesh) {
+                                                       const int* __restrict__ entries, T* __restrict__ mesh,
+                                                       int* __restrict__ clear_a, int* __restrict__ clear_b) {
   __shared__ double tile[16 * 16 * kBrickRow];
   const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
   const int bb[3] = {bx, by, bz};
@@ -148,6 +150,8 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
     mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * kBrickRow + jc];
   }
+  // this brick's binning counters are consumed: clear them for the next binning (no memset dispatches per step)
+  if (threadIdx.x == 0 && clear_a) { clear_a[blockIdx.x] = 0; clear_b[blockIdx.x] = 0; }
 }
 
 // ---- column-task spread of an entry list into the brick's LDS tile (scan kernel; the binned kernel of large systems
@@ -495,16 +499,20 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
   }
   if (nb != 1) return (int)hipErrorInvalidValue;      // batches exist for the scan kernel only
   if (reuse_bins) {   // same positions as the previous call (next dispersion power): the brick lists are still valid
-    k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh);
+    k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr);
     return 0;
   }
-  RC(hipMemsetAsync(bs.cursor, 0, sizeof(int) * (bg.ncell + 1), st));
-  k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list, bases);
+  if (!bs.counters_zero) {
+    RC(hipMemsetAsync(bs.cursor, 0, sizeof(int) * (bg.ncell + 1), st));
+    RC(hipMemsetAsync(bs.fillcur, 0, sizeof(int) * (bg.ncell + 1), st));
+  }
+  bs.counters_zero = false;
+  k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list, bases, nullptr);
   size_t need = bs.scan_bytes;
   RC(hipcub::DeviceScan::ExclusiveSum(bs.scan_tmp, need, bs.cursor, bs.cell_start, bg.ncell + 1, st));
-  RC(hipMemcpyAsync(bs.cursor, bs.cell_start, sizeof(int) * (bg.ncell + 1), hipMemcpyDeviceToDevice, st));
-  k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, bs.sorted, list, bases);
-  k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh);
+  k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.fillcur, bs.sorted, list, bases, bs.cell_start);
+  k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
+  bs.counters_zero = true;      // element ncell of both arrays is never written: it stays zero
   return 0;
 }
 #undef RC
