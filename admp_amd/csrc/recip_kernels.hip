@@ -58,6 +58,31 @@ __device__ __forceinline__ int4 atom_bases(const Site<T>* __restrict__ sites, co
   return make_int4(b[0], b[1], b[2], brick_code(b, dims, bg));
 }
 
+// exclusive prefix sum of n <= 8192 ints by ONE workgroup (1024 threads x 8 elements): the brick counts of meshes up to
+// 320^3; one dispatch where the library scan takes two
+__global__ __launch_bounds__(1024) void k_scan_small(int n, const int* __restrict__ in, int* __restrict__ out) {
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int v[8], tot = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const int i = t * 8 + k; v[k] = i < n ? in[i] : 0; tot += v[k]; }
+  int inc = tot;                                     // inclusive scan of the per-thread totals within the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off, 64); if (lane >= off) inc += u; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  if (t < 16) {
+    int w = wsum[t];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { const int u = __shfl_up(w, off, 64); if (t >= off) w += u; }
+    wsum[t] = w;                                     // inclusive over waves
+  }
+  __syncthreads();
+  int base = inc - tot + (wave ? wsum[wave - 1] : 0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const int i = t * 8 + k; if (i < n) out[i] = base; base += v[k]; }
+}
+
 // mode 0: count the (atom, brick) entries per brick; mode 1: write them (counter = running offsets)
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__ sites, RecipGeom<T> g, BrickGrid bg,
@@ -508,8 +533,12 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
   }
   bs.counters_zero = false;
   k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list, bases, nullptr);
-  size_t need = bs.scan_bytes;
-  RC(hipcub::DeviceScan::ExclusiveSum(bs.scan_tmp, need, bs.cursor, bs.cell_start, bg.ncell + 1, st));
+  if (bg.ncell + 1 <= 8192) {
+    k_scan_small<<<1, 1024, 0, st>>>(bg.ncell + 1, bs.cursor, bs.cell_start);
+  } else {
+    size_t need = bs.scan_bytes;
+    RC(hipcub::DeviceScan::ExclusiveSum(bs.scan_tmp, need, bs.cursor, bs.cell_start, bg.ncell + 1, st));
+  }
   k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.fillcur, bs.sorted, list, bases, bs.cell_start);
   k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
   bs.counters_zero = true;      // element ncell of both arrays is never written: it stays zero
