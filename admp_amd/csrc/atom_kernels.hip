@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const 
                                                             const T* __restrict__ pol, const T* __restrict__ Ucart,
                                                             int lpol, T kappa, const T* __restrict__ pot,
                                                             T* __restrict__ grad, T* __restrict__ dQlocal,
-                                                            double* energies) {
+                                                            double* energies, FieldFin<T> ff) {
   // LANES = 4 (small systems, latency bound): lane m takes the frames m, m+4, ... of the atom's inverse map (water: 3
   // frames per atom), the partial gradients are folded with two xor shuffles -- a quarter of the dependent chain
   // (3072 atoms: 14.5 -> 9.6 us).  LANES = 1 (large systems, throughput bound: at 1M atoms the 4-lane form is 3x slower).
@@ -289,6 +289,18 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const 
     atomicAdd(&energies[E_SELF], eself);
     if (lpol) atomicAdd(&energies[E_PEN], epen);
   }
+  if (ff.fmax_bits) {   // kernel-uniform: the SCF residual and its maximum ride along (k_field_finish's work)
+    double fm = 0.0;
+    if (a < top.na && m == 0) {
+      const T al = ff.pol[a];
+      T fx, fy, fz;
+      total_field(sites[a], al, ff.Ucart + 3 * a, ff.fld_pair + 3 * a, ff.fld_recip + 3 * a, ff.kappa, fx, fy, fz);
+      ff.field[3 * a] = fx; ff.field[3 * a + 1] = fy; ff.field[3 * a + 2] = fz;
+      if (al > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
+    }
+    fm = block_reduce_max<kAtomBlock>(fm);
+    if (threadIdx.x == 0 && fm > 0.0) atomicMax(ff.fmax_bits, nonneg_bits(fm));
+  }
 }
 
 template <class T>
@@ -358,16 +370,16 @@ void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, 
 template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
                    const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
-                   const int* list, int nlist) {
+                   const int* list, int nlist, const FieldFin<T>& ff) {
   if (!list && top.inv_ptr)   // single GPU: pull formulation, no atomics
   {
     static const int lanes4_max = [] { const char* e = getenv("ADMP_FINISH4_MAX"); return e ? atoi(e) : 8192; }();
     if (top.na <= lanes4_max)   // 3072 atoms: 9.6 vs 14.5 us; 30k atoms: 19.9 vs 14.2 us; 98k: 47 vs 21 us
       k_finish_pull<T, 4><<<nblk(4 * top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
-                                                                   dQlocal, energies);
+                                                                   dQlocal, energies, ff);
     else
       k_finish_pull<T, 1><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
-                                                               dQlocal, energies);
+                                                               dQlocal, energies, ff);
   }
   else
     k_finish<T><<<nblk(nlist), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
@@ -405,7 +417,7 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
                                        unsigned long long*, const int*);                                                \
   template void launch_jacobi_update<T>(hipStream_t, int, const T*, const T*, const T*, T*, Site<T>*, const int*);       \
   template void launch_finish<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const Site<T>*, const T*,        \
-                                 const T*, int, T, T*, T*, T*, double*, const int*, int);
+                                 const T*, int, T, T*, T*, T*, double*, const int*, int, const FieldFin<T>&);
 INST(float)
 INST(double)
 #undef INST

@@ -709,11 +709,19 @@ struct Engine : EngineBase {
     launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff);
   }
   // closes the evaluation: E_out = (real, recip[slot], self, penalty) of THIS rank's share
-  void launch_finish_only(T* grad_p, T* dQl) {
+  // with_field_finish (single rank, pull kernel): the SCF residual and its maximum are formed by this kernel too
+  void launch_finish_only(T* grad_p, T* dQl, bool with_field_finish = false) {
     need_eval();
+    FieldFin<T> ff;
+    if (with_field_finish) {
+      if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
+      fmax_clean = false;
+      ff.pol = ev.pol; ff.Ucart = ev.U; ff.fld_pair = fld_pair.as<T>(); ff.fld_recip = fld_recip.as<T>();
+      ff.kappa = (T)kappa; ff.field = field.as<T>(); ff.fmax_bits = fmax_word();
+    }
     TIMED("finish");
     launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
-                     dQl, Ed_cur(), ev.home, ev.n_home);
+                     dQl, Ed_cur(), ev.home, ev.n_home, ff);
   }
   // one device->host copy + sync: energies (and the max|field| word, returned)
   double read_energies(int recip_slot, double* E) {
@@ -791,8 +799,9 @@ struct Engine : EngineBase {
         static const int fuse_max = [] { const char* e = getenv("ADMP_FUSE_FF_MAX"); return e ? atoi(e) : 16384; }();
         const bool fuse_ff = top.na <= fuse_max;
         stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), fuse_ff);
-        if (!fuse_ff) launch_field_finish_only();
-        launch_finish_only(dpos ? gbuf : nullptr, dQl);
+        const bool pull = !ev.home && top.inv_ptr;          // the atomics-free closing kernel can carry the field finish
+        if (!fuse_ff && !pull) launch_field_finish_only();
+        launch_finish_only(dpos ? gbuf : nullptr, dQl, !fuse_ff && pull);
         const double fmax = read_energies(E_SCF_RECIP, E);
         if (fmax < thresh) {
           phi_valid = done = finished = true;

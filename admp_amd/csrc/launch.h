@@ -46,6 +46,18 @@ struct Topology {
 // energies[] slots on the device
 enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SCF_RECIP = 6, E_FMAX = 7 /* bit pattern */, E_SLOTS = 8 };
 
+// optional epilogue of the gather (small systems) or of the closing kernel (large ones), speculative first SCF cycle on
+// one rank: total dE/dU and its maximum, exactly what launch_field_finish computes, without a separate dispatch
+template <class T>
+struct FieldFin {
+  const T* pol = nullptr;
+  const T* Ucart = nullptr;
+  const T* fld_pair = nullptr;
+  const T* fld_recip = nullptr;                // closing-kernel variant only (the gather has it in registers)
+  T kappa = 0;
+  T* field = nullptr;
+  unsigned long long* fmax_bits = nullptr;   // nullptr = epilogue off
+};
 // ---- atom_kernels.hip
 template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
@@ -69,7 +81,8 @@ void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, 
 template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
                    const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
-                   const int* list, int nlist);
+                   const int* list, int nlist,
+                   const FieldFin<T>& ff = FieldFin<T>());
 // dispersion: site rows carrying one scalar channel (Q[0] = vals[i*stride+chan], no dipoles/quadrupoles); also
 // accumulates coef * sum_i vals^2 into energies[E_SELF] (the self term of admp/disp_pme.py:254-279)
 template <class T>
@@ -197,17 +210,6 @@ void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* b
 template <class T>
 void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec /* interleaved complex */,
                    double* energies, int slot);
-// optional epilogue of the gather (single rank, speculative first SCF cycle): total dE/dU and its maximum, exactly
-// what launch_field_finish computes, without a separate dispatch
-template <class T>
-struct FieldFin {
-  const T* pol = nullptr;
-  const T* Ucart = nullptr;
-  const T* fld_pair = nullptr;
-  T kappa = 0;
-  T* field = nullptr;
-  unsigned long long* fmax_bits = nullptr;   // nullptr = epilogue off
-};
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
                    T* grad, const int* list, T* fld_recip /* optional: cartesian reciprocal dE/dU */,
