@@ -15,4 +15,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     bench.step(f, a, U); U = f.U_ind
 torch.cuda.synchronize()
-print('%s overlap=%s: %.3f ms/step' % (name, os.environ.get('ADMP_OVERLAP', 'default'), (time.perf_counter() - t0) / steps * 1e3))
+print('%s: %.3f ms/step' % (name, (time.perf_counter() - t0) / steps * 1e3))
