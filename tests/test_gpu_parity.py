@@ -646,6 +646,43 @@ def test_pol_and_thole_gradients_vs_oracle_autograd(precision):
     assert np.all(dpol[par['pol'] == 0] == 0.0) and np.all(np.isfinite(dpol)) and np.all(np.isfinite(dth))
 
 
+def test_potential_fn_convention_and_param_gradient(precision):
+    """admp_amd.api: potential_fn(positions, box, pairs, params) closures in the reference's convention
+    (admp/api.py:183-199, 442-455); the energies are linear in mScales, so param_gradient(...)['mScales'] must equal
+    finite differences of the potential exactly (to round-off)."""
+    from admp_amd.api import pme_potential, disp_potential, param_gradient
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel
+    settings.PRECISION = 'double'
+    pos, box, at, ai, cov, par, pairs = water_system(64, 17, False)
+    n = len(pos) // 3
+    pme = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    disp = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+    tt = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+    c = par['c_list']
+    dpar = {'mScales': np.array([0.2, 0.5, 0.0, 1.0, 0.8]), 'A': par['a_list'][:2] * 2625.5,
+            'B': par['b_list'][:2] / 0.0529177249, 'Q': par['q_list'][:2], 'C6': c[:2, 0] ** 2 / 1e6,
+            'C8': c[:2, 1] ** 2 / 1e8, 'C10': c[:2, 2] ** 2 / 1e10}
+    pot_d = disp_potential(disp, tt, np.tile([0, 1, 1], n))
+    pot_p = pme_potential(pme)
+    ppar = {'mScales': dpar['mScales'], 'Q_local': par['Q_local']}
+    # the potentials are the calculators' energies
+    e_sr = tt(pos, box, pairs, dpar['mScales'], par['a_list'], par['b_list'], par['q_list'], c[:, 0])
+    e_lr = disp.get_energy(pos, box, pairs, c, dpar['mScales'])
+    assert abs(pot_d(pos, box, pairs, dpar) - (e_sr - e_lr)) < 1e-9 * abs(e_lr)
+    assert abs(pot_p(pos, box, pairs, ppar) - pme.get_energy(pos, box, pairs, par['Q_local'], dpar['mScales'])) < 1e-9
+    for pot, prm in ((pot_d, dpar), (pot_p, ppar)):
+        g = param_gradient(pot, pos, box, pairs, prm)['mScales']
+        for k in (0, 1, 4):
+            up, dn = dict(prm), dict(prm)
+            up['mScales'] = prm['mScales'].copy(); up['mScales'][k] += 0.25
+            dn['mScales'] = prm['mScales'].copy(); dn['mScales'][k] -= 0.25
+            fd = (pot(pos, box, pairs, up) - pot(pos, box, pairs, dn)) / 0.5
+            assert abs(fd - g[k]) < 1e-8 * max(abs(g).max(), 1.0), (k, fd, g[k])
+    assert param_gradient(pot_p, pos, box, pairs, ppar)['Q_local'].shape == (len(pos), 9)
+
+
 def _mixed_axis_system(seed=2):
     """8 'molecules' of 4 atoms exercising every axis rule (ZThenX, Bisector, ZBisect, ThreeFold, Zonly, none)."""
     rng = np.random.default_rng(seed)
