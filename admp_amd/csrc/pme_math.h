@@ -55,7 +55,19 @@ template <class T> ADMP_HD T val(Dual<T> a) { return a.v; }
 
 ADMP_HD float m_exp(float x) { return expf(x); }
 ADMP_HD double m_exp(double x) { return exp(x); }
+#if !defined(ADMP_LIBM_ERFC) && defined(__HIP_DEVICE_COMPILE__)
+// erfc for x >= 0 (the only use: x = kappa r): t exp(-x^2 + P(t)), t = 1/(1 + x/2), fractional error < 1.2e-7
+// (Numerical Recipes erfcc); ~20 instructions against ~55 of the library routine: pair kernel at 1M atoms 0.469 -> 0.457 ms.
+// -DADMP_LIBM_ERFC selects erfcf.
+ADMP_HD float m_erfc(float x) {
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.5f * x);
+  const float p = -1.26551223f + t * (1.00002368f + t * (0.37409196f + t * (0.09678418f + t * (-0.18628806f + t * (0.27886807f +
+                  t * (-1.13520398f + t * (1.48851587f + t * (-0.82215223f + t * 0.17087277f))))))));
+  return t * expf(p - x * x);
+}
+#else
 ADMP_HD float m_erfc(float x) { return erfcf(x); }
+#endif
 ADMP_HD double m_erfc(double x) { return erfc(x); }
 ADMP_HD float m_sqrt(float x) { return sqrtf(x); }
 ADMP_HD double m_sqrt(double x) { return sqrt(x); }

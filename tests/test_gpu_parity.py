@@ -926,7 +926,7 @@ def test_repeated_evaluations_agree_to_roundoff(precision, prec):
     import torch
     from admp_amd.pme import ADMPPmeForce
     settings.PRECISION = prec
-    tol = 1e-12 if prec == 'double' else 2e-6
+    tol = 1e-12 if prec == 'double' else 5e-6      # f32: another row order = another summation order
     for n_mol in (216, 8192):                     # scan-spread / brick-spread regimes
         pos, box, at, ai, cov, par, pairs = water_system(n_mol, 4, True)
         f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
