@@ -196,6 +196,22 @@ def recip_kernel_rooflines(kb, w, grid):
     return out
 
 
+def f32_vs_f64_force_error(w, f32_force, a32):
+    """Relative L2 difference of the single-precision gradient to the double-precision gradient of the same HIP path on
+    the same inputs (both from a cold SCF start).  The oracle cannot run at this size; the f64 path is parity-tested
+    against it at small sizes, so this is the f32 error bar of the large configuration (bar: 1e-2)."""
+    import torch
+    w64 = dict(w, prec='double')
+    f64, a64 = make_force(w64)
+    E64, G64 = step(f64, a64, None)
+    E32, G32 = step(f32_force, a32, None)
+    g64 = torch.as_tensor(G64).double()
+    g32 = torch.as_tensor(G32).double().to(g64.device)
+    err = float(torch.linalg.norm(g32 - g64) / torch.linalg.norm(g64))
+    return {'force_rel_l2_f32_vs_f64': err, 'energy_rel_f32_vs_f64': float(abs(E32 - E64) / abs(E64)),
+            'scf_cycles_f32_f64': [int(f32_force.n_cycle), int(f64.n_cycle)]}
+
+
 def other_terms_ms(w, reps=20):
     """The other calculators of the path (admp/disp_pme.py, admp/pairwise.py) on the same workload: ms per get_forces.
     Informational -- the headline metric is the electrostatics step."""
@@ -423,6 +439,7 @@ def main():
                                    'list_rebuild_ms': round(rb3, 3),
                                    'ns_per_day_rebuild_every_10_steps': round(0.0864 / (dt3 / 5 + rb3 * 1e-4), 3),
                                    'roofline': roofline_of(rep3, w3, f3.n_pairs),
+                                   'precision_check': f32_vs_f64_force_error(w3, f3, a3),
                                    'kernel_ms_per_step': kb3,
                                    'recip_kernels': recip_kernel_rooflines(kb3, w3, [f3.K1, f3.K2, f3.K3])}
             except Exception as e:      # the headline line must still be printed
