@@ -23,6 +23,7 @@ PROTOTYPES = {
     'admp_destroy': (_i32, [_vp]),
     'admp_last_error': (_c.c_char_p, [_vp]),
     'admp_set_stream': (_i32, [_vp, _vp]),
+    'admp_use_default_stream': (_i32, [_vp]),
     'admp_synchronize': (_i32, [_vp]),
     'admp_set_topology': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'admp_set_ewald': (_i32, [_vp, _dbl, _i32, _i32, _i32, _i32, _i32]),

@@ -1137,6 +1137,14 @@ int admp_destroy(admp_handle* h) {
 
 const char* admp_last_error(const admp_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+int admp_use_default_stream(admp_handle* h) {
+  return guarded(h, [&](EngineBase& e) {
+    if (e.own_stream && e.stream) HIP_TRY(hipStreamDestroy(e.stream));
+    e.stream = nullptr;          // the legacy default stream
+    e.own_stream = false;
+  });
+}
+
 int admp_set_stream(admp_handle* h, void* hip_stream) {
   return guarded(h, [&](EngineBase& e) {
     HIP_TRY(hipStreamSynchronize(e.stream));

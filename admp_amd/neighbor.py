@@ -35,8 +35,7 @@ class NeighborList:
         self.box = np.ascontiguousarray(np.asarray(box.detach().cpu() if isinstance(box, torch.Tensor) else box,
                                                    dtype=np.float64)).reshape(3, 3)
         self.rc = float(rc)
-        self._tstream = torch.cuda.Stream(device=self._device)
-        _lib.check(self._h, self._L.admp_set_stream(self._h, ctypes.c_void_p(self._tstream.cuda_stream)), 'admp_set_stream')
+        self._stream = None          # bound to the caller's current torch stream at call time (like the calculators)
         self.idx = None
 
     def __del__(self):
@@ -52,8 +51,14 @@ class NeighborList:
         if box is not None:
             self.box = np.ascontiguousarray(np.asarray(box.detach().cpu() if isinstance(box, torch.Tensor) else box,
                                                        dtype=np.float64)).reshape(3, 3)
-        self._tstream.wait_stream(torch.cuda.current_stream(self._device))
-        with torch.cuda.stream(self._tstream):
+        cur = torch.cuda.current_stream(self._device).cuda_stream
+        if cur != self._stream:
+            if cur == 0:
+                _lib.check(self._h, self._L.admp_use_default_stream(self._h), 'admp_use_default_stream')
+            else:
+                _lib.check(self._h, self._L.admp_set_stream(self._h, ctypes.c_void_p(cur)), 'admp_set_stream')
+            self._stream = cur
+        if True:
             if isinstance(positions, torch.Tensor):
                 pos = positions.detach().to(device=self._device, dtype=self._dtype).contiguous()
             else:

@@ -45,6 +45,8 @@ int admp_destroy(admp_handle* h);
 const char* admp_last_error(const admp_handle* h);
 /* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
 int admp_set_stream(admp_handle* h, void* hip_stream);
+/* run on the legacy default (null) stream -- what torch.cuda.current_stream() is unless the caller switched streams */
+int admp_use_default_stream(admp_handle* h);
 int admp_synchronize(admp_handle* h);
 
 /* ---- static environment -------------------------------------------------------------------- */
