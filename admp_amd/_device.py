@@ -74,6 +74,7 @@ class HipForceBase:
         self._pairs_key = None
         self._pairs_keep = None
         self._stream = None
+        self._hcache = {}
 
     def __del__(self):
         try:
@@ -125,6 +126,25 @@ class HipForceBase:
             raise ValueError('expected shape %s, got %s' % (tuple(shape), tuple(t.shape)))
         return t
 
+    def _harr(self, slot, x, n=None):
+        """host values -> (ctypes double array, count), cached per call-site `slot` while the content is unchanged (the
+        scale factors and the box are the same objects step after step; marshalling them anew costs microseconds of a
+        0.17 ms step)."""
+        if isinstance(x, np.ndarray) and x.dtype == np.float64:
+            b = x.tobytes()
+        elif isinstance(x, torch.Tensor):
+            b = x.detach().cpu().numpy().astype(np.float64).tobytes()
+        else:
+            b = np.asarray(x, dtype=np.float64).tobytes()
+        c = self._hcache.get(slot)
+        if c is None or c[0] != b:
+            cnt = len(b) // 8
+            c = (b, (ctypes.c_double * cnt).from_buffer_copy(b), cnt)
+            self._hcache[slot] = c
+        if n is not None and c[2] != n:
+            raise ValueError('expected %d values, got %d' % (n, c[2]))
+        return c[1], c[2]
+
     @staticmethod
     def _host64(x, n=None):
         a = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
@@ -137,7 +157,7 @@ class HipForceBase:
     def _like(result, template):
         """return `result` (device tensor) in the container type of `template`."""
         if isinstance(template, torch.Tensor):
-            return result.to(device=template.device)
+            return result if result.device == template.device else result.to(device=template.device)
         return result.cpu().numpy()
 
     @staticmethod

@@ -78,6 +78,9 @@ class ADMPPmeForce(HipForceBase):
         self.lconverg = None
         self.n_cycle = None
         self.energy_parts = None
+        self._out_E = (ctypes.c_double * 4)()
+        self._out_ncyc, self._out_conv = ctypes.c_int(0), ctypes.c_int(1)
+        self._out_ncyc_ref, self._out_conv_ref = ctypes.byref(self._out_ncyc), ctypes.byref(self._out_conv)
         self.refresh_calculators()
 
     # ---- environment (admp/pme.py:89-109) ------------------------------------------------------------------
@@ -132,11 +135,10 @@ class ADMPPmeForce(HipForceBase):
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
         Q = self._pad_Q(Q_local)
-        boxh = self._host64(box, 9)
-        mS = self._host64(mScales)
-        ns = len(mS)
-        E = (ctypes.c_double * 4)()
-        ncyc, conv = ctypes.c_int(0), ctypes.c_int(1)
+        boxa, _ = self._harr('box', box, 9)
+        mSa, ns = self._harr('mS', mScales)
+        E, ncyc, conv = self._out_E, self._out_ncyc, self._out_conv      # reused ctypes outputs
+        ncyc.value, conv.value = 0, 1
         grad = torch.empty((na, 3), dtype=self._dtype, device=self._device) if want_grad else None
         dQ = torch.empty((na, 9), dtype=self._dtype, device=self._device) if want_dQ else None
         pol_t = th_t = U = None
@@ -144,17 +146,15 @@ class ADMPPmeForce(HipForceBase):
         if self.lpol:
             pol_t = self._real(pol, (na,))
             th_t = self._real(tholes, (na,))
-            pS = self._host64(pScales, ns)
-            dS = self._host64(dScales, ns) if dScales is not None else pS
+            pS, _ = self._harr('pS', pScales, ns)
+            dS = self._harr('dS', dScales, ns)[0] if dScales is not None else pS
             U = (torch.zeros((na, 3), dtype=self._dtype, device=self._device) if U_init is None
                  else self._real(U_init, (na, 3)).clone())
         maxiter = settings.MAX_N_POL if maxiter is None else int(maxiter)
         thresh = settings.POL_CONV if thresh is None else float(thresh)
-        dptr = _lib.darr
-        rc = L.admp_pme_energy_grad(h, self._ptr(pos), dptr(boxh), self._ptr(Q), self._ptr(pol_t), self._ptr(th_t), ns,
-                                    dptr(mS), None if pS is None else dptr(pS), None if dS is None else dptr(dS),
-                                    self._ptr(U), maxiter, thresh, E, self._ptr(grad), self._ptr(dQ),
-                                    ctypes.byref(ncyc), ctypes.byref(conv), 1)
+        P = self._ptr
+        rc = L.admp_pme_energy_grad(h, P(pos), boxa, P(Q), P(pol_t), P(th_t), ns, mSa, pS, dS, P(U), maxiter, thresh, E,
+                                    P(grad), P(dQ), self._out_ncyc_ref, self._out_conv_ref, 1)
         _lib.check(h, rc, 'admp_pme_energy_grad')
         self.energy_parts = tuple(E)        # (real, recip, self, penalty)
         out = {'E': np.float64(E[0] + E[1] + E[2] + E[3])}
