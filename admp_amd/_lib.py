@@ -31,6 +31,9 @@ PROTOTYPES = {
     'admp_num_pairs': (_i64, [_vp]),
     'admp_pme_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _dp, _vp, _i32, _dbl, _dp, _vp, _vp,
                                     _ip, _ip, _i32]),
+    'admp_pme_energy_fixed_dipoles': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _dp, _vp, _vp, _vp]),
+    'admp_local_frames': (_i32, [_vp, _vp, _dp, _vp]),
+    'admp_set_option': (_i32, [_vp, _i32, _i32]),
     'admp_disp_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _i32, _dp, _dp, _vp, _i32]),
     'admp_tt_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _dp, _vp, _i32]),
     'admp_thole_sums': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _vp, _vp]),
@@ -52,6 +55,8 @@ PROTOTYPES = {
 # stage codes of admp_stage (include/admp_hip.h)
 ST_SET_U, ST_PAIR_FIELD, ST_SPREAD, ST_FFT_YZ, ST_FFT_X, ST_KSPACE, ST_GATHER_FIELD, ST_FIELD_FINISH, ST_JACOBI, \
     ST_PAIR_FULL, ST_GATHER, ST_FINISH = range(1, 13)
+
+OPT_REFERENCE_KPOINTS = 1
 
 _lib = None
 

@@ -72,6 +72,25 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
   }
 }
 
+// (Na,3,3) local frames, rows x, y, z (admp/spatial.py:76-142): the diagnostic behind ADMPPmeForce.construct_local_frames
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_local_frames(Topology top, const T* __restrict__ pos, Box<T> box,
+                                                             T* __restrict__ out) {
+  int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (i >= top.na) return;
+  int type, iz, ix, iy;
+  FrameWork<T> w;
+  frame_of(top, pos, box, i, type, iz, ix, iy, w);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { out[9 * i + k] = w.X[k]; out[9 * i + 3 + k] = w.Y[k]; out[9 * i + 6 + k] = w.Z[k]; }
+}
+template <class T>
+void launch_local_frames(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, T* out) {
+  k_local_frames<T><<<(top.na + kAtomBlock - 1) / kAtomBlock, kAtomBlock, 0, st>>>(top, pos, box, out);
+}
+template void launch_local_frames<float>(hipStream_t, const Topology&, const float*, const Box<float>&, float*);
+template void launch_local_frames<double>(hipStream_t, const Topology&, const double*, const Box<double>&, double*);
+
 template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_update_U(int na, const T* __restrict__ Ucart,
                                                          Site<T>* __restrict__ sites) {

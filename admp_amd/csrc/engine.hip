@@ -155,6 +155,7 @@ struct EngineBase {
   int K[3] = {0, 0, 0};
   int lmax = 2, lpol = 0;
   int srank = 0, snranks = 1;   // x-slab decomposition (admp_slab_configure)
+  int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
   DevBuf scan_scratch;
   size_t scan_bytes = 0;
 
@@ -162,6 +163,9 @@ struct EngineBase {
   virtual void pme(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                    const double* mS, const double* pS, void* U, int max_cycle, double thresh, double* E, void* dpos,
                    void* dQl, int* ncyc, int* conv, int on_device) = 0;
+  virtual void pme_at_U(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
+                        const double* mS, const double* pS, const void* U, double* E, void* dpos, void* dU, void* dQl) = 0;
+  virtual void local_frames(const void* pos, const double* box, void* out) = 0;
   virtual void disp(const void* pos, const double* box, const void* clist, int pmax, int ns, const double* mS, double* E,
                     void* dpos, int on_device) = 0;
   virtual void tt(const void* pos, const double* box, const void* abqc, int ns, const double* mS, double* E, void* dpos,
@@ -304,7 +308,7 @@ struct Engine : EngineBase {
   DevBuf bases_d;         // int4 per atom: lowest stencil index on each mesh axis
   bool use_dft = false;   // mesh convolution through dft_kernels.hip instead of rocFFT (single rank, a Bluestein dimension)
   // validity of the cached G table
-  struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0; } tabkey[4];
+  struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0, ref = 0; } tabkey[4];
   static int tab_slot(int which) { return which == 1 ? 0 : (which == 6 ? 1 : (which == 8 ? 2 : 3)); }
   bool warm_regime = false;   // previous polarizable call converged at its first SCF check
 
@@ -501,17 +505,17 @@ struct Engine : EngineBase {
     buf.need(nspec_t * sizeof(T));
     gtab_cur = buf.template as<T>();
     bool same = key.kappa == kappa && key.K[0] == K[0] && key.K[1] == K[1] && key.K[2] == K[2] &&
-                key.Y0 == (snranks > 1 ? Y0 : 0);
+                key.Y0 == (snranks > 1 ? Y0 : 0) && key.ref == ref_korder;
     for (int k = 0; k < 9 && same; ++k) same = key.box[k] == box[k];
     if (same) return;
     HIP_TRY(hipMemcpyAsync(binv_d.p, inv, 9 * sizeof(double), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));   // `inv` is a caller stack array
     {
       TIMED("gtab");
-      launch_gtab<T>(stream, K, snranks > 1 ? Y0 : 0, nyown(), binv_d.as<double>(), std::fabs(vol), kappa, which, gtab_cur);
+      launch_gtab<T>(stream, K, snranks > 1 ? Y0 : 0, nyown(), binv_d.as<double>(), std::fabs(vol), kappa, which, gtab_cur, ref_korder);
     }
     std::memcpy(key.box, box, sizeof(key.box));
-    key.kappa = kappa; key.K[0] = K[0]; key.K[1] = K[1]; key.K[2] = K[2]; key.Y0 = snranks > 1 ? Y0 : 0;
+    key.kappa = kappa; key.K[0] = K[0]; key.K[1] = K[1]; key.K[2] = K[2]; key.Y0 = snranks > 1 ? Y0 : 0; key.ref = ref_korder;
   }
 
   ScaleTab<T> make_tab(int ns, const double* mS, const double* pS) {
@@ -843,6 +847,37 @@ struct Engine : EngineBase {
     if (conv) *conv = flag;
   }
 
+  // energy_fn / grad_U_fn / grad_pos_fn of the reference (admp/pme.py:69-78): energy and its derivatives at dipoles the
+  // CALLER supplies -- no SCF.  Device pointers only.  dU = dE/dUind_global (Cartesian, incl. the self and penalty terms).
+  void pme_at_U(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
+                const double* mS, const double* pS, const void* U_, double* E, void* dpos_, void* dU_, void* dQl_) override {
+    ARG_CHECK(snranks == 1, "this handle is slab-decomposed: drive it through the admp_stage_* entry points");
+    ARG_CHECK(lpol, "polarizable handle required (the non-polarizable energy is admp_pme_energy_grad)");
+    ARG_CHECK(pos_ && box && Ql_ && U_ && E, "null argument");
+    ARG_CHECK(!dQl_ || dpos_, "dE_dQlocal requires dE_dpos");
+    const int na = top.na;
+    grad.need(3 * (size_t)na * sizeof(T));
+    T* gbuf = dpos_ ? reinterpret_cast<T*>(dpos_) : grad.as<T>();
+    stage_begin(pos_, box, Ql_, pol_, thole_, ns, mS, pS, const_cast<void*>(U_));
+    const bool wantU = dU_ != nullptr;
+    stage_pair_full(gbuf, wantU ? fld_pair.as<T>() : nullptr);
+    recip_pass(E_RECIP);
+    stage_gather(mesh.as<T>(), gbuf, wantU ? fld_recip.as<T>() : nullptr);
+    if (wantU) {
+      launch_field_finish_only();
+      HIP_TRY(hipMemcpyAsync(dU_, field.p, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    }
+    stage_finish(dpos_ ? gbuf : nullptr, reinterpret_cast<T*>(dQl_), E_RECIP, E);
+    warm_regime = false;
+  }
+
+  void local_frames(const void* pos, const double* box, void* out) override {
+    ARG_CHECK(have_top && pos && box && out, "topology must be set; null argument");
+    double inv[9], vol;
+    Box<T> bx = make_box(box, inv, &vol);
+    launch_local_frames<T>(stream, top, reinterpret_cast<const T*>(pos), bx, reinterpret_cast<T*>(out));
+  }
+
   // ---- neighbour search (cell list) ------------------------------------------------------------------
   CellScratch cells;
   int nb_na = 0; const T* nb_pos = nullptr; Box<T> nb_box; double nb_rc = 0;
@@ -1090,7 +1125,12 @@ static int guarded(admp_handle* h, F&& f) {
   if (!h || !h->eng) return ADMP_E_ARG;
   try {
     (void)hipSetDevice(h->eng->device);
+    (void)hipGetLastError();                 // drop anything stale from other users of this thread
     f(*h->eng);
+    // a bad launch configuration (too much LDS, too many registers after a flag change, ...) is reported by neither the
+    // launch statement nor hipStreamSynchronize: every <<<>>> of this call is covered by one check here
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) throw Err{ADMP_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le)};
     return ADMP_OK;
   } catch (const Err& e) {
     h->err = e.msg;
@@ -1139,6 +1179,7 @@ const char* admp_last_error(const admp_handle* h) { return h ? h->err.c_str() : 
 
 int admp_use_default_stream(admp_handle* h) {
   return guarded(h, [&](EngineBase& e) {
+    HIP_TRY(hipStreamSynchronize(e.stream));
     if (e.own_stream && e.stream) HIP_TRY(hipStreamDestroy(e.stream));
     e.stream = nullptr;          // the legacy default stream
     e.own_stream = false;
@@ -1182,6 +1223,27 @@ int admp_pme_energy_grad(admp_handle* h, const void* positions, const double* bo
   return guarded(h, [&](EngineBase& e) {
     e.pme(positions, box, Q_local, pol, tholes, n_scales, mScales, pScales, U_inout, max_cycle, thresh, E_out, dE_dpos,
           dE_dQlocal, n_cycle, converged, on_device);
+  });
+}
+
+int admp_pme_energy_fixed_dipoles(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                         const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
+                         double* E_out, void* dE_dpos, void* dE_dU, void* dE_dQlocal) {
+  return guarded(h, [&](EngineBase& e) {
+    e.pme_at_U(positions, box, Q_local, pol, tholes, n_scales, mScales, pScales, U, E_out, dE_dpos, dE_dU, dE_dQlocal);
+  });
+}
+
+int admp_local_frames(admp_handle* h, const void* positions, const double* box, void* frames_out) {
+  return guarded(h, [&](EngineBase& e) { e.local_frames(positions, box, frames_out); });
+}
+
+int admp_set_option(admp_handle* h, int option, int value) {
+  return guarded(h, [&](EngineBase& e) {
+    switch (option) {
+      case ADMP_OPT_REFERENCE_KPOINTS: e.ref_korder = value ? 1 : 0; break;
+      default: throw Err{ADMP_E_ARG, "unknown option"};
+    }
   });
 }
 

@@ -66,6 +66,8 @@ void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, con
                           const RecipGeom<T>& g, int4* bases /* optional: stencil base indices per atom */);
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites);
+template <class T>
+void launch_local_frames(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, T* out /* (na,3,3) */);
 // field (Cartesian dE/dU) = pair (harmonic order) + recip (cartesian) + self + penalty; also max |field| over
 // sites with pol > 0.001 (admp/pme.py:130,136) into *fmax_bits (order-preserving bit pattern of a non-negative real)
 // Every per-atom / per-row launcher below takes an optional index list (`list`/`rows`, nullptr = atoms 0..n-1):
@@ -205,7 +207,7 @@ size_t spread_scan_bytes(int ncell);
 // which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels
 template <class T>
 void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* box_inv, double volume, double kappa,
-                 int which, T* gtab);
+                 int which, T* gtab, int ref_order = 0 /* the reference's k-point table, see k_gtab */);
 // spec <- spec * gtab ; energies[slot] += sum_k w_k (gtab/2) |S_k|^2
 template <class T>
 void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec /* interleaved complex */,

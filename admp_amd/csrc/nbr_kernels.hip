@@ -58,24 +58,33 @@ __global__ void k_nbr_sort(int na, const int* __restrict__ rowptr, int* __restri
 
 #define NB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+namespace {
+struct DevTmp {   // freed on every return path
+  void* p = nullptr;
+  ~DevTmp() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
 int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, const int* pairs_dev, NbrTable& nb,
                           void** scratch, size_t* scratch_bytes) {
   const int na = top.na;
   if (!nb.rowptr) NB_CHECK(hipMalloc(&nb.rowptr, sizeof(int) * (na + 1)));
   // na + 1 degrees (reused as the fill cursor), padded to an even count, then one 64-bit pair counter
   const size_t ndeg = (size_t)((na + 2) & ~1);
-  int* deg = nullptr;
-  NB_CHECK(hipMalloc(&deg, sizeof(int) * ndeg + sizeof(unsigned long long)));
+  DevTmp degbuf;
+  NB_CHECK(hipMalloc(&degbuf.p, sizeof(int) * ndeg + sizeof(unsigned long long)));
+  int* deg = (int*)degbuf.p;
   unsigned long long* n_valid = (unsigned long long*)(deg + ndeg);
   NB_CHECK(hipMemsetAsync(deg, 0, sizeof(int) * ndeg + sizeof(unsigned long long), st));
   int blocks = (int)((n_rows + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  if (n_rows > 0) k_nbr_count<<<blocks, 256, 0, st>>>(n_rows, pairs_dev, na, deg, n_valid);
+  if (n_rows > 0) { k_nbr_count<<<blocks, 256, 0, st>>>(n_rows, pairs_dev, na, deg, n_valid); NB_CHECK(hipGetLastError()); }
   size_t need = 0;
   NB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, deg, nb.rowptr, na + 1, st));
   if (need > *scratch_bytes) {
     if (*scratch) NB_CHECK(hipFree(*scratch));
+    *scratch = nullptr; *scratch_bytes = 0;
     NB_CHECK(hipMalloc(scratch, need));
     *scratch_bytes = need;
   }
@@ -86,16 +95,17 @@ int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, c
   nb.n_half = (int64_t)nv;
   if (2 * nb.n_half > nb.cap) {
     if (nb.col) NB_CHECK(hipFree(nb.col));
+    nb.col = nullptr; nb.cap = 0;
+    NB_CHECK(hipMalloc(&nb.col, sizeof(int) * (2 * nb.n_half + 1024)));
     nb.cap = 2 * nb.n_half + 1024;
-    NB_CHECK(hipMalloc(&nb.col, sizeof(int) * nb.cap));
   }
   NB_CHECK(hipMemcpyAsync(deg, nb.rowptr, sizeof(int) * (na + 1), hipMemcpyDeviceToDevice, st));
   if (n_rows > 0) {
     k_nbr_fill<<<blocks, 256, 0, st>>>(n_rows, pairs_dev, top, deg, nb.col);
     k_nbr_sort<<<(na + 127) / 128, 128, 0, st>>>(na, nb.rowptr, nb.col);
+    NB_CHECK(hipGetLastError());
   }
   NB_CHECK(hipStreamSynchronize(st));
-  NB_CHECK(hipFree(deg));
   return 0;
 }
 

@@ -351,33 +351,49 @@ __global__ __launch_bounds__(256) void k_spread_planes(int na, const Site<T>* __
   }
 }
 
-// G table over the r2c half spectrum [K1][K2][K3/2+1].  Frequencies are assigned axis by axis
-// (k_d <- mesh axis d); the reference's meshgrid(kz, kx, ky) (recip.py:339-340) instead puts the
-// frequencies of mesh axes (1,0,2) into k-columns (0,1,2), which is the same thing whenever
-// K1 = K2 and |a| = |b| (orthorhombic) -- the only regime in which the reference is self-consistent.
+// G table over the r2c half spectrum [K1][K2][K3/2+1].  Default: frequencies are assigned axis by axis
+// (k_d <- mesh axis d).  ref_order != 0 reproduces the reference's table exactly (settings.REFERENCE_KPOINT_ORDER):
+// its meshgrid(kz, kx, ky) with 'xy' indexing (recip.py:339-340) has shape (K1, K3, K2), and row t of the flattened
+// table -- used for element t of the flattened (K1, K2, K3) spectrum (recip.py:410-426) -- is
+// (kz[j], kx[i], ky[k]) with t = (i K3 + j) K2 + k; theta_k takes the same integer triple column by column against
+// N = (K1, K2, K3) (recip.py:400-408).  For K1 = K2 = K3 this is "frequencies of mesh axes (1,0,2) in k-columns
+// (0,1,2)"; for unequal meshes it also scrambles (j,k).  The resulting factor is not symmetric under k -> -k, which
+// the half spectrum needs; since |S(-k)| = |S(k)| for a real mesh, the energy and all its derivatives only see the
+// symmetrised factor (G(t) + G(-t)) / 2, which is what is stored.
+__device__ inline double gfactor_at(int i0, int i1, int i2, int K0, int K1, int K2, const double* __restrict__ binv,
+                                    double volume, double kappa, int which, int ref_order) {
+  int m0, m1, m2;
+  if (ref_order) {
+    const long r = (long)i1 * K2 + i2;
+    const int j = (int)(r / K1), k = (int)(r % K1);
+    m0 = signed_freq(j, K2); m1 = signed_freq(i0, K0); m2 = signed_freq(k, K1);
+  } else {
+    m0 = signed_freq(i0, K0); m1 = signed_freq(i1, K1); m2 = signed_freq(i2, K2);
+  }
+  const double tp = 6.283185307179586;
+  const double kx = tp * (m0 * binv[0] + m1 * binv[3] + m2 * binv[6]);
+  const double ky = tp * (m0 * binv[1] + m1 * binv[4] + m2 * binv[7]);
+  const double kz = tp * (m0 * binv[2] + m1 * binv[5] + m2 * binv[8]);
+  const double ksq = kx * kx + ky * ky + kz * kz;
+  const double th = theta_k_1d(m0, K0) * theta_k_1d(m1, K1) * theta_k_1d(m2, K2);
+  if (which == 1)     // Ck_1 (recip.py:434-435), gamma point excluded (recip.py:413-415), x DIELECTRIC (:424)
+    return (i0 == 0 && i1 == 0 && i2 == 0) ? 0.0
+               : 2.0 * kDielectric * (tp / volume / ksq) * exp(-ksq / (4.0 * kappa * kappa)) / (th * th);
+  return 2.0 * disp_ck(which, ksq, kappa, volume) / (th * th);   // dispersion: gamma point included (recip.py:416-426)
+}
+
 template <class T>
 __global__ void k_gtab(int K0, int K1, int K2, int y0, int ny, const double* __restrict__ binv, double volume,
-                       double kappa, int which, T* __restrict__ gtab) {
+                       double kappa, int which, int ref_order, T* __restrict__ gtab) {
   const int nh = K2 / 2 + 1;
   const long n = (long)K0 * ny * nh;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
     const int i2 = (int)(t % nh);
     const int i1 = y0 + (int)((t / nh) % ny);
     const int i0 = (int)(t / ((long)nh * ny));
-    const int m0 = signed_freq(i0, K0), m1 = signed_freq(i1, K1), m2 = signed_freq(i2, K2);
-    const double tp = 6.283185307179586;
-    double kx = tp * (m0 * binv[0] + m1 * binv[3] + m2 * binv[6]);
-    double ky = tp * (m0 * binv[1] + m1 * binv[4] + m2 * binv[7]);
-    double kz = tp * (m0 * binv[2] + m1 * binv[5] + m2 * binv[8]);
-    double ksq = kx * kx + ky * ky + kz * kz;
-    double th = theta_k_1d(m0, K0) * theta_k_1d(m1, K1) * theta_k_1d(m2, K2);
-    double G;
-    if (which == 1) {   // Ck_1 (recip.py:434-435), gamma point excluded (recip.py:413-415), x DIELECTRIC (:424)
-      G = (i0 == 0 && i1 == 0 && i2 == 0) ? 0.0
-                   : 2.0 * kDielectric * (tp / volume / ksq) * exp(-ksq / (4.0 * kappa * kappa)) / (th * th);
-    } else {            // dispersion: gamma point included, no DIELECTRIC (recip.py:416-426)
-      G = 2.0 * disp_ck(which, ksq, kappa, volume) / (th * th);
-    }
+    double G = gfactor_at(i0, i1, i2, K0, K1, K2, binv, volume, kappa, which, ref_order);
+    if (ref_order)
+      G = 0.5 * (G + gfactor_at((K0 - i0) % K0, (K1 - i1) % K1, (K2 - i2) % K2, K0, K1, K2, binv, volume, kappa, which, 1));
     gtab[t] = (T)G;
   }
 }
@@ -565,11 +581,11 @@ size_t spread_scan_bytes(int ncell) {
 }
 template <class T>
 void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* box_inv, double volume, double kappa,
-                 int which, T* gtab) {
+                 int which, T* gtab, int ref_order) {
   const long n = (long)K[0] * ny * (K[2] / 2 + 1);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  k_gtab<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], y0, ny, box_inv, volume, kappa, which, gtab);
+  k_gtab<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], y0, ny, box_inv, volume, kappa, which, ref_order, gtab);
 }
 template <class T>
 void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec, double* energies, int slot) {
@@ -614,7 +630,7 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
 #define INST(T)                                                                                                       \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
                                 const int*, const int4*, int, int);                                                   \
-  template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*);            \
+  template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*, int);            \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \

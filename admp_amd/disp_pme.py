@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, settings
 from ._device import HipForceBase
 from .pme import setup_ewald_parameters
 
@@ -40,8 +40,11 @@ class ADMPDispPmeForce(HipForceBase):
     def refresh_calculators(self):
         _lib.check(self._h, self._L.admp_set_ewald(self._h, float(self.kappa), int(self.K1), int(self.K2), int(self.K3),
                                                    0, 0), 'admp_set_ewald')
+        _lib.check(self._h, self._L.admp_set_option(self._h, _lib.OPT_REFERENCE_KPOINTS,
+                                                    int(bool(settings.REFERENCE_KPOINT_ORDER))), 'admp_set_option')
         self.get_energy = self.generate_get_energy()
         self.get_forces = self._generate_get_forces()
+        self.get_energy._value_and_grad = self.get_forces          # value_and_grad(disp.get_energy) -> get_forces
 
     def _evaluate(self, positions, box, pairs, c_list, mScales, want_grad):
         with self._on_stream():

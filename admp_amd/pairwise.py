@@ -82,10 +82,27 @@ def generate_pairwise_interaction(pair_int_kernel, covalent_map, static_args):
 
 
 def value_and_grad(fn, argnums=0):
-    """Stand-in for jax.value_and_grad on the calculators of this package (positions only)."""
-    if argnums != 0:
-        raise NotImplementedError('only the gradient with respect to positions (argnums=0) is available')
+    """Stand-in for jax.value_and_grad on the calculators of this package: the reference obtains its force routines as
+    `value_and_grad(get_energy)` (admp/pme.py:108, admp/disp_pme.py:76, examples/water_1024/run_admp.py:101); here the
+    hand-coded adjoint that belongs to a calculator is looked up (positions only, argnums=0)."""
+    if argnums not in (0, (0,)):
+        raise NotImplementedError('only the gradient with respect to positions (argnums=0) is available through '
+                                  'value_and_grad; parameter gradients: admp_amd.api.param_gradient, get_box_gradient')
     if isinstance(fn, _PairInteraction):
         return fn.value_and_grad
+    vg = getattr(fn, '_value_and_grad', None)
+    if vg is not None:
+        return vg
     owner = getattr(fn, '__self__', None)
-    raise NotImplementedError('value_and_grad: use the get_forces attribute of %r' % (owner or fn))
+    raise NotImplementedError('value_and_grad: %r is not a calculator of this package' % (owner or fn))
+
+
+def grad(fn, argnums=0):
+    """Stand-in for jax.grad on the calculators of this package (admp/pme.py:77-78: grad(energy_fn, argnums=4 | 0))."""
+    table = getattr(fn, '_grads', None)
+    if table is None and getattr(fn, '__func__', None) is not None:
+        table = getattr(fn.__func__, '_grads', None)
+    if table is not None and argnums in table:
+        return table[argnums]
+    vg = value_and_grad(fn, argnums)
+    return lambda *a, **k: vg(*a, **k)[1]

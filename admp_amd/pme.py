@@ -92,10 +92,23 @@ class ADMPPmeForce(HipForceBase):
     def refresh_calculators(self):
         _lib.check(self._h, self._L.admp_set_ewald(self._h, float(self.kappa), int(self.K1), int(self.K2), int(self.K3),
                                                    int(self.lmax), 1 if self.lpol else 0), 'admp_set_ewald')
+        self._ref_korder = bool(settings.REFERENCE_KPOINT_ORDER)
+        _lib.check(self._h, self._L.admp_set_option(self._h, _lib.OPT_REFERENCE_KPOINTS, int(self._ref_korder)),
+                   'admp_set_option')
+        # the reference's attributes of the same names are closures over jitted JAX functions (admp/pme.py:102-105);
+        # here they expose the corresponding device computations
+        self.construct_local_frames = self._construct_local_frames if self.lmax > 0 else None
+        self.pme_recip = self._pme_recip
         self.get_energy = self.generate_get_energy()
         self.get_forces = self._generate_get_forces()
+        self.get_energy._value_and_grad = self.get_forces          # value_and_grad(pme_force.get_energy) -> get_forces
         if self.lpol:
             self.U_ind = np.zeros((self.n_atoms, 3))      # reset with the closures, admp/pme.py:79
+            def energy_fn(*a, **k):                       # plain function objects, like the reference's closures
+                return self._energy_fn(*a, **k)
+            energy_fn._grads = {0: self._grad_pos_fn, 4: self._grad_U_fn}
+            energy_fn.__doc__ = self._energy_fn.__doc__
+            self.energy_fn, self.grad_U_fn, self.grad_pos_fn = energy_fn, self._grad_U_fn, self._grad_pos_fn
 
     # ---- calculators ------------------------------------------------------------------------------------------
     def _pad_Q(self, Q_local):
@@ -128,10 +141,12 @@ class ADMPPmeForce(HipForceBase):
     def _evaluate_on_stream(self, positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales, U_init,
                             want_grad, want_dQ, maxiter, thresh):
         L, h, na = self._L, self._h, self.n_atoms
-        if self.K1 != self.K2 and not getattr(self, '_warned_k', False):
+        if (self.K1 != self.K2 or self.K2 != self.K3) and not self._ref_korder and not getattr(self, '_warned_k', False):
             self._warned_k = True
-            warnings.warn('K1 != K2: the reference swaps the x/y k-columns (admp/recip.py:339-340) and is not '
-                          'self-consistent here; this implementation uses the physically consistent assignment')
+            warnings.warn('unequal PME mesh dimensions: the reference assigns the k-points in the order of '
+                          'admp/recip.py:339-340, which is not self-consistent here; this implementation uses the '
+                          'physically consistent assignment (settings.REFERENCE_KPOINT_ORDER = True reproduces the '
+                          'reference\'s numbers)')
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
         Q = self._pad_Q(Q_local)
@@ -167,6 +182,77 @@ class ADMPPmeForce(HipForceBase):
         if want_dQ:
             out['dQ'] = dQ[:, :(self.lmax + 1) ** 2]
         return out
+
+    # ---- bare calculators with the dipoles as an explicit input (admp/pme.py:69-78) ---------------------------------
+    def _at_U(self, positions, box, pairs, Q_local, Uind_global, pol, tholes, mScales, pScales, dScales,
+              want_pos=False, want_U=False):
+        if not self.lpol:
+            raise RuntimeError('energy_fn / grad_U_fn / grad_pos_fn exist only for lpol=True (admp/pme.py:67-78)')
+        self._use_current_stream()
+        L, h, na = self._L, self._h, self.n_atoms
+        self.set_pairs(pairs)
+        pos = self._real(positions, (na, 3))
+        Q = self._pad_Q(Q_local)
+        U = self._real(Uind_global, (na, 3))
+        pol_t, th_t = self._real(pol, (na,)), self._real(tholes, (na,))
+        boxa, _ = self._harr('box', box, 9)
+        mSa, ns = self._harr('mS', mScales)
+        pS, _ = self._harr('pS', pScales, ns)
+        gpos = torch.empty((na, 3), dtype=self._dtype, device=self._device) if want_pos else None
+        gU = torch.empty((na, 3), dtype=self._dtype, device=self._device) if want_U else None
+        E = self._out_E
+        P = self._ptr
+        _lib.check(h, L.admp_pme_energy_fixed_dipoles(h, P(pos), boxa, P(Q), P(pol_t), P(th_t), ns, mSa, pS, P(U), E, P(gpos), P(gU),
+                                             None), 'admp_pme_energy_fixed_dipoles')
+        self.energy_parts = tuple(E)
+        return np.float64(E[0] + E[1] + E[2] + E[3]), gpos, gU
+
+    def _energy_fn(self, positions, box, pairs, Q_local, Uind_global, pol, tholes, mScales, pScales, dScales):
+        """E at the dipoles given (no SCF), admp/pme.py:69-75."""
+        return self._at_U(positions, box, pairs, Q_local, Uind_global, pol, tholes, mScales, pScales, dScales)[0]
+
+    def _grad_U_fn(self, positions, box, pairs, Q_local, Uind_global, pol, tholes, mScales, pScales, dScales):
+        """dE/dUind_global (Na,3) -- the "field" of the SCF loop: grad(energy_fn, argnums=4), admp/pme.py:77."""
+        r = self._at_U(positions, box, pairs, Q_local, Uind_global, pol, tholes, mScales, pScales, dScales, want_U=True)
+        return self._like(r[2], positions)
+
+    def _grad_pos_fn(self, positions, box, pairs, Q_local, Uind_global, pol, tholes, mScales, pScales, dScales):
+        """dE/dpositions (Na,3) at fixed dipoles: grad(energy_fn, argnums=0), admp/pme.py:78."""
+        r = self._at_U(positions, box, pairs, Q_local, Uind_global, pol, tholes, mScales, pScales, dScales, want_pos=True)
+        return self._like(r[1], positions)
+
+    def _construct_local_frames(self, positions, box):
+        """(Na,3,3) local frames, rows x, y, z (admp/spatial.py:76-142) -- a diagnostic: the hot path builds the frames
+        inside its first kernel and never materialises them."""
+        self._use_current_stream()
+        pos = self._real(positions, (self.n_atoms, 3))
+        out = torch.empty((self.n_atoms, 3, 3), dtype=self._dtype, device=self._device)
+        boxa, _ = self._harr('box', box, 9)
+        _lib.check(self._h, self._L.admp_local_frames(self._h, self._ptr(pos), boxa, self._ptr(out)), 'admp_local_frames')
+        return self._like(out, positions)
+
+    def _pme_recip(self, positions, box, Q):
+        """Reciprocal-space energy of GLOBAL multipoles Q (Na, (lmax+1)^2) (generate_pme_recip, admp/recip.py:21-431, with
+        gamma=False): evaluated by a sibling handle without local frames and with an empty pair list."""
+        b = getattr(self, '_bare', None)
+        if b is None:
+            b = self._bare = HipForceBase(self.n_atoms, None, None, None, self._dev_index)
+            b._key = None
+        key = (float(self.kappa), int(self.K1), int(self.K2), int(self.K3), int(self.lmax), self._ref_korder)
+        if b._key != key:
+            _lib.check(b._h, b._L.admp_set_ewald(b._h, key[0], key[1], key[2], key[3], key[4], 0), 'admp_set_ewald')
+            _lib.check(b._h, b._L.admp_set_option(b._h, _lib.OPT_REFERENCE_KPOINTS, int(key[5])), 'admp_set_option')
+            _lib.check(b._h, b._L.admp_set_pairs(b._h, 0, None, 1), 'admp_set_pairs')
+            b._key = key
+        b._use_current_stream()
+        pos = self._real(positions, (self.n_atoms, 3))
+        Qp = self._pad_Q(Q)
+        E = (ctypes.c_double * 4)()
+        one = (ctypes.c_double * 1)(1.0)
+        boxa, _ = self._harr('box', box, 9)
+        _lib.check(b._h, b._L.admp_pme_energy_grad(b._h, self._ptr(pos), boxa, self._ptr(Qp), None, None, 1, one, None, None,
+                                                   None, 1, 0.0, E, None, None, None, None, 1), 'admp_pme_energy_grad')
+        return np.float64(E[1])
 
     def generate_get_energy(self):
         if not self.lpol:

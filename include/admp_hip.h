@@ -61,6 +61,14 @@ int admp_set_topology(admp_handle* h, int n_atoms, const int32_t* axis_type, con
 /* replaces: the kappa / K1..K3 / lmax / lpol environment (admp/pme.py:42-50, update_env :89-94) */
 int admp_set_ewald(admp_handle* h, double kappa, int K1, int K2, int K3, int lmax, int lpol);
 
+/* behaviour switches that are not part of the reference's argument lists */
+enum {
+  ADMP_OPT_REFERENCE_KPOINTS = 1   /* value 1: build the reciprocal-space tables with the reference's literal k-point order
+                                      (meshgrid(kz, kx, ky), admp/recip.py:339-340) instead of the axis-by-axis one; the
+                                      two agree iff K1 = K2 = K3 on a cubic box.  Default 0. */
+};
+int admp_set_option(admp_handle* h, int option, int value);
+
 /* replaces: `pairs = pairs[pairs[:,0] < pairs[:,1]]` + the per-pair gathers of pme_real
  * (admp/pme.py:671-683).  pairs is (n_rows, 2) int32 [dev|host]; rows with i >= j (padding) are
  * dropped.  The list is compiled into an i-grouped neighbour table that stays valid until the
@@ -86,6 +94,19 @@ int admp_pme_energy_grad(admp_handle* h, const void* positions, const double* bo
                          const double* pScales, const double* dScales, void* U_inout, int max_cycle, double thresh,
                          double* E_out, void* dE_dpos, void* dE_dQlocal, int* n_cycle, int* converged,
                          int on_device);
+
+/* replaces: ADMPPmeForce.energy_fn / grad_U_fn / grad_pos_fn (admp/pme.py:69-78): the bare polarizable energy with the
+ * induced dipoles as an explicit input (no SCF), and its derivatives with respect to positions, dipoles and Q_local.
+ * All array arguments are DEVICE pointers; U (Na,3) global Cartesian; dE_dpos / dE_dU / dE_dQlocal may each be NULL.
+ * dE_dU is the "field" of optimize_Uind (admp/pme.py:133): real + reciprocal + self + polarization-penalty terms. */
+int admp_pme_energy_fixed_dipoles(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                         const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
+                         double* E_out, void* dE_dpos, void* dE_dU, void* dE_dQlocal);
+
+/* replaces: the `construct_local_frames(positions, box)` attribute (generate_construct_local_frames,
+ * admp/spatial.py:44-142): frames_out (Na,3,3) real, rows = local x, y, z axes in the global frame.  DEVICE pointers.
+ * Diagnostic only -- the hot path builds the frames inside its first kernel and never materialises them. */
+int admp_local_frames(admp_handle* h, const void* positions, const double* box, void* frames_out);
 
 /* replaces: ADMPDispPmeForce.get_energy / get_forces (admp/disp_pme.py:44-77, 80-279).
  *   c_list (Na,3) real: C6, C8, C10 per atom (columns above pmax ignored); E_out[3] = real, recip, self */

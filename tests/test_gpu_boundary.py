@@ -1,0 +1,194 @@
+"""Boundary rows of SURVEY.md section 8 that round 2 closed, checked on the GPU through the C ABI:
+the reference's literal k-point order (a18), the bare calculators energy_fn / grad_U_fn / grad_pos_fn and the
+construct_local_frames / pme_recip attributes (a1), the `admp` import name (b), the numpy pair-list cache."""
+import numpy as np
+import pytest
+
+from admp_amd import settings
+from admp_amd import systems as S
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+@pytest.fixture()
+def env():
+    old = (settings.PRECISION, settings.REFERENCE_KPOINT_ORDER)
+    settings.PRECISION = 'double'
+    yield
+    settings.PRECISION, settings.REFERENCE_KPOINT_ORDER = old
+
+
+def orthorhombic_water(n_mol=96, seed=3, scale=(1.0, 1.25, 1.6)):
+    """liquid box stretched to unequal edges (molecules kept rigid) so that the reference rule gives K1 != K2 != K3"""
+    pos, box = S.synthetic_water_box(n_mol, seed=seed)
+    mol = pos.reshape(n_mol, 3, 3)
+    com = mol.mean(axis=1, keepdims=True)
+    sc = np.asarray(scale)
+    pos2 = (com * sc + (mol - com)).reshape(-1, 3)
+    box2 = box * sc[None, :]
+    at, ai, cov = S.water_topology(n_mol)
+    return pos2, box2, at, ai, cov
+
+
+@pytest.mark.parametrize('lpol', [False, True])
+def test_reference_kpoint_order_vs_oracle_quirk(env, lpol):
+    """a18: with settings.REFERENCE_KPOINT_ORDER the HIP tables reproduce the reference's meshgrid(kz, kx, ky) order
+    (admp/recip.py:339-340) on a box where it matters (K1 != K2 != K3); the oracle runs UNMODIFIED (quirk=True default)."""
+    import warnings
+    from admp_amd.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    pos, box, at, ai, cov = orthorhombic_water()
+    par = S.water_parameters(len(pos) // 3, polarizable=lpol)
+    pairs = S.build_pairs(pos, box, 4.0)
+    settings.REFERENCE_KPOINT_ORDER = True
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+    assert len({f.K1, f.K2, f.K3}) == 3
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, lpol)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')            # the "not self-consistent" warning must stay silent in this mode
+        if lpol:
+            E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
+                                par['dScales'])
+            ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], par['pol'], par['tholes'],
+                                        par['pScales'])
+            assert f.n_cycle == ref['n_cycle'] and rel(f.U_ind, ref['U_ind']) < 1e-8
+        else:
+            E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['mScales'])
+            ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'])
+    scale = max(abs(p) for p in ref['parts'])
+    for got, want in zip(f.energy_parts, ref['parts']):
+        assert abs(got - want) <= 1e-9 * scale
+    assert rel(G, ref['grad']) < 1e-8
+    # and the default (consistent) assignment is a DIFFERENT number here -- the switch is not a no-op
+    settings.REFERENCE_KPOINT_ORDER = False
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        f2 = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+        if lpol:
+            f2.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
+                          par['dScales'])
+        else:
+            f2.get_forces(pos, box, pairs, par['Q_local'], par['mScales'])
+    assert abs(f2.energy_parts[1] - ref['parts'][1]) > 1e-6 * scale
+
+
+def test_reference_kpoint_order_dispersion(env):
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from oracle import admp_oracle as O
+    pos, box, at, ai, cov = orthorhombic_water()
+    par = S.water_parameters(len(pos) // 3)
+    pairs = S.build_pairs(pos, box, 4.0)
+    settings.REFERENCE_KPOINT_ORDER = True
+    d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+    E, G = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+    ref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d.kappa, (d.K1, d.K2, d.K3), 10)
+    np.testing.assert_allclose(d.energy_parts, ref['parts'], rtol=1e-9)
+    assert rel(G, ref['grad']) < 1e-8
+
+
+def test_bare_calculators_at_given_dipoles(env):
+    """energy_fn / grad_U_fn / grad_pos_fn (admp/pme.py:69-78) at dipoles that are NOT the SCF solution, against autograd
+    of the oracle's energy_pme with respect to Uind_global and positions."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.pairwise import grad
+    from oracle import admp_oracle as O
+    n_mol = 64
+    pos, box = S.synthetic_water_box(n_mol, seed=21)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, True)
+    pairs = S.build_pairs(pos, box, 4.0)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    rng = np.random.default_rng(0)
+    U = rng.normal(size=(3 * n_mol, 3)) * 0.05 * (par['pol'] > 0)[:, None]
+    args = (pos, box, pairs, par['Q_local'], U, par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    E = f.energy_fn(*args)
+    gU = f.grad_U_fn(*args)
+    gp = f.grad_pos_fn(*args)
+    assert grad(f.energy_fn, argnums=4) == f.grad_U_fn and grad(f.energy_fn, argnums=0) == f.grad_pos_fn
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, True)
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+    p, Ut = T(pos).requires_grad_(True), T(U).requires_grad_(True)
+    e = O.energy_pme(sysm, p, T(box), pairs, T(par['Q_local']), Ut, T(par['pol']), T(par['tholes']), T(par['mScales']),
+                     T(par['pScales']))
+    rp, rU = torch.autograd.grad(e, [p, Ut])
+    assert abs(E - float(e.detach())) < 1e-9 * max(abs(x) for x in f.energy_parts)
+    assert rel(gp, rp.numpy()) < 1e-8
+    site = par['pol'] > 0
+    assert rel(gU[site], rU.numpy()[site]) < 1e-8
+    # the SCF loop written by hand with the bare calculators (admp/pme.py:130-138) lands on optimize_Uind's result
+    Uc = np.zeros_like(U)
+    for i in range(30):
+        fld = f.grad_U_fn(pos, box, pairs, par['Q_local'], Uc, *args[5:])
+        if np.abs(fld[site]).max() < settings.POL_CONV:
+            break
+        Uc = Uc - fld * par['pol'][:, None] / 1389.35455846
+    U2, flag, n = f.optimize_Uind(pos, box, pairs, par['Q_local'], *args[5:])
+    assert n == i and rel(Uc, U2) < 1e-10
+
+
+def test_local_frames_and_pme_recip_attributes(env):
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    n_mol = 27
+    pos, box = S.synthetic_water_box(n_mol, seed=4)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, False)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    fr = f.construct_local_frames(pos, box)
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+    ref = O.construct_local_frames(T(pos), T(box), at, ai)
+    assert fr.shape == (3 * n_mol, 3, 3) and rel(fr, ref.numpy()) < 1e-12
+    Qg = O.rot_local2global(T(par['Q_local']), ref, 2)
+    e = f.pme_recip(pos, box, Qg.numpy())
+    want = float(O.pme_recip(T(pos), T(box), Qg, f.kappa, (f.K1, f.K2, f.K3), 2))
+    assert abs(e - want) < 1e-9 * abs(want)
+
+
+def test_admp_import_name_and_value_and_grad(env):
+    """b: the reference's import lines resolve to the HIP calculators; value_and_grad(get_energy) is get_forces."""
+    import admp.settings
+    from admp.multipole import convert_cart2harm       # noqa: F401
+    from admp.pme import ADMPPmeForce
+    from admp.disp_pme import ADMPDispPmeForce
+    from admp.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad      # noqa: F401
+    import admp_amd.pme
+    assert ADMPPmeForce is admp_amd.pme.ADMPPmeForce and admp.settings is settings
+    n_mol = 27
+    pos, box = S.synthetic_water_box(n_mol, seed=4)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, False)
+    pairs = S.build_pairs(pos, box, 4.0)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    E, G = value_and_grad(f.get_energy)(pos, box, pairs, par['Q_local'], par['mScales'])
+    E2, G2 = f.get_forces(pos, box, pairs, par['Q_local'], par['mScales'])
+    assert abs(E - E2) < 1e-9 * abs(E) and rel(G, G2) < 1e-10      # mesh sums go through atomics: round-off only
+    d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+    Ed, Gd = value_and_grad(d.get_energy)(pos, box, pairs, par['c_list'], par['mScales'])
+    assert abs(Ed - d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])[0]) < 1e-9 * abs(Ed)
+
+
+def test_numpy_pair_list_refilled_in_place(env):
+    """a caller who rewrites the same ndarray must get a fresh neighbour table (the whole array is hashed)."""
+    from admp_amd.pme import ADMPPmeForce
+    n_mol = 64
+    pos, box = S.synthetic_water_box(n_mol, seed=8)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, False)
+    full = S.build_pairs(pos, box, 4.0)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    E_full = f.get_energy(pos, box, full, par['Q_local'], par['mScales'])
+    buf = full.copy()
+    assert abs(f.get_energy(pos, box, buf, par['Q_local'], par['mScales']) - E_full) < 1e-9 * abs(E_full)
+    keep = len(full) - 500
+    buf[keep:] = 0                                  # rows with i >= j are padding (admp/pme.py:671): 500 pairs dropped
+    E_cut = f.get_energy(pos, box, buf, par['Q_local'], par['mScales'])
+    assert f.n_pairs == keep and abs(E_cut - E_full) > 1e-6 * abs(E_full)
+    buf[5000 if len(full) > 6000 else 10] = buf[5000 if len(full) > 6000 else 10][::-1]   # a single interior row swapped (i > j: dropped)
+    f.get_energy(pos, box, buf, par['Q_local'], par['mScales'])
+    assert f.n_pairs == keep - 1

@@ -720,16 +720,27 @@ def _mixed_axis_system(seed=2):
     return pos, np.eye(3) * L, at, ai, cov, Q, pol, thole
 
 
+@pytest.fixture()
+def korder():
+    old = settings.REFERENCE_KPOINT_ORDER
+    yield
+    settings.REFERENCE_KPOINT_ORDER = old
+
+
 @pytest.mark.parametrize('lpol', [False, True])
-@pytest.mark.parametrize('tric', [False, True])
-def test_all_axis_rules_and_triclinic_cell(precision, lpol, tric):
+@pytest.mark.parametrize('tric', [False, 'reference', 'consistent'])
+def test_all_axis_rules_and_triclinic_cell(precision, korder, lpol, tric):
     """Every local-axis rule, general scale tables, dense covalent map; orthorhombic and triclinic cells.
-    For the triclinic cell the oracle is evaluated with the consistent k-vector assignment."""
+    Triclinic cell, 'reference': settings.REFERENCE_KPOINT_ORDER = True against the UNMODIFIED oracle (the reference's
+    meshgrid(kz, kx, ky) order, admp/recip.py:339-340).  'consistent': the product's default assignment against the
+    oracle's quirk=False variant -- a check of the non-reference default, not a parity claim."""
     import torch
     from admp_amd.pme import ADMPPmeForce
     from oracle import admp_oracle as O
     settings.PRECISION = 'double'
+    settings.REFERENCE_KPOINT_ORDER = (tric == 'reference')
     pos, box, at, ai, cov, Q, pol, thole = _mixed_axis_system()
+    quirk = tric != 'consistent'
     if tric:
         box = np.array([[14.0, 0, 0], [1.5, 14.0, 0], [-1.0, 0.8, 14.0]])
     pairs = np.array([(i, j) for i in range(len(pos)) for j in range(i + 1, len(pos))], dtype=np.int32)
@@ -752,17 +763,17 @@ def test_all_axis_rules_and_triclinic_cell(precision, lpol, tric):
         U = T(np.zeros_like(pos))
         for i in range(30):
             Ug = U.clone().requires_grad_(True)
-            e = _oracle_energy(O, sysm, T(pos), T(box), pairs, T(Q), Ug, T(pol), T(thole), T(mS), T(pS), quirk=not tric)
+            e = _oracle_energy(O, sysm, T(pos), T(box), pairs, T(Q), Ug, T(pol), T(thole), T(mS), T(pS), quirk=quirk)
             fld, = torch.autograd.grad(e, Ug)
             if float(fld[T(pol) > 0.001].abs().max()) < 10.0:
                 break
             U = U - fld * T(pol)[:, None] / O.DIELECTRIC
         assert f.n_cycle == i
-        e = _oracle_energy(O, sysm, p, T(box), pairs, T(Q), U, T(pol), T(thole), T(mS), T(pS), quirk=not tric)
+        e = _oracle_energy(O, sysm, p, T(box), pairs, T(Q), U, T(pol), T(thole), T(mS), T(pS), quirk=quirk)
         assert rel(f.U_ind, U.numpy()) < 1e-8
     else:
         E, G = f.get_forces(pos, box, pairs, Q, mS)
-        e = _oracle_energy(O, sysm, p, T(box), pairs, T(Q), None, None, None, T(mS), None, quirk=not tric)
+        e = _oracle_energy(O, sysm, p, T(box), pairs, T(Q), None, None, None, T(mS), None, quirk=quirk)
     g, = torch.autograd.grad(e, p)
     scale = max(abs(x) for x in f.energy_parts)
     assert abs(E - float(e.detach())) < 1e-9 * scale

@@ -134,3 +134,16 @@ def test_fft_friendly_mesh_is_opt_in():
         assert setup_ewald_parameters(4.0, 1e-4, box)[1:] == (98, 98, 98)
     finally:
         settings.FFT_FRIENDLY_MESH = False
+
+
+def test_admp_alias_package_resolves_to_admp_amd():
+    """`from admp.pme import ADMPPmeForce` (the reference's import lines) works and is the same module object."""
+    import admp.settings
+    import admp_amd.settings
+    from admp.pme import ADMPPmeForce, setup_ewald_parameters      # noqa: F401
+    from admp.disp_pme import ADMPDispPmeForce                      # noqa: F401
+    from admp.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel      # noqa: F401
+    from admp.multipole import convert_cart2harm                    # noqa: F401
+    import admp_amd.pme
+    assert admp.settings is admp_amd.settings and admp.pme is admp_amd.pme
+    assert hasattr(admp.settings, 'REFERENCE_KPOINT_ORDER') and admp.settings.REFERENCE_KPOINT_ORDER is False
