@@ -32,6 +32,9 @@ PROTOTYPES = {
     'admp_pme_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _dp, _vp, _i32, _dbl, _dp, _vp, _vp,
                                     _ip, _ip, _i32]),
     'admp_pme_energy_fixed_dipoles': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _dp, _vp, _vp, _vp]),
+    'admp_pme_box_grad': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _dp, _dp]),
+    'admp_disp_box_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _i32, _dp, _dp, _dp]),
+    'admp_tt_box_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _dp, _dp]),
     'admp_local_frames': (_i32, [_vp, _vp, _dp, _vp]),
     'admp_set_option': (_i32, [_vp, _i32, _i32]),
     'admp_disp_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _i32, _dp, _dp, _vp, _i32]),

@@ -322,6 +322,46 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const 
   }
 }
 
+// Box gradient, local-frame part: the frame vectors site -> axis atom go through the same minimum image as the pairs
+// (admp/spatial.py:88-101), so a molecule that straddles the cell boundary contributes shift (x) dE/d(vector).
+// pot = dE/dQ_global of pair + reciprocal space (the self term is added here, as in the closing kernel).
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_frame_virial(Topology top, const T* __restrict__ pos, Box<T> box,
+                                                             const Site<T>* __restrict__ sites, int lpol, T kappa,
+                                                             const T* __restrict__ pot, double* vir) {
+  const int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < top.na) {
+    int type, iz, ix, iy;
+    FrameWork<T> w;
+    frame_of(top, pos, box, i, type, iz, ix, iy, w);
+    if (type != NoAxisType) {
+      T f[3], P[9], tau[3], gp[3], gz[3], gx[3], gy[3], p[3];
+      self_factors(kappa, f);
+      total_potential(sites[i], pot + 9 * (size_t)i, lpol, f, P, nullptr);
+      multipole_torque(P, sites[i].Q, tau);
+      local_frame_bwd(type, w, tau, gp, gz, gx, gy);
+      load3(pos, i, p);
+      const int member[3] = {iz, type != Zonly ? ix : -1, (type == ZBisect || type == ThreeFold) ? iy : -1};
+      const T* gk[3] = {gz, gx, gy};
+      for (int m = 0; m < 3; ++m) {
+        if (member[m] < 0) continue;
+        T q[3], sh[3];
+        load3(pos, member[m], q);
+        const T d[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
+        if (!image_shift(box, d, sh)) continue;
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) acc[3 * a + b] += (double)sh[a] * (double)gk[m][b];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double v = block_reduce_sum<kAtomBlock>(acc[k]);
+    if (threadIdx.x == 0 && v != 0.0) atomicAdd(&vir[k], v);
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_scalar_sites(int na, const T* __restrict__ pos, const T* __restrict__ vals,
                                                              int stride, int chan, SelfCoefs self_coefs,
@@ -404,6 +444,16 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
     k_finish<T><<<nblk(nlist), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
                                                     energies, list, nlist);
 }
+
+template <class T>
+void launch_frame_virial(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
+                         int lpol, T kappa, const T* pot, double* vir) {
+  k_frame_virial<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, lpol, kappa, pot, vir);
+}
+template void launch_frame_virial<float>(hipStream_t, const Topology&, const float*, const Box<float>&, const Site<float>*,
+                                         int, float, const float*, double*);
+template void launch_frame_virial<double>(hipStream_t, const Topology&, const double*, const Box<double>&,
+                                          const Site<double>*, int, double, const double*, double*);
 
 template <class T>
 void launch_scalar_sites(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, double self_coef,

@@ -99,4 +99,16 @@ ADMP_HD double disp_ck(int which, double ksq, double kappa, double V) {
   }
 }
 
+// d Ck_p / d(k^2) (box gradient: the k vectors move with the box).  With y = k^2 / 4 kappa^2:
+// f6' = 3 sqrt(pi) x erfc(x) - 3 e^-y,  f8' = 5 [(2y - 1) e^-y - 2 sqrt(pi) y^(3/2) erfc(x)],
+// f10' = 7 [(-4 y^2 + 2y - 3) e^-y + 4 sqrt(pi) y^(5/2) erfc(x)];  dC/dk^2 = C0 f'(y) / (4 kappa^2).
+ADMP_HD double disp_ck_dksq(int which, double ksq, double kappa, double V) {
+  const double sqrt_pi = 1.7724538509055159, pi = 3.141592653589793;
+  const double y = ksq / 4.0 / (kappa * kappa), x = sqrt(y), ex = exp(-y), ec = erfc(x);
+  const double k3 = kappa * kappa * kappa, pre = sqrt_pi * pi / 2 / V / (4.0 * kappa * kappa);
+  if (which == 6) return pre * k3 * (3 * sqrt_pi * x * ec - 3 * ex) / 3;
+  if (which == 8) return pre * k3 * kappa * kappa * 5 * ((2 * y - 1) * ex - 2 * sqrt_pi * y * x * ec) / 45;
+  return pre * k3 * k3 * kappa * 7 * ((-4 * y * y + 2 * y - 3) * ex + 4 * sqrt_pi * y * y * x * ec) / 1260;
+}
+
 }  // namespace admp

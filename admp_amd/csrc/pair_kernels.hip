@@ -258,6 +258,103 @@ void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, co
   else k_pair_mgrad<T, 2><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16);
 }
 
+// ---- box gradient, real-space part (jax.grad(get_energy, argnums=1) in the reference) -----------------------
+// vir[3c+b] += 1/2 sum over the directed table entries of shift_c (dE_pair/d r_I)_b, shift = the lattice translation of the
+// pair's minimum image (image_shift).  Pairs inside the cell are skipped before any arithmetic, so the pass costs the
+// boundary-crossing fraction of a pair kernel (2.7 % of the pairs at 1M atoms, 19 % at 3072).  On request only.
+template <int BLOCK>
+__device__ __forceinline__ void block_add9(double acc[9], double scale, double* out) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double v = block_reduce_sum<BLOCK>(acc[k]);
+    if (threadIdx.x == 0 && v != 0.0) atomicAdd(&out[k], scale * v);
+  }
+}
+
+template <class T, bool LPOL>
+__global__ __launch_bounds__(kPairBlock) void k_pair_virial(int na, const int* __restrict__ rowptr,
+                                                            const int* __restrict__ col, const Site<T>* __restrict__ sites,
+                                                            Box<T> box, ScaleTab<T> tab, T kappa, double* vir) {
+  __shared__ T s_tab[48];
+  stage_tab(tab, s_tab);
+  constexpr int LPR = 8;
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < na) {
+    const Site<T> I = sites[row];
+    const int end = rowptr[row + 1];
+#pragma unroll 1
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = (c >> 28) & 15;
+      const Site<T> J = sites[c & kColMask];
+      const T d[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+      T sh[3];
+      if (!image_shift(box, d, sh)) continue;
+      const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
+      T g[3] = {0, 0, 0}, P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      (void)pair_energy_grad<T, LPOL, false>(box, I, J, sc, kappa, g, P, nullptr, nullptr, nullptr);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[3 * a + b] += (double)sh[a] * (double)g[b];
+    }
+  }
+  block_add9<kPairBlock>(acc, 0.5, vir);
+}
+
+template <class T, bool TT>
+__global__ __launch_bounds__(kPairBlock) void k_pair_scalar_virial(int na, const int* __restrict__ rowptr,
+                                                                   const int* __restrict__ col, const T* __restrict__ pos,
+                                                                   const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
+                                                                   T kappa, int pmax, double* vir) {
+  __shared__ T s_tab[48];
+  stage_tab(tab, s_tab);
+  constexpr int LPR = 8, NP = TT ? 4 : 3;
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < na) {
+    T ri[3] = {pos[3 * row], pos[3 * row + 1], pos[3 * row + 2]}, pi[4] = {0, 0, 0, 0};
+    for (int k = 0; k < NP; ++k) pi[k] = par[NP * row + k];
+    const int end = rowptr[row + 1];
+#pragma unroll 1
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = (c >> 28) & 15, j = c & kColMask;
+      T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]}, pj[4] = {0, 0, 0, 0};
+      const T d[3] = {ri[0] - rj[0], ri[1] - rj[1], ri[2] - rj[2]};
+      T sh[3];
+      if (!image_shift(box, d, sh)) continue;
+      for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
+      T g[3] = {0, 0, 0};
+      if (TT) (void)tt_pair(box, ri, rj, pi, pj, s_tab[nb] + T(1), g);
+      else (void)disp_pair(box, ri, rj, pi, pj, s_tab[nb], kappa, pmax, g);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[3 * a + b] += (double)sh[a] * (double)g[b];
+    }
+  }
+  block_add9<kPairBlock>(acc, 0.5, vir);
+}
+
+template <class T>
+void launch_pair_virial(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                        const ScaleTab<T>& tab, T kappa, int lpol, double* vir) {
+  const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
+  if (lpol) k_pair_virial<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, vir);
+  else k_pair_virial<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, vir);
+}
+template <class T>
+void launch_scalar_pair_virial(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par,
+                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir) {
+  const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
+  if (tt) k_pair_scalar_virial<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir);
+  else k_pair_scalar_virial<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir);
+}
+
 // lanes of a wavefront that share one row.  Few lanes = fewer idle lanes at the row tail and less shuffle
 // folding; many lanes = enough wavefronts to fill the chip when there are few rows.  Measured (f32, polarizable):
 // 1M rows LPR 1/2/4/8 -> 0.749/0.493/0.502/0.534 ms; 98k rows 2/4/8 -> 0.068/0.064/0.065 ms; 3k rows 4/8/16/32 ->
@@ -363,7 +460,11 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
   template void launch_mscale_sums<T>(hipStream_t, int, int, const NbrTable&, const Site<T>*, const T*, const T*,   \
                                       const Box<T>&, int, double*);                                                 \
   template void launch_thole_sums<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
-                                     const ScaleTab<T>&, T*, T*);
+                                     const ScaleTab<T>&, T*, T*);                                                   \
+  template void launch_pair_virial<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,             \
+                                      const ScaleTab<T>&, T, int, double*);                                         \
+  template void launch_scalar_pair_virial<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,            \
+                                             const Box<T>&, const ScaleTab<T>&, T, int, double*);
 INST(float)
 INST(double)
 #undef INST

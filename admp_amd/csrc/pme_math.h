@@ -139,6 +139,21 @@ ADMP_HD void min_image(const Box<T>& b, T d[3]) {
   d[2] = s0 * b.h[2] + s1 * b.h[5] + s2 * b.h[8];
 }
 
+// The lattice translation min_image removes from d: sh = n . box with n = floor(d . box^-1 + 1/2) (integers).  Returns
+// false when n = 0.  Box gradient (jax.grad of the reference with respect to `box`, positions fixed): pbc_shift's floor
+// has zero derivative and dr.box^-1.box = dr, so d(shifted dr)/d(box[a][b]) = -n_a e_b -- only pairs (and local-frame
+// vectors) that cross the cell boundary contribute, with -n (x) dE/d(dr).
+template <class T>
+ADMP_HD bool image_shift(const Box<T>& b, const T d[3], T sh[3]) {
+  const T n0 = m_floor(d[0] * b.hinv[0] + d[1] * b.hinv[3] + d[2] * b.hinv[6] + T(0.5));
+  const T n1 = m_floor(d[0] * b.hinv[1] + d[1] * b.hinv[4] + d[2] * b.hinv[7] + T(0.5));
+  const T n2 = m_floor(d[0] * b.hinv[2] + d[1] * b.hinv[5] + d[2] * b.hinv[8] + T(0.5));
+  sh[0] = n0 * b.h[0] + n1 * b.h[3] + n2 * b.h[6];
+  sh[1] = n0 * b.h[1] + n1 * b.h[4] + n2 * b.h[7];
+  sh[2] = n0 * b.h[2] + n1 * b.h[5] + n2 * b.h[8];
+  return n0 != T(0) || n1 != T(0) || n2 != T(0);
+}
+
 // Pair frame with z || dr (admp/spatial.py:149-178).  The reference picks the helper axis
 // e_x unless the raw y and z coordinates coincide (spatial.py:172); the pair energy does not
 // depend on that choice (it is invariant under rotation about z), so the helper is chosen

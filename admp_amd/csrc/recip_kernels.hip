@@ -398,6 +398,89 @@ __global__ void k_gtab(int K0, int K1, int K2, int y0, int ny, const double* __r
   }
 }
 
+// ---- box gradient, k-space part -----------------------------------------------------------------------------------------
+// dG/d(k^2) and the k vector of one spectrum point (same index conventions as gfactor_at)
+__device__ inline double gprime_at(int i0, int i1, int i2, int K0, int K1, int K2, const double* __restrict__ binv,
+                                   double volume, double kappa, int which, int ref_order, double kv[3]) {
+  int m0, m1, m2;
+  if (ref_order) {
+    const long r = (long)i1 * K2 + i2;
+    const int j = (int)(r / K1), k = (int)(r % K1);
+    m0 = signed_freq(j, K2); m1 = signed_freq(i0, K0); m2 = signed_freq(k, K1);
+  } else {
+    m0 = signed_freq(i0, K0); m1 = signed_freq(i1, K1); m2 = signed_freq(i2, K2);
+  }
+  const double tp = 6.283185307179586;
+  kv[0] = tp * (m0 * binv[0] + m1 * binv[3] + m2 * binv[6]);
+  kv[1] = tp * (m0 * binv[1] + m1 * binv[4] + m2 * binv[7]);
+  kv[2] = tp * (m0 * binv[2] + m1 * binv[5] + m2 * binv[8]);
+  const double ksq = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2];
+  const double th = theta_k_1d(m0, K0) * theta_k_1d(m1, K1) * theta_k_1d(m2, K2);
+  if (which == 1) {   // G = 2 D (2 pi / V k^2) exp(-k^2 / 4 kappa^2) / theta^2 ; dG/dk^2 = -G (1/k^2 + 1/(4 kappa^2))
+    if (ksq == 0.0 || (i0 == 0 && i1 == 0 && i2 == 0)) return 0.0;
+    const double G = 2.0 * kDielectric * (tp / volume / ksq) * exp(-ksq / (4.0 * kappa * kappa)) / (th * th);
+    return -G * (1.0 / ksq + 1.0 / (4.0 * kappa * kappa));
+  }
+  return 2.0 * disp_ck_dksq(which, ksq, kappa, volume) / (th * th);
+}
+
+// tk[0..5] += sum over the half spectrum of w dG/dk^2 |S|^2 k_a k_b, (a,b) = xx, yy, zz, xy, xz, yz -- run on the
+// spectrum BEFORE k_kspace multiplies it by G.  With E = sum w G(k^2) |S|^2 and k = 2 pi m . box^-1 this is the part of
+// dE/dbox that comes from the k vectors: -2 tk . box^-T (assembled on the host, engine.hip).
+template <class T>
+__global__ __launch_bounds__(256) void k_kspace_virial(int K0, int K1, int K2, const double* __restrict__ binv,
+                                                       double volume, double kappa, int which, int ref_order,
+                                                       const T* __restrict__ spec, double* tk) {
+  const int nh = K2 / 2 + 1;
+  const long n = (long)K0 * K1 * nh;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
+    const int i2 = (int)(t % nh);
+    const int i1 = (int)((t / nh) % K1);
+    const int i0 = (int)(t / ((long)nh * K1));
+    const double re = (double)spec[2 * t], im = (double)spec[2 * t + 1];
+    const double w = ((i2 == 0 || ((K2 & 1) == 0 && i2 == K2 / 2)) ? 0.5 : 1.0) * (re * re + im * im);
+    double kv[3];
+    double gp = gprime_at(i0, i1, i2, K0, K1, K2, binv, volume, kappa, which, ref_order, kv);
+    double f = ref_order ? 0.5 * w * gp : w * gp;
+    acc[0] += f * kv[0] * kv[0]; acc[1] += f * kv[1] * kv[1]; acc[2] += f * kv[2] * kv[2];
+    acc[3] += f * kv[0] * kv[1]; acc[4] += f * kv[0] * kv[2]; acc[5] += f * kv[1] * kv[2];
+    if (ref_order) {   // the stored factor is the average over t and its mirror point (k_gtab)
+      gp = gprime_at((K0 - i0) % K0, (K1 - i1) % K1, (K2 - i2) % K2, K0, K1, K2, binv, volume, kappa, which, 1, kv);
+      f = 0.5 * w * gp;
+      acc[0] += f * kv[0] * kv[0]; acc[1] += f * kv[1] * kv[1]; acc[2] += f * kv[2] * kv[2];
+      acc[3] += f * kv[0] * kv[1]; acc[4] += f * kv[0] * kv[2]; acc[5] += f * kv[1] * kv[2];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double v = block_reduce_sum<256>(acc[k]);
+    if (threadIdx.x == 0) atomicAdd(&tk[k], v);
+  }
+}
+
+// Box gradient, mesh part: one thread per atom re-gathers its 20 F sums from phi and accumulates recip_box_terms
+// (spline_math.h): xw[9] and y[9].  On request only -- the plain loop over the 216 stencil points is good enough.
+template <class T>
+__global__ __launch_bounds__(128) void k_gather_virial(int na, const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
+                                                       const T* __restrict__ phi, double* xw, double* yy) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  double ax[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ay[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < na) {
+    T r[3], Q[9], F[NF];
+    site_qtot(sites[i], lpol, r, Q);
+    gather_atom(g, r, [&](long idx) { return phi[idx]; }, F);
+    recip_box_terms(g, r, Q, F, ax, ay);
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double v = block_reduce_sum<128>(ax[k]);
+    if (threadIdx.x == 0 && v != 0.0) atomicAdd(&xw[k], v);
+    const double u = block_reduce_sum<128>(ay[k]);
+    if (threadIdx.x == 0 && u != 0.0) atomicAdd(&yy[k], u);
+  }
+}
+
 // spec <- G * spec, E += sum over the FULL spectrum of (G/2)|S|^2 (interior half-spectrum planes count twice)
 template <class T>
 __global__ __launch_bounds__(256) void k_kspace(int K0, int ny, int K2, const T* __restrict__ gtab,
@@ -597,6 +680,21 @@ void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spe
   k_kspace<T><<<blocks, 256, 0, st>>>(K[0], ny, K[2], gtab, spec, energies, slot);
 }
 
+template <class T>
+void launch_kspace_virial(hipStream_t st, const int K[3], const double* box_inv, double volume, double kappa, int which,
+                          int ref_order, const T* spec, double* tk) {
+  const long n = (long)K[0] * K[1] * (K[2] / 2 + 1);
+  int blocks = (int)((n + 2047) / 2048);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  k_kspace_virial<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], box_inv, volume, kappa, which, ref_order, spec, tk);
+}
+template <class T>
+void launch_gather_virial(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi,
+                          double* xw, double* yy) {
+  k_gather_virial<T><<<(na + 127) / 128, 128, 0, st>>>(na, sites, lpol, g, phi, xw, yy);
+}
+
 // home list of a slab rank: atoms whose local base plane index is below the slab width
 template <class T>
 __global__ __launch_bounds__(256) void k_home_list(int na, const Site<T>* __restrict__ sites, RecipGeom<T> g, int width,
@@ -636,7 +734,11 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
                                  const int*, T*, const FieldFin<T>&);                                                   \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
-                                       const int*, int);
+                                       const int*, int);                                                              \
+  template void launch_kspace_virial<T>(hipStream_t, const int*, const double*, double, double, int, int, const T*,   \
+                                        double*);                                                                     \
+  template void launch_gather_virial<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, double*, \
+                                        double*);
 INST(float)
 INST(double)
 #undef INST

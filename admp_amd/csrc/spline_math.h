@@ -142,6 +142,34 @@ ADMP_HD void unfold_potential(const RecipGeom<T>& g, const T Q[9], const T* F, T
   for (int i = 0; i < 3; ++i) grad[i] += g.Jac[3 * i + 0] * fu[0] + g.Jac[3 * i + 1] * fu[1] + g.Jac[3 * i + 2] * fu[2];
 }
 
+// Box-gradient terms of one site from its F sums (reciprocal space, positions fixed).  The mesh energy depends on the box
+// (a) through the fractional coordinates u_j = -K_j (x . box^-1)_j: d/d(box^-1[c][j]) = x_c (-K_j) dE/du_j, which in terms
+//     of the Cartesian reciprocal gradient g = Jac . dE/du is the outer product x (x) g           -> xw[3c+b] += x_c g_b
+// (b) through the multipole operators Aop (fold_multipole): E = sum_j c1_j F1_j + sum_mn (Aop^T Th Aop)_mn F2_mn with
+//     c1 = d . Aop, Th = Theta/3                                    -> y[3i+j] += d_i F1_j + 2 (Th Aop F2)_ij = dE/dAop_ij
+// (the k vectors and the volume are handled in k space).  The host turns the sums into dE/dbox (engine.hip).
+template <class T>
+ADMP_HD void recip_box_terms(const RecipGeom<T>& g, const T r[3], const T Q[9], const T* F, double xw[9], double y[9]) {
+  const T* A = g.Aop;
+  T pot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gr[3] = {0, 0, 0};
+  unfold_potential(g, Q, F, pot, gr);
+  for (int c = 0; c < 3; ++c)
+    for (int b = 0; b < 3; ++b) xw[3 * c + b] += (double)r[c] * (double)gr[b];
+  const T F1[3] = {F[F100], F[F010], F[F001]};
+  const T F2[9] = {F[F200], F[F110], F[F101], F[F110], F[F020], F[F011], F[F101], F[F011], F[F002]};
+  const T d[3] = {Q[2], Q[3], Q[1]};                       // harmonic (z, x, y) -> cartesian
+  const T h = T(0.5 * kSqrt3 / 3.0), third = T(1.0 / 3.0);
+  const T tzz = Q[4] * third, txx = T(0.5) * (-Q[4] + T(kSqrt3) * Q[7]) * third, tyy = T(0.5) * (-Q[4] - T(kSqrt3) * Q[7]) * third;
+  const T txz = h * Q[5], tyz = h * Q[6], txy = h * Q[8];
+  const T Th[9] = {txx, txy, txz, txy, tyy, tyz, txz, tyz, tzz};
+  T AF[9];                                                 // Aop . F2
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) AF[3 * i + j] = A[3 * i + 0] * F2[0 + j] + A[3 * i + 1] * F2[3 + j] + A[3 * i + 2] * F2[6 + j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      y[3 * i + j] += (double)(d[i] * F1[j] + T(2) * (Th[3 * i + 0] * AF[0 + j] + Th[3 * i + 1] * AF[3 + j] + Th[3 * i + 2] * AF[6 + j]));
+}
+
 // All stencil weights of one atom.
 template <class T>
 struct Stencil {

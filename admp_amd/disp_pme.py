@@ -45,6 +45,7 @@ class ADMPDispPmeForce(HipForceBase):
         self.get_energy = self.generate_get_energy()
         self.get_forces = self._generate_get_forces()
         self.get_energy._value_and_grad = self.get_forces          # value_and_grad(disp.get_energy) -> get_forces
+        self.get_energy._value_and_box_grad = self.get_energy_and_box_gradient
 
     def _evaluate(self, positions, box, pairs, c_list, mScales, want_grad):
         with self._on_stream():
@@ -71,6 +72,28 @@ class ADMPDispPmeForce(HipForceBase):
         _lib.check(self._h, rc, 'admp_disp_energy_grad')
         self.energy_parts = tuple(E)
         return np.float64(E[0] + E[1] + E[2]), grad
+
+    def get_energy_and_box_gradient(self, positions, box, pairs, c_list, mScales):
+        """(E, dE/dbox (3,3)) at fixed Cartesian positions: `value_and_grad(get_energy, argnums=1)` of the reference."""
+        with self._on_stream():
+            na = self.n_atoms
+            self.set_pairs(pairs)
+            pos = self._real(positions, (na, 3))
+            nc = (self.pmax - 4) // 2
+            c = c_list.detach() if isinstance(c_list, torch.Tensor) else torch.as_tensor(np.asarray(c_list, dtype=np.float64))
+            c3 = torch.zeros((na, 3), dtype=self._dtype, device=self._device)
+            c3[:, :nc] = c.to(device=self._device, dtype=self._dtype)[:, :nc]
+            mS = self._host64(mScales)
+            E = (ctypes.c_double * 3)()
+            dbox = (ctypes.c_double * 9)()
+            rc = self._L.admp_disp_box_grad(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(c3),
+                                            self.pmax, len(mS), _lib.darr(mS), E, dbox)
+            _lib.check(self._h, rc, 'admp_disp_box_grad')
+        self.energy_parts = tuple(E)
+        return np.float64(E[0] + E[1] + E[2]), np.array(dbox[:], dtype=np.float64).reshape(3, 3)
+
+    def get_box_gradient(self, positions, box, pairs, c_list, mScales):
+        return self.get_energy_and_box_gradient(positions, box, pairs, c_list, mScales)[1]
 
     def get_mscale_gradient(self, positions, box, pairs, c_list, mScales):
         """dE/dmScales (len(mScales),): `grad(pot_disp, argnums=3)(...)['mScales']` of the reference

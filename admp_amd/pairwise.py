@@ -64,6 +64,26 @@ class _PairInteraction(HipForceBase):
         par = torch.stack([self._real(p, (self.n_atoms,)) for p in atomic_params], dim=1).contiguous()
         return self._mscale_gradient(2, positions, box, pairs, par, self.kernel.n_params, len(self._host64(mScales)))
 
+    def get_energy_and_box_gradient(self, positions, box, pairs, mScales, *atomic_params):
+        """(E, dE/dbox (3,3)) at fixed Cartesian positions: value_and_grad(pair_int, argnums=1) of the reference."""
+        with self._on_stream():
+            na = self.n_atoms
+            if len(atomic_params) != self.kernel.n_params:
+                raise TypeError('%s takes %d atomic parameter lists' % (self.kernel.name, self.kernel.n_params))
+            self.set_pairs(pairs)
+            pos = self._real(positions, (na, 3))
+            par = torch.stack([self._real(p, (na,)) for p in atomic_params], dim=1).contiguous()
+            mS = self._host64(mScales)
+            E = (ctypes.c_double * 1)()
+            dbox = (ctypes.c_double * 9)()
+            rc = self._L.admp_tt_box_grad(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(par), len(mS),
+                                          _lib.darr(mS), E, dbox)
+            _lib.check(self._h, rc, 'admp_tt_box_grad')
+        return np.float64(E[0]), np.array(dbox[:], dtype=np.float64).reshape(3, 3)
+
+    def get_box_gradient(self, positions, box, pairs, mScales, *atomic_params):
+        return self.get_energy_and_box_gradient(positions, box, pairs, mScales, *atomic_params)[1]
+
     def __call__(self, positions, box, pairs, mScales, *atomic_params):
         return self._evaluate(positions, box, pairs, mScales, atomic_params, False)[0]
 
@@ -84,15 +104,29 @@ def generate_pairwise_interaction(pair_int_kernel, covalent_map, static_args):
 def value_and_grad(fn, argnums=0):
     """Stand-in for jax.value_and_grad on the calculators of this package: the reference obtains its force routines as
     `value_and_grad(get_energy)` (admp/pme.py:108, admp/disp_pme.py:76, examples/water_1024/run_admp.py:101); here the
-    hand-coded adjoint that belongs to a calculator is looked up (positions only, argnums=0)."""
-    if argnums not in (0, (0,)):
-        raise NotImplementedError('only the gradient with respect to positions (argnums=0) is available through '
-                                  'value_and_grad; parameter gradients: admp_amd.api.param_gradient, get_box_gradient')
-    if isinstance(fn, _PairInteraction):
-        return fn.value_and_grad
-    vg = getattr(fn, '_value_and_grad', None)
-    if vg is not None:
-        return vg
+    hand-coded adjoint that belongs to a calculator is looked up.  argnums = 0 (positions), 1 (box) or (0, 1)."""
+    if isinstance(argnums, (tuple, list)):
+        parts = [value_and_grad(fn, a) for a in argnums]
+
+        def both(*a, **k):
+            outs = [p(*a, **k) for p in parts]
+            return outs[0][0], tuple(o[1] for o in outs)
+        return both
+    if argnums == 1:
+        if isinstance(fn, _PairInteraction):
+            return fn.get_energy_and_box_gradient
+        vb = getattr(fn, '_value_and_box_grad', None)
+        if vb is not None:
+            return vb
+    elif argnums == 0:
+        if isinstance(fn, _PairInteraction):
+            return fn.value_and_grad
+        vg = getattr(fn, '_value_and_grad', None)
+        if vg is not None:
+            return vg
+    else:
+        raise NotImplementedError('value_and_grad: argnums 0 (positions) and 1 (box) are available; parameter gradients: '
+                                  'admp_amd.api.param_gradient')
     owner = getattr(fn, '__self__', None)
     raise NotImplementedError('value_and_grad: %r is not a calculator of this package' % (owner or fn))
 

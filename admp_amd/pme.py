@@ -102,6 +102,7 @@ class ADMPPmeForce(HipForceBase):
         self.get_energy = self.generate_get_energy()
         self.get_forces = self._generate_get_forces()
         self.get_energy._value_and_grad = self.get_forces          # value_and_grad(pme_force.get_energy) -> get_forces
+        self.get_energy._value_and_box_grad = self.get_energy_and_box_gradient      # ... argnums=1
         if self.lpol:
             self.U_ind = np.zeros((self.n_atoms, 3))      # reset with the closures, admp/pme.py:79
             def energy_fn(*a, **k):                       # plain function objects, like the reference's closures
@@ -327,6 +328,40 @@ class ADMPPmeForce(HipForceBase):
             dpol = torch.where(live, -sx / (6.0 * safe) - DIELECTRIC * (U * U).sum(dim=1) / (2.0 * safe * safe),
                                torch.zeros_like(pol_t))
         return self._like(dpol, positions), self._like(sw, positions)
+
+    def get_box_gradient(self, positions, box, pairs, Q_local, *rest, **kw):
+        """dE/dbox (3,3) at fixed Cartesian positions -- `grad(get_energy, argnums=1)` of the reference, the quantity its
+        callers turn into the virial (README.md:7).  Arguments as get_energy.  Polarizable: the dipoles are converged first
+        and the derivative is taken at fixed dipoles, like every gradient of the reference (admp/pme.py:81-85)."""
+        return self.get_energy_and_box_gradient(positions, box, pairs, Q_local, *rest, **kw)[1]
+
+    def get_energy_and_box_gradient(self, positions, box, pairs, Q_local, *rest, **kw):
+        na = self.n_atoms
+        if self.lpol:
+            pol, tholes, mScales, pScales, dScales = rest
+            self.get_energy(positions, box, pairs, Q_local, pol, tholes, mScales, pScales, dScales,
+                            U_init=kw.get('U_init'))
+        else:
+            (mScales,) = rest
+            pol = tholes = pScales = None
+        self._use_current_stream()
+        self.set_pairs(pairs)
+        pos = self._real(positions, (na, 3))
+        Q = self._pad_Q(Q_local)
+        boxa, _ = self._harr('box', box, 9)
+        mSa, ns = self._harr('mS', mScales)
+        pol_t = th_t = U = pS = None
+        if self.lpol:
+            pol_t, th_t = self._real(pol, (na,)), self._real(tholes, (na,))
+            pS, _ = self._harr('pS', pScales, ns)
+            U = self._real(self.U_ind, (na, 3))
+        E = self._out_E
+        dbox = (ctypes.c_double * 9)()
+        P = self._ptr
+        _lib.check(self._h, self._L.admp_pme_box_grad(self._h, P(pos), boxa, P(Q), P(pol_t), P(th_t), ns, mSa, pS, P(U), E,
+                                                      dbox), 'admp_pme_box_grad')
+        self.energy_parts = tuple(E)
+        return np.float64(E[0] + E[1] + E[2] + E[3]), np.array(dbox[:], dtype=np.float64).reshape(3, 3)
 
     def get_mscale_gradient(self, positions, box, pairs, Q_local, mScales):
         """dE/dmScales, shape (len(mScales),): what `grad(pot_pme, argnums=3)(...)['mScales']` gives in the reference

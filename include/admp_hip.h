@@ -103,6 +103,20 @@ int admp_pme_energy_fixed_dipoles(admp_handle* h, const void* positions, const d
                          const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
                          double* E_out, void* dE_dpos, void* dE_dU, void* dE_dQlocal);
 
+/* replaces: jax.value_and_grad(get_energy, argnums=1) -- the gradient of the energy with respect to the cell matrix at FIXED
+ * Cartesian positions, from which callers of the reference form the virial (README.md:7; admp/pme.py:108 and
+ * admp/disp_pme.py:76 with argnums).  dE_dbox is 9 doubles (host), row-major like `box` (lattice vectors in rows).
+ * Positions / parameters are DEVICE pointers.  For a polarizable handle U holds the induced dipoles to evaluate at (the
+ * converged ones: the reference differentiates energy_fn at stop_gradient(U_ind), admp/pme.py:81-85).
+ * E_out as in the corresponding energy_grad call.  Not available on a slab-decomposed handle. */
+int admp_pme_box_grad(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                      const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
+                      double* E_out, double* dE_dbox);
+int admp_disp_box_grad(admp_handle* h, const void* positions, const double* box, const void* c_list, int pmax, int n_scales,
+                       const double* mScales, double* E_out, double* dE_dbox);
+int admp_tt_box_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
+                     const double* mScales, double* E_out, double* dE_dbox);
+
 /* replaces: the `construct_local_frames(positions, box)` attribute (generate_construct_local_frames,
  * admp/spatial.py:44-142): frames_out (Na,3,3) real, rows = local x, y, z axes in the global frame.  DEVICE pointers.
  * Diagnostic only -- the hot path builds the frames inside its first kernel and never materialises them. */

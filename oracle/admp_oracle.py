@@ -529,16 +529,23 @@ def Ck_1(ksq, kappa, V):       # recip.py:434-435
     return 2 * math.pi / V / ksq * torch.exp(-ksq / 4 / kappa ** 2)
 
 
+def _sqrt0(x2):
+    """sqrt whose derivative at 0 is 0 instead of inf.  Values are those of the reference's jnp.sqrt (recip.py:439,447,456);
+    only the BOX gradient of the k = 0 term differs: there the literal sqrt makes autodiff return inf * 0 = NaN for every
+    element of dE/dbox (in the reference as well), although that term does not depend on the k vector at all."""
+    return torch.sqrt(torch.clamp(x2, min=1e-300))
+
+
 def Ck_6(ksq, kappa, V):       # recip.py:437-443
     x2 = ksq / 4 / kappa ** 2
-    x = torch.sqrt(x2)
+    x = _sqrt0(x2)
     f = (1 - 2 * x2) * torch.exp(-x2) + 2 * x2 * x * SQRT_PI * torch.erfc(x)
     return SQRT_PI * math.pi / 2 / V * kappa ** 3 * f / 3
 
 
 def Ck_8(ksq, kappa, V):       # recip.py:445-452
     x2 = ksq / 4 / kappa ** 2
-    x = torch.sqrt(x2)
+    x = _sqrt0(x2)
     x4 = x2 * x2
     f = (3 - 2 * x2 + 4 * x4) * torch.exp(-x2) - 4 * x4 * x * SQRT_PI * torch.erfc(x)
     return SQRT_PI * math.pi / 2 / V * kappa ** 5 * f / 45
@@ -546,7 +553,7 @@ def Ck_8(ksq, kappa, V):       # recip.py:445-452
 
 def Ck_10(ksq, kappa, V):      # recip.py:454-462
     x2 = ksq / 4 / kappa ** 2
-    x = torch.sqrt(x2)
+    x = _sqrt0(x2)
     x4 = x2 * x2
     x6 = x4 * x2
     f = (15 - 6 * x2 + 4 * x4 - 8 * x6) * torch.exp(-x2) + 8 * x6 * x * SQRT_PI * torch.erfc(x)
@@ -670,13 +677,15 @@ def optimize_Uind(sysm, positions, box, pairs, Q_local, pol, tholes, mScales, pS
 
 
 def pme_energy_and_grad(sysm, positions, box, pairs, Q_local, mScales, pol=None, tholes=None,
-                        pScales=None, U_init=None, want_dQ=False):
+                        pScales=None, U_init=None, want_dQ=False, want_dbox=False):
     """``get_forces`` of the reference: (E, dE/dpositions) (+ parts, U, flags).
 
     Polarizable: SCF first, then the gradient at FIXED U (admp/pme.py:81-85).
+    want_dbox: also dE/dbox at fixed Cartesian positions -- what ``value_and_grad(get_energy, argnums=1)`` returns in
+    the reference (admp/pme.py:108 with argnums; README.md:7 "force and virial").
     """
     positions_t = _t(positions).clone().requires_grad_(True)
-    box_t = _t(box)
+    box_t = _t(box).clone().requires_grad_(want_dbox)
     Q_t = _t(Q_local).clone().requires_grad_(want_dQ)
     mS = _t(mScales)
     out = {}
@@ -688,11 +697,13 @@ def pme_energy_and_grad(sysm, positions, box, pairs, Q_local, mScales, pol=None,
     else:
         parts = energy_pme_parts(sysm, positions_t, box_t, pairs, Q_t, None, None, None, mS, None)
     e = sum(parts)
-    inputs = [positions_t] + ([Q_t] if want_dQ else [])
+    inputs = [positions_t] + ([Q_t] if want_dQ else []) + ([box_t] if want_dbox else [])
     grads = torch.autograd.grad(e, inputs)
     out.update(E=float(e.detach()), parts=[float(p.detach()) for p in parts], grad=grads[0].numpy().copy())
     if want_dQ:
         out['dQ_local'] = grads[1].numpy().copy()
+    if want_dbox:
+        out['dbox'] = grads[-1].numpy().copy()
     return out
 
 
@@ -735,12 +746,16 @@ def disp_pme_parts(positions, box, pairs, c_list, mScales, covalent_map, kappa, 
     return torch.sum(e_real), e_recip, e_self
 
 
-def disp_energy_and_grad(positions, box, pairs, c_list, mScales, covalent_map, kappa, K, pmax):
+def disp_energy_and_grad(positions, box, pairs, c_list, mScales, covalent_map, kappa, K, pmax, want_dbox=False):
     p = _t(positions).clone().requires_grad_(True)
-    parts = disp_pme_parts(p, _t(box), pairs, _t(c_list), _t(mScales), covalent_map, kappa, K, pmax)
+    b = _t(box).clone().requires_grad_(want_dbox)
+    parts = disp_pme_parts(p, b, pairs, _t(c_list), _t(mScales), covalent_map, kappa, K, pmax)
     e = sum(parts)
-    g, = torch.autograd.grad(e, p)
-    return dict(E=float(e.detach()), parts=[float(x.detach()) for x in parts], grad=g.numpy().copy())
+    gs = torch.autograd.grad(e, [p, b] if want_dbox else [p])
+    out = dict(E=float(e.detach()), parts=[float(x.detach()) for x in parts], grad=gs[0].numpy().copy())
+    if want_dbox:
+        out['dbox'] = gs[1].numpy().copy()
+    return out
 
 
 def tt_damping_energy(positions, box, pairs, mScales, covalent_map, a_list, b_list, q_list, c_list):
@@ -758,9 +773,13 @@ def tt_damping_energy(positions, box, pairs, mScales, covalent_map, a_list, b_li
     return torch.sum(f * m)
 
 
-def tt_energy_and_grad(positions, box, pairs, mScales, covalent_map, a_list, b_list, q_list, c_list):
+def tt_energy_and_grad(positions, box, pairs, mScales, covalent_map, a_list, b_list, q_list, c_list, want_dbox=False):
     p = _t(positions).clone().requires_grad_(True)
-    e = tt_damping_energy(p, _t(box), pairs, _t(mScales), covalent_map, _t(a_list), _t(b_list),
+    b = _t(box).clone().requires_grad_(want_dbox)
+    e = tt_damping_energy(p, b, pairs, _t(mScales), covalent_map, _t(a_list), _t(b_list),
                           _t(q_list), _t(c_list))
-    g, = torch.autograd.grad(e, p)
-    return dict(E=float(e.detach()), grad=g.numpy().copy())
+    gs = torch.autograd.grad(e, [p, b] if want_dbox else [p])
+    out = dict(E=float(e.detach()), grad=gs[0].numpy().copy())
+    if want_dbox:
+        out['dbox'] = gs[1].numpy().copy()
+    return out

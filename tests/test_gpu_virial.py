@@ -1,0 +1,189 @@
+"""Box gradient dE/dbox of the three calculators against torch autograd through the oracle
+(`requires_grad` on `box`, positions fixed -- what jax.value_and_grad(get_energy, argnums=1) gives in the reference,
+admp/pme.py:108, README.md:7).  Bars: f64 1e-8, f32 5e-4 relative to the largest element."""
+import numpy as np
+import pytest
+
+from admp_amd import settings
+from admp_amd import systems as S
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+@pytest.fixture()
+def env():
+    old = (settings.PRECISION, settings.REFERENCE_KPOINT_ORDER)
+    yield
+    settings.PRECISION, settings.REFERENCE_KPOINT_ORDER = old
+
+
+def wrapped_water(n_mol, seed, wrap=True):
+    """liquid box whose atoms are wrapped into the cell one by one: molecules straddle the boundary, so the local-frame
+    vectors and the intramolecular pairs need a lattice translation too"""
+    pos, box = S.synthetic_water_box(n_mol, seed=seed)
+    if wrap:
+        pos = np.mod(pos, box[0, 0])
+    at, ai, cov = S.water_topology(n_mol)
+    return pos, box, at, ai, cov
+
+
+@pytest.mark.parametrize('prec,tol', [('double', 1e-8), ('single', 5e-4)])
+@pytest.mark.parametrize('lpol', [False, True])
+def test_pme_box_gradient_cubic_vs_oracle_autograd(env, prec, tol, lpol):
+    """Reference k-point order: against the UNMODIFIED oracle.  NB even on a cubic box with K1 = K2 = K3, where energies
+    and forces do not depend on the k-point order, the reference's dE/dbox does: its k-columns (0, 1) carry the
+    frequencies of mesh axes (1, 0) (admp/recip.py:339-340), so the k-space part of its box gradient has x and y
+    exchanged.  The default (consistent) order is checked against the oracle's quirk=False variant below."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.pairwise import value_and_grad
+    from oracle import admp_oracle as O
+    from tests.test_gpu_parity import _oracle_energy
+    settings.PRECISION = prec
+    settings.REFERENCE_KPOINT_ORDER = True
+    n_mol = 64
+    pos, box, at, ai, cov = wrapped_water(n_mol, 13)
+    par = S.water_parameters(n_mol, polarizable=lpol)
+    pairs = S.build_pairs(pos, box, 4.0)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, lpol)
+    if lpol:
+        args = (pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+        ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], par['pol'], par['tholes'],
+                                    par['pScales'], want_dbox=True)
+    else:
+        args = (pos, box, pairs, par['Q_local'], par['mScales'])
+        ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], want_dbox=True)
+    dbox = f.get_box_gradient(*args)
+    assert dbox.shape == (3, 3)
+    assert relmax(dbox, ref['dbox']) < tol, (dbox, ref['dbox'])
+    # the jax-style spelling, and energy + both gradients in one go
+    E, d2 = value_and_grad(f.get_energy, argnums=1)(*args)
+    assert abs(E - ref['E']) < (1e-9 if prec == 'double' else 5e-4) * max(abs(p) for p in ref['parts'])
+    assert relmax(d2, ref['dbox']) < tol
+    E3, (G3, d3) = value_and_grad(f.get_energy, argnums=(0, 1))(*args)
+    assert relmax(d3, ref['dbox']) < tol and relmax(G3, ref['grad']) < (1e-8 if prec == 'double' else 5e-4)
+    # default order: same energy and forces on this box, another box gradient (the physically consistent one)
+    settings.REFERENCE_KPOINT_ORDER = False
+    f2 = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+    dc = f2.get_box_gradient(*args)
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+    b = T(box).clone().requires_grad_(True)
+    if lpol:
+        e = _oracle_energy(O, sysm, T(pos), b, pairs, T(par['Q_local']), T(ref['U_ind']), T(par['pol']), T(par['tholes']),
+                           T(par['mScales']), T(par['pScales']), quirk=False)
+    else:
+        e = _oracle_energy(O, sysm, T(pos), b, pairs, T(par['Q_local']), None, None, None, T(par['mScales']), None,
+                           quirk=False)
+    rc, = torch.autograd.grad(e, b)
+    assert relmax(dc, rc.numpy()) < tol
+    assert relmax(dc, ref['dbox']) > 1e-3          # ... and the two really differ
+    # With charges only (lmax = 0) the consistent derivative is the physical strain derivative: after the change to scaled
+    # coordinates, box^T dE/dbox|_s is the symmetric virial tensor of a rotation-invariant energy.  (With dipoles and
+    # quadrupoles the reference's spread operators use the transposed cell matrix, admp/recip.py:52,177 -- identical on an
+    # orthorhombic cell, but not rotation invariant around it, so its box gradient has no such symmetry; reproduced.)
+    if prec == 'double' and not lpol:
+        f0 = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 0)
+        q = par['Q_local'][:, :1].copy()
+        d0 = f0.get_box_gradient(pos, box, pairs, q, par['mScales'])
+        G0 = np.asarray(f0.get_forces(pos, box, pairs, q, par['mScales'])[1])
+        vir = box.T @ (d0 + np.linalg.inv(box).T @ pos.T @ G0)      # dE/dbox at fixed SCALED coordinates
+        assert np.abs(vir - vir.T).max() < 1e-6 * np.abs(vir).max()
+
+
+@pytest.mark.parametrize('lpol', [False, True])
+@pytest.mark.parametrize('mode', ['reference', 'consistent'])
+def test_pme_box_gradient_triclinic_all_axis_rules(env, lpol, mode):
+    """every local-axis rule, general scale tables, a triclinic cell; 'reference' = the reference's k-point order against
+    the unmodified oracle, 'consistent' = the default order against the oracle's quirk=False variant."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    from tests.test_gpu_parity import _mixed_axis_system, _oracle_energy
+    settings.PRECISION = 'double'
+    settings.REFERENCE_KPOINT_ORDER = (mode == 'reference')
+    pos, box, at, ai, cov, Q, pol, thole = _mixed_axis_system()
+    box = np.array([[14.0, 0, 0], [1.5, 14.0, 0], [-1.0, 0.8, 14.0]])
+    frac = pos @ np.linalg.inv(box)
+    pos = (frac - np.floor(frac)) @ box                 # atoms wrapped one by one
+    pairs = np.array([(i, j) for i in range(len(pos)) for j in range(i + 1, len(pos))], dtype=np.int32)
+    d = pos[pairs[:, 0]] - pos[pairs[:, 1]]
+    s = d @ np.linalg.inv(box)
+    d = (s - np.floor(s + 0.5)) @ box
+    pairs = pairs[np.linalg.norm(d, axis=1) < 6.0]
+    mS = np.array([0.0, 0.4, 0.8, 1.0, 1.0])
+    pS = np.array([0.0, 0.0, 1.0, 1.0, 1.0])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        f = ADMPPmeForce(box, at, ai, cov, 6.0, 1e-5, 2, lpol=lpol)
+        f.update_env('K2', f.K1 + 2)
+        f.update_env('K3', f.K1 + 5)
+        K = (f.K1, f.K2, f.K3)
+        sysm = O.PmeSystem(at, ai, cov, f.kappa, K, 2, lpol)
+        T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+        b = T(box).clone().requires_grad_(True)
+        if lpol:
+            dbox = f.get_box_gradient(pos, box, pairs, Q, pol, thole, mS, pS, pS)
+            e = _oracle_energy(O, sysm, T(pos), b, pairs, T(Q), T(f.U_ind), T(pol), T(thole), T(mS), T(pS),
+                               quirk=(mode == 'reference'))
+        else:
+            dbox = f.get_box_gradient(pos, box, pairs, Q, mS)
+            e = _oracle_energy(O, sysm, T(pos), b, pairs, T(Q), None, None, None, T(mS), None, quirk=(mode == 'reference'))
+    ref, = torch.autograd.grad(e, b)
+    assert relmax(dbox, ref.numpy()) < 1e-8, (dbox, ref.numpy())
+
+
+@pytest.mark.parametrize('prec,tol', [('double', 1e-8), ('single', 5e-4)])
+def test_dispersion_and_tt_box_gradient(env, prec, tol):
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
+    from oracle import admp_oracle as O
+    settings.PRECISION = prec
+    settings.REFERENCE_KPOINT_ORDER = True       # the oracle is the reference: its k-space box gradient has x/y exchanged
+    n_mol = 64
+    pos, box, at, ai, cov = wrapped_water(n_mol, 17)
+    par = S.water_parameters(n_mol)
+    pairs = S.build_pairs(pos, box, 4.0)
+    for pmax in (6, 10):
+        d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, pmax)
+        ref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d.kappa, (d.K1, d.K2, d.K3), pmax,
+                                     want_dbox=True)
+        E, db = value_and_grad(d.get_energy, argnums=1)(pos, box, pairs, par['c_list'], par['mScales'])
+        assert abs(E - ref['E']) < max(tol, 1e-9) * abs(ref['E'])
+        assert relmax(db, ref['dbox']) < tol, (pmax, db, ref['dbox'])
+    tt = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+    a = (par['a_list'], par['b_list'], par['q_list'], par['c_list'][:, 0])
+    ref = O.tt_energy_and_grad(pos, box, pairs, par['mScales'], cov, *a, want_dbox=True)
+    E, db = value_and_grad(tt, argnums=1)(pos, box, pairs, par['mScales'], *a)
+    assert abs(E - ref['E']) < max(tol, 1e-9) * abs(ref['E'])
+    assert relmax(db, ref['dbox']) < tol
+
+
+def test_box_gradient_finite_strain_at_config_size(env):
+    """configs[2] size (98 304 atoms, K = 128), where the oracle cannot run: dE/dbox against central differences of the
+    energy under a small change of the cell matrix (positions fixed), f64 path."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    n_mol = 32768
+    pos, box, at, ai, cov = wrapped_water(n_mol, 20240)
+    par = S.water_parameters(n_mol, polarizable=False)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    for k in ('K1', 'K2', 'K3'):
+        f.update_env(k, 128)
+    p = torch.as_tensor(pos, dtype=torch.float64, device='cuda')
+    Q = torch.as_tensor(par['Q_local'], dtype=torch.float64, device='cuda')
+    f.update_neighbors(p, box, rc=4.0)
+    dbox = f.get_box_gradient(p, box, None, Q, par['mScales'])
+    h = 2e-4
+    for (a, b) in ((0, 0), (1, 2), (2, 1)):
+        bp, bm = box.copy(), box.copy()
+        bp[a, b] += h
+        bm[a, b] -= h
+        fd = (f.get_energy(p, bp, None, Q, par['mScales']) - f.get_energy(p, bm, None, Q, par['mScales'])) / (2 * h)
+        assert abs(fd - dbox[a, b]) < 2e-4 * np.abs(dbox).max(), ((a, b), fd, dbox[a, b])
