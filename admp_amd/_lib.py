@@ -60,6 +60,7 @@ ST_SET_U, ST_PAIR_FIELD, ST_SPREAD, ST_FFT_YZ, ST_FFT_X, ST_KSPACE, ST_GATHER_FI
     ST_PAIR_FULL, ST_GATHER, ST_FINISH = range(1, 13)
 
 OPT_REFERENCE_KPOINTS = 1
+OPT_KEEP_POL_SITES = 2
 
 _lib = None
 

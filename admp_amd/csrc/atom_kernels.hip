@@ -39,9 +39,27 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
                                                               const T* __restrict__ Ucart, const T* __restrict__ pol,
                                                               const T* __restrict__ thole, Box<T> box,
                                                               Site<T>* __restrict__ sites, double* zero_next,
-                                                              RecipGeom<T> g, int4* __restrict__ bases) {
+                                                              RecipGeom<T> g, int4* __restrict__ bases,
+                                                              int* __restrict__ act_list, int* __restrict__ act_count) {
   int i = blockIdx.x * kAtomBlock + threadIdx.x;
-  if (zero_next && i < E_SLOTS) zero_next[i] = 0.0;   // the NEXT evaluation's energy words (engine.hip: Ed_cur)
+  if (zero_next && i < E_WORDS) zero_next[i] = 0.0;   // the NEXT evaluation's energy words (engine.hip: Ed_cur)
+  if (act_list) {   // kernel-uniform: list of the polarizable sites (pol > 0); ONE counter update per workgroup (every
+                    // workgroup of the launch hits the same word: 16k per-wave atomics cost 0.16 ms at 1M atoms), and
+                    // a workgroup's sites stay together and in order, which keeps the consumers' gathers local
+    __shared__ int wcnt[kAtomBlock / 64], wbase;
+    const bool act = i < top.na && pol && pol[i] > T(0);
+    const unsigned long long m = __ballot(act);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < kAtomBlock / 64; ++w) { const int c = wcnt[w]; wcnt[w] = tot; tot += c; }
+      wbase = tot ? atomicAdd(act_count, tot) : 0;
+    }
+    __syncthreads();
+    if (act) act_list[wbase + wcnt[wave] + __popcll(m & ((1ull << lane) - 1ull))] = i;
+  }
   if (i >= top.na) return;
   int type, iz, ix, iy;
   FrameWork<T> w;
@@ -70,6 +88,28 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
     const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
     bases[i] = make_int4(b[0], b[1], b[2], brick_code(b, dims, make_bricks(dims)));
   }
+}
+
+// Jacobi step of the incremental SCF, over the polarizable sites only (see launch.h)
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_jacobi_delta(int n_act, const int* __restrict__ act,
+                                                             const T* __restrict__ pol, const T* __restrict__ field,
+                                                             T* __restrict__ Ucart, Site<T>* __restrict__ sites,
+                                                             Site<T>* __restrict__ isites) {
+  const int slot = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (slot >= n_act) return;
+  const int i = act[slot];
+  const T s = -pol[i] * T(1.0 / kDielectric);
+  const T dx = field[3 * i] * s, dy = field[3 * i + 1] * s, dz = field[3 * i + 2] * s;     // admp/pme.py:138
+  Ucart[3 * i] += dx; Ucart[3 * i + 1] += dy; Ucart[3 * i + 2] += dz;
+  Site<T> r = sites[i];
+  r.U[0] += dz; r.U[1] += dx; r.U[2] += dy;                  // harmonic order (z, x, y)
+  r.pad[0] = dz; r.pad[1] = dx; r.pad[2] = dy;
+  sites[i] = r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.Q[k] = T(0);
+  r.U[0] = dz; r.U[1] = dx; r.U[2] = dy;
+  isites[slot] = r;
 }
 
 // (Na,3,3) local frames, rows x, y, z (admp/spatial.py:76-142): the diagnostic behind ADMPPmeForce.construct_local_frames
@@ -108,8 +148,9 @@ __global__ __launch_bounds__(kAtomBlock) void k_field_finish(int na, const Site<
                                                              const T* __restrict__ fld_pair,
                                                              const T* __restrict__ fld_recip, T kappa,
                                                              T* __restrict__ field, unsigned long long* fmax_bits,
-                                                             const int* __restrict__ list) {
+                                                             const int* __restrict__ list, const int* __restrict__ n_dev) {
   const int slot = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (n_dev) na = min(na, *n_dev);
   double fm = 0.0;
   if (slot < na) {
     const int i = list ? list[slot] : slot;
@@ -322,6 +363,99 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_pull(Topology top, const 
   }
 }
 
+// Closing kernel for topologies made of small frame groups (Topology::grp_ptr; one molecule = one group): one thread per
+// group evaluates each frame of the group ONCE and keeps the gradient contributions of the group's <= kMaxGroup atoms in
+// registers -- the pull form above re-evaluates every frame once per member atom (3x for water) and re-reads its inputs.
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_finish_groups(Topology top, const T* __restrict__ pos, Box<T> box,
+                                                              const Site<T>* __restrict__ sites,
+                                                              const T* __restrict__ pol, const T* __restrict__ Ucart,
+                                                              int lpol, T kappa, const T* __restrict__ pot,
+                                                              T* __restrict__ grad, T* __restrict__ dQlocal,
+                                                              double* energies, FieldFin<T> ff) {
+  const int gidx = blockIdx.x * kAtomBlock + threadIdx.x;
+  double eself = 0.0, epen = 0.0, fm = 0.0;
+  if (gidx < top.ngroups) {
+    const int a0 = top.grp_ptr[gidx], n = top.grp_ptr[gidx + 1] - a0;
+    T f[3];
+    self_factors(kappa, f);
+    T acc[kMaxGroup][3];
+#pragma unroll
+    for (int q = 0; q < kMaxGroup; ++q) acc[q][0] = acc[q][1] = acc[q][2] = T(0);
+#pragma unroll
+    for (int m = 0; m < kMaxGroup; ++m) {
+      if (m >= n) break;
+      const int i = a0 + m;
+      T P[9];
+      double es;
+      total_potential(sites[i], pot + 9 * (size_t)i, lpol, f, P, &es);
+      eself += es;
+      if (lpol) {
+        T al = pol[i];
+        al = al < T(1e-8) ? T(1e-8) : al;
+        const double u2 = (double)Ucart[3 * i] * Ucart[3 * i] + (double)Ucart[3 * i + 1] * Ucart[3 * i + 1] +
+                          (double)Ucart[3 * i + 2] * Ucart[3 * i + 2];
+        epen += kDielectric * 0.5 * u2 / (double)al;
+      }
+      if (ff.fmax_bits) {
+        const T al = ff.pol[i];
+        T fx, fy, fz;
+        total_field(sites[i], al, ff.Ucart + 3 * i, ff.fld_pair + 3 * i, ff.fld_recip + 3 * i, ff.kappa, fx, fy, fz);
+        ff.field[3 * i] = fx; ff.field[3 * i + 1] = fy; ff.field[3 * i + 2] = fz;
+        if (al > T(0.001)) fm = fmax(fm, fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz))));
+      }
+      if (!grad) continue;
+      int type, iz, ix, iy;
+      FrameWork<T> w;
+      frame_of(top, pos, box, i, type, iz, ix, iy, w);
+      if (type == NoAxisType) {
+        if (dQlocal) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) dQlocal[9 * i + q] = P[q];
+        }
+        continue;
+      }
+      T tau[3], gp[3], gz[3], gx[3], gy[3];
+      multipole_torque(P, sites[i].Q, tau);
+      local_frame_bwd(type, w, tau, gp, gz, gx, gy);
+      const int lz = iz - a0, lx = type != Zonly ? ix - a0 : -1, ly = (type == ZBisect || type == ThreeFold) ? iy - a0 : -1;
+#pragma unroll
+      for (int q = 0; q < kMaxGroup; ++q) {         // register array: compare-select, no dynamic indexing
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          T v = T(0);
+          if (q == m) v += gp[c];
+          if (q == lz) v += gz[c];
+          if (q == lx) v += gx[c];
+          if (q == ly) v += gy[c];
+          acc[q][c] += v;
+        }
+      }
+      if (dQlocal) {
+        T dl[9];
+        rot_harm(P, w.X, w.Y, w.Z, dl);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) dQlocal[9 * i + q] = dl[q];
+      }
+    }
+    if (grad) {
+#pragma unroll
+      for (int m = 0; m < kMaxGroup; ++m)
+        if (m < n) { grad[3 * (a0 + m)] += acc[m][0]; grad[3 * (a0 + m) + 1] += acc[m][1]; grad[3 * (a0 + m) + 2] += acc[m][2]; }
+    }
+  }
+  eself = block_reduce_sum<kAtomBlock>(eself);
+  epen = block_reduce_sum<kAtomBlock>(epen);
+  if (threadIdx.x == 0) {
+    atomicAdd(&energies[E_SELF], eself);
+    if (lpol) atomicAdd(&energies[E_PEN], epen);
+  }
+  if (ff.fmax_bits) {
+    fm = block_reduce_max<kAtomBlock>(fm);
+    if (threadIdx.x == 0 && fm > 0.0) atomicMax(ff.fmax_bits, nonneg_bits(fm));
+  }
+}
+
 // Box gradient, local-frame part: the frame vectors site -> axis atom go through the same minimum image as the pairs
 // (admp/spatial.py:88-101), so a molecule that straddles the cell boundary contributes shift (x) dE/d(vector).
 // pot = dE/dQ_global of pair + reciprocal space (the self term is added here, as in the closing kernel).
@@ -408,9 +542,9 @@ static inline int nblk(int n) { return (n + kAtomBlock - 1) / kAtomBlock; }
 template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
                           const T* pol, const T* thole, const Box<T>& box, Site<T>* sites, double* zero_next,
-                          const RecipGeom<T>& g, int4* bases) {
+                          const RecipGeom<T>& g, int4* bases, int* act_list, int* act_count) {
   k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites, zero_next, g,
-                                                          bases);
+                                                          bases, act_list, act_count);
 }
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites) {
@@ -418,8 +552,15 @@ void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites) {
 }
 template <class T>
 void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* pol, const T* Ucart, const T* fld_pair,
-                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits, const int* list) {
-  k_field_finish<T><<<nblk(na), kAtomBlock, 0, st>>>(na, sites, pol, Ucart, fld_pair, fld_recip, kappa, field, fmax_bits, list);
+                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits, const int* list,
+                         const int* n_dev) {
+  k_field_finish<T><<<nblk(na), kAtomBlock, 0, st>>>(na, sites, pol, Ucart, fld_pair, fld_recip, kappa, field, fmax_bits, list,
+                                                     n_dev);
+}
+template <class T>
+void launch_jacobi_delta(hipStream_t st, int n_act, const int* act, const T* pol, const T* field, T* Ucart, Site<T>* sites,
+                         Site<T>* isites) {
+  if (n_act > 0) k_jacobi_delta<T><<<nblk(n_act), kAtomBlock, 0, st>>>(n_act, act, pol, field, Ucart, sites, isites);
 }
 template <class T>
 void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, const T* Ucart, T* Unew,
@@ -430,6 +571,15 @@ template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
                    const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
                    const int* list, int nlist, const FieldFin<T>& ff) {
+  // molecular liquid at scale: one thread per frame group (below ~8k atoms the 4-lane pull form is faster: latency bound).
+  // ADMP_FINISH_GROUPS_MIN overrides the threshold; read per call so that the parity tests can force either form.
+  const char* gmin_env = getenv("ADMP_FINISH_GROUPS_MIN");
+  const int gmin = gmin_env ? atoi(gmin_env) : 8192;
+  if (!list && top.ngroups > 0 && top.na > gmin) {
+    k_finish_groups<T><<<nblk(top.ngroups), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
+                                                                 energies, ff);
+    return;
+  }
   if (!list && top.inv_ptr)   // single GPU: pull formulation, no atomics
   {
     static const int lanes4_max = [] { const char* e = getenv("ADMP_FINISH4_MAX"); return e ? atoi(e) : 8192; }();
@@ -480,10 +630,11 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
   template void launch_scalar_sites_batch<T>(hipStream_t, int, const T*, const T*, int, int, const double*, Site<T>*,   \
                                              double*);                                                                  \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
-                                        const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*);                  \
+                                        const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*, int*, int*);      \
   template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
-                                       unsigned long long*, const int*);                                                \
+                                       unsigned long long*, const int*, const int*);                                    \
+  template void launch_jacobi_delta<T>(hipStream_t, int, const int*, const T*, const T*, T*, Site<T>*, Site<T>*);       \
   template void launch_jacobi_update<T>(hipStream_t, int, const T*, const T*, const T*, T*, Site<T>*, const int*);       \
   template void launch_finish<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const Site<T>*, const T*,        \
                                  const T*, int, T, T*, T*, T*, double*, const int*, int, const FieldFin<T>&);

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -156,6 +157,8 @@ struct EngineBase {
   int lmax = 2, lpol = 0;
   int srank = 0, snranks = 1;   // x-slab decomposition (admp_slab_configure)
   int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
+  int keep_pol_sites = 0;       // ADMP_OPT_KEEP_POL_SITES: the caller vouches that the set {i : pol_i > 0} has not changed
+  long nbr_gen = 0;             // bumped whenever the neighbour table is rebuilt
   DevBuf scan_scratch;
   size_t scan_bytes = 0;
 
@@ -197,12 +200,14 @@ struct EngineBase {
     if (top.excl_nb) (void)hipFree(top.excl_nb);
     if (top.inv_ptr) (void)hipFree(top.inv_ptr);
     if (top.inv_idx) (void)hipFree(top.inv_idx);
+    if (top.grp_ptr) (void)hipFree(top.grp_ptr);
     top = Topology();
     if (nbr.rowptr) (void)hipFree(nbr.rowptr);
     if (nbr.col) (void)hipFree(nbr.col);
     if (nbr.order) (void)hipFree(nbr.order);
     nbr = NbrTable();
     have_top = have_pairs = false;
+    ++nbr_gen;
   }
 
   // row order of the freshly built table (see launch_row_order); ADMP_PAIR_SORT=0 keeps the natural order
@@ -262,6 +267,38 @@ struct EngineBase {
       HIP_TRY(hipMemcpy(top.inv_ptr, ptr.data(), sizeof(int) * (na + 1), hipMemcpyHostToDevice));
       if (!idx.empty()) HIP_TRY(hipMemcpy(top.inv_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
     }
+    {   // frame groups (see Topology): union-find over "site i uses atom m in its frame"
+      std::vector<int> parent(na);
+      for (int i = 0; i < na; ++i) parent[i] = i;
+      auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+      for (int i = 0; i < na; ++i) {
+        if (at[i] == NoAxisType || ai[3 * i] < 0) continue;
+        const int mem[3] = {ai[3 * i], at[i] != Zonly ? ai[3 * i + 1] : -1,
+                            (at[i] == ZBisect || at[i] == ThreeFold) ? ai[3 * i + 2] : -1};
+        for (int m = 0; m < 3; ++m)
+          if (mem[m] >= 0) { const int a = find(i), b = find(mem[m]); if (a != b) parent[std::max(a, b)] = std::min(a, b); }
+      }
+      // the root of a component is its lowest atom: components are runs of consecutive atoms iff root(i) is
+      // non-decreasing in i and every run is short enough
+      std::vector<int> gp;
+      bool ok = true;
+      int prev_root = -1;
+      for (int i = 0; i < na && ok; ++i) {
+        const int r = find(i);
+        if (r != prev_root) {
+          if (r != i) ok = false;                      // joins an earlier, already closed run
+          gp.push_back(i);
+          prev_root = r;
+        } else if (i - r >= kMaxGroup) ok = false;
+      }
+      gp.push_back(na);
+      static const bool off = [] { const char* e = getenv("ADMP_FINISH_GROUPS"); return e && atoi(e) == 0; }();
+      if (ok && !off) {
+        HIP_TRY(hipMalloc(&top.grp_ptr, sizeof(int) * gp.size()));
+        HIP_TRY(hipMemcpy(top.grp_ptr, gp.data(), sizeof(int) * gp.size(), hipMemcpyHostToDevice));
+        top.ngroups = (int)gp.size() - 1;
+      }
+    }
     have_top = true;
   }
 
@@ -284,6 +321,7 @@ struct EngineBase {
     HIP_TRY(hipStreamSynchronize(stream));
     staged.release();
     have_pairs = true;
+    ++nbr_gen;
   }
 };
 
@@ -299,7 +337,7 @@ struct Engine : EngineBase {
   bool other_clean = false;
   void* energies_seen = nullptr;
   double* Eh = nullptr;
-  double* Ed_cur() { return energies_d.as<double>() + (size_t)ehalf * E_SLOTS; }
+  double* Ed_cur() { return energies_d.as<double>() + (size_t)ehalf * E_WORDS; }
   // staging for host-pointer calls
   DevBuf s_pos, s_Q, s_pol, s_thole, s_U, s_out, s_dQ, s_par;
   // mesh
@@ -310,6 +348,12 @@ struct Engine : EngineBase {
   rocfft_execution_info info_f = nullptr;
   int planK[3] = {0, 0, 0}, planR = 0, planRank = 0;
   DevBuf home_list;
+  DevBuf act_d, isites, mesh2;   // incremental SCF: polarizable-site list, their compact delta rows, the increment's mesh
+  IndTable ind;                  // ... and the polarizable-polarizable part of the neighbour table
+  long act_gen = 0, act_top_na = -1;   // act_gen: bumped when the list is rebuilt; the list belongs to a topology of act_top_na atoms
+  int act_n = -1;                // its length once the host has seen it (-1: not yet)
+  bool act_fresh = false;        // this evaluation rebuilt the list (count still on the device)
+  long ind_nbr_gen = -1, ind_act_gen = -1;
   DevBuf dft_tw;          // twiddle tables of the direct-DFT path
   DevBuf bases_d;         // int4 per atom: lowest stencil index on each mesh axis
   bool use_dft = false;   // mesh convolution through dft_kernels.hip instead of rocFFT (single rank, a Bluestein dimension)
@@ -322,9 +366,11 @@ struct Engine : EngineBase {
     destroy_plans();
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
-                      &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d})
+                      &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2})
       b->release();
     free_topology();
+    if (ind.rowptr) (void)hipFree(ind.rowptr);
+    if (ind.col) (void)hipFree(ind.col);
     cells.release();
     if (Eh) (void)hipHostFree(Eh);
     prof.destroy();
@@ -592,7 +638,7 @@ struct Engine : EngineBase {
     ev.U = lpol ? reinterpret_cast<T*>(U_) : nullptr;
     sites.need(sizeof(Site<T>) * (size_t)na);
     pot.need(9 * (size_t)na * sizeof(T));
-    energies_d.need(2 * E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_WORDS * sizeof(double));
     if (energies_d.p != energies_seen) { energies_seen = energies_d.p; other_clean = false; }
     if (lpol) {
       fld_pair.need(3 * (size_t)na * sizeof(T));
@@ -605,15 +651,22 @@ struct Engine : EngineBase {
       ehalf ^= 1;                      // zeroed by the previous evaluation's first kernel
     } else {
       ehalf = 0;
-      HIP_TRY(hipMemsetAsync(energies_d.p, 0, E_SLOTS * sizeof(double), stream));   // energies and the max|field| word
+      HIP_TRY(hipMemsetAsync(energies_d.p, 0, E_WORDS * sizeof(double), stream));   // energies and the max|field| word
     }
     other_clean = false;
     fmax_clean = true;
     for (bool& c : slot_clean) c = true;
     {
       TIMED("prepare_sites");
+      // list of the polarizable sites for the incremental SCF: rebuilt by this kernel unless the caller vouches that the
+      // set is the one of the previous call (ADMP_OPT_KEEP_POL_SITES; the Python wrapper sets it while `pol` is unchanged)
+      const bool have_list = act_n >= 0 && act_top_na == na && act_d.p;
+      const bool want_act = lpol && snranks == 1 && !(keep_pol_sites && have_list);
+      act_fresh = want_act;
+      if (want_act) { act_d.need(sizeof(int) * (size_t)na); act_n = -1; act_top_na = na; ++act_gen; }
       launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, ev.U, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>(),
-                              energies_d.as<double>() + (size_t)(ehalf ^ 1) * E_SLOTS, ev.g, bases_d.as<int4>());
+                              energies_d.as<double>() + (size_t)(ehalf ^ 1) * E_WORDS, ev.g, bases_d.as<int4>(),
+                              want_act ? act_d.as<int>() : nullptr, want_act ? nact_dev() : nullptr);
       ev.bases = bases_d.as<int4>();
     }
     other_clean = true;
@@ -706,7 +759,8 @@ struct Engine : EngineBase {
                         Ed_cur(), ev.home ? ev.home : nbr.order, fld_out);
   }
   // with_field_finish: the gather also forms the total dE/dU and its maximum (launch_field_finish's work, fused)
-  void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr, bool with_field_finish = false) {
+  void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr, bool with_field_finish = false,
+                    double* e_recip = nullptr) {
     need_eval();
     FieldFin<T> ff;
     if (with_field_finish) {
@@ -716,7 +770,8 @@ struct Engine : EngineBase {
       ff.field = field.as<T>(); ff.fmax_bits = fmax_word();
     }
     TIMED("gather");
-    launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff);
+    launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff,
+                     e_recip);
   }
   // closes the evaluation: E_out = (real, recip[slot], self, penalty) of THIS rank's share
   // with_field_finish (single rank, pull kernel): the SCF residual and its maximum are formed by this kernel too
@@ -733,12 +788,76 @@ struct Engine : EngineBase {
     launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
                      dQl, Ed_cur(), ev.home, ev.n_home, ff);
   }
+  // ---- incremental SCF (single rank) --------------------------------------------------------------------------
+  // The field dE/dU is LINEAR in the induced dipoles and only sites with pol > 0 ever change theirs.  So after the first
+  // (full) field evaluation of a call, every further SCF cycle evaluates only the field of the Jacobi step's dipole CHANGE
+  // dU: real space over polarizable-polarizable pairs (k_pair_field_ind), reciprocal space by spreading the dU of the
+  // polarizable sites alone, and adds it to the stored field; phi is kept current by adding the increment's mesh.  For
+  // water that is 1/9 of the pairs and 1/3 of the spread / gather work per cycle; the arithmetic is the reference's
+  // (admp/pme.py:130-138) regrouped, same dipoles and cycle count to round-off.
+  enum { E_PARTS_SUM = -1 };   // read_energies: the reciprocal energy is the sum of the E_PARTS partial words
+  int* nact_dev() { return reinterpret_cast<int*>(Ed_cur() + E_NACT); }
+  // device-side count for the kernels of the first cycle when the list is fresh (nullptr: the host knows it: act_n)
+  const int* nact_arg() { return act_fresh ? nact_dev() : nullptr; }
+  int nact_rows() const { return act_fresh ? top.na : act_n; }      // grid bound of those kernels
+  void nact_seen() {                                                 // after a read_energies of this evaluation
+    if (act_fresh) { int n = 0; std::memcpy(&n, &Eh[E_NACT], sizeof(n)); act_n = n; act_fresh = false; }
+  }
+  double scf_check(int* n_act) {          // total field + its maximum over the polarizable sites; one host read
+    if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
+    fmax_clean = false;
+    {
+      TIMED("field_finish");
+      launch_field_finish<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
+                             (T)kappa, field.as<T>(), fmax_word(), act_d.as<int>(), nact_arg());
+    }
+    double dummy[4];
+    const double fmax = read_energies(E_SCF_RECIP, dummy);
+    nact_seen();
+    *n_act = act_n;
+    return fmax;
+  }
+  void scf_jacobi(int n_act) {
+    if (n_act <= 0) return;
+    isites.need(sizeof(Site<T>) * (size_t)n_act);
+    TIMED("jacobi_update");
+    launch_jacobi_delta<T>(stream, n_act, act_d.as<int>(), ev.pol, field.as<T>(), ev.U, sites.as<Site<T>>(),
+                           isites.as<Site<T>>());
+  }
+  void scf_increment(int n_act) {         // fld_pair / fld_recip / phi <- their values for the dipoles after scf_jacobi
+    if (n_act <= 0) return;
+    if (ind_nbr_gen != nbr_gen || ind_act_gen != act_gen) {      // neighbour table or polarizable set changed
+      TIMED("ind_table");
+      int rc = build_ind_table<T>(stream, top.na, nbr, sites.as<Site<T>>(), ind, &scan_scratch.p, &scan_bytes);
+      if (rc != 0) throw Err{ADMP_E_HIP, std::string("build_ind_table: ") + hipGetErrorString((hipError_t)rc)};
+      ind_nbr_gen = nbr_gen; ind_act_gen = act_gen;
+    }
+    { TIMED("pair_field_ind");
+      launch_pair_field_ind<T>(stream, n_act, ind, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
+                               act_d.as<int>()); }
+    const size_t nreal = (size_t)K[0] * K[1] * K[2];
+    mesh2.need(nreal * sizeof(T));
+    { TIMED("spread_ind");
+      int rc = launch_spread<T>(stream, n_act, isites.as<Site<T>>(), 1, ev.g, bins, mesh2.as<T>(), nullptr, nullptr);
+      if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)}; }
+    convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH);
+    { TIMED("gather_field_ind");
+      launch_gather_field<T>(stream, n_act, isites.as<Site<T>>(), ev.g, mesh2.as<T>(), fld_recip.as<T>(), nullptr, 1, nullptr,
+                             act_d.as<int>()); }
+    { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)nreal, mesh.as<T>(), mesh2.as<T>()); }
+  }
+
   // one device->host copy + sync: energies (and the max|field| word, returned)
   double read_energies(int recip_slot, double* E) {
-    if (!Eh) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&Eh), E_SLOTS * sizeof(double), hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(Eh, Ed_cur(), E_SLOTS * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (!Eh) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&Eh), E_WORDS * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(Eh, Ed_cur(), E_WORDS * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    E[0] = Eh[E_REAL]; E[1] = Eh[recip_slot]; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
+    E[0] = Eh[E_REAL]; E[1] = recip_slot >= 0 ? Eh[recip_slot] : 0.0; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
+    if (recip_slot == E_PARTS_SUM) {         // atom-side reciprocal energy: the partial words of k_gather<.., true>
+      double e = 0.0;
+      for (int k = 0; k < E_PARTS; ++k) e += Eh[E_SLOTS + k];
+      E[1] = e;
+    }
     return Eh[E_FMAX];   // same bits as the device word
   }
   void stage_finish(T* grad_p, T* dQl, int recip_slot, double* E) {
@@ -791,11 +910,14 @@ struct Engine : EngineBase {
 
     // phi_valid: the mesh holds phi = c2r(G S) of the CURRENT dipoles (last SCF field evaluation, no update since):
     // the closing gather can then reuse it instead of spreading and transforming again.
-    bool phi_valid = false, done = false, finished = false;
+    // phi_accum: that phi was assembled from increments, so no single k-space pass saw its energy -- the closing gather
+    // sums it over the atoms instead.
+    bool phi_valid = false, done = false, finished = false, phi_accum = false;
     int cyc = 0, flag = 1;
     if (lpol) {
       ARG_CHECK(max_cycle >= 1, "max_cycle must be >= 1");
-      int i = 0;
+      int i = 0, n_act = 0;
+      bool have_base = false;    // fld_pair / fld_recip / phi belong to the dipoles before the last Jacobi step
       if (warm_regime) {
         // Steady-state MD regime (the previous call converged at its first check): evaluate the FIRST SCF cycle
         // with the full kernels -- they produce dE/dU alongside the gradient -- so that, when the check passes
@@ -813,22 +935,35 @@ struct Engine : EngineBase {
         if (!fuse_ff && !pull) launch_field_finish_only();
         launch_finish_only(dpos ? gbuf : nullptr, dQl, !fuse_ff && pull);
         const double fmax = read_energies(E_SCF_RECIP, E);
+        nact_seen();
+        n_act = act_n;
         if (fmax < thresh) {
           phi_valid = done = finished = true;
           ev.active = false;
         } else {   // undo the speculative energy sums; gradient / dQ are rewritten by the regular closing pass
           HIP_TRY(hipMemsetAsync(Ed_cur() + E_SELF, 0, 2 * sizeof(double), stream));
-          stage_jacobi(U);
+          scf_jacobi(n_act);
           i = 1;
+          have_base = true;      // the full kernels left the field of the old dipoles behind: continue by increments
         }
       }
       for (; !done && i < max_cycle; ++i) {     // admp/pme.py:132-138
-        stage_pair_field();
-        recip_pass(E_SCF_RECIP);
-        stage_gather_field(mesh.as<T>());
-        const double fmax = stage_field_finish();
+        if (!have_base) {        // first field evaluation of the call: everything, at the polarizable sites
+          { TIMED("pair_field");
+            launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
+                                 act_d.as<int>(), nact_arg()); }
+          recip_pass(E_SCF_RECIP);
+          { TIMED("gather_field");
+            launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(),
+                                   act_d.as<int>(), 1, nact_arg()); }
+          have_base = true;
+        } else {
+          scf_increment(n_act);
+          phi_accum = true;
+        }
+        const double fmax = scf_check(&n_act);
         if (fmax < thresh) { phi_valid = true; break; }
-        stage_jacobi(U);
+        scf_jacobi(n_act);
       }
       if (i == max_cycle) i = max_cycle - 1;   // python's loop variable after exhaustion
       cyc = i;
@@ -836,12 +971,15 @@ struct Engine : EngineBase {
       warm_regime = (cyc == 0);
     }
 
+    const bool atoms_energy = phi_valid && phi_accum;
     if (!done) {
       stage_pair_full(gbuf);
       if (!phi_valid) recip_pass(E_RECIP);
-      stage_gather(mesh.as<T>(), gbuf);
+      // (the partial words are zero: nothing else of this evaluation writes them)
+      stage_gather(mesh.as<T>(), gbuf, nullptr, false, atoms_energy ? Ed_cur() + E_SLOTS : nullptr);
     }
-    if (!finished) stage_finish(dpos ? gbuf : nullptr, dQl, phi_valid ? E_SCF_RECIP : E_RECIP, E);
+    if (!finished)
+      stage_finish(dpos ? gbuf : nullptr, dQl, atoms_energy ? (int)E_PARTS_SUM : (phi_valid ? (int)E_SCF_RECIP : (int)E_RECIP), E);
 
     if (!on_device) {
       if (dpos_) HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
@@ -987,7 +1125,7 @@ struct Engine : EngineBase {
     const T* pos = reinterpret_cast<const T*>(pos_);
     const T* cl = reinterpret_cast<const T*>(clist_);
     grad.need(3 * (size_t)na * sizeof(T));
-    energies_d.need(2 * E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_WORDS * sizeof(double));
     ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
@@ -1025,7 +1163,7 @@ struct Engine : EngineBase {
     const T* pos = reinterpret_cast<const T*>(pos_);
     const T* par = reinterpret_cast<const T*>(abqc_);
     grad.need(3 * (size_t)na * sizeof(T));
-    energies_d.need(2 * E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_WORDS * sizeof(double));
     ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
@@ -1079,6 +1217,7 @@ struct Engine : EngineBase {
     if (r != 0) throw Err{ADMP_E_HIP, std::string("cell_build_table: ") + hipGetErrorString((hipError_t)r)};
     order_rows();
     have_pairs = true;
+    ++nbr_gen;
   }
 
   void slab_info(int64_t* o) override {
@@ -1129,7 +1268,7 @@ struct Engine : EngineBase {
     grad.need(3 * (size_t)na * sizeof(T));
     if (dpos_ && on_device) dpos = reinterpret_cast<T*>(dpos_);
     else dpos = grad.as<T>();
-    energies_d.need(2 * E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_WORDS * sizeof(double));
     ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
@@ -1213,7 +1352,7 @@ struct Engine : EngineBase {
     const T* par = stage_in(s_par, abqc_, 4 * (size_t)na, on_device);
     grad.need(3 * (size_t)na * sizeof(T));
     T* dpos = (dpos_ && on_device) ? reinterpret_cast<T*>(dpos_) : grad.as<T>();
-    energies_d.need(2 * E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_WORDS * sizeof(double));
     ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
@@ -1253,7 +1392,7 @@ struct Engine : EngineBase {
     const T* pos = stage_in(s_pos, pos_, 3 * (size_t)na, on_device);
     const size_t npar = kind == 0 ? 9 : (kind == 1 ? 3 : 4);
     const T* par = stage_in(kind == 0 ? s_Q : s_par, par_, npar * (size_t)na, on_device);
-    energies_d.need(2 * E_SLOTS * sizeof(double));
+    energies_d.need(2 * E_WORDS * sizeof(double));
     ehalf = 0; other_clean = false;
     double* cls = energies_d.as<double>();          // 16 class sums
     HIP_TRY(hipMemsetAsync(cls, 0, 16 * sizeof(double), stream));
@@ -1419,6 +1558,7 @@ int admp_set_option(admp_handle* h, int option, int value) {
   return guarded(h, [&](EngineBase& e) {
     switch (option) {
       case ADMP_OPT_REFERENCE_KPOINTS: e.ref_korder = value ? 1 : 0; break;
+      case ADMP_OPT_KEEP_POL_SITES: e.keep_pol_sites = value ? 1 : 0; break;
       default: throw Err{ADMP_E_ARG, "unknown option"};
     }
   });

@@ -41,10 +41,21 @@ struct Topology {
   // inverse frame map: inv_idx[inv_ptr[a] .. inv_ptr[a+1]) = sites whose local frame involves atom a
   int* inv_ptr = nullptr;     // na + 1
   int* inv_idx = nullptr;
+  // frame groups: when every connected component of the "takes part in the frame of" graph is a run of <= kMaxGroup
+  // consecutive atoms (molecular liquids: one group per molecule), group g = atoms grp_ptr[g] .. grp_ptr[g+1]-1 and the
+  // closing kernel evaluates each frame ONCE, by one thread per group (k_finish_groups); else ngroups = 0 (pull form)
+  int* grp_ptr = nullptr;     // ngroups + 1
+  int ngroups = 0;
 };
+constexpr int kMaxGroup = 4;
 
 // energies[] slots on the device
-enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_SCF_RECIP = 6, E_FMAX = 7 /* bit pattern */, E_SLOTS = 8 };
+enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_NACT = 4 /* int: number of polarizable sites (k_prepare_sites) */,
+       E_SCRATCH = 5 /* energy of passes whose energy nobody reads */, E_SCF_RECIP = 6, E_FMAX = 7 /* bit pattern */,
+       E_SLOTS = 8,
+       E_PARTS = 64 /* partial sums of the atom-side reciprocal energy (k_gather<.., true>): 32k workgroups adding into ONE
+                       word serialise at the memory side (0.2 ms at 1M atoms); 64 words take them in parallel */,
+       E_WORDS = E_SLOTS + E_PARTS /* one half of the double-buffered energy block */ };
 
 // optional epilogue of the gather (small systems) or of the closing kernel (large ones), speculative first SCF cycle on
 // one rank: total dE/dU and its maximum, exactly what launch_field_finish computes, without a separate dispatch
@@ -62,8 +73,10 @@ struct FieldFin {
 template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
                           const T* pol, const T* thole, const Box<T>& box, Site<T>* sites,
-                          double* zero_next /* E_SLOTS doubles cleared for the next evaluation, or nullptr */,
-                          const RecipGeom<T>& g, int4* bases /* optional: stencil base indices per atom */);
+                          double* zero_next /* E_WORDS doubles cleared for the next evaluation, or nullptr */,
+                          const RecipGeom<T>& g, int4* bases /* optional: stencil base indices per atom */,
+                          int* act_list = nullptr /* optional: the atoms with pol > 0 (unordered) ... */,
+                          int* act_count = nullptr /* ... and their number: an int the caller has zeroed */);
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites);
 template <class T>
@@ -74,7 +87,14 @@ void launch_local_frames(hipStream_t st, const Topology& top, const T* pos, cons
 // with the x-slab decomposition a rank works on its "home" atoms only and n is the list length.
 template <class T>
 void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* pol, const T* Ucart, const T* fld_pair,
-                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits, const int* list);
+                         const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits, const int* list,
+                         const int* n_dev = nullptr);
+// Jacobi step over the polarizable sites (act list): dU = -field pol / D, U += dU (Cartesian array and packed harmonic
+// copy), dU (harmonic order) into the pad words of the site row and into the compact row isites[slot] = {r, Q = 0, U = dU}
+// that the increment's spread / gather read
+template <class T>
+void launch_jacobi_delta(hipStream_t st, int n_act, const int* act, const T* pol, const T* field, T* Ucart, Site<T>* sites,
+                         Site<T>* isites);
 // Unew <- U - field * pol / DIELECTRIC (admp/pme.py:138), refreshing the packed harmonic copy (Unew may be U)
 template <class T>
 void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, const T* Ucart, T* Unew,
@@ -131,9 +151,25 @@ template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows,
                       T* fld /* optional: also write the real-space dE/dU (speculative SCF pass) */);
+// n_dev (optional): the row count lives on the device (na is then the upper bound the grid is sized for)
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                       const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows);
+                       const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows, const int* n_dev = nullptr);
+// incremental SCF: fld_pair[row] += sum_j T_ij dU_j over the polarizable partners, dU_j in the pad words of sites[j];
+// `it` = the polarizable-polarizable sub-table (rows keyed by atom), `rows` = the n_rows polarizable sites
+struct IndTable {
+  int* rowptr = nullptr;   // na + 1
+  int* col = nullptr;
+  int64_t n = 0, cap = 0;
+};
+template <class T>
+void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const Site<T>* sites, const Box<T>& box,
+                           const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows);
+// (nbr_kernels.hip) it <- the polarizable-polarizable entries of nb; rows keyed by atom, empty for non-polarizable atoms.
+// Returns a hipError_t as int; one host synchronisation.
+template <class T>
+int build_ind_table(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, IndTable& it, void** scratch,
+                    size_t* scratch_bytes);
 int pair_lanes_per_row(int n_rows);   // 2/4/8 by row count; env ADMP_PAIR_LPR overrides
 // sumX[i] = sum_j dE_ij/d ln(au_ij), sumXw[i] = sum_j (same) * d ln(au_ij)/d thole_i  (pme_math.h pair_thole_logderiv)
 template <class T>
@@ -236,10 +272,16 @@ void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spe
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
                    T* grad, const int* list, T* fld_recip /* optional: cartesian reciprocal dE/dU */,
-                   const FieldFin<T>& ff = FieldFin<T>());
+                   const FieldFin<T>& ff = FieldFin<T>(),
+                   double* e_recip = nullptr /* optional: += 1/2 sum_i Q_tot,i . dE_recip/dQ_i = the reciprocal energy */);
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
-                         T* fld_recip, const int* list, int nb = 1 /* batch: phi of b at phi + b * mesh size, fld + b * 3 * na */);
+                         T* fld_recip, const int* list, int nb = 1 /* batch: phi of b at phi + b * mesh size, fld + b * 3 * na */,
+                         const int* n_dev = nullptr /* atom count on the device (na = grid bound) */,
+                         const int* add_to = nullptr /* rows are compact: ADD the result to fld_recip[3 * add_to[slot]] */);
+// a += b over n mesh points
+template <class T>
+void launch_mesh_add(hipStream_t st, long n, T* a, const T* b);
 // ---- cell_kernels.hip: positions -> half pair list (cell list), two phases so that the caller can size `pairs`
 struct CellScratch {
   int n[3] = {0, 0, 0};

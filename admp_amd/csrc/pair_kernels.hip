@@ -17,16 +17,6 @@ namespace admp {
 
 constexpr int kPairBlock = 256;
 
-// XCD-aware block order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with
-// its own L2; remapping block b -> (b % 8) * ceil(n/8) + b / 8 gives every XCD one contiguous range of rows, so the
-// partner rows gathered by neighbouring workgroups are shared in that XCD's L2 instead of being fetched by all eight.
-__device__ __forceinline__ long xcd_block(unsigned b, unsigned n) {
-  const unsigned per = (n + 7u) / 8u;
-  const unsigned m = (b & 7u) * per + (b >> 3);
-  return m < n ? (long)m : -1;
-}
-static inline unsigned xcd_grid(unsigned n) { return ((n + 7u) / 8u) * 8u; }
-
 template <class T, int LPR>
 __device__ __forceinline__ T row_reduce(T v) {
 #pragma unroll
@@ -97,9 +87,14 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __
                                                            const int* __restrict__ col,
                                                            const Site<T>* __restrict__ sites, Box<T> box,
                                                            ScaleTab<T> tab, T kappa, T* __restrict__ fld,
-                                                           const int* __restrict__ rows, unsigned nblocks) {
+                                                           const int* __restrict__ rows, unsigned nblocks,
+                                                           const int* __restrict__ n_dev) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
+  if (n_dev) {                              // row count known on the device only (the polarizable-site list of this call):
+    na = min(na, *n_dev);                   // re-derive the XCD block ranges from it, or only the first XCDs would get rows
+    nblocks = (unsigned)(((long)na * LPR + kPairBlock - 1) / kPairBlock);
+  }
   const long blk = xcd_block(blockIdx.x, nblocks);
   const long t = (blk < 0 ? (long)na * LPR : blk * kPairBlock) + threadIdx.x;
   const int slot = (int)(t / LPR), sub = (int)(t % LPR);
@@ -122,6 +117,42 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __
   if (slot < na && sub == 0) {
     fld[3 * row] = F[0]; fld[3 * row + 1] = F[1]; fld[3 * row + 2] = F[2];
   }
+}
+
+// Incremental SCF (engine.hip): fld[row] += sum over the polarizable partners of T_ij . dU_j, rows = the polarizable
+// sites.  dU_j (global harmonic order) rides in the pad words of the partner's site row (k_jacobi_delta).  The kernel
+// walks the polarizable-polarizable SUB-table (irow / icol, rows keyed by atom, built by build_ind_table when the
+// neighbour table or the set of polarizable sites changes): for water the O-O pairs, 1/9 of the directed entries.
+template <class T, int LPR>
+__global__ __launch_bounds__(kPairBlock) void k_pair_field_ind(int na, const int* __restrict__ irow,
+                                                               const int* __restrict__ icol,
+                                                               const Site<T>* __restrict__ sites, Box<T> box,
+                                                               ScaleTab<T> tab, T kappa, T* __restrict__ fld,
+                                                               const int* __restrict__ rows) {
+  __shared__ T s_tab[48];
+  stage_tab(tab, s_tab);
+  const unsigned nblocks = (unsigned)(((long)na * LPR + kPairBlock - 1) / kPairBlock);
+  const long blk = xcd_block(blockIdx.x, nblocks);
+  const long t = (blk < 0 ? (long)na * LPR : blk * kPairBlock) + threadIdx.x;
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
+  const int row = slot < na ? rows[slot] : -1;
+  T F[3] = {0, 0, 0};
+  if (row >= 0) {
+    const T rI[3] = {sites[row].r[0], sites[row].r[1], sites[row].r[2]};
+    const T p6I = sites[row].p6, thI = sites[row].thole;
+    const int end = irow[row + 1];
+#pragma unroll 1
+    for (int k = irow[row] + sub; k < end; k += LPR) {
+      const int c = icol[k];
+      const Site<T>& J = sites[c & kColMask];
+      const T rJ[3] = {J.r[0], J.r[1], J.r[2]};
+      const T dU[3] = {J.pad[0], J.pad[1], J.pad[2]};
+      pair_field_ind<T>(box, rI, p6I, thI, rJ, J.p6, J.thole, dU, s_tab[32 + ((c >> 28) & 15)], kappa, F);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) F[q] = row_reduce<T, LPR>(F[q]);
+  if (row >= 0 && sub == 0) { fld[3 * row] += F[0]; fld[3 * row + 1] += F[1]; fld[3 * row + 2] += F[2]; }
 }
 
 // dispersion / Tang-Toennies: scalar pair terms, same row layout
@@ -418,15 +449,25 @@ void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>*
 
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                       const ScaleTab<T>& tab, T kappa, T* fld, const int* rows) {
+                       const ScaleTab<T>& tab, T kappa, T* fld, const int* rows, const int* n_dev) {
   const int lpr = pair_lanes_per_row(na);
 #define CALL(L)                                                                                              \
   k_pair_field<T, L><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
-                                                                       fld, rows, grid_for(na, L))
+                                                                       fld, rows, grid_for(na, L), n_dev)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
-
+template <class T>
+void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const Site<T>* sites, const Box<T>& box,
+                           const ScaleTab<T>& tab, T kappa, T* fld, const int* rows) {
+  if (n_rows <= 0) return;
+  const int lpr = pair_lanes_per_row(n_rows);
+#define CALL(L)                                                                                                          \
+  k_pair_field_ind<T, L><<<xcd_grid(grid_for(n_rows, L)), kPairBlock, 0, st>>>(n_rows, it.rowptr, it.col, sites, box, tab, \
+                                                                               kappa, fld, rows)
+  ADMP_LPR_SWITCH(lpr, CALL)
+#undef CALL
+}
 template <class T>
 void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies) {
@@ -452,7 +493,9 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
   template void launch_pair_full<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,               \
                                     const ScaleTab<T>&, T, int, T*, T*, double*, const int*, T*);                   \
   template void launch_pair_field<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
-                                     const ScaleTab<T>&, T, T*, const int*);                                        \
+                                     const ScaleTab<T>&, T, T*, const int*, const int*);                            \
+  template void launch_pair_field_ind<T>(hipStream_t, int, const IndTable&, const Site<T>*, const Box<T>&,          \
+                                         const ScaleTab<T>&, T, T*, const int*);                                    \
   template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,           \
                                     const ScaleTab<T>&, T, int, T*, double*);                                       \
   template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,             \

@@ -649,4 +649,33 @@ ADMP_HD void pair_field(const Box<T>& box, const Site<T>& I, const Site<T>& J, c
   fldI[0] += t[0]; fldI[1] += t[1]; fldI[2] += t[2];
 }
 
+// Change of the real-space dE/dU_I when the partner's induced dipole changes by dUJ (global harmonic order z, x, y): two
+// induced dipoles couple only through udud_m0 / udud_m1 (admp/pme.py:472-474, uscales = 1) -- the field is linear in the
+// dipoles, so the SCF cycles after the first only need this increment over the polarizable-polarizable pairs
+// (engine.hip, "incremental SCF").  Positions / damping data are read from the two site rows.
+template <class T>
+ADMP_HD void pair_field_ind(const Box<T>& box, const T rI[3], T p6I, T thI, const T rJ[3], T p6J, T thJ, const T dUJ[3],
+                            T w0, T kappa, T fldI[3]) {
+  T d[3] = {rI[0] - rJ[0], rI[1] - rJ[1], rI[2] - rJ[2]};
+  min_image(box, d);
+  const T r = m_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const T rinv = T(1) / r;
+  const T z[3] = {d[0] * rinv, d[1] * rinv, d[2] * rinv};
+  T x[3], y[3], UB[3];
+  qi_frame(z, x, y);
+  rot_dip(dUJ, x, y, z, UB);
+  T c[NCOEF];
+  Radial<T, T> rad;
+  rad.init(r, kappa);
+  const T aw = w0 * T(kDefaultTholeWidth) + (T(1) - w0) * (thI + thJ);
+  T dmp = p6I * p6J;
+  dmp = dmp < T(1e-8) ? T(1e-8) : dmp;
+  ind_coefs(rad, r, aw, dmp, T(0), c);      // only the two induced-induced coefficients are used (the rest is dead code)
+  const T FA[3] = {c[UDUD0] * UB[0], c[UDUD1] * UB[1], c[UDUD1] * UB[2]};
+  T cx[3], cy[3], cz[3], t[3];
+  frame_cols(x, y, z, cx, cy, cz);
+  rot_dip(FA, cx, cy, cz, t);
+  fldI[0] += t[0]; fldI[1] += t[1]; fldI[2] += t[2];
+}
+
 }  // namespace admp

@@ -136,10 +136,17 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   }
   for (int t = threadIdx.x; t < 16 * 16 * kBrickRow; t += 256) tile[t] = 0.0;
   __syncthreads();
-  const int end = brick_start[blockIdx.x + 1];
-  for (int k = brick_start[blockIdx.x] + threadIdx.x; k < end; k += 256) {
+  // Entries arrive in atom order, so neighbours in the list are neighbours in space (O, H, H of one molecule: stencils
+  // that share most of their 216 points).  Side by side in a wavefront they would add to the SAME tile words in the same
+  // instruction, which the LDS serialises; the list is therefore read transposed -- lane l of the wavefront's pass p takes
+  // entry l * rows + p, so the 64 entries of one instruction are `rows` (about 9) list positions apart.
+  const int beg = brick_start[blockIdx.x], cnt = brick_start[blockIdx.x + 1] - beg;
+  const int rows = (cnt + 63) >> 6, lane = threadIdx.x & 63;
+  for (int pass = threadIdx.x >> 6; pass < rows; pass += 4) {
+    const int e = lane * rows + pass;
+    if (e >= cnt) continue;
     T r[3], Q[9];
-    site_qtot(sites[entries[k]], lpol, r, Q);
+    site_qtot(sites[entries[beg + e]], lpol, r, Q);
     Stencil<T> st;
     st.init(g, r);
     T c1[3], c2[6];
@@ -525,19 +532,23 @@ __device__ __forceinline__ void zcol_weights(const Stencil<T>& st, int c, T w[4]
     if (k == c) { w[0] = st.M[2][k]; w[1] = st.D1[2][k]; w[2] = st.D2[2][k]; w[3] = st.D3[2][k]; }
 }
 
-template <class T>
+template <class T, bool ERECIP>
 __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* __restrict__ sites, int lpol,
                                                          RecipGeom<T> g, const T* __restrict__ phi,
                                                          T* __restrict__ pot, T* __restrict__ grad,
                                                          const int* __restrict__ list, T* __restrict__ fld,
-                                                         FieldFin<T> ff) {
-  const int t = blockIdx.x * kGatherBlock + threadIdx.x;
-  const int slot = t >> 3, a = t & 7;
+                                                         FieldFin<T> ff, double* e_recip) {
+  // XCD-aware block order: consecutive atoms (neighbours in space when the caller's order is) stay on one XCD, so a phi
+  // line is pulled into ONE L2 instead of all eight (measured L2-fabric traffic of this kernel: 629 MB for a 67 MB mesh)
+  const long blk = xcd_block(blockIdx.x, (unsigned)((8l * na + kGatherBlock - 1) / kGatherBlock));
+  const long t = (blk < 0 ? 8l * na : blk * kGatherBlock) + threadIdx.x;
+  const int slot = (int)(t >> 3), a = (int)(t & 7);
   const int i = slot < na ? (list ? list[slot] : slot) : na;
   T F[NF];
 #pragma unroll
   for (int k = 0; k < NF; ++k) F[k] = T(0);
   T r[3] = {0, 0, 0}, Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  T er = T(0);
   if (slot < na) {
     site_qtot(sites[i], lpol, r, Q);
     if (a < 6) {
@@ -559,6 +570,14 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* 
     if (grad) {
       grad[3 * i] += gr[0]; grad[3 * i + 1] += gr[1]; grad[3 * i + 2] += gr[2];
     }
+    if (ERECIP) {       // the mesh energy is a quadratic form of the multipoles: E = 1/2 sum_h Q_h dE/dQ_h
+#pragma unroll
+      for (int k = 0; k < 9; ++k) er += Q[k] * P[k];
+    }
+  }
+  if (ERECIP) {
+    const double e = block_reduce_sum<kGatherBlock>((double)er);
+    if (threadIdx.x == 0) atomicAdd(&e_recip[(blockIdx.x >> 3) & (E_PARTS - 1)], 0.5 * e);
   }
   if (ff.fmax_bits) {   // kernel-uniform
     double fm = 0.0;
@@ -577,11 +596,15 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* 
 template <class T>
 __global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Site<T>* __restrict__ sites,
                                                                RecipGeom<T> g, const T* __restrict__ phi,
-                                                               T* __restrict__ fld, const int* __restrict__ list) {
+                                                               T* __restrict__ fld, const int* __restrict__ list,
+                                                               const int* __restrict__ n_dev,
+                                                               const int* __restrict__ add_to) {
   phi += (size_t)blockIdx.y * ((size_t)g.nloc0 * g.K[1] * g.K[2]);            // batch: same atoms, another mesh
   fld += (size_t)blockIdx.y * 3 * na;
-  const int t = blockIdx.x * kGatherBlock + threadIdx.x;
-  const int slot = t >> 3, a = t & 7;
+  if (n_dev) na = min(na, *n_dev);
+  const long blk = xcd_block(blockIdx.x, (unsigned)((8l * na + kGatherBlock - 1) / kGatherBlock));
+  const long t = (blk < 0 ? 8l * na : blk * kGatherBlock) + threadIdx.x;
+  const int slot = (int)(t >> 3), a = (int)(t & 7);
   const int i = slot < na ? (list ? list[slot] : slot) : na;
   T f[3] = {0, 0, 0};
   if (slot < na && a < 6) {
@@ -595,10 +618,29 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Sit
   f[0] = group8_sum(f[0]); f[1] = group8_sum(f[1]); f[2] = group8_sum(f[2]);
   if (slot < na && a == 0) {
     const T* A = g.Aop;
+    if (add_to) {      // compact rows (incremental SCF): accumulate into the owning atom's entry
+      T* o = fld + 3 * (size_t)add_to[slot];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) fld[3 * i + k] = A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
+      for (int k = 0; k < 3; ++k) o[k] += A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fld[3 * i + k] = A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
+    }
   }
 }
+
+template <class T>
+__global__ __launch_bounds__(256) void k_mesh_add(long n, T* __restrict__ a, const T* __restrict__ b) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) a[t] += b[t];
+}
+template <class T>
+void launch_mesh_add(hipStream_t st, long n, T* a, const T* b) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  k_mesh_add<T><<<(int)blocks, 256, 0, st>>>(n, a, b);
+}
+template void launch_mesh_add<float>(hipStream_t, long, float*, const float*);
+template void launch_mesh_add<double>(hipStream_t, long, double*, const double*);
 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 
@@ -717,13 +759,19 @@ void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipG
 }
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad, const int* list, T* fld, const FieldFin<T>& ff) {
-  k_gather<T><<<nblk(na * 8, kGatherBlock), kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff);
+                   T* grad, const int* list, T* fld, const FieldFin<T>& ff, double* e_recip) {
+  const unsigned grid = xcd_grid((unsigned)nblk(na * 8, kGatherBlock));
+  if (e_recip)
+    k_gather<T, true><<<grid, kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
+  else
+    k_gather<T, false><<<grid, kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
 }
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
-                         const int* list, int nb) {
-  k_gather_field<T><<<dim3(nblk(na * 8, kGatherBlock), nb), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list);
+                         const int* list, int nb, const int* n_dev, const int* add_to) {
+  if (na <= 0) return;
+  k_gather_field<T><<<dim3(xcd_grid((unsigned)nblk(na * 8, kGatherBlock)), nb), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list,
+                                                                                                      n_dev, add_to);
 }
 #define INST(T)                                                                                                       \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
@@ -732,9 +780,9 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
-                                 const int*, T*, const FieldFin<T>&);                                                   \
+                                 const int*, T*, const FieldFin<T>&, double*);                                          \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
-                                       const int*, int);                                                              \
+                                       const int*, int, const int*, const int*);                                      \
   template void launch_kspace_virial<T>(hipStream_t, const int*, const double*, double, double, int, int, const T*,   \
                                         double*);                                                                     \
   template void launch_gather_virial<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, double*, \

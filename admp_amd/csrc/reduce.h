@@ -47,4 +47,15 @@ __device__ __forceinline__ double block_reduce_max(double v) {
   return r;
 }
 
+// XCD-aware block order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, each with
+// its own L2; remapping block b -> (b % 8) * ceil(n/8) + b / 8 gives every XCD one contiguous range of rows, so the
+// partner rows gathered by neighbouring workgroups are shared in that XCD's L2 instead of being fetched by all eight.
+__device__ __forceinline__ long xcd_block(unsigned b, unsigned n) {
+  const unsigned per = (n + 7u) / 8u;
+  if ((b >> 3) >= per) return -1;          // grid sized for more rows than there are (device-side row count)
+  const unsigned m = (b & 7u) * per + (b >> 3);
+  return m < n ? (long)m : -1;
+}
+static inline unsigned xcd_grid(unsigned n) { return ((n + 7u) / 8u) * 8u; }
+
 }  // namespace admp

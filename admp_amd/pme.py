@@ -130,6 +130,20 @@ class ADMPPmeForce(HipForceBase):
         out[:, :nh] = q[:, :nh]
         return out
 
+    def _hint_pol_sites(self, pol, pol_t):
+        """ADMP_OPT_KEEP_POL_SITES: tell the library when the polarizabilities are the ones of the previous call (same torch
+        tensor, not written since / same numpy content), so that it keeps its list of polarizable sites."""
+        if isinstance(pol, torch.Tensor):
+            key = ('t', id(pol), pol.data_ptr(), pol._version, tuple(pol.shape))
+        else:
+            key = ('n', np.asarray(pol, dtype=np.float64).tobytes())
+        same = key == getattr(self, '_pol_key', None)
+        if same != getattr(self, '_pol_hint', None):
+            _lib.check(self._h, self._L.admp_set_option(self._h, _lib.OPT_KEEP_POL_SITES, int(same)), 'admp_set_option')
+            self._pol_hint = same
+        self._pol_key = key
+        self._pol_keep = pol          # keeps id() unique while cached
+
     def _evaluate(self, positions, box, pairs, Q_local, mScales, pol=None, tholes=None, pScales=None, dScales=None,
                   U_init=None, want_grad=True, want_dQ=False, maxiter=None, thresh=None):
         prev = self._enter_stream()
@@ -162,6 +176,7 @@ class ADMPPmeForce(HipForceBase):
         if self.lpol:
             pol_t = self._real(pol, (na,))
             th_t = self._real(tholes, (na,))
+            self._hint_pol_sites(pol, pol_t)
             pS, _ = self._harr('pS', pScales, ns)
             dS = self._harr('dS', dScales, ns)[0] if dScales is not None else pS
             U = (torch.zeros((na, 3), dtype=self._dtype, device=self._device) if U_init is None

@@ -63,9 +63,13 @@ int admp_set_ewald(admp_handle* h, double kappa, int K1, int K2, int K3, int lma
 
 /* behaviour switches that are not part of the reference's argument lists */
 enum {
-  ADMP_OPT_REFERENCE_KPOINTS = 1   /* value 1: build the reciprocal-space tables with the reference's literal k-point order
+  ADMP_OPT_REFERENCE_KPOINTS = 1,  /* value 1: build the reciprocal-space tables with the reference's literal k-point order
                                       (meshgrid(kz, kx, ky), admp/recip.py:339-340) instead of the axis-by-axis one; the
                                       two agree iff K1 = K2 = K3 on a cubic box.  Default 0. */
+  ADMP_OPT_KEEP_POL_SITES = 2      /* value 1: the caller vouches that the SET of polarizable sites {i : pol_i > 0} of the
+                                      following admp_pme_energy_grad calls is the one of the previous call (the values may
+                                      change); the library then keeps its list of those sites instead of rebuilding it in
+                                      every call.  Default 0 (rebuild every call).  Speed only, never results. */
 };
 int admp_set_option(admp_handle* h, int option, int value);
 

@@ -192,3 +192,38 @@ def test_numpy_pair_list_refilled_in_place(env):
     buf[5000 if len(full) > 6000 else 10] = buf[5000 if len(full) > 6000 else 10][::-1]   # a single interior row swapped (i > j: dropped)
     f.get_energy(pos, box, buf, par['Q_local'], par['mScales'])
     assert f.n_pairs == keep - 1
+
+
+@pytest.mark.parametrize('lpol', [False, True])
+def test_group_closing_kernel_matches_oracle(env, lpol, monkeypatch):
+    """k_finish_groups (one thread per molecule, used above 8192 atoms) forced at a size the oracle can do: energies,
+    gradient, dE/dQ_local; and the pull form on the same inputs gives the same numbers."""
+    from admp_amd.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    n_mol = 125
+    pos, box = S.synthetic_water_box(n_mol, seed=31)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, polarizable=lpol)
+    pairs = S.build_pairs(pos, box, 4.0)
+    out = {}
+    for mode, gmin in (('groups', '0'), ('pull', '100000000')):
+        monkeypatch.setenv('ADMP_FINISH_GROUPS_MIN', gmin)
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+        if lpol:
+            out[mode] = f.get_forces_and_dQ(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
+                                            par['pScales'], par['dScales']) + (f.energy_parts,)
+        else:
+            out[mode] = f.get_forces_and_dQ(pos, box, pairs, par['Q_local'], par['mScales']) + (f.energy_parts,)
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, lpol)
+    if lpol:
+        ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], par['pol'], par['tholes'],
+                                    par['pScales'], want_dQ=True)
+    else:
+        ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], want_dQ=True)
+    scale = max(abs(p) for p in ref['parts'])
+    for mode in ('groups', 'pull'):
+        E, G, dQ, parts = out[mode]
+        for got, want in zip(parts, ref['parts']):
+            assert abs(got - want) <= 1e-9 * scale, mode
+        assert rel(G, ref['grad']) < 1e-8 and rel(dQ, ref['dQ_local']) < 1e-8, mode
+    assert rel(out['groups'][1], out['pull'][1]) < 1e-12
