@@ -57,7 +57,7 @@ PROTOTYPES = {
 
 # stage codes of admp_stage (include/admp_hip.h)
 ST_SET_U, ST_PAIR_FIELD, ST_SPREAD, ST_FFT_YZ, ST_FFT_X, ST_KSPACE, ST_GATHER_FIELD, ST_FIELD_FINISH, ST_JACOBI, \
-    ST_PAIR_FULL, ST_GATHER, ST_FINISH = range(1, 13)
+    ST_PAIR_FULL, ST_GATHER, ST_FINISH, ST_MARK_IMPORTS, ST_HOME_LIST, ST_FIELD_MAX_DEV, ST_FINISH_DEV = range(1, 17)
 
 OPT_REFERENCE_KPOINTS = 1
 OPT_KEEP_POL_SITES = 2

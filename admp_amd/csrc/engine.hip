@@ -1244,6 +1244,35 @@ struct Engine : EngineBase {
       case ADMP_ST_PAIR_FULL: stage_pair_full((T*)a, (iarg && lpol) ? fld_pair.as<T>() : nullptr); break;
       case ADMP_ST_GATHER: stage_gather((const T*)a, (T*)b, (iarg && lpol) ? fld_recip.as<T>() : nullptr); break;
       case ADMP_ST_FINISH: ARG_CHECK(dout, "null"); stage_finish((T*)a, (T*)b, iarg ? E_SCF_RECIP : E_RECIP, dout); break;
+      case ADMP_ST_MARK_IMPORTS:
+        need_eval();
+        ARG_CHECK(a && snranks > 1 && ev.home, "MARK_IMPORTS is a slab stage");
+        launch_mark_imports(stream, ev.n_home, ev.home, nbr, top, ev.bases, X1 - X0, K[0], X0, snranks, (int*)a);
+        break;
+      case ADMP_ST_HOME_LIST:
+        need_eval();
+        ARG_CHECK(a && ev.home, "HOME_LIST is a slab stage");
+        HIP_TRY(hipMemcpyAsync(a, ev.home, sizeof(int) * (size_t)ev.n_home, hipMemcpyDeviceToDevice, stream));
+        break;
+      case ADMP_ST_FIELD_MAX_DEV: {
+        need_eval();
+        ARG_CHECK(a, "null");
+        TIMED("field_finish");
+        launch_field_finish<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
+                               (T)kappa, field.as<T>(), (unsigned long long*)a, ev.home);
+        break;
+      }
+      case ADMP_ST_FINISH_DEV: {
+        ARG_CHECK(b, "null");
+        launch_finish_only((T*)a, nullptr);
+        const int slot = iarg ? E_SCF_RECIP : E_RECIP;
+        double* o = (double*)b;
+        HIP_TRY(hipMemcpyAsync(o, Ed_cur() + E_REAL, sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(o + 1, Ed_cur() + slot, sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(o + 2, Ed_cur() + E_SELF, 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        ev.active = false;
+        break;
+      }
       default: throw Err{ADMP_E_ARG, "unknown stage"};
     }
   }

@@ -126,6 +126,11 @@ template <class T>
 void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
                       int* count);
 
+// slab decomposition: mark[j] <- 1 + owner rank for every atom the rank's kernels read without owning it (see
+// ADMP_ST_MARK_IMPORTS); bases = the per-atom stencil records of launch_prepare_sites (local x index in .x)
+void launch_mark_imports(hipStream_t st, int n_home, const int* home, const NbrTable& nb, const Topology& top,
+                         const int4* bases, int width, int K0, int X0, int nranks, int* mark);
+
 // ---- dft_kernels.hip: direct-DFT mesh convolution for mesh sizes rocFFT only does with Bluestein (dft_math.h)
 // tw = (cos, sin)(2 pi m / K[d]) tables of the three dimensions back to back (K[0] + K[1] + K[2] complex numbers)
 int dft_tile_cols(int N);

@@ -175,6 +175,46 @@ int build_ind_table(hipStream_t st, int na, const NbrTable& nb, const Site<T>* s
 template int build_ind_table<float>(hipStream_t, int, const NbrTable&, const Site<float>*, IndTable&, void**, size_t*);
 template int build_ind_table<double>(hipStream_t, int, const NbrTable&, const Site<double>*, IndTable&, void**, size_t*);
 
+// slab owner of global mesh plane gx: the s with floor(s K / N) <= gx < floor((s + 1) K / N)  (engine.hip update_slab)
+__device__ __forceinline__ int slab_owner(int gx, int K0, int N) {
+  int s = (int)(((long)gx * N) / K0);
+  while ((int)(((long)s * K0) / N) > gx) --s;
+  while ((int)(((long)(s + 1) * K0) / N) <= gx) ++s;
+  return s;
+}
+__global__ __launch_bounds__(256) void k_mark_imports(int n_home, const int* __restrict__ home, const int* __restrict__ rowptr,
+                                                      const int* __restrict__ col, Topology top,
+                                                      const int4* __restrict__ bases, int width, int K0, int X0, int N,
+                                                      int* __restrict__ mark) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int slot = (int)(t >> 3), sub = (int)(t & 7);
+  if (slot >= n_home) return;
+  const int i = home[slot];
+  auto visit = [&](int j) {
+    const int b = bases[j].x;                      // local plane index of j's stencil base, relative to this rank's X0
+    if (b < width) return;                         // home atom
+    int gx = b + X0;
+    if (gx >= K0) gx -= K0;
+    mark[j] = 1 + slab_owner(gx, K0, N);           // same value from every writer
+  };
+  for (int k = rowptr[i] + sub; k < rowptr[i + 1]; k += 8) visit(col[k] & kColMask);
+  if (sub == 0 && top.axis_type) {
+    const int type = top.axis_type[i];
+    if (type != NoAxisType) {
+      const int iz = top.axis_idx[3 * i], ix = top.axis_idx[3 * i + 1], iy = top.axis_idx[3 * i + 2];
+      if (iz >= 0) visit(iz);
+      if (type != Zonly && ix >= 0) visit(ix);
+      if ((type == ZBisect || type == ThreeFold) && iy >= 0) visit(iy);
+    }
+  }
+}
+void launch_mark_imports(hipStream_t st, int n_home, const int* home, const NbrTable& nb, const Topology& top,
+                         const int4* bases, int width, int K0, int X0, int nranks, int* mark) {
+  if (n_home <= 0) return;
+  k_mark_imports<<<(unsigned)(((long)n_home * 8 + 255) / 256), 256, 0, st>>>(n_home, home, nb.rowptr, nb.col, top, bases, width,
+                                                                         K0, X0, nranks, mark);
+}
+
 // one workgroup per kRowWindow rows = kRowWindow / W windows: bitonic network of (length << 10 | local index) in LDS,
 // stopped at span W so that every aligned W-chunk is sorted on its own (ascending)
 __global__ __launch_bounds__(256) void k_row_order(int na, const int* __restrict__ rowptr, int* __restrict__ order, int W) {

@@ -1,23 +1,36 @@
 """Multi-GPU evaluation of the PME path: 1-D slab decomposition along x, one process per GPU.
 
-The reference is single-device; this module is the multi-GPU layer of the MI355X build:
+The reference is single-device; this module is the multi-GPU layer of the MI355X build.  Every rank is
+handed the same full input arrays (the reference's calling convention), owns the mesh planes [X0, X1) and works on its
+"home" atoms (lowest B-spline stencil plane inside the slab).  The DATA PATH between the ranks is halo-only:
 
-    every rank holds all atoms' inputs, owns the mesh planes [X0, X1) and works on its "home" atoms
-    (lowest B-spline stencil plane inside the slab).  Per evaluation:
-      * real space   : pair kernel over the home rows only -- the i-grouped neighbour table evaluates each
-                       pair from the row atom's side, so no force is ever written to a remote atom;
-      * spread       : home atoms -> local mesh (slab + 5 ghost planes), ghost planes sent to the next rank;
-      * 3-D FFT      : batched 2-D r2c on the owned planes, all-to-all transpose (RCCL over xGMI: every
-                       GPU exchanges an equal block with each of the other N-1 peers), batched 1-D c2c
-                       along x, k-space multiply on the y-slab, and back;
-      * gather       : phi ghost planes fetched from the next rank, home atoms gathered;
-      * SCF          : max|field| by a scalar MAX all-reduce, new dipoles by a SUM all-reduce;
-      * result       : gradient and the four energies by SUM all-reduce.
+  * real space   : pair kernels over the home rows only -- the i-grouped neighbour table evaluates each pair from the
+                   row atom's side, so nothing is written to a remote atom;
+  * imports      : once per evaluation the library marks the atoms a rank reads without owning them (partners of its
+                   home rows, axis atoms of its home sites' frames: ADMP_ST_MARK_IMPORTS); the owners learn who needs
+                   what through one small all-to-all of index lists;
+  * spread       : home atoms -> local mesh (slab + 5 ghost planes), ghost planes sent to the next rank (point to point);
+  * 3-D FFT      : batched 2-D r2c on the owned planes, all-to-all transpose (RCCL over xGMI: every GPU exchanges an equal
+                   block with each of the other N-1 peers, all 7 links busy), batched 1-D c2c along x, k-space multiply on
+                   the y-slab, and back; blocks go through pre-allocated send / receive buffers, one collective each way;
+  * gather       : phi ghost planes fetched from the next rank, home atoms gathered;
+  * SCF          : max|field| reduced ON THE DEVICE (one MAX all-reduce of a device word, one host read per cycle); after
+                   a Jacobi step only the dipoles of the imported atoms travel (all-to-all-v of n_import x 3 reals);
+  * gradient     : contributions a rank made to atoms it does not own (local-frame adjoint of molecules that straddle a
+                   slab boundary) go back to the owners over the same lists; the four energies by one SUM all-reduce.
 
-`SlabPme` drives the staged C ABI (admp_stage_*, include/admp_hip.h) and is written against a small
-communicator interface so that the same code runs over torch.distributed (`TorchComm`: nccl = RCCL, or
-gloo with host staging) and over an in-process thread communicator (`ThreadComm`) used by the tests.
+With outputs='replicated' (default: the reference's API hands every caller the full arrays) the home rows of gradient
+and dipoles are finally summed over the ranks once per evaluation; with outputs='home' nothing proportional to the
+number of atoms is ever sent -- each rank returns its home rows (`home_atoms`), the form an MD driver that keeps the
+atoms distributed would use.  Not decomposed yet: dispersion PME and the Tang-Toennies term; the incremental SCF of the
+single-GPU path (engine.hip) is not used here.
+
+`SlabPme` drives the staged C ABI (admp_stage_*, include/admp_hip.h) and is written against a small communicator
+interface so that the same code runs over torch.distributed (`TorchComm`: nccl = RCCL, or gloo with host staging) and
+over an in-process thread communicator (`ThreadComm`) used by the tests.  Both count the bytes they send per label
+(`bytes_sent`) and, on request, time every collective with device events (`report`).
 """
+import collections
 import ctypes
 import threading
 
@@ -29,7 +42,52 @@ from .pme import ADMPPmeForce
 
 
 # ------------------------------------------------------------------------------------------ communicators
-class TorchComm:
+class _CommBase:
+    def _init_stats(self):
+        self.bytes_sent = collections.defaultdict(int)     # label -> bytes this rank sent to OTHER ranks
+        self.calls = collections.defaultdict(int)
+        self.profile = False
+        self._events = []
+        self._ms = collections.defaultdict(float)
+
+    def _count(self, label, nbytes):
+        self.bytes_sent[label] += int(nbytes)
+        self.calls[label] += 1
+
+    def _timed(self, label):
+        comm = self
+
+        class _T:
+            def __enter__(self_):
+                if comm.profile:
+                    self_.a = torch.cuda.Event(enable_timing=True)
+                    self_.b = torch.cuda.Event(enable_timing=True)
+                    self_.a.record()
+
+            def __exit__(self_, *exc):
+                if comm.profile:
+                    self_.b.record()
+                    comm._events.append((label, self_.a, self_.b))
+        return _T()
+
+    def report(self, steps=1):
+        """{label: ms per step} of the collectives since the last call (device-event time: includes waiting for peers)."""
+        torch.cuda.synchronize()
+        for label, a, b in self._events:
+            self._ms[label] += a.elapsed_time(b)
+        self._events = []
+        out = {k: round(v / max(steps, 1), 4) for k, v in sorted(self._ms.items())}
+        self._ms = collections.defaultdict(float)
+        return out
+
+    def reset_stats(self):
+        self.bytes_sent.clear()
+        self.calls.clear()
+        self._events = []
+        self._ms = collections.defaultdict(float)
+
+
+class TorchComm(_CommBase):
     """torch.distributed backend.  nccl (= RCCL on ROCm) works on device tensors directly; with gloo the
     tensors are staged through host memory (functional testing on one GPU / CPU only)."""
 
@@ -40,59 +98,67 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.native = dist.get_backend(group) == 'nccl'
+        self._init_stats()
 
-    def _host(self, t):
-        return t if self.native else t.cpu()
-
-    def all_reduce_sum(self, t):
-        if self.native:
-            self.dist.all_reduce(t, group=self.group)
-        else:
-            h = t.cpu()
-            self.dist.all_reduce(h, group=self.group)
-            t.copy_(h)
+    def all_reduce(self, t, op='sum', label='all_reduce'):
+        """in place on a device tensor"""
+        rop = self.dist.ReduceOp.SUM if op == 'sum' else self.dist.ReduceOp.MAX
+        # ring all-reduce: every rank sends 2 (N-1)/N of the buffer
+        self._count(label, 2 * (self.size - 1) * t.numel() * t.element_size() // max(self.size, 1))
+        with self._timed(label):
+            if self.native:
+                self.dist.all_reduce(t, op=rop, group=self.group)
+            else:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=rop, group=self.group)
+                t.copy_(h)
         return t
 
-    def all_reduce_max(self, x):
-        t = torch.tensor([x], dtype=torch.float64, device='cuda' if self.native else 'cpu')
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return float(t.item())
+    def all_to_all_v(self, recv, send, rsplits, ssplits, label='all_to_all'):
+        """flat 1-D buffers; segment t of `send` (ssplits[t] elements) goes to rank t, segment s of `recv` comes from s"""
+        self._count(label, (sum(ssplits) - ssplits[self.rank]) * send.element_size())
+        with self._timed(label):
+            if self.native:
+                self.dist.all_to_all_single(recv, send, output_split_sizes=list(rsplits), input_split_sizes=list(ssplits),
+                                            group=self.group)
+                return
+            so = np.concatenate([[0], np.cumsum(ssplits)]).astype(np.int64)
+            ro = np.concatenate([[0], np.cumsum(rsplits)]).astype(np.int64)
+            hs = send.cpu()
+            hr = torch.empty(recv.shape, dtype=recv.dtype)
+            ops = []
+            for p in range(self.size):
+                if p == self.rank:
+                    hr[ro[p]:ro[p + 1]] = hs[so[p]:so[p + 1]]
+                    continue
+                if ssplits[p]:
+                    ops.append(self.dist.P2POp(self.dist.isend, hs[so[p]:so[p + 1]].contiguous(), p, self.group))
+                if rsplits[p]:
+                    ops.append(self.dist.P2POp(self.dist.irecv, hr[ro[p]:ro[p + 1]], p, self.group))
+            if ops:
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+            recv.copy_(hr)
 
-    def all_to_all(self, recv, send):
-        """recv[s] <- the block rank s addressed to this rank (send[t] goes to rank t)."""
-        if self.native:
-            self.dist.all_to_all(recv, send, group=self.group)
-            return
-        ops, hrecv = [], [torch.empty(r.shape, dtype=r.dtype) for r in recv]
-        for s in range(self.size):
-            if s == self.rank:
-                hrecv[s].copy_(send[s])
-                continue
-            ops.append(self.dist.P2POp(self.dist.isend, send[s].cpu(), s, self.group))
-            ops.append(self.dist.P2POp(self.dist.irecv, hrecv[s], s, self.group))
-        if ops:
-            for w in self.dist.batch_isend_irecv(ops):
-                w.wait()
-        for r, h in zip(recv, hrecv):
-            r.copy_(h)
-
-    def shift(self, send, recv, to_next):
+    def shift(self, send, recv, to_next, label='shift'):
         """ring shift: send to rank+1 (to_next) or rank-1, receive from the opposite neighbour."""
         if self.size == 1:
             recv.copy_(send)
             return
+        self._count(label, send.numel() * send.element_size())
         dst = (self.rank + (1 if to_next else -1)) % self.size
         src = (self.rank - (1 if to_next else -1)) % self.size
-        s = send.contiguous() if self.native else send.cpu().contiguous()
-        r = recv if self.native else torch.empty(recv.shape, dtype=recv.dtype)
-        ops = [self.dist.P2POp(self.dist.isend, s, dst, self.group), self.dist.P2POp(self.dist.irecv, r, src, self.group)]
-        for w in self.dist.batch_isend_irecv(ops):
-            w.wait()
-        if not self.native:
-            recv.copy_(r)
+        with self._timed(label):
+            s = send.contiguous() if self.native else send.cpu().contiguous()
+            r = recv if self.native else torch.empty(recv.shape, dtype=recv.dtype)
+            ops = [self.dist.P2POp(self.dist.isend, s, dst, self.group), self.dist.P2POp(self.dist.irecv, r, src, self.group)]
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+            if not self.native:
+                recv.copy_(r)
 
 
-class ThreadComm:
+class ThreadComm(_CommBase):
     """In-process communicator: N python threads (one SlabPme each, all on the same GPU) exchange tensors
     through a shared mailbox guarded by a barrier.  Test infrastructure for the decomposition logic."""
 
@@ -104,6 +170,7 @@ class ThreadComm:
 
     def __init__(self, world, rank):
         self.w, self.rank, self.size = world, rank, world.size
+        self._init_stats()
 
     def _exchange(self, item):
         torch.cuda.current_stream().synchronize()
@@ -113,20 +180,27 @@ class ThreadComm:
         self.w.barrier.wait()
         return got
 
-    def all_reduce_sum(self, t):
-        parts = self._exchange(t.clone())
-        t.copy_(torch.stack(parts).sum(dim=0))
+    def all_reduce(self, t, op='sum', label='all_reduce'):
+        self._count(label, 2 * (self.size - 1) * t.numel() * t.element_size() // max(self.size, 1))
+        parts = torch.stack(self._exchange(t.clone()))
+        t.copy_(parts.sum(dim=0) if op == 'sum' else parts.max(dim=0).values)
         return t
 
-    def all_reduce_max(self, x):
-        return max(self._exchange(float(x)))
-
-    def all_to_all(self, recv, send):
-        got = self._exchange([s.clone() for s in send])
+    def all_to_all_v(self, recv, send, rsplits, ssplits, label='all_to_all'):
+        self._count(label, (sum(ssplits) - ssplits[self.rank]) * send.element_size())
+        got = self._exchange((send.clone(), list(ssplits)))
+        off = 0
         for s in range(self.size):
-            recv[s].copy_(got[s][self.rank])
+            buf, sp = got[s]
+            o = sum(sp[:self.rank])
+            n = sp[self.rank]
+            assert n == rsplits[s]
+            recv[off:off + n] = buf[o:o + n]
+            off += n
 
-    def shift(self, send, recv, to_next):
+    def shift(self, send, recv, to_next, label='shift'):
+        if self.size > 1:
+            self._count(label, send.numel() * send.element_size())
         got = self._exchange(send.clone())
         src = (self.rank - (1 if to_next else -1)) % self.size
         recv.copy_(got[src])
@@ -140,12 +214,19 @@ def slab_bounds(K, size):
 
 class SlabPme(ADMPPmeForce):
     """ADMPPmeForce whose evaluation is spread over the ranks of `comm` (SPMD: every rank makes the same
-    get_energy / get_forces call with the same full arrays and receives the same full results)."""
+    get_energy / get_forces call with the same full input arrays).  outputs='replicated': every rank receives the full
+    gradient / dipoles; outputs='home': only the rows of `home_atoms` are valid on a rank (no O(Na) communication)."""
 
     GHOST = 5
 
-    def __init__(self, comm, box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol=False, device=None):
+    def __init__(self, comm, box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol=False, device=None,
+                 outputs='replicated'):
+        if outputs not in ('replicated', 'home'):
+            raise ValueError("outputs must be 'replicated' or 'home'")
         self.comm = comm
+        self.outputs = outputs
+        self.home_atoms = None
+        self.n_import = 0
         super().__init__(box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol, device)
 
     def refresh_calculators(self):
@@ -166,43 +247,76 @@ class SlabPme(ADMPPmeForce):
             K2 = int(self.K3)
             dev, dt = self._device, self._dtype
             nx, ny = X1 - X0, Y1 - Y0
+            xs, ys = slab_bounds(K0, self.comm.size), slab_bounds(K1, self.comm.size)
+            # transposes: block (x in slab s) x (y in slab t) x K2h complex numbers travels between ranks s and t
+            fwd_send = [nx * (y1 - y0) * K2h * 2 for (y0, y1) in ys]          # my x-slab, peer's y-slab
+            fwd_recv = [(x1 - x0) * ny * K2h * 2 for (x0, x1) in xs]          # peer's x-slab, my y-slab
             self._bufs = dict(key=key, nx=nx, ny=ny, K0=K0, K1=K1, K2h=K2h,
                               mesh=torch.empty((nloc, K1, K2), dtype=dt, device=dev),
                               spec=torch.empty((nx, K1, K2h, 2), dtype=dt, device=dev),
                               tbuf=torch.empty((K0, ny, K2h, 2), dtype=dt, device=dev),
+                              pack=torch.empty(sum(fwd_send), dtype=dt, device=dev),
                               ghost=torch.empty((ghost, K1, K2), dtype=dt, device=dev),
-                              xs=slab_bounds(K0, self.comm.size), ys=slab_bounds(K1, self.comm.size))
+                              xs=xs, ys=ys, fwd_send=fwd_send, fwd_recv=fwd_recv,
+                              mark=torch.zeros(self.n_atoms, dtype=torch.int32, device=dev),
+                              fmax=torch.zeros(1, dtype=torch.float64, device=dev),
+                              e4=torch.zeros(4, dtype=torch.float64, device=dev))
         return self._bufs
 
     def _recip(self, scf):
         """spread -> distributed r2c -> G multiply (+ energy) -> distributed c2r; mesh then holds phi incl. ghosts."""
         B, c = self._buffers(), self.comm
-        mesh, spec, tbuf, nx = B['mesh'], B['spec'], B['tbuf'], B['nx']
+        mesh, spec, tbuf, pack, nx = B['mesh'], B['spec'], B['tbuf'], B['pack'], B['nx']
         self._stage(_lib.ST_SPREAD, mesh)
         if c.size > 1:
             # stencil overhang: my ghost planes are the next rank's first planes
-            c.shift(mesh[nx:nx + self.GHOST], B['ghost'], to_next=True)
+            c.shift(mesh[nx:nx + self.GHOST], B['ghost'], to_next=True, label='ghost_planes')
             mesh[:self.GHOST] += B['ghost']
             self._stage(_lib.ST_FFT_YZ, mesh, spec, 0)
-            send = [spec[:, y0:y1].contiguous() for (y0, y1) in B['ys']]
-            recv = [torch.empty((x1 - x0, B['ny'], B['K2h'], 2), dtype=spec.dtype, device=spec.device) for (x0, x1) in B['xs']]
-            c.all_to_all(recv, send)
-            torch.cat(recv, dim=0, out=tbuf)
+            off = 0
+            for (y0, y1), n in zip(B['ys'], B['fwd_send']):          # pack: one strided copy per peer, no allocation
+                pack[off:off + n].view(nx, y1 - y0, B['K2h'], 2).copy_(spec[:, y0:y1])
+                off += n
+            # the rows of tbuf that belong to peer s are contiguous: receive straight into the transposed layout
+            c.all_to_all_v(tbuf.view(-1), pack, B['fwd_recv'], B['fwd_send'], label='transpose')
             self._stage(_lib.ST_FFT_X, tbuf, None, 0)
             self._stage(_lib.ST_KSPACE, tbuf, None, 1 if scf else 0)
             self._stage(_lib.ST_FFT_X, tbuf, None, 1)
-            send = [tbuf[x0:x1].contiguous() for (x0, x1) in B['xs']]
-            recv = [torch.empty((nx, y1 - y0, B['K2h'], 2), dtype=spec.dtype, device=spec.device) for (y0, y1) in B['ys']]
-            c.all_to_all(recv, send)
-            torch.cat(recv, dim=1, out=spec)
+            c.all_to_all_v(pack, tbuf.view(-1), B['fwd_send'], B['fwd_recv'], label='transpose')
+            off = 0
+            for (y0, y1), n in zip(B['ys'], B['fwd_send']):
+                spec[:, y0:y1].copy_(pack[off:off + n].view(nx, y1 - y0, B['K2h'], 2))
+                off += n
             self._stage(_lib.ST_FFT_YZ, mesh, spec, 1)
             # phi halo: my ghost planes hold the next rank's first planes
-            c.shift(mesh[:self.GHOST], B['ghost'], to_next=False)
+            c.shift(mesh[:self.GHOST], B['ghost'], to_next=False, label='ghost_planes')
             mesh[nx:nx + self.GHOST] = B['ghost']
         else:
             self._stage(_lib.ST_FFT_YZ, mesh, spec, 0)
             self._stage(_lib.ST_KSPACE, spec, None, 1 if scf else 0)
             self._stage(_lib.ST_FFT_YZ, mesh, spec, 1)
+
+    def _exchange_lists(self, B):
+        """Import set of this evaluation: the atoms this rank reads without owning them, grouped by owner; and, from the
+        peers' requests, the home atoms of this rank that others import.  Two small collectives, one host read."""
+        c = self.comm
+        mark = B['mark']
+        mark.zero_()
+        self._stage(_lib.ST_MARK_IMPORTS, mark)
+        imp = torch.nonzero(mark).squeeze(1)                        # ascending atom index
+        owner = (mark[imp] - 1).to(torch.int64)
+        order = torch.sort(owner, stable=True).indices
+        imp = imp[order].contiguous()                               # grouped by owner, ascending inside a group
+        counts = torch.bincount(owner, minlength=c.size).to(torch.int64)
+        req_counts = torch.empty_like(counts)
+        ones = [1] * c.size
+        c.all_to_all_v(req_counts, counts, ones, ones, label='halo_lists')
+        both = torch.stack([counts, req_counts]).cpu().tolist()     # the one host read
+        imp_counts, req_counts = [int(x) for x in both[0]], [int(x) for x in both[1]]
+        req = torch.empty(sum(req_counts), dtype=torch.int32, device=self._device)
+        c.all_to_all_v(req, imp.to(torch.int32), req_counts, imp_counts, label='halo_lists')
+        self.n_import = int(imp.numel())
+        return imp, imp_counts, req.to(torch.int64), req_counts
 
     # -- the evaluation --------------------------------------------------------------------------------------
     def _evaluate_on_stream(self, positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales, U_init,
@@ -233,21 +347,44 @@ class SlabPme(ADMPPmeForce):
         self.n_home = int(nhome.value)
         B = self._buffers()
         mesh = B['mesh']
+        multi = c.size > 1
+        if multi:
+            imp, imp_counts, req, req_counts = self._exchange_lists(B)
+            home = torch.empty(self.n_home, dtype=torch.int32, device=self._device)
+            self._stage(_lib.ST_HOME_LIST, home)
+            self.home_atoms = home.to(torch.int64)
+            w3i, w3r = [3 * n for n in imp_counts], [3 * n for n in req_counts]
+
+            def pull_import_dipoles(U):
+                """U[imports] <- the owners' current values: n_import x 3 reals per rank, never (Na, 3)"""
+                send = U.index_select(0, req).reshape(-1)
+                recv = torch.empty(3 * self.n_import, dtype=U.dtype, device=U.device)
+                c.all_to_all_v(recv, send, w3i, w3r, label='halo_dipoles')
+                U.index_copy_(0, imp, recv.view(-1, 3))
+                self._stage(_lib.ST_SET_U, U)
+            if self.lpol and U_init is not None:
+                pull_import_dipoles(U)      # the result must not depend on rows of U_init this rank does not own
+        else:
+            self.home_atoms = torch.arange(na, device=self._device)
         phi_valid, cyc, flag, done = False, 0, True, False
         grad = torch.empty((na, 3), dtype=self._dtype, device=self._device)
+        fmax_d = B['fmax']
+
+        def field_max():
+            """max |dE/dU| over all ranks' polarizable home atoms: device word, one MAX all-reduce, one host read"""
+            fmax_d.zero_()
+            self._stage(_lib.ST_FIELD_MAX_DEV, fmax_d)
+            if multi:
+                c.all_reduce(fmax_d, op='max', label='scf_max')
+            return float(fmax_d.item())
 
         def jacobi(U):
-            if c.size > 1:
-                Unew = torch.zeros_like(U)
-                self._stage(_lib.ST_JACOBI, Unew)
-                c.all_reduce_sum(Unew)
-                self._stage(_lib.ST_SET_U, Unew)
-                return Unew
-            self._stage(_lib.ST_JACOBI, U)
+            self._stage(_lib.ST_JACOBI, U)                          # home rows of U (and their packed copies) in place
+            if multi:
+                pull_import_dipoles(U)      # only the dipoles somebody imports travel, instead of all-reducing (Na, 3)
             return U
 
         if self.lpol:
-            fm = (ctypes.c_double * 1)()
             start = 0
             if getattr(self, '_warm_regime', False):
                 # steady-state regime (previous call passed its first check): first cycle with the full kernels, which
@@ -255,8 +392,7 @@ class SlabPme(ADMPPmeForce):
                 self._stage(_lib.ST_PAIR_FULL, grad, None, 1)
                 self._recip(scf=True)
                 self._stage(_lib.ST_GATHER, mesh, grad, 1)
-                self._stage(_lib.ST_FIELD_FINISH, dout=fm)
-                if c.all_reduce_max(fm[0]) < thresh:
+                if field_max() < thresh:
                     phi_valid = done = True
                 else:
                     U = jacobi(U)
@@ -266,8 +402,7 @@ class SlabPme(ADMPPmeForce):
                 self._stage(_lib.ST_PAIR_FIELD)
                 self._recip(scf=True)
                 self._stage(_lib.ST_GATHER_FIELD, mesh)
-                self._stage(_lib.ST_FIELD_FINISH, dout=fm)
-                if c.all_reduce_max(fm[0]) < thresh:
+                if field_max() < thresh:
                     phi_valid = True
                     break
                 U = jacobi(U)
@@ -279,15 +414,34 @@ class SlabPme(ADMPPmeForce):
             if not phi_valid:
                 self._recip(scf=False)
             self._stage(_lib.ST_GATHER, mesh, grad)
-        E = (ctypes.c_double * 4)()
-        self._stage(_lib.ST_FINISH, grad if want_grad else None, None, 1 if phi_valid else 0, E)
-        Et = torch.tensor(list(E), dtype=torch.float64, device=self._device)
-        if c.size > 1:
-            c.all_reduce_sum(Et)
+        e4 = B['e4']
+        self._stage(_lib.ST_FINISH_DEV, grad if want_grad else None, e4, 1 if phi_valid else 0)
+        if multi:
+            c.all_reduce(e4, op='sum', label='energies')
             if want_grad:
-                c.all_reduce_sum(grad)
-        Eh = Et.cpu().tolist()
-        torch.cuda.current_stream(self._device).synchronize()
+                # what this rank added to atoms it does not own (frame adjoint across a slab boundary) goes to the owners
+                send = grad.index_select(0, imp).reshape(-1)
+                recv = torch.empty(3 * int(req.numel()), dtype=grad.dtype, device=grad.device)
+                c.all_to_all_v(recv, send, w3r, w3i, label='halo_gradient')
+                grad.index_add_(0, req, recv.view(-1, 3))
+            if self.outputs == 'replicated':
+                # the reference's API returns full arrays to every caller: one sum over the ranks' home rows per evaluation
+                def assemble(x):
+                    full = torch.zeros_like(x)
+                    full.index_copy_(0, self.home_atoms, x.index_select(0, self.home_atoms))
+                    return c.all_reduce(full, op='sum', label='replicate_outputs')
+                if want_grad:
+                    grad = assemble(grad)
+                if self.lpol:
+                    U = assemble(U)
+            else:
+                keep = torch.zeros(na, dtype=torch.bool, device=self._device)
+                keep[self.home_atoms] = True
+                if want_grad:
+                    grad = grad * keep[:, None]
+                if self.lpol:
+                    U = U * keep[:, None]
+        Eh = e4.cpu().tolist()
         self.energy_parts = tuple(Eh)
         out = {'E': np.float64(sum(Eh))}
         if self.lpol:

@@ -433,7 +433,10 @@ def slab_child(outpath):
     comm = TorchComm()
     f3, a3 = make_force(w3, comm)
     fr3 = ThermalFrames(w3, torch.device('cuda', local))
-    dt3, rep3, cyc3 = run_timed(f3, a3, 5, 2, fr3, dist.barrier, only=None)
+    run_timed(f3, a3, 2, 0, fr3, dist.barrier, only=False)          # warm-up (plans, buffers, RCCL channels)
+    comm.reset_stats()
+    comm.profile = True                                              # device events around every collective
+    dt3, rep3, cyc3 = run_timed(f3, a3, 5, 0, fr3, dist.barrier, only=None)
     dt3 = reduce_max_seconds(dt3, dist, rdev)
     if rank == 0:
         res = {'workload': w3['desc'], 'decomposition': 'x-slab over %d GPUs (RCCL all-to-all transposes, ghost-plane '
@@ -443,8 +446,9 @@ def slab_child(outpath):
                'geometry': 'moving (thermal frames)', 'dtype': 'f32',
                'rank0_kernel_ms_per_step': {k: round(v[0] / 5, 4) for k, v in sorted(rep3.items())}}
         res.update(cyc3)
-        if hasattr(comm, 'report'):
-            res['rank0_collective_ms_per_step'] = comm.report(5)
+        res['rank0_collective_ms_per_step'] = comm.report(5)
+        res['rank0_bytes_sent_per_step'] = {k: int(v / 5) for k, v in sorted(comm.bytes_sent.items())}
+        res['rank0_import_atoms'] = int(f3.n_import)
         with open(outpath, 'w') as fh:
             json.dump(res, fh)
     dist.barrier()

@@ -201,8 +201,17 @@ enum {
                                 iarg 1: the real-space dE/dU is produced as well (speculative first SCF cycle)      */
   ADMP_ST_GATHER = 11,       /* a = phi mesh, b = gradient: adds reciprocal dE/dr, dE/dQ of the home atoms;
                                 iarg 1: the reciprocal dE/dU is produced as well                                   */
-  ADMP_ST_FINISH = 12        /* a = gradient (or NULL), b = dE/dQ_local (or NULL), iarg = which reciprocal slot,
+  ADMP_ST_FINISH = 12,       /* a = gradient (or NULL), b = dE/dQ_local (or NULL), iarg = which reciprocal slot,
                                 dout[4] = this rank's (real, recip, self, penalty) energies                        */
+  /* halo-only data path (no host read-back in any of these; the caller reduces / exchanges the device words): */
+  ADMP_ST_MARK_IMPORTS = 13, /* a = int32 mark[Na], zeroed by the caller: mark[j] <- 1 + owner rank of every atom j that
+                                is NOT a home atom of this rank but is read by its kernels: partner of a home row in the
+                                neighbour table, or axis atom of a home site's local frame (the rank's "import" set)  */
+  ADMP_ST_HOME_LIST = 14,    /* a = int32 out[n_home]: the home atoms of this evaluation                             */
+  ADMP_ST_FIELD_MAX_DEV = 15,/* a = device double, zeroed by the caller: max |dE/dU| over this rank's polarizable home
+                                atoms (what ADMP_ST_FIELD_FINISH returns through the host)                            */
+  ADMP_ST_FINISH_DEV = 16    /* a = gradient (or NULL), b = device double[4] <- this rank's (real, recip, self,
+                                penalty), iarg = which reciprocal slot; closes the evaluation like ADMP_ST_FINISH      */
 };
 int admp_stage(admp_handle* h, int what, void* a, void* b, int iarg, double* dout);
 

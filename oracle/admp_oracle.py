@@ -27,6 +27,12 @@ SQRT_PI = 1.7724538509055159        # admp/recip.py:19
 
 F64 = torch.float64
 
+# Memory control for large systems (the reference materialises (Na, 216, 9) and (Np, ~100) intermediates, 16 GB at 1M atoms):
+# when set, spread_Q works through the atoms and pme_real through the pairs in chunks of this many rows, and
+# torch.utils.checkpoint recomputes a chunk's intermediates in the backward pass.  Same arithmetic, bounded memory.
+CHUNK_ATOMS = None
+CHUNK_PAIRS = None
+
 
 def _t(x):
     if isinstance(x, torch.Tensor):
@@ -397,8 +403,26 @@ def _scale_lookup(scales, nbonds):
 
 def pme_real(positions, box, pairs, Q_global, U_harm, pol, tholes, mScales, pScales,
              covalent_map, kappa, lmax, lpol):
-    """admp/pme.py:628-729."""
+    """admp/pme.py:628-729; chunked over the pairs if CHUNK_PAIRS is set."""
     pairs = filter_pairs(pairs)
+    if CHUNK_PAIRS is not None and len(pairs) > CHUNK_PAIRS:
+        from torch.utils.checkpoint import checkpoint
+        tot = torch.zeros((), dtype=F64)
+        dummy = torch.zeros(1, dtype=F64)
+        Uh = U_harm if U_harm is not None else dummy
+        for p0 in range(0, len(pairs), CHUNK_PAIRS):
+            chunk = pairs[p0:p0 + CHUNK_PAIRS]
+            tot = tot + checkpoint(
+                lambda pos, b, Qg, Uu, chunk=chunk: _pme_real_rows(pos, b, chunk, Qg, Uu if U_harm is not None else None, pol, tholes,
+                                                      mScales, pScales, covalent_map, kappa, lmax, lpol),
+                positions, box, Q_global, Uh, use_reentrant=False)
+        return tot
+    return _pme_real_rows(positions, box, pairs, Q_global, U_harm, pol, tholes, mScales, pScales, covalent_map, kappa,
+                          lmax, lpol)
+
+
+def _pme_real_rows(positions, box, pairs, Q_global, U_harm, pol, tholes, mScales, pScales,
+                   covalent_map, kappa, lmax, lpol):
     nb = pair_nbonds(covalent_map, pairs)
     pi = torch.as_tensor(pairs[:, 0])
     pj = torch.as_tensor(pairs[:, 1])
@@ -474,7 +498,20 @@ def kpts_integer(K):
 
 
 def spread_Q(positions, box, Q, K, lmax):
-    """Mesh of B-spline-spread multipoles (admp/recip.py:215-329, 368-392)."""
+    """Mesh of B-spline-spread multipoles (admp/recip.py:215-329, 368-392); chunked over the atoms if CHUNK_ATOMS is set."""
+    na = positions.shape[0]
+    if CHUNK_ATOMS is None or na <= CHUNK_ATOMS:
+        return _spread_rows(positions, box, Q, K, lmax)
+    from torch.utils.checkpoint import checkpoint
+    mesh = None
+    for a0 in range(0, na, CHUNK_ATOMS):
+        sl = slice(a0, min(na, a0 + CHUNK_ATOMS))
+        part = checkpoint(lambda p, b, q: _spread_rows(p, b, q, K, lmax), positions[sl], box, Q[sl], use_reentrant=False)
+        mesh = part if mesh is None else mesh + part
+    return mesh
+
+
+def _spread_rows(positions, box, Q, K, lmax):
     N = torch.as_tensor(np.asarray(K, dtype=np.float64))
     box_inv = torch.linalg.inv(box)
     Nstar = (N.reshape(1, 3) * box_inv).T                      # recip.py:52

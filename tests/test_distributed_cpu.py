@@ -1,6 +1,6 @@
-"""The N > 1 leg of bench.py on CPU: two gloo ranks, barrier + max-over-ranks timing, aggregate value.
-(The PME path itself is "replicas only" across GPUs this round -- DESIGN.md -- so the only collective
-is the timing reduction.)"""
+"""The N > 1 plumbing on CPU (gloo): bench.py's barrier + max-over-ranks timing and aggregate value, and the
+communicator primitives of the slab-decomposed path (admp_amd/parallel.py TorchComm: all-reduce, all-to-all-v with the
+transposes' buffer layout and with ragged halo lists, ring shifts, byte accounting)."""
 import os
 import subprocess
 import sys
@@ -49,8 +49,9 @@ COMM_WORKER = textwrap.dedent('''
     r, n = c.rank, c.size
     # sum / max reductions
     t = torch.full((4,), float(r + 1), dtype=torch.float64)
-    assert c.all_reduce_sum(t).tolist() == [float(sum(range(1, n + 1)))] * 4
-    assert c.all_reduce_max(10.0 * r) == 10.0 * (n - 1)
+    assert c.all_reduce(t, op='sum').tolist() == [float(sum(range(1, n + 1)))] * 4
+    m = torch.tensor([10.0 * r], dtype=torch.float64)
+    assert c.all_reduce(m, op='max').item() == 10.0 * (n - 1)
     # the distributed transform's transposes: x-slabs -> y-slabs -> x-slabs must reproduce a global 3-D FFT
     K0, K1, K2 = 14, 9, 8
     g = torch.Generator().manual_seed(3)
@@ -58,12 +59,27 @@ COMM_WORKER = textwrap.dedent('''
     xs, ys = slab_bounds(K0, n), slab_bounds(K1, n)
     (x0, x1), (y0, y1) = xs[r], ys[r]
     spec = torch.view_as_real(torch.fft.rfft2(mesh[x0:x1]))                     # (nx, K1, K2h, 2)
-    send = [spec[:, a:b].contiguous() for (a, b) in ys]
-    recv = [torch.empty((b - a, y1 - y0, spec.shape[2], 2), dtype=torch.float64) for (a, b) in xs]
-    c.all_to_all(recv, send)
-    tb = torch.fft.fft(torch.view_as_complex(torch.cat(recv, dim=0)), dim=0)    # (K0, ny, K2h)
+    K2h = spec.shape[2]
+    ssp = [(x1 - x0) * (b - a) * K2h * 2 for (a, b) in ys]                      # SlabPme._recip's pack layout
+    rsp = [(b - a) * (y1 - y0) * K2h * 2 for (a, b) in xs]
+    pack = torch.cat([spec[:, a:b].reshape(-1) for (a, b) in ys])
+    tbuf = torch.empty((K0, y1 - y0, K2h, 2), dtype=torch.float64)
+    c.reset_stats()
+    c.all_to_all_v(tbuf.view(-1), pack, rsp, ssp, label='transpose')           # straight into the transposed layout
+    assert c.bytes_sent['transpose'] == 8 * (sum(ssp) - ssp[r])
+    tb = torch.fft.fft(torch.view_as_complex(tbuf), dim=0)                      # (K0, ny, K2h)
     want = torch.fft.rfftn(mesh)[:, y0:y1]
     assert torch.allclose(tb, want, atol=1e-10)
+    back = torch.empty_like(pack)
+    c.all_to_all_v(back, tbuf.view(-1), ssp, rsp)                               # and the way back
+    assert torch.equal(back, pack)
+    # ragged lists (halo index exchange): rank r sends (r + p) %% 3 entries to rank p, possibly none
+    cnt = [(r + p) %% 3 for p in range(n)]
+    got = [(p + r) %% 3 for p in range(n)]
+    send = torch.cat([torch.full((k,), 100 * r + p, dtype=torch.int32) for p, k in enumerate(cnt)] + [torch.zeros(0, dtype=torch.int32)])
+    recv = torch.empty(sum(got), dtype=torch.int32)
+    c.all_to_all_v(recv, send, got, cnt)
+    assert recv.tolist() == [100 * p + r for p, k in enumerate(got) for _ in range(k)]
     # ring shifts (ghost planes to the next rank, phi halo from the next rank)
     a = torch.full((2, 3), float(r)); b = torch.empty((2, 3))
     c.shift(a, b, to_next=True);  assert b[0, 0].item() == float((r - 1) %% n)

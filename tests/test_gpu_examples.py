@@ -1,0 +1,66 @@
+"""The example drivers executed end to end on the GPU and checked against the goldens:
+examples/water_1024 (P1: the reference example's geometry; electrostatics, dispersion PME, Tang-Toennies),
+examples/water_pol_1024 (S1 golden) and a short NVE run of examples/md/nve_water.py (energy conservation)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def run_script(rel, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, rel)] + list(args), capture_output=True, text=True, timeout=600,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def floats_after(out, header):
+    lines = out.splitlines()
+    k = next(i for i, l in enumerate(lines) if header in l)
+    return float(lines[k + 1].split()[0])
+
+
+def test_water_1024_example_reproduces_p1_golden():
+    out = run_script('examples/water_1024/run_admp.py')
+    g = np.load(os.path.join(GOLD, 'p1_water1024.npz'))
+    e_es = floats_after(out, 'Electrostatic Energy')
+    e_disp = floats_after(out, 'Dispersion Energy')
+    e_tt = floats_after(out, 'Tang-Tonnies Damping')
+    scale = np.abs(g['es_parts']).max()
+    assert abs(e_es - g['es_parts'].sum()) < 1e-9 * scale
+    assert abs(e_disp - g['disp_parts'].sum()) < 1e-9 * abs(g['disp_parts']).max()
+    assert abs(e_tt - float(g['tt_E'])) < 1e-9 * abs(float(g['tt_E']))
+
+
+def test_water_pol_1024_example_reproduces_s1_golden():
+    out = run_script('examples/water_pol_1024/run_admp.py')
+    g = np.load(os.path.join(GOLD, 's1_water_pol.npz'))
+    lines = [l for l in out.splitlines() if l and not l.startswith('#')]
+    e = float(lines[0].split()[0])
+    # the example overrides kappa (0.657...) like the reference's script; the golden was made with the default kappa, so
+    # only the physics-level agreement of the Ewald total is expected (kappa independence, ethresh 1e-4)
+    assert abs(e - float(g['parts'].sum())) < 5e-3 * abs(float(g['parts'].sum()))
+    m = re.search(r'SCF cycles \(warm start\): (\d+), converged: (\w+)', out)
+    assert m and int(m.group(1)) == 0 and m.group(2) == 'True'
+
+
+@pytest.mark.parametrize('pol', [False, True])
+def test_nve_water_conserves_energy(pol):
+    """20 velocity-Verlet steps of the full water potential (PME + dispersion PME + Tang-Toennies + bonded terms) after a
+    short minimisation: the hand-coded adjoints are the gradient of the energies iff the total energy is conserved."""
+    args = ['--waters', '216', '--steps', '20', '--minimize', '60', '--dt', '0.5']
+    if pol:
+        args.append('--pol')
+    out = run_script('examples/md/nve_water.py', *args)
+    m = re.search(r'relative energy drift ([-+0-9.e]+)', out)
+    assert m, out[-500:]
+    assert abs(float(m.group(1))) < 2e-4, out[-800:]
+    assert 'ns/day' in out

@@ -1022,3 +1022,71 @@ def test_slab_warm_regime_matches_fused_path(precision):
             assert abs(b[0] - E1) < 1e-10 * scale and rel(b[1], G1) < 1e-10
             assert n_c == 0 and abs(c[0] - E1) < 1e-10 * scale and rel(c[1], G1) < 1e-10
             assert n_d == 2 and abs(d[0] - E0) < 1e-10 * scale and rel(d[1], G0) < 1e-10 and rel(U, U0) < 1e-10
+
+
+def test_slab_halo_only_traffic_and_home_outputs(precision):
+    """outputs='home': a rank returns its home rows and nothing proportional to the number of atoms is ever sent -- the
+    SCF exchanges only the dipoles of imported atoms (all-to-all-v over index lists), the gradient only what a rank
+    added to atoms it does not own.  Wrapped atoms so that molecules straddle the slab boundaries (frame adjoint across
+    ranks).  Results: the home rows equal the single-GPU rows."""
+    import threading
+    import torch
+    from admp_amd.parallel import SlabPme, ThreadComm
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    n_mol, nranks = 4096, 2
+    pos, box = S.synthetic_water_box(n_mol, seed=12)
+    pos = np.mod(pos, box[0, 0])
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, True)
+    na = 3 * n_mol
+    args = (pos, box, None, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    ref = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    ref.update_neighbors(torch.as_tensor(pos, device='cuda'), box)
+    E0, G0 = ref.get_forces(*args)
+    U0 = np.asarray(ref.U_ind)
+    world = ThreadComm.World(nranks)
+    out, errors = [None] * nranks, []
+
+    def work(rank):
+        try:
+            comm = ThreadComm(world, rank)
+            f = SlabPme(comm, box, at, ai, cov, 4.0, 1e-4, 2, lpol=True, outputs='home')
+            f.update_neighbors(torch.as_tensor(pos, device='cuda'), box)
+            E, G = f.get_forces(*args)
+            first = (dict(comm.bytes_sent), dict(comm.calls), f.n_cycle, f.n_import)
+            Uh = np.asarray(f.U_ind).copy()
+            comm.reset_stats()
+            E2, G2 = f.get_forces(*args, U_init=Uh)          # warm start from HOME rows only: imports are pulled
+            out[rank] = (E, np.asarray(G), Uh, f.home_atoms.cpu().numpy(), first, E2, np.asarray(G2), f.n_cycle,
+                         dict(comm.bytes_sent))
+        except Exception as e:      # noqa: BLE001
+            errors.append((rank, repr(e)))
+            try:
+                world.barrier.abort()
+            except Exception:
+                pass
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in ts]
+    [t.join(timeout=600) for t in ts]
+    assert not errors, errors
+    scale = max(abs(p) for p in ref.energy_parts)
+    homes = np.concatenate([o[3] for o in out])
+    assert len(homes) == na and len(np.unique(homes)) == na               # the home sets partition the atoms
+    for (E, G, U, home, (sent, calls, ncyc, n_imp), E2, G2, ncyc2, sent2) in out:
+        assert abs(E - E0) < 1e-10 * scale and ncyc == ref.n_cycle
+        assert rel(G[home], G0[home]) < 1e-10 and rel(U[home], U0[home]) < 1e-10
+        other = np.setdiff1d(np.arange(na), home)
+        assert np.abs(G[other]).max() == 0.0                               # only home rows are handed out
+        assert abs(E2 - E0) < 1e-6 * scale and rel(G2[home], G0[home]) < 1e-6 and ncyc2 == 0
+        # halo-only: the imports are a surface layer (rc + a bond on both faces of a 24.8 A slab), not the volume
+        assert 0 < n_imp < 0.45 * na
+        w = 8
+        assert 'replicate_outputs' not in sent and 'all_reduce' not in sent
+        assert sent['halo_gradient'] == 3 * w * n_imp                     # my contributions to my imports, back to the owners
+        assert sent['halo_dipoles'] % (calls['halo_dipoles'] * 3 * w) == 0 and \
+            sent['halo_dipoles'] // (calls['halo_dipoles'] * 3 * w) < 0.45 * na   # rows my peers import from me, per cycle
+        assert calls['halo_dipoles'] == ncyc and calls['halo_gradient'] == 1 and calls['scf_max'] == ncyc + 1
+        per_atom_traffic = sent['halo_dipoles'] + sent['halo_gradient'] + sent['halo_lists']
+        assert per_atom_traffic < 0.5 * (ncyc + 1) * na * 3 * w            # what the full-array all-reduces used to move
+        assert sent['scf_max'] <= 8 * (ncyc + 1) and sent['energies'] <= 32
