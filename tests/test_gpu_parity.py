@@ -1090,3 +1090,46 @@ def test_slab_halo_only_traffic_and_home_outputs(precision):
         per_atom_traffic = sent['halo_dipoles'] + sent['halo_gradient'] + sent['halo_lists']
         assert per_atom_traffic < 0.5 * (ncyc + 1) * na * 3 * w            # what the full-array all-reduces used to move
         assert sent['scf_max'] <= 8 * (ncyc + 1) and sent['energies'] <= 32
+
+
+@pytest.mark.parametrize('prec,tol', [('single', 1e-2), ('double', 2e-6)])
+def test_s2_config_size_vs_oracle_golden(precision, prec, tol):
+    """BASELINE configs[2] AT SIZE (98 304 atoms, K = 128, rc 4 A) against the float64 oracle's numbers committed in
+    tests/golden/s2_98304.npz (tests/golden/make_s2_golden.py, chunked evaluation): energy parts, gradient, dipoles and
+    SCF cycle count, non-polarizable and polarizable.  Bar (north_star): 1e-2 relative in single precision; the achieved
+    errors are printed.  The stored gradient / dipoles are float32 (6e-8), hence 2e-6 for the double-precision check."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    g = np.load(os.path.join(GOLD, 's2_98304.npz'))
+    settings.PRECISION = prec
+    nm = int(g['n_mol'])
+    pos, box = S.synthetic_water_box(nm, seed=int(g['seed']))
+    np.testing.assert_allclose([pos.sum(), (pos ** 2).sum()], g['pos_checksum'], rtol=1e-12)
+    at, ai, cov = S.water_topology(nm)
+    K = int(g['K'])
+    dt = torch.float32 if prec == 'single' else torch.float64
+    p = torch.as_tensor(pos, dtype=dt, device='cuda')
+    for lpol in (False, True):
+        par = S.water_parameters(nm, polarizable=lpol)
+        f = ADMPPmeForce(box, at, ai, cov, float(g['rc']), 1e-4, 2, lpol=lpol)
+        assert abs(f.kappa - float(g['kappa'])) < 1e-15
+        for k in ('K1', 'K2', 'K3'):
+            f.update_env(k, K)
+        f.update_neighbors(p, box)                      # GPU cell list: the same pair set as the oracle's cKDTree list
+        assert f.n_pairs == int(g['n_pairs'])
+        if lpol:
+            E, G = f.get_forces(p, box, None, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
+                                par['dScales'])
+            parts, Gref = g['pol_parts'], g['pol_grad'].astype(np.float64)
+            assert f.n_cycle == int(g['pol_n_cycle']) and f.lconverg == bool(g['pol_lconverg'])
+            eu = rel(f.U_ind.cpu().numpy(), g['pol_U'].astype(np.float64))
+            assert eu < tol
+        else:
+            E, G = f.get_forces(p, box, None, par['Q_local'], par['mScales'])
+            parts, Gref, eu = g['np_parts'], g['np_grad'].astype(np.float64), 0.0
+        scale = np.abs(parts).max()
+        ee = max(abs(a - b) for a, b in zip(f.energy_parts, parts)) / scale
+        eg = rel(G.cpu().numpy(), Gref)
+        print('S2 %s lpol=%s: energy parts %.2e of the largest part, gradient rel L2 %.2e, dipoles rel L2 %.2e' %
+              (prec, lpol, ee, eg, eu))
+        assert ee < (1e-9 if prec == 'double' else 1e-6) and eg < tol
