@@ -8,8 +8,9 @@ ADMPDispPmeForce, generate_pairwise_interaction) and wrapped here.
     g = param_gradient(pot_pme, positions, box, pairs, params)
     g['mScales'], g['Q_local'], g['pol'], g['tholes']       # jax.grad(pot_pme, argnums=3) of examples/openmm_api/run.py:44-46
 
-`param_gradient` returns the entries that have hand-coded adjoints on this path; there is no
-autodiff, so entries without one (pScales, dScales, the per-type A/B/Q/C tables) are absent rather than zero.
+`param_gradient` returns the entries that have hand-coded adjoints on this path: mScales, pScales,
+dScales, Q_local, pol, tholes; there is no autodiff, so entries without one (the per-type A/B/Q/C tables of the
+dispersion front-end) are absent rather than zero.
 """
 import numpy as np
 
@@ -44,6 +45,10 @@ def pme_potential(pme_force, pol=None, tholes=None):
             out['pol'], out['tholes'] = pme_force.get_pol_thole_gradients(
                 positions, box, pairs, params['Q_local'], pol, tholes, params['mScales'], params['pScales'],
                 params['dScales'], U_init=pme_force.U_ind)
+            out['pScales'] = pme_force.get_pscale_gradient(
+                positions, box, pairs, params['Q_local'], pol, tholes, params['mScales'], params['pScales'],
+                params['dScales'], U_init=pme_force.U_ind)
+            out['dScales'] = np.zeros(len(out['pScales']))          # the reference ignores dScales (uscales = 1, pme.py:472)
         else:
             _, _, dQ = pme_force.get_forces_and_dQ(positions, box, pairs, params['Q_local'], params['mScales'])
         out['Q_local'] = dQ

@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
     if force or _stale(LIB, objs):
         rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
         cmd = ['hipcc', '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs + \
-              ['-L' + os.path.join(rocm, 'lib'), '-lrocfft', '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
+              ['-L' + os.path.join(rocm, 'lib'), '-lrocfft', '-lhiprtc', '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])

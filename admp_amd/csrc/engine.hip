@@ -10,6 +10,7 @@
 //   spread, r2c, kspace (energy + G multiply), c2r, gather                          [recip_kernels.hip + rocFFT]
 //   finish          self + penalty, frame adjoint, dE/dQ_local                      [atom_kernels.hip]
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
@@ -169,6 +170,44 @@ struct EngineBase {
   virtual void pme_at_U(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                         const double* mS, const double* pS, const void* U, double* E, void* dpos, void* dU, void* dQl) = 0;
   virtual void local_frames(const void* pos, const double* box, void* out) = 0;
+  virtual void pair_program_eval(int id, const void* pos, const double* box, const void* par, int ns, const double* mS,
+                                 double* E, void* dpos, int on_device) = 0;
+
+  // ---- user-defined pair kernels (admp_amd/xp.py traces a Python kernel into HIP source; compiled here with hiprtc) ----
+  struct PairProgram { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; int n_params = 0; };
+  std::vector<PairProgram> programs;
+  int pair_program_build(const char* source, int n_params) {
+    ARG_CHECK(source && n_params >= 0 && n_params <= 16, "bad pair program");
+    hiprtcProgram prog = nullptr;
+    auto rtc = [&](hiprtcResult r, const char* what) {
+      if (r != HIPRTC_SUCCESS) throw Err{ADMP_E_HIP, std::string(what) + ": " + hiprtcGetErrorString(r)};
+    };
+    rtc(hiprtcCreateProgram(&prog, source, "admp_pair_custom.hip", 0, nullptr, nullptr), "hiprtcCreateProgram");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", prec == 4 ? "-DREAL_T=float" : "-DREAL_T=double"};
+    const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
+    if (cr != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      std::string log;
+      if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); (void)hiprtcGetProgramLog(prog, &log[0]); }
+      (void)hiprtcDestroyProgram(&prog);
+      throw Err{ADMP_E_HIP, std::string("hiprtc could not compile the traced pair kernel: ") + log.substr(0, 1500)};
+    }
+    size_t sz = 0;
+    rtc(hiprtcGetCodeSize(prog, &sz), "hiprtcGetCodeSize");
+    std::vector<char> code(sz);
+    rtc(hiprtcGetCode(prog, code.data()), "hiprtcGetCode");
+    (void)hiprtcDestroyProgram(&prog);
+    PairProgram p;
+    p.n_params = n_params;
+    HIP_TRY(hipModuleLoadData(&p.mod, code.data()));
+    HIP_TRY(hipModuleGetFunction(&p.fn, p.mod, "admp_pair_custom"));
+    programs.push_back(p);
+    return (int)programs.size() - 1;
+  }
+  void free_programs() {
+    for (auto& p : programs) if (p.mod) (void)hipModuleUnload(p.mod);
+    programs.clear();
+  }
   virtual void pme_box_grad(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                             const double* mS, const double* pS, const void* U, double* E, double* dbox) = 0;
   virtual void disp_box_grad(const void* pos, const double* box, const void* clist, int pmax, int ns, const double* mS,
@@ -181,6 +220,8 @@ struct EngineBase {
                   int on_device) = 0;
   virtual void thole_sums(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                           const double* mS, const double* pS, const void* U, void* sumX, void* sumXw) = 0;
+  virtual void pscale_grad(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
+                           const double* mS, const double* pS, const void* U, double* out) = 0;
   virtual void mscale_grad(int kind, const void* pos, const double* box, const void* par, int pmax, int ns, double* out,
                            int on_device) = 0;
   // staged evaluation (device pointers only)
@@ -348,6 +389,7 @@ struct Engine : EngineBase {
   rocfft_execution_info info_f = nullptr;
   int planK[3] = {0, 0, 0}, planR = 0, planRank = 0;
   DevBuf home_list;
+  DevBuf act_tmp;
   DevBuf act_d, isites, mesh2;   // incremental SCF: polarizable-site list, their compact delta rows, the increment's mesh
   IndTable ind;                  // ... and the polarizable-polarizable part of the neighbour table
   long act_gen = 0, act_top_na = -1;   // act_gen: bumped when the list is rebuilt; the list belongs to a topology of act_top_na atoms
@@ -366,12 +408,13 @@ struct Engine : EngineBase {
     destroy_plans();
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
-                      &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2})
+                      &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp})
       b->release();
     free_topology();
     if (ind.rowptr) (void)hipFree(ind.rowptr);
     if (ind.col) (void)hipFree(ind.col);
     cells.release();
+    free_programs();
     if (Eh) (void)hipHostFree(Eh);
     prof.destroy();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -801,7 +844,17 @@ struct Engine : EngineBase {
   const int* nact_arg() { return act_fresh ? nact_dev() : nullptr; }
   int nact_rows() const { return act_fresh ? top.na : act_n; }      // grid bound of those kernels
   void nact_seen() {                                                 // after a read_energies of this evaluation
-    if (act_fresh) { int n = 0; std::memcpy(&n, &Eh[E_NACT], sizeof(n)); act_n = n; act_fresh = false; }
+    if (!act_fresh) return;
+    int n = 0;
+    std::memcpy(&n, &Eh[E_NACT], sizeof(n));
+    act_n = n;
+    act_fresh = false;
+    // The workgroups of k_prepare_sites append their chunks in completion order; in atom order the rows that neighbouring
+    // workgroups (and XCDs) of the pair kernels work on are neighbours in space again (measured HBM traffic of the field
+    // pass over the list at 1M atoms: 1.42 GB unsorted -- more than the full pair kernel's 0.44 GB).
+    act_tmp.need(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    int rc = sort_ints(stream, act_d.as<int>(), act_tmp.as<int>(), n, &scan_scratch.p, &scan_bytes);
+    if (rc != 0) throw Err{ADMP_E_HIP, std::string("sort_ints: ") + hipGetErrorString((hipError_t)rc)};
   }
   double scf_check(int* n_act) {          // total field + its maximum over the polarizable sites; one host read
     if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
@@ -1393,6 +1446,50 @@ struct Engine : EngineBase {
     E[0] = Eh[E_REAL];
   }
 
+  // a traced pair kernel (pair_program_build) on the current neighbour table: admp/pairwise.py:67-91 with any kernel
+  DevBuf prog_consts;
+  void pair_program_eval(int id, const void* pos_, const double* box, const void* par_, int ns, const double* mS, double* E,
+                         void* dpos_, int on_device) override {
+    ARG_CHECK(have_top && have_pairs, "topology and pairs must be set first");
+    ARG_CHECK(id >= 0 && id < (int)programs.size(), "unknown pair program");
+    ARG_CHECK(pos_ && box && E && ns >= 1 && mS, "null argument");
+    const PairProgram& pg = programs[id];
+    ARG_CHECK(pg.n_params == 0 || par_, "atomic parameters missing");
+    const int na = top.na;
+    double inv[9], vol;
+    make_box(box, inv, &vol);
+    const T* pos = stage_in(s_pos, pos_, 3 * (size_t)na, on_device);
+    const T* par = pg.n_params ? stage_in(s_par, par_, (size_t)pg.n_params * na, on_device) : nullptr;
+    grad.need(3 * (size_t)na * sizeof(T));
+    T* dpos = (dpos_ && on_device) ? reinterpret_cast<T*>(dpos_) : grad.as<T>();
+    energies_d.need(2 * E_WORDS * sizeof(double));
+    ehalf = 0; other_clean = false;
+    double* Ed = energies_d.as<double>();
+    HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
+    T consts[34];                                   // box (9), box^-1 (9), mscale per covalent class (16)
+    for (int k = 0; k < 9; ++k) { consts[k] = (T)box[k]; consts[9 + k] = (T)inv[k]; }
+    for (int nb = 0; nb < 16; ++nb) consts[18 + nb] = (T)mS[((nb - 1) % ns + ns) % ns];      // admp/pme.py:681-683 wrap
+    prog_consts.need(sizeof(consts));
+    HIP_TRY(hipMemcpyAsync(prog_consts.p, consts, sizeof(consts), hipMemcpyHostToDevice, stream));
+    const T* boxd = prog_consts.as<T>();
+    const T* mtab = boxd + 18;
+    int na_arg = na;
+    const int* rowptr = nbr.rowptr; const int* colp = nbr.col; const int* order = nbr.order;
+    T* gradp = dpos_ ? dpos : nullptr;
+    double* eptr = Ed + E_REAL;
+    void* args[] = {&na_arg, &rowptr, &colp, &order, &pos, &par, &boxd, &mtab, &gradp, &eptr};
+    const unsigned grid = (unsigned)(((long)na * 8 + 255) / 256);
+    {
+      TIMED("pair_custom");
+      HIP_TRY(hipModuleLaunchKernel(pg.fn, grid, 1, 1, 256, 1, 1, 0, stream, args, nullptr));
+    }
+    double Eh2[E_SLOTS];
+    HIP_TRY(hipMemcpyAsync(Eh2, Ed, sizeof(Eh2), hipMemcpyDeviceToHost, stream));
+    if (dpos_ && !on_device) HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    E[0] = Eh2[E_REAL];
+  }
+
   // raw per-atom sums behind dE/dpol and dE/dtholes (device pointers only); the caller finishes them (admp_amd/pme.py)
   void thole_sums(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                   const double* mS, const double* pS, const void* U, void* sumX, void* sumXw) override {
@@ -1404,6 +1501,25 @@ struct Engine : EngineBase {
     { TIMED("thole_sums"); launch_thole_sums<T>(stream, top.na, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T*)sumX, (T*)sumXw); }
     ev.active = false;
     HIP_TRY(hipStreamSynchronize(stream));
+  }
+
+  // dE/dpScales[k] at the dipoles given (device pointers): class sums of pair_pscale_deriv, folded like dE/dmScales
+  void pscale_grad(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
+                   const double* mS, const double* pS, const void* U, double* out) override {
+    ARG_CHECK(lpol, "polarizable handle required");
+    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
+    ARG_CHECK(out && U && ns >= 1 && ns <= 16, "bad argument");
+    stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, const_cast<void*>(U));
+    vir_d.need(V_WORDS * sizeof(double));
+    double* cls = vir_d.as<double>();
+    HIP_TRY(hipMemsetAsync(cls, 0, 16 * sizeof(double), stream));
+    { TIMED("pscale_grad"); launch_pscale_sums<T>(stream, top.na, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, cls); }
+    ev.active = false;
+    double h16[16];
+    HIP_TRY(hipMemcpyAsync(h16, cls, sizeof(h16), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < ns; ++k) out[k] = 0.0;
+    for (int nb = 0; nb < 16; ++nb) out[((nb - 1) % ns + ns) % ns] += h16[nb];
   }
 
   // dE/dmScales[k] = sum over the covalent classes nb that read mScales[k] (index (nb - 1) mod ns, with the reference's
@@ -1579,6 +1695,20 @@ int admp_tt_box_grad(admp_handle* h, const void* positions, const double* box, c
   return guarded(h, [&](EngineBase& e) { e.tt_box_grad(positions, box, abqc, n_scales, mScales, E_out, dE_dbox); });
 }
 
+int admp_pair_program_build(admp_handle* h, const char* hip_source, int n_params, int* program_id) {
+  return guarded(h, [&](EngineBase& e) {
+    ARG_CHECK(program_id, "null");
+    *program_id = e.pair_program_build(hip_source, n_params);
+  });
+}
+int admp_pair_program_energy_grad(admp_handle* h, int program_id, const void* positions, const double* box,
+                                  const void* params, int n_scales, const double* mScales, double* E_out, void* dE_dpos,
+                                  int on_device) {
+  return guarded(h, [&](EngineBase& e) {
+    e.pair_program_eval(program_id, positions, box, params, n_scales, mScales, E_out, dE_dpos, on_device);
+  });
+}
+
 int admp_local_frames(admp_handle* h, const void* positions, const double* box, void* frames_out) {
   return guarded(h, [&](EngineBase& e) { e.local_frames(positions, box, frames_out); });
 }
@@ -1606,6 +1736,14 @@ int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box
 int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const double* box, const void* params, int pmax,
                      int n_scales, double* dE_dmScales, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.mscale_grad(kind, positions, box, params, pmax, n_scales, dE_dmScales, on_device); });
+}
+
+int admp_pscale_grad(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                     const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
+                     double* dE_dpScales) {
+  return guarded(h, [&](EngineBase& e) {
+    e.pscale_grad(positions, box, Q_local, pol, tholes, n_scales, mScales, pScales, U, dE_dpScales);
+  });
 }
 
 int admp_thole_sums(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,

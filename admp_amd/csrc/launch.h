@@ -170,6 +170,8 @@ struct IndTable {
 template <class T>
 void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const Site<T>* sites, const Box<T>& box,
                            const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows);
+// (nbr_kernels.hip) ascending in-place sort of n ints; keys_tmp = n ints of scratch.  hipError_t as int.
+int sort_ints(hipStream_t st, int* keys, int* keys_tmp, int n, void** scratch, size_t* scratch_bytes);
 // (nbr_kernels.hip) it <- the polarizable-polarizable entries of nb; rows keyed by atom, empty for non-polarizable atoms.
 // Returns a hipError_t as int; one host synchronisation.
 template <class T>
@@ -185,6 +187,10 @@ void launch_thole_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>
 template <class T>
 void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, const Site<T>* sites, const T* pos,
                         const T* par, const Box<T>& box, int pmax, double* cls16);
+// cls16[nb] += sum over the pairs of covalent class nb of d(pair energy)/d(pscale) (pme_math.h pair_pscale_deriv)
+template <class T>
+void launch_pscale_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                        const ScaleTab<T>& tab, double* cls16);
 template <class T>
 void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies);

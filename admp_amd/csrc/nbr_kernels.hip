@@ -175,6 +175,22 @@ int build_ind_table(hipStream_t st, int na, const NbrTable& nb, const Site<T>* s
 template int build_ind_table<float>(hipStream_t, int, const NbrTable&, const Site<float>*, IndTable&, void**, size_t*);
 template int build_ind_table<double>(hipStream_t, int, const NbrTable&, const Site<double>*, IndTable&, void**, size_t*);
 
+// ascending sort of n ints in place (keys_tmp: n ints of scratch); returns a hipError_t as int
+int sort_ints(hipStream_t st, int* keys, int* keys_tmp, int n, void** scratch, size_t* scratch_bytes) {
+  if (n <= 1) return 0;
+  size_t need = 0;
+  NB_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, keys, keys_tmp, n, 0, 32, st));
+  if (need > *scratch_bytes) {
+    if (*scratch) NB_CHECK(hipFree(*scratch));
+    *scratch = nullptr; *scratch_bytes = 0;
+    NB_CHECK(hipMalloc(scratch, need));
+    *scratch_bytes = need;
+  }
+  NB_CHECK(hipcub::DeviceRadixSort::SortKeys(*scratch, need, keys, keys_tmp, n, 0, 32, st));
+  NB_CHECK(hipMemcpyAsync(keys, keys_tmp, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
 // slab owner of global mesh plane gx: the s with floor(s K / N) <= gx < floor((s + 1) K / N)  (engine.hip update_slab)
 __device__ __forceinline__ int slab_owner(int gx, int K0, int N) {
   int s = (int)(((long)gx * N) / K0);

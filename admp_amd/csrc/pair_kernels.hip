@@ -244,6 +244,48 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_mgrad(int na, const int* __
   if (threadIdx.x >= 1 && threadIdx.x < 16 && s_cls[threadIdx.x] != 0.0) atomicAdd(&cls[threadIdx.x], 0.5 * s_cls[threadIdx.x]);
 }
 
+// dE/dpScales: per covalent class the sum over its pairs of pair_pscale_deriv (polarizable handle, dipoles given)
+template <class T>
+__global__ __launch_bounds__(kPairBlock) void k_pair_pgrad(int na, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                           const Site<T>* __restrict__ sites, Box<T> box, ScaleTab<T> tab,
+                                                           double* __restrict__ cls) {
+  __shared__ T s_tab[48];
+  __shared__ double s_cls[16];
+  stage_tab(tab, s_tab);
+  if (threadIdx.x < 16) s_cls[threadIdx.x] = 0.0;
+  __syncthreads();
+  constexpr int LPR = 8;
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  double e0 = 0.0;
+  if (row < na) {
+    const Site<T> I = sites[row];
+    const int end = rowptr[row + 1];
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = (c >> 28) & 15;
+      const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
+      const T v = pair_pscale_deriv<T>(box, I, sites[c & kColMask], sc);
+      if (nb == 0) e0 += (double)v;
+      else atomicAdd(&s_cls[nb], (double)v);
+    }
+  }
+  e0 = block_reduce_sum<kPairBlock>(e0);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&cls[0], 0.5 * e0);
+  if (threadIdx.x >= 1 && threadIdx.x < 16 && s_cls[threadIdx.x] != 0.0) atomicAdd(&cls[threadIdx.x], 0.5 * s_cls[threadIdx.x]);
+}
+template <class T>
+void launch_pscale_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                        const ScaleTab<T>& tab, double* cls16) {
+  const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
+  k_pair_pgrad<T><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, cls16);
+}
+template void launch_pscale_sums<float>(hipStream_t, int, const NbrTable&, const Site<float>*, const Box<float>&,
+                                        const ScaleTab<float>&, double*);
+template void launch_pscale_sums<double>(hipStream_t, int, const NbrTable&, const Site<double>*, const Box<double>&,
+                                         const ScaleTab<double>&, double*);
+
 // per-atom sums of d(pair energy)/d ln(au) (pair_thole_logderiv): sumX[i] = sum_j X_ij, sumXw[i] = sum_j X_ij wth_ij
 template <class T>
 __global__ __launch_bounds__(kPairBlock) void k_pair_tholegrad(int na, const int* __restrict__ rowptr,

@@ -616,6 +616,46 @@ ADMP_HD T pair_thole_logderiv(const Box<T>& box, const Site<T>& I, const Site<T>
   return X;
 }
 
+// d(pair energy)/d(pscale) at fixed Thole width: pscale multiplies the Thole factor of the five permanent-induced
+// coefficients (cud, dud_m0, dud_m1, udq_m0, udq_m1: admp/pme.py:455-470), so the derivative is R_n x const x thole_k
+// contracted with the same bilinear shapes as in pair_thole_logderiv.  pscale also enters the Fermi switch of the Thole
+// width (pme.py:337-348, 411); that weight is flat to < 1e-38 at every pscale the model uses (0 or 1), and in the reference
+// its autodiff derivative is NaN as soon as pscale > ~0.008 (exp overflow); the analytic limit, 0, is used here.
+template <class T>
+ADMP_HD T pair_pscale_deriv(const Box<T>& box, const Site<T>& I, const Site<T>& J, const PairScales<T>& sc) {
+  T d[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
+  min_image(box, d);
+  const T r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const T rinv = T(1) / m_sqrt(r2);
+  const T r = r2 * rinv;
+  T z[3] = {d[0] * rinv, d[1] * rinv, d[2] * rinv}, x[3], y[3];
+  qi_frame(z, x, y);
+  T A[9], B[9], UA[3], UB[3];
+  rot_harm(I.Q, x, y, z, A);
+  rot_harm(J.Q, x, y, z, B);
+  rot_dip(I.U, x, y, z, UA);
+  rot_dip(J.U, x, y, z, UB);
+  const T aw = sc.w0 * T(kDefaultTholeWidth) + (T(1) - sc.w0) * (I.thole + J.thole);
+  T dmp = I.p6 * J.p6;
+  dmp = dmp < T(1e-8) ? T(1e-8) : dmp;
+  const T u = trim_inf(r * (T(1) / dmp), T(1e8));
+  const T au = u * aw;
+  const T expau = au < T(50) ? m_exp(-au) : T(0);
+  const T au2 = trim_inf(au * au, T(1e8)), au3 = trim_inf(au2 * au, T(1e8)), au4 = trim_inf(au3 * au, T(1e8));
+  const T base = au + T(1) + au2 * T(0.5);
+  const T th_c = T(1) - expau * base;
+  const T th_d0 = T(1) - expau * (base + au3 * T(0.25));
+  const T th_q1 = T(1) - expau * (base + au3 * T(1.0 / 6.0));
+  const T th_q0 = T(1) - expau * (base + au3 * T(1.0 / 6.0) + au4 * T(1.0 / 18.0));
+  const T R2 = T(kDielectric) * rinv * rinv, R3 = R2 * rinv, R4 = R3 * rinv, hf = T(0.5);
+  T X = R2 * (T(2) * th_c) * hf * (A[0] * UB[0] - B[0] * UA[0]);
+  X += R3 * (T(-4) * th_d0) * hf * (B[1] * UA[0] + A[1] * UB[0]);
+  X += R3 * (T(2) * th_c) * hf * (B[2] * UA[1] + B[3] * UA[2] + A[2] * UB[1] + A[3] * UB[2]);
+  X += R4 * (T(6) * th_q0) * hf * (A[4] * UB[0] - B[4] * UA[0]);
+  X += R4 * (T(-2.0 * kSqrt3) * th_q1) * hf * (A[5] * UB[1] + A[6] * UB[2] - B[5] * UA[1] - B[6] * UA[2]);
+  return X;
+}
+
 // Field-only evaluation for the SCF (dE/dU_I of the real-space term, admp/pme.py:133):
 // only the seven induced coefficients, no radial derivative, no torque.
 template <class T>

@@ -378,6 +378,29 @@ class ADMPPmeForce(HipForceBase):
         self.energy_parts = tuple(E)
         return np.float64(E[0] + E[1] + E[2] + E[3]), np.array(dbox[:], dtype=np.float64).reshape(3, 3)
 
+    def get_pscale_gradient(self, positions, box, pairs, Q_local, pol, tholes, mScales, pScales, dScales, U_init=None):
+        """dE/dpScales (len(pScales),): the 'pScales' entry of `grad(pot_pme, argnums=3)` in the reference.  The dipoles are
+        converged first and held fixed (admp/pme.py:81-85).  pscale scales the Thole factor of the permanent-induced
+        coefficients (admp/pme.py:455-470); the Fermi switch it also drives (pme.py:411) is flat wherever its derivative is
+        finite -- the reference's autodiff returns NaN there for pscale > ~0.008, this returns the analytic limit.
+        dE/ddScales is identically zero (the reference ignores dScales: uscales = 1, pme.py:472)."""
+        if not self.lpol:
+            raise RuntimeError('get_pscale_gradient needs lpol=True')
+        self.get_energy(positions, box, pairs, Q_local, pol, tholes, mScales, pScales, dScales, U_init=U_init)
+        self._use_current_stream()
+        na = self.n_atoms
+        pos = self._real(positions, (na, 3))
+        Q = self._pad_Q(Q_local)
+        mS = self._host64(mScales)
+        pS = self._host64(pScales, len(mS))
+        out = (ctypes.c_double * len(mS))()
+        pol_t, th_t, U = self._real(pol, (na,)), self._real(tholes, (na,)), self._real(self.U_ind, (na, 3))   # kept alive
+        rc = self._L.admp_pscale_grad(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(Q),
+                                      self._ptr(pol_t), self._ptr(th_t), len(mS), _lib.darr(mS), _lib.darr(pS), self._ptr(U),
+                                      out)
+        _lib.check(self._h, rc, 'admp_pscale_grad')
+        return np.array(out[:], dtype=np.float64)
+
     def get_mscale_gradient(self, positions, box, pairs, Q_local, mScales):
         """dE/dmScales, shape (len(mScales),): what `grad(pot_pme, argnums=3)(...)['mScales']` gives in the reference
         (examples/openmm_api/run.py:44-46).  The energy is linear in mScales and its induced part carries pScales, so neither

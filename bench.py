@@ -110,12 +110,19 @@ class ThermalFrames:
         self.rel = mol - self.com[:, None, :]
         kt = KB * TEMP_K
         self.v = xi[:, :3] * float(np.sqrt(kt / float(m.sum()))) * 1e-2            # A/fs
-        r2 = (self.rel ** 2).sum(-1)
-        inertia = (m[None, :, None, None] * (r2[:, :, None, None] * torch.eye(3, dtype=torch.float64, device=device)
-                                            - self.rel[:, :, :, None] * self.rel[:, :, None, :])).sum(1)
-        chol = torch.linalg.cholesky(inertia)                                      # I = C C^T ; omega = C^-T xi sqrt(kT)
-        omega = torch.linalg.solve_triangular(chol.transpose(1, 2), (xi[:, 3:, None] * float(np.sqrt(kt))), upper=True)
-        omega = omega[:, :, 0] * 1e-2                                              # rad/fs
+        # principal axes of a C2v water: bisector, in-plane perpendicular, plane normal; omega_k ~ N(0, kT / I_k) about each
+        rel = self.rel
+        e1 = rel[:, 1] + rel[:, 2] - 2 * rel[:, 0]
+        e1 = e1 / e1.norm(dim=1, keepdim=True)
+        e3 = torch.linalg.cross(rel[:, 1] - rel[:, 0], rel[:, 2] - rel[:, 0])
+        e3 = e3 / e3.norm(dim=1, keepdim=True)
+        e2 = torch.linalg.cross(e3, e1)
+        axes = torch.stack([e1, e2, e3], dim=1)                                    # (n_mol, 3 axes, 3)
+        proj = torch.einsum('nak,nbk->nab', rel, axes)                             # atom coordinates on the axes
+        r2 = (proj ** 2).sum(-1, keepdim=True)
+        inertia = (m[None, :, None] * (r2 - proj ** 2)).sum(1)                     # (n_mol, 3) principal moments
+        omega = (xi[:, 3:] * torch.sqrt(kt / inertia))[:, :, None] * axes          # (n_mol, 3, 3)
+        omega = omega.sum(1) * 1e-2                                                # rad/fs
         self.wnorm = omega.norm(dim=1, keepdim=True)
         self.axis = omega / self.wnorm
         self.cache = {}

@@ -136,6 +136,20 @@ int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* b
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
                         const double* mScales, double* E_out, void* dE_dpos, int on_device);
 
+/* replaces: generate_pairwise_interaction(pair_int_kernel, covalent_map, static_args) for an ARBITRARY kernel
+ * (admp/pairwise.py:45-91): the Python layer traces `pair_int_kernel(dr, m, p1i, p1j, ...)` once into HIP source
+ * (admp_amd/xp.py: one statement per arithmetic operation, d/d(dr) by forward-mode dual numbers) and this call compiles
+ * it for gfx950 with hiprtc and loads it.  The source must define
+ *   extern "C" __global__ void admp_pair_custom(int na, const int* rowptr, const int* col, const int* order,
+ *       const REAL_T* pos, const REAL_T* par, const REAL_T* box18, const REAL_T* mscale16, REAL_T* grad, double* energy)
+ * (REAL_T is defined on the command line as the handle's precision).  program_id receives a handle-local id. */
+int admp_pair_program_build(admp_handle* h, const char* hip_source, int n_params, int* program_id);
+/* energy and +dE/dpositions of a built program on the current pair list; params (Na, n_params) real [dev|host],
+ * other arguments as admp_tt_energy_grad; E_out[1] */
+int admp_pair_program_energy_grad(admp_handle* h, int program_id, const void* positions, const double* box,
+                                  const void* params, int n_scales, const double* mScales, double* E_out, void* dE_dpos,
+                                  int on_device);
+
 /* replaces: jax.grad(potential, argnums=3)(...)['mScales'] of the reference's parameter-gradient example
  * (examples/openmm_api/run.py:41-46): dE/dmScales[k], k = 0..n_scales-1, of one calculator on the current pair list.
  *   kind 0  multipolar PME         params = Q_local (Na,9) real   (admp/pme.py:681-683: mscales = mScales[nbonds-1])
@@ -156,6 +170,15 @@ int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const doub
 int admp_thole_sums(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
                     const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
                     void* sumX, void* sumXw);
+
+/* replaces: the 'pScales' entry of jax.grad(pot_pme, argnums=3): dE/dpScales[k], k = 0..n_scales-1, at the induced dipoles U
+ * given (DEVICE pointers).  pscale multiplies the Thole factor of the permanent-induced coefficients (admp/pme.py:455-470);
+ * its second role, the Fermi switch of the Thole width (pme.py:411), has a derivative below 1e-38 wherever it is finite
+ * and is NaN in the reference's autodiff for pscale > ~0.008 (exp overflow): the analytic limit 0 is used.  The 'dScales'
+ * entry is identically zero (the reference ignores dScales, uscales = 1, pme.py:472). */
+int admp_pscale_grad(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
+                     const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
+                     double* dE_dpScales);
 
 /* ---- neighbour search ("next" row of SURVEY.md 8f) --------------------------------------------------------
  * replaces: jax_md.partition.neighbor_list(displacement_fn, box, rc, 0, format=OrderedSparse).allocate(positions)

@@ -227,3 +227,47 @@ def test_group_closing_kernel_matches_oracle(env, lpol, monkeypatch):
             assert abs(got - want) <= 1e-9 * scale, mode
         assert rel(G, ref['grad']) < 1e-8 and rel(dQ, ref['dQ_local']) < 1e-8, mode
     assert rel(out['groups'][1], out['pull'][1]) < 1e-12
+
+
+def test_pscale_gradient_vs_oracle(env):
+    """dE/dpScales: entries with pscale = 0 against torch autograd through the oracle (finite there); entries with
+    pscale = 1, where autodiff through the Fermi switch gives NaN (in the reference as well: exp overflow), against
+    central differences of the oracle energy -- the switch is exactly flat on both sides.  dE/ddScales = 0."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.api import pme_potential, param_gradient
+    from oracle import admp_oracle as O
+    n_mol = 64
+    pos, box = S.synthetic_water_box(n_mol, seed=41)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, True)
+    pairs = S.build_pairs(pos, box, 4.0)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    args = (pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    g = f.get_pscale_gradient(*args)
+    U = np.asarray(f.U_ind)
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, True)
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+
+    def energy(pS):
+        return O.energy_pme(sysm, T(pos), T(box), pairs, T(par['Q_local']), T(U), T(par['pol']), T(par['tholes']),
+                            T(par['mScales']), pS)
+    pS = T(par['pScales']).clone().requires_grad_(True)
+    auto, = torch.autograd.grad(energy(pS), pS)
+    auto = auto.numpy()
+    assert np.isnan(auto[4]) and np.all(np.isfinite(auto[:2]))            # the reference's own behaviour
+    scale = np.abs(g).max()
+    assert scale > 1.0
+    for k in (0, 1):                                                       # 1-2 and 1-3 pairs: pscale 0
+        assert abs(g[k] - auto[k]) < 1e-8 * scale, (k, g[k], auto[k])
+    h = 1e-4
+    for k in (3, 4):                                                       # pscale 1 (k = 4: every non-bonded pair)
+        pp, pm = par['pScales'].copy(), par['pScales'].copy()
+        pp[k] += h
+        pm[k] -= h
+        fd = float(energy(T(pp)) - energy(T(pm))) / (2 * h)
+        assert abs(g[k] - fd) < 1e-6 * scale, (k, g[k], fd)
+    assert g[2] == 0.0                                                     # no 1-4 pairs in water
+    out = param_gradient(pme_potential(f, par['pol'], par['tholes']), pos, box, pairs,
+                         dict(Q_local=par['Q_local'], mScales=par['mScales'], pScales=par['pScales'], dScales=par['dScales']))
+    assert np.allclose(out['pScales'], g, rtol=1e-9, atol=1e-9 * scale) and not out['dScales'].any()

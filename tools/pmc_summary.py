@@ -20,7 +20,7 @@ rows_out = []
 for wl in ('S1', 'S2', 'S3'):
     per = collections.defaultdict(dict)
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-        f = glob.glob(os.path.join(src, 'pmc_%s_%s' % (wl, c), '*counter_collection.csv'))
+        f = glob.glob(os.path.join(src, 'pmc_%s_%s' % (wl, c), '**', '*counter_collection.csv'), recursive=True)
         if not f:
             continue
         agg = collections.defaultdict(list)
@@ -42,6 +42,8 @@ for wl in ('S1', 'S2', 'S3'):
             out[wl]['pair_full_bytes_per_launch'] = int(hbm)
             out[wl]['pair_full_fetch_kb_raw'] = round(fk[0], 1)
             out[wl]['pair_full_write_kb'] = round(wk[0], 1)
+for wl in out:
+    out[wl]['measured_at'] = tag
 with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w') as fh:
     json.dump(out, fh, indent=1)
 with open(os.path.join(ROOT, 'profiles', '%s_pmc_per_kernel.csv' % tag), 'w') as fh:
