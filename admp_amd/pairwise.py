@@ -5,9 +5,12 @@ The reference builds a calculator from an arbitrary JAX kernel:
     pot = generate_pairwise_interaction(TT_damping_qq_c6_kernel, covalent_map, static_args={})
     E, G = value_and_grad(pot)(positions, box, pairs, mScales, a_list, b_list, q_list, c_list)
 
-There is no tracing compiler here; a "kernel" is a named HIP kernel of libadmp_hip.  The one the
-reference ships, TT_damping_qq_c6_kernel, is provided; any other object raises NotImplementedError.
-`value_and_grad` below plays the role of jax.value_and_grad for these calculators (argnums = 0 only).
+Two kinds of kernel are accepted here:
+  * the one the reference ships, `TT_damping_qq_c6_kernel`: a hand-written HIP kernel of libadmp_hip;
+  * ANY Python function `kernel(dr, m, p1i, p1j, p2i, p2j, ...)` written against `admp_amd.xp` (the stand-in for
+    jax.numpy: sqrt, exp, erf, ..., where): it is traced once into HIP source, compiled for gfx950 at run time with hiprtc
+    and run as a row-per-atom pair kernel; the gradient comes from forward-mode dual numbers in the generated code.
+`value_and_grad` below plays the role of jax.value_and_grad for these calculators (argnums 0 = positions, 1 = box).
 """
 import ctypes
 
@@ -92,13 +95,58 @@ class _PairInteraction(HipForceBase):
         return e, self._like(g, positions)
 
 
+class _TracedPairInteraction(_PairInteraction):
+    """generate_pairwise_interaction for a user-supplied Python kernel: traced (admp_amd/xp.py) and compiled (hiprtc) at
+    the first call, when the number of atomic parameter lists is known."""
+
+    def __init__(self, fn, covalent_map, static_args):
+        HipForceBase.__init__(self, int(covalent_map.shape[0]), covalent_map, None, None, None)
+        self.kernel = fn
+        self.static_args = dict(static_args or {})
+        self._programs = {}                      # n_params -> program id
+        self.source = None
+
+    def _program(self, n_params):
+        if n_params not in self._programs:
+            from . import xp
+            self.source = xp.generate_source(self.kernel, n_params)
+            pid = ctypes.c_int(-1)
+            rc = self._L.admp_pair_program_build(self._h, self.source.encode(), n_params, ctypes.byref(pid))
+            _lib.check(self._h, rc, 'admp_pair_program_build')
+            self._programs[n_params] = pid.value
+        return self._programs[n_params]
+
+    def _evaluate_on_stream(self, positions, box, pairs, mScales, atomic_params, want_grad):
+        na = self.n_atoms
+        pid = self._program(len(atomic_params))
+        self.set_pairs(pairs)
+        pos = self._real(positions, (na, 3))
+        par = (torch.stack([self._real(p, (na,)) for p in atomic_params], dim=1).contiguous() if atomic_params
+               else None)
+        mS = self._host64(mScales)
+        E = (ctypes.c_double * 1)()
+        grad = torch.empty((na, 3), dtype=self._dtype, device=self._device) if want_grad else None
+        rc = self._L.admp_pair_program_energy_grad(self._h, pid, self._ptr(pos), _lib.darr(self._host64(box, 9)),
+                                                   self._ptr(par), len(mS), _lib.darr(mS), E, self._ptr(grad), 1)
+        _lib.check(self._h, rc, 'admp_pair_program_energy_grad')
+        return np.float64(E[0]), grad
+
+    def get_mscale_gradient(self, *a, **k):
+        raise NotImplementedError('dE/dmScales is available for the named kernels only')
+
+    def get_energy_and_box_gradient(self, *a, **k):
+        raise NotImplementedError('the box gradient is available for the named kernels only')
+
+
 def generate_pairwise_interaction(pair_int_kernel, covalent_map, static_args):
     """(kernel, covalent_map, static_args) -> pair_int(positions, box, pairs, mScales, *atomic_params)
-    (admp/pairwise.py:45-91)."""
-    if not isinstance(pair_int_kernel, _HipPairKernel):
-        raise NotImplementedError('only the HIP kernels exported by admp_amd.pairwise can be used '
-                                  '(arbitrary Python kernels need a tracing compiler, which this path does not have)')
-    return _PairInteraction(pair_int_kernel, covalent_map, static_args)
+    (admp/pairwise.py:45-91).  `pair_int_kernel`: TT_damping_qq_c6_kernel, or any Python function
+    kernel(dr, m, p1i, p1j, ...) written against admp_amd.xp (see the module docstring)."""
+    if isinstance(pair_int_kernel, _HipPairKernel):
+        return _PairInteraction(pair_int_kernel, covalent_map, static_args)
+    if callable(pair_int_kernel):
+        return _TracedPairInteraction(pair_int_kernel, covalent_map, static_args)
+    raise TypeError('pair_int_kernel must be a kernel of admp_amd.pairwise or a Python function of (dr, m, *params)')
 
 
 def value_and_grad(fn, argnums=0):

@@ -271,3 +271,47 @@ def test_pscale_gradient_vs_oracle(env):
     out = param_gradient(pme_potential(f, par['pol'], par['tholes']), pos, box, pairs,
                          dict(Q_local=par['Q_local'], mScales=par['mScales'], pScales=par['pScales'], dScales=par['dScales']))
     assert np.allclose(out['pScales'], g, rtol=1e-9, atol=1e-9 * scale) and not out['dScales'].any()
+
+
+@pytest.mark.parametrize('prec,tol', [('double', 1e-11), ('single', 2e-5)])
+def test_traced_pair_kernels_on_gpu(env, prec, tol):
+    """a22: generate_pairwise_interaction with ARBITRARY Python kernels (traced by admp_amd/xp.py, compiled by hiprtc):
+    (1) the reference's TT kernel restated as a Python function gives the numbers of the hand-written HIP kernel;
+    (2) a kernel with branches (switched, screened Lennard-Jones) against a torch restatement of the reference's driver
+        (pairs i<j, mScales[nbonds-1] with wrap, minimum image, sum of kernel values) and its autograd gradient."""
+    import torch
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
+    from tests.test_host_logic import _tt_kernel, _switched_lj
+    from oracle import admp_oracle as O
+    settings.PRECISION = prec
+    n_mol = 216
+    pos, box = S.synthetic_water_box(n_mol, seed=23)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol)
+    pairs = S.build_pairs(pos, box, 4.5)
+    mS = np.array([0.0, 0.3, 0.7, 1.0, 1.0])
+    abqc = (par['a_list'], par['b_list'], par['q_list'], par['c_list'][:, 0])
+    named = value_and_grad(generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={}))
+    traced = generate_pairwise_interaction(_tt_kernel, cov, static_args={})
+    E0, G0 = named(pos, box, pairs, mS, *abqc)
+    E1, G1 = value_and_grad(traced)(pos, box, pairs, mS, *abqc)
+    assert abs(E1 - E0) < tol * abs(E0) and rel(G1, G0) < 10 * tol
+    assert abs(traced(pos, box, pairs, mS, *abqc) - E1) < 1e-12 * abs(E1)           # energy-only call
+    # (2) a kernel the library has never seen, two parameter lists
+    rng = np.random.default_rng(2)
+    sig = np.tile(np.array([3.1, 1.8, 1.8]), n_mol) * rng.uniform(0.95, 1.05, 3 * n_mol)
+    eps = np.tile(np.array([0.65, 0.05, 0.05]), n_mol)
+    lj = generate_pairwise_interaction(_switched_lj, cov, static_args={})
+    E2, G2 = value_and_grad(lj)(pos, box, pairs, mS, sig, eps)
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))   # noqa: E731
+    p = T(pos).requires_grad_(True)
+    pi, pj, drv, m = O._pair_distances(p, T(box), pairs, T(mS), cov)
+    dr = torch.linalg.norm(drv, dim=1)
+    s, e = 0.5 * (T(sig)[pi] + T(sig)[pj]), torch.sqrt(T(eps)[pi] * T(eps)[pj])
+    x6 = (s / dr) ** 6
+    t = dr - 3.0
+    sw = torch.where(dr < 3.0, torch.ones_like(dr), torch.where(dr > 4.0, torch.zeros_like(dr), 1.0 - t * t * (3.0 - 2.0 * t)))
+    ref = torch.sum(m * 4.0 * e * (x6 * x6 - x6) * sw * torch.erfc(0.3 * dr) * dr ** -0.25)
+    g, = torch.autograd.grad(ref, p)
+    assert abs(E2 - float(ref)) < max(tol, 1e-12) * abs(float(ref)) * 10 and rel(G2, g.numpy()) < 10 * tol
+    assert 'admp_pair_custom' in lj.source

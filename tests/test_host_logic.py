@@ -147,3 +147,57 @@ def test_admp_alias_package_resolves_to_admp_amd():
     import admp_amd.pme
     assert admp.settings is admp_amd.settings and admp.pme is admp_amd.pme
     assert hasattr(admp.settings, 'REFERENCE_KPOINT_ORDER') and admp.settings.REFERENCE_KPOINT_ORDER is False
+
+
+def _tt_kernel(dr, m, ai, aj, bi, bj, qi, qj, ci, cj):
+    """the reference's TT_damping_qq_c6_kernel (admp/pairwise.py:96-113), its arithmetic restated against admp_amd.xp"""
+    from admp_amd import xp as jnp
+    a = jnp.sqrt(ai * aj)
+    b = jnp.sqrt(bi * bj)
+    c = ci * cj
+    q = qi * qj
+    br = b * (dr * 1.889726878)
+    ebr = jnp.exp(-br)
+    poly = 1 + br + br ** 2 / 2 + br ** 3 / 6 + br ** 4 / 24 + br ** 5 / 120 + br ** 6 / 720
+    return (2625.5 * a * ebr + (-2625.5) * ebr * (1 + br) * q / br + ebr * poly * c / dr ** 6) * m
+
+
+def _switched_lj(dr, m, si, sj, ei, ej):
+    """a kernel with a branch: Lennard-Jones, smoothly switched off between 3 and 4 A, erfc-screened"""
+    from admp_amd import xp
+    s = 0.5 * (si + sj)
+    e = xp.sqrt(ei * ej)
+    x6 = (s / dr) ** 6
+    lj = 4.0 * e * (x6 * x6 - x6)
+    t = (dr - 3.0) / 1.0
+    sw = xp.where(dr < 3.0, 1.0, xp.where(dr > 4.0, 0.0, 1.0 - t * t * (3.0 - 2.0 * t)))
+    return m * lj * sw * xp.erfc(0.3 * dr) * xp.power(dr, -0.25)
+
+
+@pytest.mark.parametrize('kernel,npar', [(_tt_kernel, 4), (_switched_lj, 2)])
+def test_traced_pair_kernel_value_and_derivative(tmp_path, kernel, npar):
+    """admp_amd/xp.py: a Python pair kernel is traced once into C++/HIP source.  The traced expression and its forward-mode
+    derivative (compiled here as HOST code with g++: no GPU needed) equal the Python function and its central difference."""
+    import subprocess
+    from admp_amd import xp
+    src = xp.generate_host_source(kernel, npar)
+    cpp, so = tmp_path / 'k.cpp', tmp_path / 'k.so'
+    cpp.write_text(src)
+    r = subprocess.run(['g++', '-O2', '-shared', '-fPIC', '-o', str(so), str(cpp)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    L = ctypes.CDLL(str(so))
+    rng = np.random.default_rng(5)
+    out = (ctypes.c_double * 2)()
+    for dr in (0.9, 2.2, 2.99, 3.4, 3.999, 5.5):
+        pi, pj = rng.uniform(0.5, 3.0, npar), rng.uniform(0.5, 3.0, npar)
+        args = [v for pair in zip(pi, pj) for v in pair]
+        L.eval(ctypes.c_double(dr), ctypes.c_double(0.7), (ctypes.c_double * npar)(*pi), (ctypes.c_double * npar)(*pj), out)
+        want = kernel(dr, 0.7, *args)                      # the same function on plain floats
+        h = 1e-6
+        fd = (kernel(dr + h, 0.7, *args) - kernel(dr - h, 0.7, *args)) / (2 * h)
+        assert abs(out[0] - want) <= 1e-13 * max(1.0, abs(want))
+        assert abs(out[1] - fd) <= 1e-6 * max(1.0, abs(fd))
+    dev = xp.generate_source(kernel, npar)                 # the device flavour: same body inside the pair kernel
+    assert 'extern "C" __global__' in dev and 'admp_pair_custom' in dev
+    with pytest.raises(TypeError):                         # Python control flow on traced values is refused, not mis-traced
+        xp.trace_pair_kernel(lambda dr, m: dr if dr > 1 else m, 0)
