@@ -114,19 +114,35 @@ __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__
 // One workgroup per brick: each listed atom adds the part of its stencil that falls inside the brick into a
 // 16^3 LDS tile; the tile is then stored once -- no memset, no global atomics.  The spline weights are
 // recomputed per (atom, brick) entry: ~0.5 kflop against up to 216 LDS atomics.
-// The tile is DOUBLE in both precisions: measured on MI355X (tools/ubench/lds_atomics.hip) ds_add_f32 sustains
-// only 0.33 lane-adds/clk/CU whereas ds_add_f64 sustains 7.4 (ds_add_u32: 13.6) -- a 22x difference that made
-// the f32 tile the bottleneck of the whole step; the f64 tile also makes the mesh sums precision-independent.
+// The tile is 64-bit FIXED POINT in both precisions (round 2).  Measured on MI355X, wave-level LDS atomics with 64 scattered
+// addresses -- the access shape of this kernel, 64 unrelated atoms per instruction (tools/ubench/lds_atomics_lanes.hip):
+// ds_add_f32 193 CU-cycles per instruction (why round 1 moved from an f32 to an f64 tile), ds_add_f64 27.3, ds_add_u64 13.6.
+// The LDS array was the bound of the f64 form (SQ_LDS_IDX_ACTIVE = 63 % of the kernel time), so the integer form halves
+// it; and integer sums do not depend on the order of the adds: the mesh is bitwise reproducible.
+// Scale, per brick: a first pass over the brick's entries finds bmax = max |q| + |c1|_1 + |c2|_1 of the folded multipoles
+// (every spline weight and derivative is <= 1 in magnitude), so no word can exceed bmax * entries; the scale is the power
+// of two that keeps 8x that below 2^62 (>= 2^45 for any brick a 16^3 tile can hold: finer than f64 on values of O(1)).
+// v * scale is turned into an integer by the 2^52 + 2^51 trick (one f64 fma + a 64-bit subtract; |v * scale| < 2^51 holds
+// by construction).
 #ifndef ADMP_BRICK_ROW
 #define ADMP_BRICK_ROW 17
 #endif
 constexpr int kBrickRow = ADMP_BRICK_ROW;   // z-row pitch of the LDS tile in words (17: bank skew)
+__device__ __forceinline__ unsigned long long fixed_bits(double v) {     // v already scaled, |v| < 2^51
+  const double t = v + 6755399441055744.0;                                // 2^52 + 2^51: the integer sits in the mantissa
+  return (unsigned long long)__double_as_longlong(t) - 0x4338000000000000ull;
+}
+__device__ __forceinline__ unsigned long long fixed_bits(float v) {      // v already scaled, |v| < 2^30: one conversion
+  const int i = (int)v;                                                   // (truncation: half an LSB of 2^-30 bmax) and a
+  return (unsigned long long)(long long)i;                                // sign extension instead of f64 arithmetic
+}
 template <class T>
 __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                        BrickGrid bg, const int* __restrict__ brick_start,
                                                        const int* __restrict__ entries, T* __restrict__ mesh,
                                                        int* __restrict__ clear_a, int* __restrict__ clear_b) {
-  __shared__ double tile[16 * 16 * kBrickRow];
+  __shared__ unsigned long long tile[16 * 16 * kBrickRow];
+  __shared__ unsigned s_bmax;
   const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
   const int bb[3] = {bx, by, bz};
   int lo[3], n[3];
@@ -134,13 +150,48 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     lo[d] = (bb[d] * g.dim(d)) / bg.nb[d];
     n[d] = ((bb[d] + 1) * g.dim(d)) / bg.nb[d] - lo[d];
   }
-  for (int t = threadIdx.x; t < 16 * 16 * kBrickRow; t += 256) tile[t] = 0.0;
+  for (int t = threadIdx.x; t < 16 * 16 * kBrickRow; t += 256) tile[t] = 0ull;
+  if (threadIdx.x == 0) s_bmax = 0u;
   __syncthreads();
-  // Entries arrive in atom order, so neighbours in the list are neighbours in space (O, H, H of one molecule: stencils
-  // that share most of their 216 points).  Side by side in a wavefront they would add to the SAME tile words in the same
-  // instruction, which the LDS serialises; the list is therefore read transposed -- lane l of the wavefront's pass p takes
-  // entry l * rows + p, so the 64 entries of one instruction are `rows` (about 9) list positions apart.
   const int beg = brick_start[blockIdx.x], cnt = brick_start[blockIdx.x + 1] - beg;
+  // pass 1: magnitude bound of this brick's folded multipoles -> fixed-point scale
+  {
+    // |c1|_1 <= amax |d|_1 and |c2|_1 <= 2 amax^2 |Theta/3|_1 with amax = the largest row (or column) sum of |Aop|
+    // (fold_multipole): a bound from norms costs a dozen instructions per entry instead of the fold itself
+    T amax = T(0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      amax = fmax(amax, m_abs(g.Aop[j]) + m_abs(g.Aop[3 + j]) + m_abs(g.Aop[6 + j]));
+      amax = fmax(amax, m_abs(g.Aop[3 * j]) + m_abs(g.Aop[3 * j + 1]) + m_abs(g.Aop[3 * j + 2]));
+    }
+    float bm = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+      T r[3], Q[9];
+      site_qtot(sites[entries[beg + e]], lpol, r, Q);
+      const T d1 = m_abs(Q[1]) + m_abs(Q[2]) + m_abs(Q[3]);
+      const T q2 = m_abs(Q[4]) + m_abs(Q[5]) + m_abs(Q[6]) + m_abs(Q[7]) + m_abs(Q[8]);
+      bm = fmaxf(bm, (float)(m_abs(Q[0]) + amax * d1 + T(2) * amax * amax * q2));
+    }
+    if (bm > 0.f) atomicMax(&s_bmax, __float_as_uint(bm * 1.0001f));    // non-negative floats order like their bits
+  }
+  __syncthreads();
+  const double bmax = (double)__uint_as_float(s_bmax), bound = 8.0 * bmax * (double)(cnt > 0 ? cnt : 1);
+  int ex = 20;
+  if (bmax > 0.0) {
+    if (sizeof(T) == 4) {
+      ex = 29 - ilogb(bmax);                             // f32: every term fits an int32 (|term| 2^ex < 2^30); the 64-bit
+                                                         // words then hold 2^32 of them; resolution bmax 2^-30 << f32 eps
+    } else {
+      ex = 61 - ilogb(bound);                            // f64: 2^ex * bound < 2^62, no word can overflow ...
+      const int e1 = 49 - ilogb(bmax);                   // ... and 2^ex * bmax < 2^50: every term fits the mantissa trick
+      ex = ex < e1 ? ex : e1;
+      ex = ex > 60 ? 60 : ex;
+    }
+  }
+  const T scale = (T)ldexp(1.0, ex);
+  const double inv_scale = ldexp(1.0, -ex);
+  // Entries arrive in atom order; the list is read transposed -- lane l of the wavefront's pass p takes entry
+  // l * rows + p -- so the 64 entries of one instruction are `rows` list positions apart (different molecules).
   const int rows = (cnt + 63) >> 6, lane = threadIdx.x & 63;
   for (int pass = threadIdx.x >> 6; pass < rows; pass += 4) {
     const int e = lane * rows + pass;
@@ -152,27 +203,54 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     T c1[3], c2[6];
     fold_multipole(g, Q, c1, c2);
     const T q = Q[0];
+    // The kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU = 86 % of its time at 18 instructions per stencil point), so
+    // the per-point work is stripped to 3 FMAs, the integer conversion and one mask test: the stencil's position is
+    // expressed once per entry RELATIVE to the brick (off = base - lo, folded by the period when the stencil reaches the
+    // brick across the periodic seam), so that point p of an axis sits at local index off + p with no wrap, the LDS
+    // address is "row + constant", and validity is one bit of a 6-bit mask per axis.
+    int off[3], ok[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int period = d == 0 ? g.wrap0 : g.K[d];
+      int o = st.base[d] - lo[d];
+      if (o + 5 < 0) o += period;                      // stencil starts before the seam, ends inside this brick
+      else if (o >= n[d]) o -= period;                 // brick at the low end, stencil wraps around from the high end
+      off[d] = o;
+      int m = 0;
+#pragma unroll
+      for (int p6 = 0; p6 < 6; ++p6) m |= ((unsigned)(o + p6) < (unsigned)n[d]) << p6;
+      ok[d] = m;
+    }
+    if (!(ok[0] && ok[1] && ok[2])) continue;
+    // z axis: no branch per point -- an out-of-brick point gets zero weights and a clamped (in-tile) index, so it adds an
+    // exact integer 0 to a word of the row; x and y keep their `continue` (they skip 36 / 6 points at a time)
+    T wz[6], w1z[6], w2z[6];
+    int jz[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const bool in = (ok[2] >> c) & 1;
+      wz[c] = in ? st.M[2][c] : T(0); w1z[c] = in ? st.D1[2][c] : T(0); w2z[c] = in ? st.D2[2][c] : T(0);
+      const int j = off[2] + c;
+      jz[c] = j < 0 ? 0 : (j >= n[2] ? n[2] - 1 : j);
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const int ja = wrap_add(st.base[0], a, g.wrap0) - lo[0];
-      if ((unsigned)ja >= (unsigned)n[0]) continue;
+      if (!((ok[0] >> a) & 1)) continue;
+      const int ja = off[0] + a;
       const T m0 = st.M[0][a], d0 = st.D1[0][a], e0 = st.D2[0][a];
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        const int jb = wrap_add(st.base[1], b, g.K[1]) - lo[1];
-        if ((unsigned)jb >= (unsigned)n[1]) continue;
+        if (!((ok[1] >> b) & 1)) continue;
+        const int jb = off[1] + b;
         const T m1 = st.M[1][b], d1 = st.D1[1][b], e1 = st.D2[1][b];
         const T mm = m0 * m1;
-        const T P0 = q * mm + c1[0] * d0 * m1 + c1[1] * m0 * d1 + c2[0] * e0 * m1 + c2[1] * m0 * e1 + c2[3] * d0 * d1;
-        const T P1 = c1[2] * mm + c2[4] * d0 * m1 + c2[5] * m0 * d1;
-        const T P2 = c2[2] * mm;
-        double* row = tile + (ja * 16 + jb) * kBrickRow;
+        // the power-of-two scale goes into the three (a, b) factors: exact, and no multiply per point
+        const T P0 = scale * (q * mm + c1[0] * d0 * m1 + c1[1] * m0 * d1 + c2[0] * e0 * m1 + c2[1] * m0 * e1 + c2[3] * d0 * d1);
+        const T P1 = scale * (c1[2] * mm + c2[4] * d0 * m1 + c2[5] * m0 * d1);
+        const T P2 = scale * (c2[2] * mm);
+        unsigned long long* row = tile + (ja * 16 + jb) * kBrickRow;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const int jc = wrap_add(st.base[2], c, g.K[2]) - lo[2];
-          if ((unsigned)jc < (unsigned)n[2])
-            atomicAdd(&row[jc], (double)(P0 * st.M[2][c] + P1 * st.D1[2][c] + P2 * st.D2[2][c]));
-        }
+        for (int c = 0; c < 6; ++c) atomicAdd(&row[jz[c]], fixed_bits(P0 * wz[c] + P1 * w1z[c] + P2 * w2z[c]));
       }
     }
   }
@@ -180,7 +258,8 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   const int nyz = n[1] * n[2], ntot = n[0] * nyz;
   for (int t = threadIdx.x; t < ntot; t += 256) {
     const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
-    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * kBrickRow + jc];
+    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] =
+        (T)((double)(long long)tile[(ja * 16 + jb) * kBrickRow + jc] * inv_scale);
   }
   // this brick's binning counters are consumed: clear them for the next binning (no memset dispatches per step)
   if (threadIdx.x == 0 && clear_a) { clear_a[blockIdx.x] = 0; clear_b[blockIdx.x] = 0; }
@@ -650,11 +729,14 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
                   T* mesh, const int* list, const int4* bases, int nb, int reuse_bins) {
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
-  if (na < spread_brick_min_atoms()) {
+  // the binned brick kernel expresses a stencil as ONE run of local indices per axis, which needs >= 2 bricks per axis
+  // (a stencil that wraps around inside a single brick is two runs): meshes of <= 16 points per axis take the scan kernel
+  const bool one_brick_axis = bg.nb[0] == 1 || bg.nb[1] == 1 || bg.nb[2] == 1;
+  if (na < spread_brick_min_atoms() || one_brick_axis) {
     // measured (f32, reference K rule): 12 288 atoms scan 0.052 / bricks 0.066 / global atomics 0.130 ms; 18 000 atoms
     // 0.070 / 0.083 / 0.189; 30 000 atoms 0.144 / 0.109 -- the scan kernel serves everything below the brick threshold
     static const int scan_max = [] { const char* e = getenv("ADMP_SPREAD_SCAN_MAX"); return e ? atoi(e) : 20000; }();
-    if (na <= scan_max) {
+    if (na <= scan_max || one_brick_axis) {
       k_spread_scan<T><<<dim3(bg.ncell, nb), 256, 0, st>>>(na, sites, lpol, g, bg, mesh, list, bases);
       return 0;
     }

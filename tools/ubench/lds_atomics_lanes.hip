@@ -6,10 +6,10 @@
 
 // pattern 0: lane l -> word l (+ moving offset): conflict free; 1: scattered (hash); 2: stride 17 words;
 // 3: 36 active lanes laid out as 6 rows of 6 consecutive words, row pitch `pitch`
-template <int PATTERN>
+template <int PATTERN, class V = double>
 __global__ __launch_bounds__(256) void k(double* out, int iters, int active, int pitch) {
-  __shared__ double tile[8192];
-  for (int t = threadIdx.x; t < 8192; t += 256) tile[t] = 0.0;
+  __shared__ V tile[8192];
+  for (int t = threadIdx.x; t < 8192; t += 256) tile[t] = V(0);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   int base;
@@ -21,24 +21,24 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, int active, int
   if (lane < active) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) atomicAdd(&tile[(base + u * 97 + it * 13) & 8191], 1.0);
+      for (int u = 0; u < 16; ++u) atomicAdd(&tile[(base + u * 97 + it * 13) & 8191], V(1));
     }
   }
   __syncthreads();
   double s = 0;
-  for (int t = threadIdx.x; t < 8192; t += 256) s += tile[t];
+  for (int t = threadIdx.x; t < 8192; t += 256) s += (double)tile[t];
   if (s == -1.0) out[0] = s;
 }
 
-template <int PATTERN>
+template <int PATTERN, class V = double>
 void run(const char* name, int active, int pitch) {
   double* out; hipMalloc(&out, 64);
   const int blocks = 256 * 8, iters = 256;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  k<PATTERN><<<blocks, 256>>>(out, 4, active, pitch);
+  k<PATTERN, V><<<blocks, 256>>>(out, 4, active, pitch);
   hipDeviceSynchronize();
   hipEventRecord(a);
-  k<PATTERN><<<blocks, 256>>>(out, iters, active, pitch);
+  k<PATTERN, V><<<blocks, 256>>>(out, iters, active, pitch);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   const double winstr = (double)blocks * 4 * iters * 16;          // wave-level instructions
@@ -53,5 +53,12 @@ int main() {
   for (int act : {64, 36, 16}) run<1>("scattered", act, 0);
   for (int act : {64, 36}) run<2>("stride 17 words", act, 0);
   for (int pitch : {16, 17, 20, 21, 22, 24}) run<3>("6 rows x 6 words", 36, pitch);
+  // integer atomics (fixed-point accumulation): 64-bit and 32-bit
+  run<0, unsigned long long>("u64 consecutive", 64, 0);
+  run<1, unsigned long long>("u64 scattered", 64, 0);
+  run<0, unsigned>("u32 consecutive", 64, 0);
+  run<1, unsigned>("u32 scattered", 64, 0);
+  run<0, float>("f32 consecutive", 64, 0);
+  run<1, float>("f32 scattered", 64, 0);
   return 0;
 }
