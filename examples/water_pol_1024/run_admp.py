@@ -1,35 +1,59 @@
 #!/usr/bin/env python
-"""Counterpart of the reference's examples/water_pol_1024/run_admp.py: polarizable MPID water, induced
-dipoles by Jacobi SCF, energy and gradient at the converged dipoles (warm-started second call).
+"""Counterpart of the reference's examples/water_pol_1024/run_admp.py: polarizable MPID water, induced dipoles by Jacobi
+SCF, energy and gradient at the converged dipoles (warm-started second call).  The reference's statements
+(run_admp.py:19-141): inputs read from `water1024.pdb` / `mpidwater.xml` next to the script (examples/make_inputs.py writes
+them; the geometry is the seeded synthetic liquid box -- on the reference's shipped random placement, 0.67 A contacts, the
+Jacobi SCF of the reference itself diverges).
 
-    python examples/water_pol_1024/run_admp.py [box.pdb]
-
-Default geometry: the seeded synthetic liquid box of 1024 waters (L = 31.289 A) -- on the reference's
-shipped water1024.pdb (random placement, 0.67 A contacts) the Jacobi SCF of the reference itself diverges
-(SURVEY.md section 4), so that file is only useful for the non-polarizable example.
+    python examples/make_inputs.py && python examples/water_pol_1024/run_admp.py
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
+import numpy as np
 
-from admp_amd import systems as S            # noqa: E402
-from admp_amd.pme import ADMPPmeForce        # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as jnp                                                              # noqa: E402  (set-up arrays only)
+import admp.settings                                                             # noqa: E402,F401
+from admp.multipole import convert_cart2harm                                     # noqa: E402
+from admp.pme import ADMPPmeForce                                                # noqa: E402
+from admp.parser import *                                                        # noqa: E402,F401,F403
+from admp_amd.neighbor import NeighborList                                       # noqa: E402
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1:
-        positions, box = S.load_pdb_positions(sys.argv[1])
-    else:
-        positions, box = S.synthetic_water_box(1024, seed=20240)
-    n_mol = len(positions) // 3
-    axis_type, axis_indices, covalent_map = S.water_topology(n_mol)
-    par = S.water_parameters(n_mol, polarizable=True)
-    Q_local, pol, tholes = par['Q_local'], par['pol'], par['tholes']
-    mScales, pScales, dScales = par['mScales'], par['pScales'], par['dScales']
-    rc, ethresh, lmax = 4, 1e-4, 2
+    here = os.path.dirname(os.path.abspath(__file__))
+    pdbinfo = read_pdb(os.path.join(here, 'water1024.pdb'))
+    serials, names, resNames, resSeqs = (pdbinfo[k] for k in ('serials', 'names', 'resNames', 'resSeqs'))
+    positions = jnp.asarray(pdbinfo['positions'])
+    charges = pdbinfo['charges']
+    lx, ly, lz, _, _, _ = pdbinfo['box']
+    box = jnp.eye(3) * jnp.array([lx, ly, lz])
 
-    pairs = S.build_pairs(positions, box, rc)
+    mScales = jnp.array([0.0, 0.0, 0.0, 1.0, 1.0])
+    pScales = jnp.array([0.0, 0.0, 0.0, 1.0, 1.0])
+    dScales = jnp.array([0.0, 0.0, 0.0, 1.0, 1.0])
+    rc = 4        # in Angstrom
+    ethresh = 1e-4
+    n_atoms = len(serials)
+
+    atomTemplate, residueTemplate = read_xml(os.path.join(here, 'mpidwater.xml'))
+    atomDicts, residueDicts = init_residues(serials, names, resNames, resSeqs, positions, charges, atomTemplate,
+                                            residueTemplate)
+    Q = np.vstack([(atom.c0, atom.dX * 10, atom.dY * 10, atom.dZ * 10, atom.qXX * 300, atom.qYY * 300, atom.qZZ * 300,
+                    atom.qXY * 300, atom.qXZ * 300, atom.qYZ * 300) for atom in atomDicts.values()])
+    Q_local = convert_cart2harm(Q, 2)
+    axis_type = np.array([atom.axisType for atom in atomDicts.values()])
+    axis_indices = np.vstack([atom.axis_indices for atom in atomDicts.values()])
+    covalent_map = assemble_covalent(residueDicts, n_atoms)
+
+    # induction parameters: nm^3 -> A^3 through float32, like the reference (run_admp.py:58-69)
+    pol = np.vstack([(atom.polarizabilityXX, atom.polarizabilityYY, atom.polarizabilityZZ) for atom in atomDicts.values()])
+    pol = 1000 * jnp.mean(pol.astype(np.float32), axis=1)
+    tholes = np.vstack([atom.thole for atom in atomDicts.values()])
+    tholes = jnp.mean(tholes.astype(np.float32), axis=1)
+
+    lmax = 2
+    pairs = NeighborList(box, rc).allocate(positions)
 
     pme_force = ADMPPmeForce(box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol=True)
     pme_force.update_env('kappa', 0.657065221219616)

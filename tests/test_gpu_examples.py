@@ -15,6 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 
+@pytest.fixture(scope='module', autouse=True)
+def example_inputs():
+    """the PDB / XML files the drivers read from their directories (generated, not committed)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'make_inputs.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def run_script(rel, *args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, rel)] + list(args), capture_output=True, text=True, timeout=600,
                        cwd=ROOT)

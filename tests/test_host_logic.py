@@ -201,3 +201,33 @@ def test_traced_pair_kernel_value_and_derivative(tmp_path, kernel, npar):
     assert 'extern "C" __global__' in dev and 'admp_pair_custom' in dev
     with pytest.raises(TypeError):                         # Python control flow on traced values is refused, not mis-traced
         xp.trace_pair_kernel(lambda dr, m: dr if dr > 1 else m, 0)
+
+
+def test_parser_reproduces_example_inputs(tmp_path):
+    """admp.parser (this package's reader of the drivers' PDB / XML inputs) on the files examples/make_inputs.py writes:
+    multipoles, axis types / anchors and covalent map equal the hard-wired water preparation of admp_amd/systems.py, i.e.
+    what the reference's tests/test_sptial.py:74-84 lists for O, H1, H2 waters."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'make_inputs.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    from admp.parser import read_pdb, read_xml, init_residues, assemble_covalent
+    from admp.multipole import convert_cart2harm
+    from admp_amd import systems as S
+    d = os.path.join(ROOT, 'examples', 'water_pol_1024')
+    info = read_pdb(os.path.join(d, 'water1024.pdb'))
+    at, rt = read_xml(os.path.join(d, 'mpidwater.xml'))
+    atoms, residues = init_residues(info['serials'], info['names'], info['resNames'], info['resSeqs'], info['positions'],
+                                    info['charges'], at, rt)
+    n = len(info['serials'])
+    assert n == 3072 and info['box'][:3] == [31.289, 31.289, 31.289]
+    Q = np.vstack([(a.c0, a.dX * 10, a.dY * 10, a.dZ * 10, a.qXX * 300, a.qYY * 300, a.qZZ * 300, a.qXY * 300, a.qXZ * 300,
+                    a.qYZ * 300) for a in atoms.values()])
+    t, idx, cov = S.water_topology(n // 3)
+    par = S.water_parameters(n // 3, True)
+    assert np.abs(convert_cart2harm(Q, 2) - par['Q_local']).max() < 1e-15
+    assert (np.array([a.axisType for a in atoms.values()]) == t).all()
+    assert (np.vstack([a.axis_indices for a in atoms.values()]) == idx).all()
+    assert (assemble_covalent(residues, n) == cov.toarray()).all()
+    pol = np.vstack([(a.polarizabilityXX, a.polarizabilityYY, a.polarizabilityZZ) for a in atoms.values()]).astype(np.float32)
+    assert np.abs(1000 * np.mean(pol, axis=1) - par['pol']).max() < 1e-12
