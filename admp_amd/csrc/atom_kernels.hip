@@ -40,7 +40,9 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
                                                               const T* __restrict__ thole, Box<T> box,
                                                               Site<T>* __restrict__ sites, double* zero_next,
                                                               RecipGeom<T> g, int4* __restrict__ bases,
-                                                              int* __restrict__ act_list, int* __restrict__ act_count) {
+                                                              int* __restrict__ act_list, int* __restrict__ act_count,
+                                                              const int* __restrict__ cls, int* __restrict__ cls_flags,
+                                                              RQ4<T>* __restrict__ rq) {
   int i = blockIdx.x * kAtomBlock + threadIdx.x;
   if (zero_next && i < E_WORDS) zero_next[i] = 0.0;   // the NEXT evaluation's energy words (engine.hip: Ed_cur)
   if (act_list) {   // kernel-uniform: list of the polarizable sites (pol > 0); ONE counter update per workgroup (every
@@ -80,7 +82,21 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
   s.p6 = a > T(0) ? (T)pow((double)a, 1.0 / 6.0) : T(0);
   s.thole = thole ? thole[i] : T(0);
   s.pad[0] = s.pad[1] = s.pad[2] = T(0);
+  // charge-only site (pme_math.h site_is_mono): no dipole, no quadrupole, not polarizable, no dipole handed in.  pad[0] is
+  // free for the mark: the pad words carry dU only on polarizable sites.  (Q_local zero <=> Q_global zero: orthogonal map.)
+  if (s.p6 == T(0) && s.U[0] == T(0) && s.U[1] == T(0) && s.U[2] == T(0)) {
+    bool mono = true;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) mono = mono && ql[k] == T(0);
+    s.pad[0] = mono ? T(1) : T(0);
+  }
+  if (cls_flags) {   // does the neighbour table's idea of the charge-only atoms (NbrTable::cls) still hold?
+    const bool was = cls && cls[i] != 0, is = s.pad[0] == T(1) && s.p6 == T(0);
+    const int f = was && !is ? CLS_STALE : (!was && is ? CLS_BETTER : 0);
+    if (f && !(*(volatile int*)cls_flags & f)) atomicOr(cls_flags, f);
+  }
   sites[i] = s;
+  if (rq) { RQ4<T> q; q.v[0] = s.r[0]; q.v[1] = s.r[1]; q.v[2] = s.r[2]; q.v[3] = s.Q[0]; rq[i] = q; }
   if (bases) {   // lowest mesh index of the atom's stencil on every axis: what the spread's binning needs, 16 B per atom
     int b[3];
 #pragma unroll
@@ -88,6 +104,13 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
     const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
     bases[i] = make_int4(b[0], b[1], b[2], brick_code(b, dims, make_bricks(dims)));
   }
+}
+
+// NbrTable::cls from the sites of the last evaluation
+template <class T>
+__global__ __launch_bounds__(kAtomBlock) void k_site_classes(int na, const Site<T>* __restrict__ sites, int* __restrict__ cls) {
+  const int i = blockIdx.x * kAtomBlock + threadIdx.x;
+  if (i < na) cls[i] = site_is_mono(sites[i]) ? 1 : 0;
 }
 
 // Jacobi step of the incremental SCF, over the polarizable sites only (see launch.h)
@@ -542,9 +565,14 @@ static inline int nblk(int n) { return (n + kAtomBlock - 1) / kAtomBlock; }
 template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
                           const T* pol, const T* thole, const Box<T>& box, Site<T>* sites, double* zero_next,
-                          const RecipGeom<T>& g, int4* bases, int* act_list, int* act_count) {
+                          const RecipGeom<T>& g, int4* bases, int* act_list, int* act_count, const int* cls,
+                          int* cls_flags, RQ4<T>* rq) {
   k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites, zero_next, g,
-                                                          bases, act_list, act_count);
+                                                          bases, act_list, act_count, cls, cls_flags, rq);
+}
+template <class T>
+void launch_site_classes(hipStream_t st, int na, const Site<T>* sites, int* cls) {
+  if (na > 0) k_site_classes<T><<<nblk(na), kAtomBlock, 0, st>>>(na, sites, cls);
 }
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites) {
@@ -630,8 +658,10 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
   template void launch_scalar_sites_batch<T>(hipStream_t, int, const T*, const T*, int, int, const double*, Site<T>*,   \
                                              double*);                                                                  \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
-                                        const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*, int*, int*);      \
+                                        const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*, int*, int*,       \
+                                        const int*, int*, RQ4<T>*);                                                     \
   template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \
+  template void launch_site_classes<T>(hipStream_t, int, const Site<T>*, int*);                                         \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
                                        unsigned long long*, const int*, const int*);                                    \
   template void launch_jacobi_delta<T>(hipStream_t, int, const int*, const T*, const T*, T*, Site<T>*, Site<T>*);       \

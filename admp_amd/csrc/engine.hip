@@ -246,7 +246,9 @@ struct EngineBase {
     if (nbr.rowptr) (void)hipFree(nbr.rowptr);
     if (nbr.col) (void)hipFree(nbr.col);
     if (nbr.order) (void)hipFree(nbr.order);
+    if (nbr.cls) (void)hipFree(nbr.cls);
     nbr = NbrTable();
+    cls_pending = false; cls_quiet = 1 << 20;
     have_top = have_pairs = false;
     ++nbr_gen;
   }
@@ -256,7 +258,24 @@ struct EngineBase {
     static const bool off = [] { const char* e = getenv("ADMP_PAIR_SORT"); return e && atoi(e) == 0; }();
     if (off || snranks != 1) { if (nbr.order) { (void)hipFree(nbr.order); nbr.order = nullptr; } return; }
     if (!nbr.order) HIP_TRY(hipMalloc(&nbr.order, sizeof(int) * (size_t)top.na));
-    launch_row_order(stream, top.na, nbr.rowptr, nbr.order);
+    launch_row_order(stream, top.na, nbr.rowptr, nbr.order, nbr.cls);
+  }
+  // Site classes of the neighbour table (NbrTable::cls).  k_prepare_sites compares them with the sites of every evaluation
+  // and leaves CLS_STALE / CLS_BETTER next to E_NACT; read_energies hands the word to cls_seen, and the next evaluation
+  // recompiles the table (part the rows, regroup the row order) before it starts.  A table that is merely not as good as
+  // it could be (CLS_BETTER) is left alone for a while after a CLS_STALE, so that a caller alternating between parameter
+  // sets does not pay a recompilation per call.
+  bool cls_pending = false;
+  int cls_quiet = 1 << 20;      // evaluations since the last CLS_STALE
+  void cls_seen(int flags) {
+    if (snranks != 1) return;
+    if (flags & CLS_STALE) { cls_pending = true; cls_quiet = 0; }
+    else if ((flags & CLS_BETTER) && cls_quiet > 8) cls_pending = true;
+  }
+  void apply_classes() {        // after a table build: part the fresh rows by the classes already known
+    if (!nbr.cls) return;
+    int rc = launch_class_partition(stream, top.na, nbr);
+    if (rc != 0) throw Err{ADMP_E_HIP, std::string("class partition: ") + hipGetErrorString((hipError_t)rc)};
   }
 
   void set_topology(int na, const int32_t* atype, const int32_t* aidx, const int32_t* eptr, const int32_t* ecol,
@@ -278,7 +297,8 @@ struct EngineBase {
     if (eptr) {
       int nnz = eptr[na];
       ARG_CHECK(nnz >= 0, "bad exclusion rowptr");
-      for (int k = 0; k < nnz; ++k) ARG_CHECK(ecol[k] >= 0 && ecol[k] < na && enb[k] >= 0 && enb[k] <= 15, "bad exclusion entry");
+      for (int k = 0; k < nnz; ++k) ARG_CHECK(ecol[k] >= 0 && ecol[k] < na && enb[k] >= 0 && enb[k] <= kNbMask,
+                                                "bad exclusion entry (atom index out of range, or nbonds outside 0..7)");
       HIP_TRY(hipMalloc(&top.excl_ptr, sizeof(int) * (na + 1)));
       HIP_TRY(hipMalloc(&top.excl_col, sizeof(int) * (nnz > 0 ? nnz : 1)));
       HIP_TRY(hipMalloc(&top.excl_nb, sizeof(int) * (nnz > 0 ? nnz : 1)));
@@ -357,6 +377,7 @@ struct EngineBase {
       TIMED("nbr_build");
       int rc = build_neighbour_table(stream, top, n_rows, dev, nbr, &scan_scratch.p, &scan_bytes);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("build_neighbour_table: ") + hipGetErrorString((hipError_t)rc)};
+      apply_classes();
       order_rows();
     }
     HIP_TRY(hipStreamSynchronize(stream));
@@ -403,6 +424,7 @@ struct Engine : EngineBase {
   struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0, ref = 0; } tabkey[4];
   static int tab_slot(int which) { return which == 1 ? 0 : (which == 6 ? 1 : (which == 8 ? 2 : 3)); }
   bool warm_regime = false;   // previous polarizable call converged at its first SCF check
+  bool mono_ok = false;       // this evaluation may use the charge-only pair forms (no dE/dQ_local requested)
 
   ~Engine() override {
     destroy_plans();
@@ -707,9 +729,19 @@ struct Engine : EngineBase {
       const bool want_act = lpol && snranks == 1 && !(keep_pol_sites && have_list);
       act_fresh = want_act;
       if (want_act) { act_d.need(sizeof(int) * (size_t)na); act_n = -1; act_top_na = na; ++act_gen; }
+      if (cls_pending && snranks == 1 && have_pairs && cls_sites_na == na) {   // `sites` still holds the last evaluation's
+        if (!nbr.cls) HIP_TRY(hipMalloc(&nbr.cls, sizeof(int) * (size_t)na));
+        launch_site_classes<T>(stream, na, sites.as<Site<T>>(), nbr.cls);
+        apply_classes();
+        order_rows();
+      }
+      cls_pending = false;
+      cls_sites_na = na;
+      ++cls_quiet;
       launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, ev.U, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>(),
                               energies_d.as<double>() + (size_t)(ehalf ^ 1) * E_WORDS, ev.g, bases_d.as<int4>(),
-                              want_act ? act_d.as<int>() : nullptr, want_act ? nact_dev() : nullptr);
+                              want_act ? act_d.as<int>() : nullptr, want_act ? nact_dev() : nullptr, nbr.cls,
+                              cls_flags_dev(), rq_p());
       ev.bases = bases_d.as<int4>();
     }
     other_clean = true;
@@ -743,7 +775,8 @@ struct Engine : EngineBase {
     need_eval();
     TIMED("pair_field");
     launch_pair_field<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                         ev.home ? ev.home : nbr.order);
+                         ev.home ? ev.home : nbr.order, nullptr, snranks == 1 && !ev.home ? cls_flags_dev() : nullptr,
+                         rq_d.as<RQ4<T>>(), ev.thole);
   }
   void stage_spread(T* mesh_p) {
     need_eval();
@@ -799,7 +832,8 @@ struct Engine : EngineBase {
     slot_clean[E_REAL] = false;
     TIMED("pair_full");
     launch_pair_full<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, lpol, grad_p, pot.as<T>(),
-                        Ed_cur(), ev.home ? ev.home : nbr.order, fld_out);
+                        Ed_cur(), ev.home ? ev.home : nbr.order, fld_out, mono_ok && !ev.home && snranks == 1 ? 1 : 0,
+                        cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole);
   }
   // with_field_finish: the gather also forms the total dE/dU and its maximum (launch_field_finish's work, fused)
   void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr, bool with_field_finish = false,
@@ -840,6 +874,14 @@ struct Engine : EngineBase {
   // (admp/pme.py:130-138) regrouped, same dipoles and cycle count to round-off.
   enum { E_PARTS_SUM = -1 };   // read_energies: the reciprocal energy is the sum of the E_PARTS partial words
   int* nact_dev() { return reinterpret_cast<int*>(Ed_cur() + E_NACT); }
+  DevBuf rq_d;                                      // compact (position, charge) rows: what the pair kernels read of a
+  RQ4<T>* rq_p() {                                  // charge-only partner
+    if (snranks != 1) return nullptr;
+    rq_d.need(sizeof(RQ4<T>) * (size_t)top.na);
+    return rq_d.as<RQ4<T>>();
+  }
+  int* cls_flags_dev() { return nact_dev() + 1; }   // the other half of that word: CLS_* of this evaluation (k_prepare_sites)
+  int cls_sites_na = -1;                            // `sites` holds an evaluation of this many atoms
   // device-side count for the kernels of the first cycle when the list is fresh (nullptr: the host knows it: act_n)
   const int* nact_arg() { return act_fresh ? nact_dev() : nullptr; }
   int nact_rows() const { return act_fresh ? top.na : act_n; }      // grid bound of those kernels
@@ -905,6 +947,11 @@ struct Engine : EngineBase {
     if (!Eh) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&Eh), E_WORDS * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(Eh, Ed_cur(), E_WORDS * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    {
+      int w[2];
+      std::memcpy(w, &Eh[E_NACT], sizeof(w));
+      cls_seen(w[1]);
+    }
     E[0] = Eh[E_REAL]; E[1] = recip_slot >= 0 ? Eh[recip_slot] : 0.0; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
     if (recip_slot == E_PARTS_SUM) {         // atom-side reciprocal energy: the partial words of k_gather<.., true>
       double e = 0.0;
@@ -958,6 +1005,7 @@ struct Engine : EngineBase {
     }
     grad.need(3 * (size_t)na * sizeof(T));   // the gradient buffer is needed internally even for energy-only calls
     T* gbuf = dpos ? dpos : grad.as<T>();
+    mono_ok = (dQl == nullptr);
 
     stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, U);
 
@@ -1004,7 +1052,7 @@ struct Engine : EngineBase {
         if (!have_base) {        // first field evaluation of the call: everything, at the polarizable sites
           { TIMED("pair_field");
             launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                                 act_d.as<int>(), nact_arg()); }
+                                 act_d.as<int>(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole); }
           recip_pass(E_SCF_RECIP);
           { TIMED("gather_field");
             launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(),
@@ -1055,6 +1103,7 @@ struct Engine : EngineBase {
     const int na = top.na;
     grad.need(3 * (size_t)na * sizeof(T));
     T* gbuf = dpos_ ? reinterpret_cast<T*>(dpos_) : grad.as<T>();
+    mono_ok = (dQl_ == nullptr);
     stage_begin(pos_, box, Ql_, pol_, thole_, ns, mS, pS, const_cast<void*>(U_));
     const bool wantU = dU_ != nullptr;
     stage_pair_full(gbuf, wantU ? fld_pair.as<T>() : nullptr);
@@ -1142,6 +1191,7 @@ struct Engine : EngineBase {
     const int na = top.na;
     grad.need(3 * (size_t)na * sizeof(T));
     T* gbuf = grad.as<T>();
+    mono_ok = true;
     stage_begin(pos_, box, Ql_, pol_, thole_, ns, mS, pS, const_cast<void*>(U_));
     double inv[9], vol;
     make_box(box, inv, &vol);
@@ -1185,6 +1235,7 @@ struct Engine : EngineBase {
     double* acc = vir_begin();
     launch_disp_pair<T>(stream, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, grad.as<T>(), Ed);
     launch_scalar_pair_virial<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, acc + V_XW);
+    cls_sites_na = -1;   // other rows than an electrostatics evaluation's
     sites.need(sizeof(Site<T>) * (size_t)na);
     ensure_bins(na);
     const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
@@ -1268,6 +1319,7 @@ struct Engine : EngineBase {
     TIMED("neighbor_table");
     int r = cell_build_table<T>(stream, top, reinterpret_cast<const T*>(pos), b, heights, rc, cells, nbr);
     if (r != 0) throw Err{ADMP_E_HIP, std::string("cell_build_table: ") + hipGetErrorString((hipError_t)r)};
+    apply_classes();
     order_rows();
     have_pairs = true;
     ++nbr_gen;
@@ -1281,6 +1333,7 @@ struct Engine : EngineBase {
   }
   int v_stage_begin(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                     const double* mS, const double* pS, void* U) override {
+    mono_ok = false;            // the staged caller may still ask for dE/dQ_local at ADMP_ST_FINISH
     return stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, U);
   }
   void v_stage(int what, void* a, void* b, int iarg, double* dout) override {
@@ -1357,6 +1410,7 @@ struct Engine : EngineBase {
     { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, dpos, Ed); }
     // one scalar reciprocal pass per power through the same brick spread / lane-group gather as the electrostatics:
     // the channel is packed into charge-only site rows (which also accumulates the self term, disp_pme.py:254-279)
+    cls_sites_na = -1;   // other rows than an electrostatics evaluation's
     sites.need(sizeof(Site<T>) * (size_t)na);
     fld_recip.need(3 * (size_t)na * sizeof(T));
     ensure_bins(na);
@@ -1375,6 +1429,7 @@ struct Engine : EngineBase {
         ensure_gtab(box, inv, vol, 6 + 2 * c);
         tabs.p[c] = gtab_cur;
       }
+      cls_sites_na = -1;   // other rows than an electrostatics evaluation's
       sites.need(sizeof(Site<T>) * (size_t)na * nch);
       fld_recip.need(3 * (size_t)na * sizeof(T) * nch);
       const bool batch_spread = na < spread_brick_min_atoms();     // the scan-spread regime takes the channels as a batch
@@ -1543,6 +1598,7 @@ struct Engine : EngineBase {
     HIP_TRY(hipMemsetAsync(cls, 0, 16 * sizeof(double), stream));
     if (kind == 0) {
       ARG_CHECK(have_ewald, "ewald parameters must be set first");
+      cls_sites_na = -1;   // other rows than an electrostatics evaluation's
       sites.need(sizeof(Site<T>) * (size_t)na);
       RecipGeom<T> g = make_geom(inv);
       launch_prepare_sites<T>(stream, top, pos, par, nullptr, nullptr, nullptr, bx, sites.as<Site<T>>(), nullptr, g, nullptr);

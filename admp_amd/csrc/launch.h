@@ -27,9 +27,18 @@ struct NbrTable {
   int64_t n_half = 0;
   int64_t cap = 0;         // allocated entries of col
   int* order = nullptr;    // na: rows sorted by length inside windows of kRowWindow rows (launch_row_order), or nullptr
+  // Site classes the table was compiled with: cls[a] = 1 for a charge-only atom (no dipole/quadrupole, not polarizable).
+  // Entries whose PARTNER is charge-only carry kColMono and stand after all the others of their row, so the pair kernel
+  // walks each row as two runs of uniform arithmetic.  k_prepare_sites checks cls against the sites of every call
+  // (CLS_STALE / CLS_BETTER in the flag word next to E_NACT); a stale table is still a valid table of the general form.
+  int* cls = nullptr;      // na
 };
 constexpr int kRowWindow = 1024;
 constexpr int kColMask = 0x0fffffff;
+constexpr int kColMono = (int)0x80000000u;   // partner is charge-only (NbrTable::cls)
+constexpr int kNbMask = 7;                   // covalent class in bits 28..30
+__host__ __device__ inline int col_nb(int c) { return (c >> 28) & kNbMask; }
+enum { CLS_STALE = 1 /* an atom marked charge-only no longer is: ignore kColMono */, CLS_BETTER = 2 /* atoms became charge-only */ };
 
 struct Topology {
   int na = 0;
@@ -71,12 +80,17 @@ struct FieldFin {
 };
 // ---- atom_kernels.hip
 template <class T>
+void launch_site_classes(hipStream_t st, int na, const Site<T>* sites, int* cls);   // NbrTable::cls <- site_is_mono
+template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
                           const T* pol, const T* thole, const Box<T>& box, Site<T>* sites,
                           double* zero_next /* E_WORDS doubles cleared for the next evaluation, or nullptr */,
                           const RecipGeom<T>& g, int4* bases /* optional: stencil base indices per atom */,
                           int* act_list = nullptr /* optional: the atoms with pol > 0 (unordered) ... */,
-                          int* act_count = nullptr /* ... and their number: an int the caller has zeroed */);
+                          int* act_count = nullptr /* ... and their number: an int the caller has zeroed */,
+                          const int* cls = nullptr /* NbrTable::cls, checked against the sites: flags OR-ed into ... */,
+                          int* cls_flags = nullptr /* ... this word (CLS_STALE / CLS_BETTER) */,
+                          RQ4<T>* rq = nullptr /* optional: compact copy (position, charge) of every row */);
 template <class T>
 void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites);
 template <class T>
@@ -155,11 +169,18 @@ void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, con
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows,
-                      T* fld /* optional: also write the real-space dE/dU (speculative SCF pass) */);
+                      T* fld /* optional: also write the real-space dE/dU (speculative SCF pass) */,
+                      int use_mono = 0 /* 1: charge-only sites take the reduced pair forms (pme_math.h); pot of such a
+                                          ROW then holds only its monopole component: not for dE/dQ_local requests */,
+                      const int* cls_flags = nullptr /* the flag word launch_prepare_sites wrote for THIS evaluation */,
+                      const RQ4<T>* rq = nullptr /* compact position/charge rows of launch_prepare_sites */,
+                      const T* tholes = nullptr /* the caller's per-atom thole array, or nullptr */);
 // n_dev (optional): the row count lives on the device (na is then the upper bound the grid is sized for)
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                       const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows, const int* n_dev = nullptr);
+                       const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows, const int* n_dev = nullptr,
+                       const int* cls_flags = nullptr /* as launch_pair_full: charge-only partners take the short form */,
+                       const RQ4<T>* rq = nullptr, const T* tholes = nullptr);
 // incremental SCF: fld_pair[row] += sum_j T_ij dU_j over the polarizable partners, dU_j in the pad words of sites[j];
 // `it` = the polarizable-polarizable sub-table (rows keyed by atom), `rows` = the n_rows polarizable sites
 struct IndTable {
@@ -177,7 +198,7 @@ int sort_ints(hipStream_t st, int* keys, int* keys_tmp, int n, void** scratch, s
 template <class T>
 int build_ind_table(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, IndTable& it, void** scratch,
                     size_t* scratch_bytes);
-int pair_lanes_per_row(int n_rows);   // 2/4/8 by row count; env ADMP_PAIR_LPR overrides
+int pair_lanes_per_row(int n_rows);   // 4/8/16 by row count; env ADMP_PAIR_LPR overrides
 // sumX[i] = sum_j dE_ij/d ln(au_ij), sumXw[i] = sum_j (same) * d ln(au_ij)/d thole_i  (pme_math.h pair_thole_logderiv)
 template <class T>
 void launch_thole_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
@@ -320,7 +341,9 @@ int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Bo
 // pair kernels give each row a fixed group of lanes, so a wavefront runs as long as its longest row: with rows of
 // equal length side by side the lanes stay busy (water, rc 4 A: 85 % -> 99 % of the lane-iterations useful), while the
 // window keeps the rows' site / output accesses local.
-void launch_row_order(hipStream_t st, int na, const int* rowptr, int* order);
+void launch_row_order(hipStream_t st, int na, const int* rowptr, int* order, const int* cls = nullptr);
+// re-parts every row of nb by nb.cls (see NbrTable); replaces nb.col.  Returns hipError_t as int.
+int launch_class_partition(hipStream_t st, int na, NbrTable& nb);
 // builds nb from (n_rows, 2) device pairs; scratch (deg/cursor) is managed inside. Returns hipError_t as int.
 int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, const int* pairs_dev, NbrTable& nb,
                           void** scratch, size_t* scratch_bytes);

@@ -56,6 +56,47 @@ __global__ void k_nbr_sort(int na, const int* __restrict__ rowptr, int* __restri
   }
 }
 
+// Class partition of the rows (NbrTable::cls): entries whose partner is charge-only get kColMono and move behind the
+// others, both runs keeping their order.  8 lanes per row, two sweeps (count, then place through ballot prefix counts).
+constexpr int kPartLanes = 8;
+__global__ __launch_bounds__(256) void k_class_partition(int na, const int* __restrict__ rowptr, const int* __restrict__ cin,
+                                                         int* __restrict__ cout, const int* __restrict__ cls) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int row = (int)(t / kPartLanes), sub = (int)(t % kPartLanes);
+  const int shift = (threadIdx.x & 63) & ~(kPartLanes - 1);
+  const unsigned below = (1u << sub) - 1u, gmask = (1u << kPartLanes) - 1u;
+  const int b = row < na ? rowptr[row] : 0, e = row < na ? rowptr[row + 1] : 0;
+  int nfull = 0;
+  for (int k0 = b; k0 < e; k0 += kPartLanes) {
+    const int k = k0 + sub;
+    const bool full = k < e && cls[cin[k] & kColMask] == 0;
+    nfull += __popc((unsigned)(__ballot(full) >> shift) & gmask);
+  }
+  int pf = b, pm = b + nfull;
+  for (int k0 = b; k0 < e; k0 += kPartLanes) {
+    const int k = k0 + sub;
+    const int c = k < e ? cin[k] : 0;
+    const bool mono = k < e && cls[c & kColMask] != 0, full = k < e && !mono;
+    const unsigned mf = (unsigned)(__ballot(full) >> shift) & gmask, mm = (unsigned)(__ballot(mono) >> shift) & gmask;
+    if (full) cout[pf + __popc(mf & below)] = c & ~kColMono;
+    if (mono) cout[pm + __popc(mm & below)] = c | kColMono;
+    pf += __popc(mf); pm += __popc(mm);
+  }
+}
+int launch_class_partition(hipStream_t st, int na, NbrTable& nb) {
+  if (!nb.cls || !nb.col || na <= 0 || nb.cap <= 0) return 0;
+  int* out = nullptr;
+  hipError_t e = hipMalloc(&out, sizeof(int) * (size_t)nb.cap);
+  if (e != hipSuccess) return (int)e;
+  k_class_partition<<<(unsigned)(((long)na * kPartLanes + 255) / 256), 256, 0, st>>>(na, nb.rowptr, nb.col, out, nb.cls);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { (void)hipFree(out); return (int)e; }
+  (void)hipFree(nb.col);
+  nb.col = out;
+  return 0;
+}
+
 #define NB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 namespace {
@@ -233,15 +274,41 @@ void launch_mark_imports(hipStream_t st, int n_home, const int* home, const NbrT
 
 // one workgroup per kRowWindow rows = kRowWindow / W windows: bitonic network of (length << 10 | local index) in LDS,
 // stopped at span W so that every aligned W-chunk is sorted on its own (ascending)
-__global__ __launch_bounds__(256) void k_row_order(int na, const int* __restrict__ rowptr, int* __restrict__ order, int W) {
+// With site classes (NbrTable::cls) the rows of the whole kRowWindow are first parted by class (full network on
+// class << 10 | index), then every W-chunk is sorted by (class, length): a wavefront of the pair kernel then holds rows of
+// one class, but for one chunk per window.
+__global__ __launch_bounds__(256) void k_row_order(int na, const int* __restrict__ rowptr, int* __restrict__ order, int W,
+                                                   const int* __restrict__ cls) {
   __shared__ unsigned key[kRowWindow];
   const int w0 = blockIdx.x * kRowWindow;
-  for (int t = threadIdx.x; t < kRowWindow; t += 256) {
-    const int i = w0 + t;
-    unsigned len = 0x1fffffu;                                   // padding sorts to the end
-    if (i < na) { len = (unsigned)(rowptr[i + 1] - rowptr[i]); if (len > 0x1ffffeu) len = 0x1ffffeu; }
-    key[t] = (len << 10) | (unsigned)t;
+  if (cls) {
+    for (int t = threadIdx.x; t < kRowWindow; t += 256) {
+      const int i = w0 + t;
+      key[t] = ((i < na ? (cls[i] != 0 ? 1u : 0u) : 2u) << 10) | (unsigned)t;
+    }
+    __syncthreads();
+    for (int k = 2; k <= kRowWindow; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < kRowWindow; t += 256) {
+          const int p = t ^ j;
+          if (p > t) {
+            const unsigned a = key[t], b = key[p];
+            if ((a > b) == ((t & k) == 0)) { key[t] = b; key[p] = a; }
+          }
+        }
+        __syncthreads();
+      }
   }
+  unsigned mine[kRowWindow / 256];
+  for (int t = threadIdx.x, q = 0; t < kRowWindow; t += 256, ++q) {
+    const int loc = cls ? (int)(key[t] & 1023u) : t, i = w0 + loc;
+    unsigned len = 0xfffffu;                                    // padding sorts to the end
+    if (i < na) { len = (unsigned)(rowptr[i + 1] - rowptr[i]); if (len > 0xffffeu) len = 0xffffeu; }
+    const unsigned c = cls ? (key[t] >> 10 != 0 ? 1u : 0u) : 0u;
+    mine[q] = (c << 31) | (len << 10) | (unsigned)loc;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x, q = 0; t < kRowWindow; t += 256, ++q) key[t] = mine[q];
   __syncthreads();
   for (int k = 2; k <= W; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -258,7 +325,7 @@ __global__ __launch_bounds__(256) void k_row_order(int na, const int* __restrict
   for (int t = threadIdx.x; t < kRowWindow; t += 256)
     if (w0 + t < na) order[w0 + t] = w0 + (int)(key[t] & 1023u);
 }
-void launch_row_order(hipStream_t st, int na, const int* rowptr, int* order) {
+void launch_row_order(hipStream_t st, int na, const int* rowptr, int* order, const int* cls) {
   // window = the rows one workgroup of the pair kernel owns (256 lanes / lanes per row): measured at 1M atoms
   // 0.446 ms (window 128 = one workgroup) vs 0.458-0.474 (64, 256, 512, 1024) vs 0.495 unsorted
   static const int Wenv = [] { const char* e = getenv("ADMP_ROW_WINDOW"); return e ? atoi(e) : 0; }();
@@ -267,7 +334,7 @@ void launch_row_order(hipStream_t st, int na, const int* rowptr, int* order) {
   if (Wenv >= 64 && Wenv <= kRowWindow) W = Wenv;
   int p2 = 64;
   while (p2 * 2 <= W) p2 *= 2;                 // power of two (the bitonic network's span)
-  if (na > 0) k_row_order<<<(na + kRowWindow - 1) / kRowWindow, 256, 0, st>>>(na, rowptr, order, p2);
+  if (na > 0) k_row_order<<<(na + kRowWindow - 1) / kRowWindow, 256, 0, st>>>(na, rowptr, order, p2, cls);
 }
 
 }  // namespace admp

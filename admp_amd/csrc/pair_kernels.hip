@@ -41,7 +41,9 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
                                                           ScaleTab<T> tab, T kappa, T* __restrict__ grad,
                                                           T* __restrict__ pot, double* energies,
                                                           const int* __restrict__ rows, T* __restrict__ fld,
-                                                          unsigned nblocks) {
+                                                          unsigned nblocks, int use_mono,
+                                                          const int* __restrict__ cls_flags,
+                                                          const RQ4<T>* __restrict__ rq, const T* __restrict__ tholes) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   const long blk = xcd_block(blockIdx.x, nblocks);
@@ -53,14 +55,75 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
   double e = 0.0;
   if (slot < na) {
     const Site<T> I = sites[row];
-    const int end = rowptr[row + 1];
+    const int beg = rowptr[row] + sub, end = rowptr[row + 1];
+    T* Fp = (LPOL && fld) ? F : nullptr;
+    // Charge-only sites (pme_math.h).  The neighbour table was compiled with the atoms' classes (NbrTable::cls): the entries
+    // of a row whose partner is charge-only carry kColMono and stand behind the others, and `rows` groups the rows by class
+    // (launch_row_order) -- so each lane walks two runs of uniform arithmetic, and the lanes of a wavefront walk the same
+    // kind of run.  The row's own class is read from the site (k_prepare_sites marks it every call, so it is always true);
+    // when the table's classes are out of date (CLS_STALE: an atom it has as charge-only is not any more) the marks are
+    // ignored and every partner takes the general form -- valid for any site.
+    const bool use = use_mono && !(*cls_flags & CLS_STALE);
+    const bool imono = use_mono && site_is_mono(I);
+    // The loops are software-pipelined: an iteration's col entry (and, in the light loops, the partner's position / charge
+    // words) are fetched one or two iterations ahead -- the dependent chain col -> site -> arithmetic otherwise leaves the
+    // waves waiting (SQ_WAIT_ANY 71 % of the wave cycles at 4 waves per SIMD once the arithmetic per partner had shrunk).
+    // Out-of-range prefetches read entry 0 / site 0: valid addresses, results unused.
+    int k = beg;
+    if (!imono) {
+      {
+        int c = k < end ? col[k] : 0;
 #pragma unroll 1
-    for (int k = rowptr[row] + sub; k < end; k += LPR) {
-      const int c = col[k];
-      const int nb = (c >> 28) & 15;
-      const Site<T> J = sites[c & kColMask];
-      const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
-      e += (double)pair_energy_grad<T, LPOL, false>(box, I, J, sc, kappa, g, P, (LPOL && fld) ? F : nullptr, nullptr, nullptr);
+        for (; k < end; k += LPR) {
+          if (use && c < 0) break;
+          const int cn = k + LPR < end ? col[k + LPR] : 0;
+          const Site<T> J = sites[c & kColMask];
+          const int nb = col_nb(c);
+          const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
+          e += (double)pair_energy_grad<T, LPOL, false>(box, I, J, sc, kappa, g, P, Fp, nullptr, nullptr);
+          c = cn;
+        }
+      }
+      if (use) {   // (rq is only there in this mode)
+        int c0 = k < end ? col[k] : 0, c1 = k + LPR < end ? col[k + LPR] : 0;
+        RQ4<T> q0 = rq[c0 & kColMask];
+        T t0 = tholes ? tholes[c0 & kColMask] : T(0);
+#pragma unroll 1
+        for (; k < end; k += LPR) {
+          const int c2 = k + 2 * LPR < end ? col[k + 2 * LPR] : 0;
+          const RQ4<T> q1 = rq[c1 & kColMask];
+          const T t1 = tholes ? tholes[c1 & kColMask] : T(0);
+          const int nb = col_nb(c0);
+          const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
+          e += (double)pair_full_mono<T, LPOL>(box, I, q0.v, q0.v[3], t0, sc, kappa, g, P, Fp);
+          c0 = c1; c1 = c2; q0 = q1; t0 = t1;
+        }
+      }
+    } else {
+      {
+        int c = k < end ? col[k] : 0;
+#pragma unroll 1
+        for (; k < end; k += LPR) {
+          if (use && c < 0) break;
+          const int cn = k + LPR < end ? col[k + LPR] : 0;
+          const Site<T> J = sites[c & kColMask];
+          const int nb = col_nb(c);
+          const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
+          e += (double)pair_mono_full<T, LPOL>(box, I.r, I.Q[0], I.thole, J, sc, kappa, g, P[0]);
+          c = cn;
+        }
+      }
+      if (use) {
+        int c0 = k < end ? col[k] : 0, c1 = k + LPR < end ? col[k + LPR] : 0;
+        RQ4<T> q0 = rq[c0 & kColMask];
+#pragma unroll 1
+        for (; k < end; k += LPR) {
+          const int c2 = k + 2 * LPR < end ? col[k + 2 * LPR] : 0;
+          const RQ4<T> q1 = rq[c1 & kColMask];
+          e += (double)pair_mono_mono<T>(box, I.r, I.Q[0], q0.v, q0.v[3], s_tab[col_nb(c0)], kappa, g, P[0]);
+          c0 = c1; c1 = c2; q0 = q1;
+        }
+      }
     }
   }
 #pragma unroll
@@ -88,7 +151,9 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __
                                                            const Site<T>* __restrict__ sites, Box<T> box,
                                                            ScaleTab<T> tab, T kappa, T* __restrict__ fld,
                                                            const int* __restrict__ rows, unsigned nblocks,
-                                                           const int* __restrict__ n_dev) {
+                                                           const int* __restrict__ n_dev,
+                                                           const int* __restrict__ cls_flags,
+                                                           const RQ4<T>* __restrict__ rq, const T* __restrict__ tholes) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   if (n_dev) {                              // row count known on the device only (the polarizable-site list of this call):
@@ -103,13 +168,36 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __
   if (slot < na) {
     const Site<T> I = sites[row];
     const int end = rowptr[row + 1];
+    // two runs per row, as in k_pair_full: partners with higher moments, then (kColMono) the charge-only ones, whose field
+    // is one radial coefficient along the pair axis; both loops fetch ahead (see k_pair_full)
+    const bool use = cls_flags && !(*cls_flags & CLS_STALE);
+    int k = rowptr[row] + sub;
+    {
+      int c = k < end ? col[k] : 0;
 #pragma unroll 1
-    for (int k = rowptr[row] + sub; k < end; k += LPR) {
-      const int c = col[k];
-      const int nb = (c >> 28) & 15;
-      const Site<T> J = sites[c & kColMask];
-      const PairScales<T> sc = {T(0), s_tab[16 + nb], s_tab[32 + nb]};
-      pair_field(box, I, J, sc, kappa, F);
+      for (; k < end; k += LPR) {
+        if (use && c < 0) break;
+        const int cn = k + LPR < end ? col[k + LPR] : 0;
+        const int nb = col_nb(c);
+        const Site<T> J = sites[c & kColMask];
+        const PairScales<T> sc = {T(0), s_tab[16 + nb], s_tab[32 + nb]};
+        pair_field(box, I, J, sc, kappa, F);
+        c = cn;
+      }
+    }
+    if (use) {
+      int c0 = k < end ? col[k] : 0, c1 = k + LPR < end ? col[k + LPR] : 0;
+      RQ4<T> q0 = rq[c0 & kColMask];
+      T t0 = tholes ? tholes[c0 & kColMask] : T(0);
+#pragma unroll 1
+      for (; k < end; k += LPR) {
+        const int c2 = k + 2 * LPR < end ? col[k + 2 * LPR] : 0;
+        const RQ4<T> q1 = rq[c1 & kColMask];
+        const T t1 = tholes ? tholes[c1 & kColMask] : T(0);
+        const int nb = col_nb(c0);
+        pair_field_mono<T>(box, I.r, I.thole, q0.v, q0.v[3], t0, s_tab[16 + nb], s_tab[32 + nb], kappa, F);
+        c0 = c1; c1 = c2; q0 = q1; t0 = t1;
+      }
     }
   }
 #pragma unroll
@@ -147,7 +235,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field_ind(int na, const int
       const Site<T>& J = sites[c & kColMask];
       const T rJ[3] = {J.r[0], J.r[1], J.r[2]};
       const T dU[3] = {J.pad[0], J.pad[1], J.pad[2]};
-      pair_field_ind<T>(box, rI, p6I, thI, rJ, J.p6, J.thole, dU, s_tab[32 + ((c >> 28) & 15)], kappa, F);
+      pair_field_ind<T>(box, rI, p6I, thI, rJ, J.p6, J.thole, dU, s_tab[32 + (col_nb(c))], kappa, F);
     }
   }
 #pragma unroll
@@ -177,7 +265,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
 #pragma unroll 1
     for (int k = rowptr[row] + sub; k < end; k += LPR) {
       const int c = col[k];
-      const int nb = (c >> 28) & 15, j = c & kColMask;
+      const int nb = col_nb(c), j = c & kColMask;
       T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]}, pj[4] = {0, 0, 0, 0};
       for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
       if (TT) e += (double)tt_pair(box, ri, rj, pi, pj, s_tab[nb] + T(1), g);
@@ -221,7 +309,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_mgrad(int na, const int* __
     const int end = rowptr[row + 1];
     for (int k = rowptr[row] + sub; k < end; k += LPR) {
       const int c = col[k];
-      const int nb = (c >> 28) & 15, j = c & kColMask;
+      const int nb = col_nb(c), j = c & kColMask;
       T v;
       if (KIND == 0) {
         v = pair_bare_energy<T>(box, I, sites[j]);
@@ -263,7 +351,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_pgrad(int na, const int* __
     const int end = rowptr[row + 1];
     for (int k = rowptr[row] + sub; k < end; k += LPR) {
       const int c = col[k];
-      const int nb = (c >> 28) & 15;
+      const int nb = col_nb(c);
       const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
       const T v = pair_pscale_deriv<T>(box, I, sites[c & kColMask], sc);
       if (nb == 0) e0 += (double)v;
@@ -303,7 +391,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_tholegrad(int na, const int
     const int end = rowptr[row + 1];
     for (int k = rowptr[row] + sub; k < end; k += LPR) {
       const int c = col[k];
-      const int nb = (c >> 28) & 15;
+      const int nb = col_nb(c);
       const PairScales<T> sc = {s_tab[nb], s_tab[16 + nb], s_tab[32 + nb]};
       T wth;
       const T X = pair_thole_logderiv<T>(box, I, sites[c & kColMask], sc, &wth);
@@ -360,7 +448,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_virial(int na, const int* _
 #pragma unroll 1
     for (int k = rowptr[row] + sub; k < end; k += LPR) {
       const int c = col[k];
-      const int nb = (c >> 28) & 15;
+      const int nb = col_nb(c);
       const Site<T> J = sites[c & kColMask];
       const T d[3] = {I.r[0] - J.r[0], I.r[1] - J.r[1], I.r[2] - J.r[2]};
       T sh[3];
@@ -395,7 +483,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_virial(int na, const
 #pragma unroll 1
     for (int k = rowptr[row] + sub; k < end; k += LPR) {
       const int c = col[k];
-      const int nb = (c >> 28) & 15, j = c & kColMask;
+      const int nb = col_nb(c), j = c & kColMask;
       T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]}, pj[4] = {0, 0, 0, 0};
       const T d[3] = {ri[0] - rj[0], ri[1] - rj[1], ri[2] - rj[2]};
       T sh[3];
@@ -440,7 +528,22 @@ int pair_lanes_per_row(int n_rows) {
     forced = (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32) ? x : -1;
   }
   if (forced > 0) return forced;
-  return n_rows >= 262144 ? 2 : (n_rows >= 32768 ? 4 : (n_rows >= 8192 ? 8 : 16));
+  // round 2, rows parted by site class (water: a third of the rows and partners carry higher moments), pipelined loops:
+  // 1M rows LPR 2/4/8 -> 0.325/0.303/0.422 ms, 98k rows 0.044/0.041/0.052 ms
+  return n_rows >= 32768 ? 4 : (n_rows >= 8192 ? 8 : 16);
+}
+// the field kernels (k_pair_field, k_pair_field_ind): env ADMP_FIELD_LPR overrides
+static int field_lanes_per_row(int n_rows, bool ind) {
+  static const int forced = [] {
+    const char* s = getenv("ADMP_FIELD_LPR");
+    const int x = s ? atoi(s) : -1;
+    return (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32) ? x : -1;
+  }();
+  if (forced > 0) return forced;
+  // light arithmetic per partner, bound by the partner fetches: more lanes per row = more fetches in flight.  350k rows (the
+  // polarizable sites of 1M atoms) LPR 2/4/8/16 -> 0.110/0.093/0.083/0.091 ms (k_pair_field), 0.034/0.030/0.033/0.041 ms
+  // (k_pair_field_ind); 32k rows: 0.0069/0.0052/0.0051/0.0052 and 0.0019/0.0018/0.0026/0.0017 ms
+  return ind ? (n_rows >= 32768 ? 4 : (n_rows >= 8192 ? 8 : 16)) : (n_rows >= 8192 ? 8 : 16);
 }
 
 // minimum waves per SIMD requested from the register allocator for the polarizable kernel
@@ -472,30 +575,39 @@ static inline unsigned grid_for(int na, int lpr) { return (unsigned)(((long)na *
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows,
-                      T* fld) {
+                      T* fld, int use_mono, const int* cls_flags, const RQ4<T>* rq, const T* tholes) {
   const int lpr = pair_lanes_per_row(na);
   const int minw = pair_min_waves<T>();
+  static const bool mono_off = [] { const char* e = getenv("ADMP_PAIR_MONO"); return e && atoi(e) == 0; }();
+  if (mono_off || !cls_flags || !rq) use_mono = 0;
 #define CALL(L)                                                                                                        \
   if (lpol && minw >= 2)                                                                                               \
     k_pair_full<T, true, L, 2><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                      \
-        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L));               \
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L), use_mono,     \
+        cls_flags, rq, tholes);                                                                                        \
   else if (lpol)                                                                                                       \
     k_pair_full<T, true, L, 1><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                      \
-        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L));               \
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L), use_mono,     \
+        cls_flags, rq, tholes);                                                                                        \
   else                                                                                                                 \
     k_pair_full<T, false, L, 2><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                     \
-        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L))
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L), use_mono, cls_flags, rq,    \
+        tholes)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
 
 template <class T>
 void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                       const ScaleTab<T>& tab, T kappa, T* fld, const int* rows, const int* n_dev) {
-  const int lpr = pair_lanes_per_row(na);
+                       const ScaleTab<T>& tab, T kappa, T* fld, const int* rows, const int* n_dev, const int* cls_flags,
+                       const RQ4<T>* rq, const T* tholes) {
+  static const bool mono_off = [] { const char* e = getenv("ADMP_PAIR_MONO"); return e && atoi(e) == 0; }();
+  if (mono_off || !rq) cls_flags = nullptr;
+  const int lpr = field_lanes_per_row(na, false);
 #define CALL(L)                                                                                              \
   k_pair_field<T, L><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
-                                                                       fld, rows, grid_for(na, L), n_dev)
+                                                                       fld, rows, grid_for(na, L), n_dev, cls_flags, \
+                                                                       rq, tholes)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
@@ -503,7 +615,7 @@ template <class T>
 void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const Site<T>* sites, const Box<T>& box,
                            const ScaleTab<T>& tab, T kappa, T* fld, const int* rows) {
   if (n_rows <= 0) return;
-  const int lpr = pair_lanes_per_row(n_rows);
+  const int lpr = field_lanes_per_row(n_rows, true);
 #define CALL(L)                                                                                                          \
   k_pair_field_ind<T, L><<<xcd_grid(grid_for(n_rows, L)), kPairBlock, 0, st>>>(n_rows, it.rowptr, it.col, sites, box, tab, \
                                                                                kappa, fld, rows)
@@ -533,9 +645,11 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
 
 #define INST(T)                                                                                                     \
   template void launch_pair_full<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,               \
-                                    const ScaleTab<T>&, T, int, T*, T*, double*, const int*, T*);                   \
+                                    const ScaleTab<T>&, T, int, T*, T*, double*, const int*, T*, int, const int*,   \
+                                    const RQ4<T>*, const T*);                                                       \
   template void launch_pair_field<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
-                                     const ScaleTab<T>&, T, T*, const int*, const int*);                            \
+                                     const ScaleTab<T>&, T, T*, const int*, const int*, const int*,                 \
+                                     const RQ4<T>*, const T*);                                                      \
   template void launch_pair_field_ind<T>(hipStream_t, int, const IndTable&, const Site<T>*, const Box<T>&,          \
                                          const ScaleTab<T>&, T, T*, const int*);                                    \
   template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,           \

@@ -281,7 +281,7 @@ extern "C" __global__ __launch_bounds__(256) void admp_pair_custom(int na, const
       R d[3] = {ri[0] - pos[3 * j], ri[1] - pos[3 * j + 1], ri[2] - pos[3 * j + 2]};
       min_image(s_box, s_box + 9, d);
       const R r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-      const D f = pair_kernel(D(r, R(1)), s_m[(c >> 28) & 15], pi, pj);
+      const D f = pair_kernel(D(r, R(1)), s_m[(c >> 28) & 7], pi, pj);
       e += (double)f.v;
       const R s = f.d / r;
       g[0] += s * d[0]; g[1] += s * d[1]; g[2] += s * d[2];

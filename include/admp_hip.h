@@ -52,7 +52,8 @@ int admp_synchronize(admp_handle* h);
 /* ---- static environment -------------------------------------------------------------------- */
 /* replaces: axis_type / axis_indices / covalent_map ctor arguments (admp/pme.py:37-51,
  * generate_construct_local_frames admp/spatial.py:44-74).  covalent_map is passed in CSR form
- * (row i: atoms j with covalent_map[i,j] = nbonds > 0); all pointers are HOST pointers.
+ * (row i: atoms j with covalent_map[i,j] = nbonds > 0, nbonds <= 7: ADMP_E_ARG beyond -- the reference's
+ * parser marks 1..2, its scale lists have 5 entries); all pointers are HOST pointers.
  * axis_type[i] in 0..5 (ZThenX, Bisector, ZBisect, ThreeFold, Zonly, NoAxisType);
  * axis_idx[i*3 + {0,1,2}] = z, x, y atom (-1 = none). */
 int admp_set_topology(admp_handle* h, int n_atoms, const int32_t* axis_type, const int32_t* axis_idx,

@@ -33,11 +33,17 @@ static Site<T> load_site(int i, const double* pos, const double* Q, const double
   for (int k = 0; k < 3; ++k) s.U[k] = U ? (T)U[3 * i + k] : T(0);
   s.p6 = p6 ? (T)p6[i] : T(0);
   s.thole = th ? (T)th[i] : T(0);
+  s.pad[0] = s.pad[1] = s.pad[2] = T(0);
+  // the charge-only mark of k_prepare_sites (atom_kernels.hip)
+  bool mono = s.p6 == T(0) && s.U[0] == T(0) && s.U[1] == T(0) && s.U[2] == T(0);
+  for (int k = 1; k < 9; ++k) mono = mono && s.Q[k] == T(0);
+  s.pad[0] = mono ? T(1) : T(0);
   return s;
 }
 
 // mode 0: half list, both sites updated from one evaluation; mode 1: every pair evaluated from
-// both ends, centre-only accumulation (what the GPU kernel does); energy halves summed.
+// both ends, centre-only accumulation (what the GPU kernel does); energy halves summed;
+// mode 2: as mode 1 with the charge-only dispatch of k_pair_full (pair_full_mono / pair_mono_full / pair_mono_mono).
 template <class T>
 static double pair_real(int na, const double* pos, const double* Q, const double* U, const double* p6, const double* th,
                         const double* boxh, long np, const int32_t* pairs, const int32_t* nb, const double* mtab,
@@ -63,6 +69,13 @@ static double pair_real(int na, const double* pos, const double* Q, const double
         for (int k = 0; k < 9; ++k) { pot[9 * ci + k] += pi[k]; pot[9 * pi_ + k] += pj[k]; }
         for (int k = 0; k < 3; ++k) { fld[3 * ci + k] += fi[k]; fld[3 * pi_ + k] += fj[k]; }
       } else {
+        const bool cm = mode == 2 && site_is_mono(C), pm = mode == 2 && site_is_mono(P);
+        if (cm && pm) ep = pair_mono_mono<T>(box, C.r, C.Q[0], P.r, P.Q[0], sc.mm, (T)kappa, g, pi[0]);
+        else if (cm) ep = lpol ? pair_mono_full<T, true>(box, C.r, C.Q[0], C.thole, P, sc, (T)kappa, g, pi[0])
+                               : pair_mono_full<T, false>(box, C.r, C.Q[0], C.thole, P, sc, (T)kappa, g, pi[0]);
+        else if (pm) ep = lpol ? pair_full_mono<T, true>(box, C, P.r, P.Q[0], P.thole, sc, (T)kappa, g, pi, fi)
+                               : pair_full_mono<T, false>(box, C, P.r, P.Q[0], P.thole, sc, (T)kappa, g, pi, fi);
+        else
         ep = lpol ? pair_energy_grad<T, true, false>(box, C, P, sc, (T)kappa, g, pi, fi, pj, fj)
                   : pair_energy_grad<T, false, false>(box, C, P, sc, (T)kappa, g, pi, fi, pj, fj);
         e += 0.5 * ep;
@@ -78,14 +91,18 @@ static double pair_real(int na, const double* pos, const double* Q, const double
 template <class T>
 static void pair_field_all(int na, const double* pos, const double* Q, const double* U, const double* p6, const double* th,
                            const double* boxh, long np, const int32_t* pairs, const int32_t* nb, const double* ptab,
-                           const double* w0tab, double kappa, double* fld) {
+                           const double* w0tab, double kappa, double* fld, int mono = 0) {
   Box<T> box = make_box<T>(boxh);
   for (long p = 0; p < np; ++p) {
     int i = pairs[2 * p], j = pairs[2 * p + 1];
     PairScales<T> sc = {T(0), (T)ptab[nb[p]], (T)w0tab[nb[p]]};
     Site<T> I = load_site<T>(i, pos, Q, U, p6, th), J = load_site<T>(j, pos, Q, U, p6, th);
     T fi[3] = {0, 0, 0}, fj[3] = {0, 0, 0};
-    pair_field(box, I, J, sc, (T)kappa, fi);
+    // mono: the dispatch of k_pair_field (charge-only partner -> pair_field_mono)
+    if (mono && site_is_mono(J)) pair_field_mono<T>(box, I.r, I.thole, J.r, J.Q[0], J.thole, sc.p, sc.w0, (T)kappa, fi);
+    else pair_field(box, I, J, sc, (T)kappa, fi);
+    if (mono && site_is_mono(I)) pair_field_mono<T>(box, J.r, J.thole, I.r, I.Q[0], I.thole, sc.p, sc.w0, (T)kappa, fj);
+    else
     pair_field(box, J, I, sc, (T)kappa, fj);
     for (int k = 0; k < 3; ++k) { fld[3 * i + k] += fi[k]; fld[3 * j + k] += fj[k]; }
   }
@@ -288,6 +305,12 @@ void shim_pair_field(int prec, int na, const double* pos, const double* Q, const
                      const double* ptab, const double* w0tab, double kappa, double* fld) {
   if (prec == 4) pair_field_all<float>(na, pos, Q, U, p6, th, boxh, np, pairs, nb, ptab, w0tab, kappa, fld);
   else pair_field_all<double>(na, pos, Q, U, p6, th, boxh, np, pairs, nb, ptab, w0tab, kappa, fld);
+}
+void shim_pair_field_mono(int prec, int na, const double* pos, const double* Q, const double* U, const double* p6,
+                          const double* th, const double* boxh, long np, const int32_t* pairs, const int32_t* nb,
+                          const double* ptab, const double* w0tab, double kappa, double* fld) {
+  if (prec == 4) pair_field_all<float>(na, pos, Q, U, p6, th, boxh, np, pairs, nb, ptab, w0tab, kappa, fld, 1);
+  else pair_field_all<double>(na, pos, Q, U, p6, th, boxh, np, pairs, nb, ptab, w0tab, kappa, fld, 1);
 }
 void shim_frames(int prec, int na, const double* pos, const double* boxh, const int32_t* atype, const int32_t* aidx,
                  const double* Qlocal, const double* pot, double* frames_out, double* Qglobal, double* grad,

@@ -1133,3 +1133,58 @@ def test_s2_config_size_vs_oracle_golden(precision, prec, tol):
         print('S2 %s lpol=%s: energy parts %.2e of the largest part, gradient rel L2 %.2e, dipoles rel L2 %.2e' %
               (prec, lpol, ee, eg, eu))
         assert ee < (1e-9 if prec == 'double' else 1e-6) and eg < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec,tolE,tolG', [('double', 1e-9, 1e-8), ('single', 2e-4, 5e-4)])
+def test_charge_only_site_classes_follow_the_parameters(precision, prec, tolE, tolG):
+    """The neighbour table is compiled with the atoms' classes (charge-only or not: NbrTable::cls in launch.h) one call
+    after the sites show them, and the pair kernel takes the reduced forms of pme_math.h for charge-only sites from then
+    on.  Every call must match the oracle whatever the table currently assumes: (1) first call, nothing known, general
+    form; (2) classes compiled in, reduced forms; (3) the hydrogens get a dipole: the table is stale, its marks are
+    ignored; (4) recompiled without charge-only atoms; (5) back to charge-only hydrogens within the quiet period (general
+    form, table not recompiled); (6) a new pair list keeps the classes; and dE/dQ_local requests (which need the full
+    potential of every row) on a table with classes."""
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = prec
+    pos, box, at, ai, cov, par, pairs = water_system(216, 23, True)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    rest = (par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    Q0 = par['Q_local']
+    Q1 = Q0.copy()
+    Q1[1::3, 1] = 0.11; Q1[2::3, 3] = -0.07; Q1[1::3, 4] = 0.05     # hydrogens with a dipole / a quadrupole component
+    refs = {}
+
+    def check(Q, what):
+        key = id(Q)
+        if key not in refs:
+            p = dict(par, Q_local=Q)
+            refs[key] = oracle_es(pos, box, at, ai, cov, p, pairs, f.kappa, (f.K1, f.K2, f.K3), True)
+        ref = refs[key]
+        E, G = f.get_forces(pos, box, pairs, Q, *rest)
+        scale = max(abs(p) for p in ref['parts'])
+        for got, want in zip(f.energy_parts, ref['parts']):
+            assert abs(got - want) <= tolE * scale, what
+        assert f.n_cycle == ref['n_cycle'], what
+        assert rel(G, ref['grad']) < tolG and rel(f.U_ind, ref['U_ind']) < tolG, what
+
+    check(Q0, 'first call')
+    check(Q0, 'classes compiled in')
+    check(Q0, 'steady state')
+    check(Q1, 'stale table')
+    check(Q1, 'recompiled, no charge-only atoms')
+    check(Q0, 'charge-only again, quiet period')
+    pairs = pairs[::-1].copy()                      # another pair list (same set): table rebuilt, classes kept
+    check(Q0, 'new pair list')
+    for _ in range(10):
+        f.get_forces(pos, box, pairs, Q0, *rest)
+    check(Q0, 'after the quiet period')
+    # dE/dQ_local on a table with classes: general form, full potential on every row
+    p = dict(par, Q_local=Q0)
+    fn = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2)
+    ref = oracle_es(pos, box, at, ai, cov, p, pairs, fn.kappa, (fn.K1, fn.K2, fn.K3), False, want_dQ=True)
+    for rep in range(3):
+        if rep == 1:
+            fn.get_forces(pos, box, pairs, Q0, par['mScales'])      # a call that may take the reduced forms
+        E, G, dQ = fn.get_forces_and_dQ(pos, box, pairs, Q0, par['mScales'])
+        assert rel(G, ref['grad']) < tolG and rel(dQ, ref['dQ_local']) < tolG

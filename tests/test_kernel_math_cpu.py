@@ -86,6 +86,52 @@ def test_pair_kernel_matches_oracle(lpol, mode, tric):
         np.testing.assert_allclose(f2, g_ref[2], rtol=1e-9, atol=1e-9 * np.abs(g_ref[2]).max())
 
 
+@pytest.mark.parametrize('lpol', [False, True])
+def test_charge_only_pair_forms_match_oracle(lpol):
+    """pair_full_mono / pair_mono_full / pair_mono_mono (pme_math.h: the forms k_pair_full takes for sites that carry a
+    charge and nothing else) against the oracle on a mix of charge-only and fully equipped sites, triclinic cell, bonded
+    classes with pscale 0 and 1, Thole parameters incl. zero.  The pot of a charge-only ROW is complete only in its monopole
+    slot (such a site has no torque), so pot is compared there and everywhere for the other sites."""
+    n, L = 16, 9.5
+    pos, Q, U, pol, thole = random_sites(n, L, 19)
+    mono = np.arange(n) % 3 != 0                      # two of three sites charge-only, like water
+    Q[mono, 1:] = 0.0
+    U[mono] = 0.0
+    pol[mono] = 0.0
+    thole[mono] = 0.0
+    thole[3] = 0.0                                    # a polarizable site with thole 0 next to charge-only partners
+    box = np.array([[L, 0, 0], [1.1, L * 0.97, 0], [-0.7, 0.9, L * 1.04]])
+    pairs = all_pairs(n)
+    rng = np.random.default_rng(8)
+    cov = np.zeros((n, n), dtype=np.int64)
+    for (i, j) in pairs[rng.random(len(pairs)) < 0.3]:
+        cov[i, j] = cov[j, i] = rng.integers(1, 6)
+    mS = np.array([0.0, 0.2, 0.5, 0.8, 1.0])
+    pS = np.array([0.0, 0.0, 1.0, 1.0, 1.0])
+    kappa = 0.43
+    e_ref, g_ref = oracle_pair(pos, box, pairs, cov, Q, U, pol, thole, mS, pS, kappa, lpol)
+    nb = i32(cov[pairs[:, 0], pairs[:, 1]])
+    mtab, ptab, w0 = scale_tables(mS, pS)
+    grad = np.zeros((n, 3)); pot = np.zeros((n, 9)); fld = np.zeros((n, 3))
+    e = lib().shim_pair_real(8, n, dp(c64(pos)), dp(c64(Q)), dp(c64(U)), dp(c64(pol ** (1.0 / 6.0))), dp(c64(thole)),
+                             dp(c64(box)), ctypes.c_long(len(pairs)), dp(i32(pairs)), dp(nb), dp(mtab), dp(ptab), dp(w0),
+                             ctypes.c_double(kappa), int(lpol), 2, dp(grad), dp(pot), dp(fld))
+    assert abs(e - e_ref) <= 1e-10 * max(1.0, abs(e_ref))
+    np.testing.assert_allclose(grad, g_ref[0], rtol=1e-9, atol=1e-8 * np.abs(g_ref[0]).max())
+    tol = 1e-9 * np.abs(g_ref[1]).max()
+    np.testing.assert_allclose(pot[~mono], g_ref[1][~mono], rtol=1e-9, atol=tol)
+    np.testing.assert_allclose(pot[mono, 0], g_ref[1][mono, 0], rtol=1e-9, atol=tol)
+    assert not pot[mono, 1:].any()
+    if lpol:
+        np.testing.assert_allclose(fld[~mono], g_ref[2][~mono], rtol=1e-9, atol=1e-9 * np.abs(g_ref[2]).max())
+        # field-only kernel of the SCF with its short form for charge-only partners (pair_field_mono); dE/dU at every site
+        f2 = np.zeros((n, 3))
+        lib().shim_pair_field_mono(8, n, dp(c64(pos)), dp(c64(Q)), dp(c64(U)), dp(c64(pol ** (1.0 / 6.0))), dp(c64(thole)),
+                                   dp(c64(box)), ctypes.c_long(len(pairs)), dp(i32(pairs)), dp(nb), dp(ptab), dp(w0),
+                                   ctypes.c_double(kappa), dp(f2))
+        np.testing.assert_allclose(f2, g_ref[2], rtol=1e-9, atol=1e-9 * np.abs(g_ref[2]).max())
+
+
 def test_pair_kernel_float32_close():
     n, L = 14, 9.0
     pos, Q, U, pol, thole = random_sites(n, L, 11)
