@@ -300,9 +300,19 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
     default: { constexpr int KQ = 2; CALL; } break; \
   }
 
+// matrix-core forms (dft_mfma.hip), opt-in with ADMP_DFT_MFMA=1: measured no faster than the vector forms below
+bool dftm_enabled(int N);
+template <class T>
+void launch_dftm_z(hipStream_t, const int*, const T*, T*, T*, int, int, long, long);
+template <class T>
+void launch_dftm_y(hipStream_t, const int*, const T*, T*, int, int, long);
+template <class T>
+void launch_dftm_x_conv(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long);
+
 template <class T>
 void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb, long mesh_stride,
                   long spec_stride) {
+  if (dftm_enabled(K[2])) return launch_dftm_z<T>(st, K, tw, mesh, spec, inverse, nb, mesh_stride, spec_stride);
   const int N = K[2], nlines = K[0] * K[1], H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NL = dft_cols(N, dft_kq(), sizeof(Cx<T>) * (size_t)H + 2 * sizeof(T), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(Cx<T>) * (size_t)(N + H * NL) + sizeof(T) * 2 * (size_t)NL;
@@ -317,6 +327,7 @@ void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec,
 }
 template <class T>
 void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse, int nb, long spec_stride) {
+  if (dftm_enabled(K[1])) return launch_dftm_y<T>(st, K, tw, spec, inverse, nb, spec_stride);
   const int N = K[1], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + 2 * sizeof(Cx<T>), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC);
@@ -333,6 +344,7 @@ void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inve
 template <class T>
 void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
                        int slot, int nb, long spec_stride) {
+  if (dftm_enabled(K[0])) return launch_dftm_x_conv<T>(st, K, tw, spec, tabs, energies, slot, nb, spec_stride);
   const int N = K[0], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + sizeof(Cx<T>) * (size_t)(2 + N), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC + N * NC);

@@ -189,8 +189,8 @@ print('BRICK-OK')
 
 
 def test_direct_dft_convolution_vs_rocfft(tmp_path):
-    """Meshes with a Bluestein dimension go through dft_kernels.hip instead of rocFFT (engine.hip setup_dft).  The two
-    k-space legs must agree to round-off: polarizable PME and dispersion PME, even / odd / prime dimensions, both
+    """Meshes with a Bluestein dimension go through dft_mfma.hip / dft_kernels.hip instead of rocFFT (engine.hip setup_dft).
+    The k-space legs must agree to round-off: polarizable PME and dispersion PME, even / odd / prime dimensions, both
     precisions; ADMP_DFT is read per handle, the child processes only keep the runs independent."""
     import subprocess
     import sys
@@ -221,7 +221,9 @@ np.savez(sys.argv[1], **out)
 print('DFT-RUN-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'dft_kq4': dict(ADMP_DFT='1', ADMP_DFT_KQ='4')}
+    # 'dft', 'dft_kq4': the vector forms of dft_kernels.hip (the default); 'dft_mfma': the matrix-core kernels of dft_mfma.hip
+    modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'dft_mfma': dict(ADMP_DFT='1', ADMP_DFT_MFMA='1'),
+             'dft_kq4': dict(ADMP_DFT='1', ADMP_DFT_KQ='4')}
     for mode, extra in modes.items():
         path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
@@ -230,7 +232,7 @@ print('DFT-RUN-OK')
         res[mode] = dict(np.load(path))
     assert len(res['rocfft']) == 2 * 4 * 5
     for key, a in res['rocfft'].items():
-        for mode in ('dft', 'dft_kq4'):
+        for mode in ('dft', 'dft_mfma', 'dft_kq4'):
             b = res[mode][key]
             tol = 1e-10 if key.startswith('double') else 2e-4
             scale = np.abs(a).max()
