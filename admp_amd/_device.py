@@ -215,6 +215,7 @@ class HipForceBase:
         _lib.check(self._h, self._L.admp_set_pairs(self._h, t.shape[0], self._ptr(t), 1), 'admp_set_pairs')
         self._pairs_key = key
         self._pairs_keep = pairs      # keeps id() unique while cached
+        self._lender = None           # a list of its own ends a loan (share_neighbors)
 
     def _mscale_gradient(self, kind, positions, box, pairs, params, n_params, n_scales, pmax=0):
         """dE/dmScales (n_scales,) of this calculator: the gradient jax.grad(potential, argnums=3)(...)['mScales'] of the
@@ -239,6 +240,19 @@ class HipForceBase:
             _lib.check(self._h, self._L.admp_set_pairs_from_positions(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), rc),
                        'admp_set_pairs_from_positions')
         self._pairs_key = ('from_positions',)
+        self._pairs_keep = None
+        self._lender = None
+
+    def share_neighbors(self, lender):
+        """Walk `lender`'s neighbour table instead of compiling one of its own (include/admp_hip.h admp_share_neighbors):
+        the calculators of one system get the same pair list from the reference's drivers -- here one of them is given
+        the list (`set_pairs` / `update_neighbors` / the `pairs` argument) and the others borrow its table, then take
+        `pairs=None`.  Same atoms and covalent map required.  `lender=None`, or passing a pair list again, ends the loan."""
+        with self._on_stream():
+            _lib.check(self._h, self._L.admp_share_neighbors(self._h, lender._h if lender is not None else None),
+                       'admp_share_neighbors')
+        self._lender = lender                       # keeps the lender's handle alive
+        self._pairs_key = ('shared', id(lender)) if lender is not None else None
         self._pairs_keep = None
 
     @property

@@ -28,6 +28,7 @@ PROTOTYPES = {
     'admp_set_topology': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'admp_set_ewald': (_i32, [_vp, _dbl, _i32, _i32, _i32, _i32, _i32]),
     'admp_set_pairs': (_i32, [_vp, _i64, _vp, _i32]),
+    'admp_share_neighbors': (_i32, [_vp, _vp]),
     'admp_num_pairs': (_i64, [_vp]),
     'admp_pme_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _dp, _vp, _i32, _dbl, _dp, _vp, _vp,
                                     _ip, _ip, _i32]),

@@ -20,6 +20,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -160,6 +161,49 @@ struct EngineBase {
   int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
   int keep_pol_sites = 0;       // ADMP_OPT_KEEP_POL_SITES: the caller vouches that the set {i : pol_i > 0} has not changed
   long nbr_gen = 0;             // bumped whenever the neighbour table is rebuilt
+  // Neighbour table borrowed from another handle (admp_share_neighbors): the calculators of one system walk ONE compiled
+  // table instead of compiling the same pair list once each.  `nbr` is then a copy of the lender's struct, refreshed at
+  // the start of every call (adopt_shared), never freed or modified here.
+  EngineBase* nbr_src = nullptr;
+  long nbr_src_gen = -1;
+  static std::set<EngineBase*>& live() { static std::set<EngineBase*> s; return s; }
+  static std::mutex& live_mu() { static std::mutex m; return m; }
+  static bool is_live(EngineBase* e) { std::lock_guard<std::mutex> g(live_mu()); return live().count(e) != 0; }
+  void detach_shared() {
+    if (!nbr_src) return;
+    nbr = NbrTable();            // forget the lender's pointers
+    nbr_src = nullptr; nbr_src_gen = -1;
+    have_pairs = false;
+    ++nbr_gen;
+  }
+  void adopt_shared() {
+    if (!nbr_src) return;
+    if (!is_live(nbr_src)) { nbr = NbrTable(); nbr_src = nullptr; have_pairs = false; throw Err{ADMP_E_ARG, "the handle the neighbour table was borrowed from has been destroyed"}; }
+    if (!nbr_src->have_pairs || nbr_src->top.na != top.na) { nbr = NbrTable(); have_pairs = false; return; }
+    if (nbr_src_gen != nbr_src->nbr_gen || nbr.col != nbr_src->nbr.col || nbr.order != nbr_src->nbr.order) {
+      if (nbr_src->stream != stream) HIP_TRY(hipStreamSynchronize(nbr_src->stream));   // built / ordered on the lender's stream
+      nbr = nbr_src->nbr;
+      nbr_src_gen = nbr_src->nbr_gen;
+      ++nbr_gen;
+    }
+    have_pairs = true;
+  }
+  void share_neighbors(EngineBase* src) {
+    ARG_CHECK(have_top, "admp_set_topology must precede admp_share_neighbors");
+    if (!src) { detach_shared(); return; }
+    ARG_CHECK(src != this && !src->nbr_src, "the lender must own its neighbour table");
+    ARG_CHECK(src->have_top && src->top.na == top.na && src->device == device, "handles of different systems / devices");
+    if (!nbr_src) {              // drop the table this handle owns
+      if (nbr.rowptr) (void)hipFree(nbr.rowptr);
+      if (nbr.col) (void)hipFree(nbr.col);
+      if (nbr.order) (void)hipFree(nbr.order);
+      if (nbr.cls) (void)hipFree(nbr.cls);
+    }
+    nbr = NbrTable();
+    nbr_src = src; nbr_src_gen = -1;
+    have_pairs = false;
+    adopt_shared();
+  }
   DevBuf scan_scratch;
   size_t scan_bytes = 0;
 
@@ -243,10 +287,13 @@ struct EngineBase {
     if (top.inv_idx) (void)hipFree(top.inv_idx);
     if (top.grp_ptr) (void)hipFree(top.grp_ptr);
     top = Topology();
-    if (nbr.rowptr) (void)hipFree(nbr.rowptr);
-    if (nbr.col) (void)hipFree(nbr.col);
-    if (nbr.order) (void)hipFree(nbr.order);
-    if (nbr.cls) (void)hipFree(nbr.cls);
+    if (!nbr_src) {
+      if (nbr.rowptr) (void)hipFree(nbr.rowptr);
+      if (nbr.col) (void)hipFree(nbr.col);
+      if (nbr.order) (void)hipFree(nbr.order);
+      if (nbr.cls) (void)hipFree(nbr.cls);
+    }
+    nbr_src = nullptr; nbr_src_gen = -1;
     nbr = NbrTable();
     cls_pending = false; cls_quiet = 1 << 20;
     have_top = have_pairs = false;
@@ -366,6 +413,7 @@ struct EngineBase {
   void set_pairs(int64_t n_rows, const int32_t* pairs, int on_device) {
     ARG_CHECK(have_top, "admp_set_topology must precede admp_set_pairs");
     ARG_CHECK(n_rows >= 0, "negative pair count");
+    detach_shared();             // a pair list of its own ends a borrowed table
     DevBuf staged;
     const int* dev = pairs;
     if (!on_device && n_rows > 0) {
@@ -729,7 +777,7 @@ struct Engine : EngineBase {
       const bool want_act = lpol && snranks == 1 && !(keep_pol_sites && have_list);
       act_fresh = want_act;
       if (want_act) { act_d.need(sizeof(int) * (size_t)na); act_n = -1; act_top_na = na; ++act_gen; }
-      if (cls_pending && snranks == 1 && have_pairs && cls_sites_na == na) {   // `sites` still holds the last evaluation's
+      if (cls_pending && snranks == 1 && have_pairs && cls_sites_na == na && !nbr_src) {   // `sites` still holds the last evaluation's
         if (!nbr.cls) HIP_TRY(hipMalloc(&nbr.cls, sizeof(int) * (size_t)na));
         launch_site_classes<T>(stream, na, sites.as<Site<T>>(), nbr.cls);
         apply_classes();
@@ -1310,6 +1358,7 @@ struct Engine : EngineBase {
   void nbr_table(const void* pos, const double* box, double rc) override {
     ARG_CHECK(have_top, "admp_set_topology must precede admp_set_pairs_from_positions");
     ARG_CHECK(pos && box && rc > 0, "bad argument");
+    detach_shared();
     double inv[9], vol;
     Box<T> b = make_box(box, inv, &vol);
     double heights[3];
@@ -1627,6 +1676,7 @@ static int guarded(admp_handle* h, F&& f) {
   try {
     (void)hipSetDevice(h->eng->device);
     (void)hipGetLastError();                 // drop anything stale from other users of this thread
+    h->eng->adopt_shared();
     f(*h->eng);
     // a bad launch configuration (too much LDS, too many registers after a flag change, ...) is reported by neither the
     // launch statement nor hipStreamSynchronize: every <<<>>> of this call is covered by one check here
@@ -1661,6 +1711,7 @@ int admp_create(admp_handle** out, int device, int precision) {
     e->own_stream = true;
     admp_handle* h = new admp_handle();
     h->eng = std::move(e);
+    { std::lock_guard<std::mutex> g(EngineBase::live_mu()); EngineBase::live().insert(h->eng.get()); }
     *out = h;
     return ADMP_OK;
   } catch (const Err& e) {
@@ -1671,7 +1722,11 @@ int admp_create(admp_handle** out, int device, int precision) {
 
 int admp_destroy(admp_handle* h) {
   if (!h) return ADMP_E_ARG;
-  if (h->eng) { (void)hipSetDevice(h->eng->device); (void)hipStreamSynchronize(h->eng->stream); }
+  if (h->eng) {
+    (void)hipSetDevice(h->eng->device);
+    (void)hipStreamSynchronize(h->eng->stream);
+    { std::lock_guard<std::mutex> g(EngineBase::live_mu()); EngineBase::live().erase(h->eng.get()); }
+  }
   delete h;
   return ADMP_OK;
 }
@@ -1711,6 +1766,13 @@ int admp_set_ewald(admp_handle* h, double kappa, int K1, int K2, int K3, int lma
 
 int admp_set_pairs(admp_handle* h, int64_t n_rows, const int32_t* pairs, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.set_pairs(n_rows, pairs, on_device); });
+}
+
+int admp_share_neighbors(admp_handle* h, admp_handle* lender) {
+  return guarded(h, [&](EngineBase& e) {
+    ARG_CHECK(!lender || lender->eng, "bad lender handle");
+    e.share_neighbors(lender ? lender->eng.get() : nullptr);
+  });
 }
 
 int64_t admp_num_pairs(const admp_handle* h) { return (h && h->eng) ? h->eng->nbr.n_half : -1; }

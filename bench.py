@@ -343,8 +343,10 @@ def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10):
     seq = [frames.step_frame(k) for k in range(warmup + steps)]
 
     def rebuild_lists(p):
-        for obj in (f, disp, tt_obj):
-            obj.update_neighbors(p, w['box'], rc=RC + SKIN)
+        # one search + one compiled table for the three calculators (the reference's drivers hand them one `pairs` array)
+        f.update_neighbors(p, w['box'], rc=RC + SKIN)
+        for obj in (disp, tt_obj):
+            obj.share_neighbors(f)
 
     def one(k, U, terms=(1, 1, 1)):
         p = seq[k]

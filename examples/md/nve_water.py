@@ -66,11 +66,13 @@ def main():
 
     class Lists:
         """Verlet lists with a skin, rebuilt every --rebuild steps (the pair kernels have no cutoff test of their own,
-        like the reference).  Each calculator compiles its own neighbour table on the GPU straight from the positions
-        (`update_neighbors`, search fused with the table build) and is then called with pairs=None."""
+        like the reference).  The PME calculator compiles the neighbour table on the GPU straight from the positions
+        (`update_neighbors`, search fused with the table build); the other two borrow it (`share_neighbors` -- the
+        reference's drivers hand one `pairs` array to every force object) and all are then called with pairs=None."""
         def allocate(self, p):
-            for obj in (pme, disp, tt_obj):
-                obj.update_neighbors(p, box, rc=rc + skin)
+            pme.update_neighbors(p, box, rc=rc + skin)
+            for obj in (disp, tt_obj):
+                obj.share_neighbors(pme)
             return None
     nbl = Lists()
     pos = torch.as_tensor(pos0, dtype=dt, device=dev)

@@ -79,6 +79,14 @@ int admp_set_option(admp_handle* h, int option, int value);
  * dropped.  The list is compiled into an i-grouped neighbour table that stays valid until the
  * next call. */
 int admp_set_pairs(admp_handle* h, int64_t n_rows, const int32_t* pairs, int on_device);
+
+/* The calculators of one system (PME, dispersion PME, pair potentials) are handed the SAME pair list by the reference's
+ * drivers (examples/water_pol_1024/run_admp.py:117-136: one `pairs` array for every force object).  Instead of compiling
+ * that list once per handle, `h` walks the neighbour table of `lender` (same atoms, same covalent map, same device):
+ * whatever list the lender holds when `h` is next called -- also after the lender's admp_set_pairs /
+ * admp_set_pairs_from_positions.  lender = NULL, or a pair list of its own, ends the loan; calling `h` after the lender
+ * was destroyed is ADMP_E_ARG. */
+int admp_share_neighbors(admp_handle* h, admp_handle* lender);
 int64_t admp_num_pairs(const admp_handle* h);   /* pairs kept (i < j) */
 
 /* ---- the hot path -------------------------------------------------------------------------- */

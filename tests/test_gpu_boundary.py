@@ -315,3 +315,69 @@ def test_traced_pair_kernels_on_gpu(env, prec, tol):
     g, = torch.autograd.grad(ref, p)
     assert abs(E2 - float(ref)) < max(tol, 1e-12) * abs(float(ref)) * 10 and rel(G2, g.numpy()) < 10 * tol
     assert 'admp_pair_custom' in lj.source
+
+
+@pytest.mark.gpu
+def test_calculators_share_one_neighbour_table():
+    """admp_share_neighbors: dispersion PME and a pair potential walk the PME calculator's compiled table (the reference's
+    drivers hand ONE `pairs` array to every force object, examples/water_pol_1024/run_admp.py:117-136).  Results equal the
+    ones with a table of their own; the loan follows the lender's list updates, ends with a list of the borrower's own, and
+    a destroyed lender is an error, not a dangling pointer."""
+    import gc
+    from admp_amd import settings
+    from admp_amd import systems as S
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
+    old = settings.PRECISION
+    settings.PRECISION = 'double'
+    try:
+        n_mol = 216
+        pos, box = S.synthetic_water_box(n_mol, seed=3)
+        at, ai, cov = S.water_topology(n_mol)
+        par = S.water_parameters(n_mol, polarizable=True)
+        pairs = S.build_pairs(pos, box, 4.0)
+        pairs5 = S.build_pairs(pos, box, 5.0)
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+        pme_args = (par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+        mS = par['mScales']
+        c6 = np.ascontiguousarray(par['c_list'][:, 0])
+
+        def fresh():
+            d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+            t = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+            return d, t
+
+        def both(d, t, p):
+            Ed, Gd = d.get_forces(pos, box, p, par['c_list'], mS)
+            Et, Gt = value_and_grad(t)(pos, box, p, mS, par['a_list'], par['b_list'], par['q_list'], c6)
+            return float(Ed), np.asarray(Gd), float(Et), np.asarray(Gt)
+
+        d0, t0 = fresh()
+        ref4 = both(d0, t0, pairs)
+        ref5 = both(d0, t0, pairs5)
+        d, t = fresh()
+        f.get_forces(pos, box, pairs, *pme_args)
+        f.get_forces(pos, box, pairs, *pme_args)            # second call: the lender's table now carries site classes
+        d.share_neighbors(f)
+        t.share_neighbors(f)
+        assert d.n_pairs == f.n_pairs == len(pairs)
+        for got, want in zip(both(d, t, None), ref4):
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+        Ef, Gf = f.get_forces(pos, box, pairs5, *pme_args)  # the lender takes another list: the borrowers follow
+        for got, want in zip(both(d, t, None), ref5):
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+        f.update_neighbors(pos, box, rc=4.0)                # ... also one built on the GPU
+        for got, want in zip(both(d, t, None), ref4):
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+        for got, want in zip(both(d, t, pairs5), ref5):     # a list of their own ends the loan
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+        E2, G2 = f.get_forces(pos, box, None, *pme_args)    # the lender is unaffected
+        d.share_neighbors(f)
+        d._lender = None                                    # (the wrapper keeps the lender alive; not so a C caller)
+        del f
+        gc.collect()
+        with pytest.raises(Exception):
+            d.get_forces(pos, box, None, par['c_list'], mS)
+    finally:
+        settings.PRECISION = old
