@@ -791,6 +791,21 @@ struct Engine : EngineBase {
                               want_act ? act_d.as<int>() : nullptr, want_act ? nact_dev() : nullptr, nbr.cls,
                               cls_flags_dev(), rq_p());
       ev.bases = bases_d.as<int4>();
+      // First evaluation on a table compiled without classes: look at the flags right away (one extra host read, once) so
+      // that this call already walks the parted rows -- a caller who evaluates once gets the reduced forms too.
+      if (!nbr.cls && snranks == 1 && have_pairs && !nbr_src && !cls_first_done) {
+        cls_first_done = true;
+        int flags = 0;
+        HIP_TRY(hipMemcpyAsync(&flags, cls_flags_dev(), sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (flags & CLS_BETTER) {
+          HIP_TRY(hipMalloc(&nbr.cls, sizeof(int) * (size_t)na));
+          launch_site_classes<T>(stream, na, sites.as<Site<T>>(), nbr.cls);
+          apply_classes();
+          order_rows();
+          HIP_TRY(hipMemsetAsync(cls_flags_dev(), 0, sizeof(int), stream));   // the table now agrees with these sites
+        }
+      }
     }
     other_clean = true;
     if (snranks > 1) {
@@ -930,6 +945,7 @@ struct Engine : EngineBase {
   }
   int* cls_flags_dev() { return nact_dev() + 1; }   // the other half of that word: CLS_* of this evaluation (k_prepare_sites)
   int cls_sites_na = -1;                            // `sites` holds an evaluation of this many atoms
+  bool cls_first_done = false;                      // the flags of the first evaluation have been looked at
   // device-side count for the kernels of the first cycle when the list is fresh (nullptr: the host knows it: act_n)
   const int* nact_arg() { return act_fresh ? nact_dev() : nullptr; }
   int nact_rows() const { return act_fresh ? top.na : act_n; }      // grid bound of those kernels
