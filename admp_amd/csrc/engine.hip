@@ -468,8 +468,11 @@ struct Engine : EngineBase {
   DevBuf dft_tw;          // twiddle tables of the direct-DFT path
   DevBuf bases_d;         // int4 per atom: lowest stencil index on each mesh axis
   bool use_dft = false;   // mesh convolution through dft_kernels.hip instead of rocFFT (single rank, a Bluestein dimension)
+  bool use_pfa = false;   // ... through pfa_kernels.hip: a Bluestein dimension too long for plain lines, split N = N1 * N2;
+  PfaPlan pfa;            //     spectrum and G tables then live in slot order with pfa.Khp z columns
+  DevBuf pfa_tw, pfa_fmap, gtab_nat;
   // validity of the cached G table
-  struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0, ref = 0; } tabkey[4];
+  struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0, ref = 0; bool pfa = false; } tabkey[4];
   static int tab_slot(int which) { return which == 1 ? 0 : (which == 6 ? 1 : (which == 8 ? 2 : 3)); }
   bool warm_regime = false;   // previous polarizable call converged at its first SCF check
   bool mono_ok = false;       // this evaluation may use the charge-only pair forms (no dE/dQ_local requested)
@@ -478,7 +481,8 @@ struct Engine : EngineBase {
     destroy_plans();
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
-                      &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp})
+                      &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp,
+                      &rq_d, &pfa_tw, &pfa_fmap, &gtab_nat})
       b->release();
     free_topology();
     if (ind.rowptr) (void)hipFree(ind.rowptr);
@@ -586,7 +590,7 @@ struct Engine : EngineBase {
   // above 13) and the mesh is small enough for O(N^2) lines.  ADMP_DFT=0 disables it, ADMP_DFT=1 forces it for any mesh
   // with all dimensions <= 160 (tests).
   void setup_dft() {
-    use_dft = false;
+    use_dft = use_pfa = false;
     if (snranks != 1) return;
     const char* e = getenv("ADMP_DFT");
     const int mode = e ? atoi(e) : -1;
@@ -596,7 +600,9 @@ struct Engine : EngineBase {
       small = small && K[d] >= 2 && K[d] <= 160;
       hard = hard || largest_prime_factor(K[d]) > 13;
     }
-    if (!small || !(hard || mode == 1)) return;
+    if (mode == 2 && setup_pfa()) return;                 // tests: the split form for any mesh it can take
+    if (!small && hard && setup_pfa()) return;
+    if (!small || !(hard || mode == 1 || mode == 2)) return;
     std::vector<T> tw(2 * (size_t)(K[0] + K[1] + K[2]));
     size_t o = 0;
     for (int d = 0; d < 3; ++d)
@@ -609,9 +615,50 @@ struct Engine : EngineBase {
     HIP_TRY(hipMemcpy(dft_tw.p, tw.data(), tw.size() * sizeof(T), hipMemcpyHostToDevice));
     use_dft = true;
   }
+  // Two-level direct DFT (pfa_kernels.hip): every dimension either fits the plain lines (<= 160) or splits into a smooth
+  // cofactor N1 <= 32 and a prime power N2 <= 160.  ADMP_DFT=2 forces it for any mesh it can split (tests); ADMP_PFA=0 off.
+  bool setup_pfa() {
+    static const bool off = [] { const char* e = getenv("ADMP_PFA"); return e && atoi(e) == 0; }();
+    if (off) return false;
+    for (int d = 0; d < 3; ++d)
+      if (!pfa_split(K[d], &pfa.ax[d])) return false;
+    pfa.Khp = pfa.ax[2].N1 * (pfa.ax[2].N2 / 2 + 1);
+    std::vector<T> tw;
+    for (int d = 0; d < 3; ++d) {
+      pfa.tw_off[d] = (int)(tw.size() / 2);
+      for (int n : {pfa.ax[d].N2, pfa.ax[d].N1})
+        for (int m = 0; m < n; ++m) {
+          const double th = 2.0 * M_PI * (double)m / (double)n;
+          tw.push_back((T)std::cos(th));
+          tw.push_back((T)std::sin(th));
+        }
+    }
+    pfa_tw.need(tw.size() * sizeof(T));
+    HIP_TRY(hipMemcpy(pfa_tw.p, tw.data(), tw.size() * sizeof(T), hipMemcpyHostToDevice));
+    std::vector<int> fm((size_t)K[0] + K[1] + pfa.Khp);
+    pfa_freq_of_slot(pfa.ax[0], fm.data());
+    pfa_freq_of_slot(pfa.ax[1], fm.data() + K[0]);
+    pfa_freq_of_zcolumn(pfa.ax[2], fm.data() + K[0] + K[1]);
+    pfa_fmap.need(fm.size() * sizeof(int));
+    HIP_TRY(hipMemcpy(pfa_fmap.p, fm.data(), fm.size() * sizeof(int), hipMemcpyHostToDevice));
+    spec.need((size_t)K[0] * K[1] * pfa.Khp * 2 * sizeof(T));
+    use_pfa = true;
+    return true;
+  }
   // mesh <- IFFT( G * FFT(mesh) ), energies[slot] += sum w G |S|^2 : the whole k-space leg of one reciprocal pass
   void convolve(T* mesh_p, T* spec_p, const T* gtab, int slot) {
     double* Ed = Ed_cur();
+    if (use_pfa) {
+      const T* tw = pfa_tw.as<T>();
+      { TIMED("dft_z_r2c"); launch_pfa_z<T>(stream, pfa, tw, mesh_p, spec_p, 0); }
+      { TIMED("dft_y_fwd"); launch_pfa_y<T>(stream, pfa, tw, spec_p, 0); }
+      DftTabs<T> tabs;
+      tabs.p[0] = gtab;
+      { TIMED("dft_x_kspace"); launch_pfa_x_conv<T>(stream, pfa, tw, spec_p, tabs, Ed, slot); }
+      { TIMED("dft_y_inv"); launch_pfa_y<T>(stream, pfa, tw, spec_p, 1); }
+      { TIMED("dft_z_c2r"); launch_pfa_z<T>(stream, pfa, tw, mesh_p, spec_p, 1); }
+      return;
+    }
     if (use_dft) {
       const T* tw = dft_tw.as<T>();
       { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 0); }
@@ -666,21 +713,23 @@ struct Engine : EngineBase {
     const int slot = tab_slot(which);
     TabKey& key = tabkey[slot];
     DevBuf& buf = gtabs[slot];
-    const size_t nspec_t = (size_t)K[0] * nyown() * (K[2] / 2 + 1);
+    const size_t nspec_t = (size_t)K[0] * nyown() * (use_pfa ? pfa.Khp : K[2] / 2 + 1);
     buf.need(nspec_t * sizeof(T));
     gtab_cur = buf.template as<T>();
     bool same = key.kappa == kappa && key.K[0] == K[0] && key.K[1] == K[1] && key.K[2] == K[2] &&
-                key.Y0 == (snranks > 1 ? Y0 : 0) && key.ref == ref_korder;
+                key.Y0 == (snranks > 1 ? Y0 : 0) && key.ref == ref_korder && key.pfa == use_pfa;
     for (int k = 0; k < 9 && same; ++k) same = key.box[k] == box[k];
     if (same) return;
     HIP_TRY(hipMemcpyAsync(binv_d.p, inv, 9 * sizeof(double), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));   // `inv` is a caller stack array
     {
       TIMED("gtab");
-      launch_gtab<T>(stream, K, snranks > 1 ? Y0 : 0, nyown(), binv_d.as<double>(), std::fabs(vol), kappa, which, gtab_cur, ref_korder);
+      launch_gtab<T>(stream, K, snranks > 1 ? Y0 : 0, nyown(), binv_d.as<double>(), std::fabs(vol), kappa, which, gtab_cur, ref_korder,
+                     use_pfa ? pfa_fmap.as<int>() : nullptr, use_pfa ? pfa.Khp : 0);
     }
     std::memcpy(key.box, box, sizeof(key.box));
     key.kappa = kappa; key.K[0] = K[0]; key.K[1] = K[1]; key.K[2] = K[2]; key.Y0 = snranks > 1 ? Y0 : 0; key.ref = ref_korder;
+    key.pfa = use_pfa;
   }
 
   ScaleTab<T> make_tab(int ns, const double* mS, const double* pS) {
@@ -1237,7 +1286,13 @@ struct Engine : EngineBase {
     }
     fft_forward(mesh.as<T>(), spec.as<T>());
     launch_kspace_virial<T>(stream, K, binv_d.as<double>(), std::fabs(vol), kappa, which, ref_korder, spec.as<T>(), acc + V_TK);
-    { TIMED("kspace"); launch_kspace<T>(stream, K, nyown(), gtab_cur, spec.as<T>(), Ed_cur(), slot); }
+    const T* gt = gtab_cur;
+    if (use_pfa) {   // this pass goes through rocFFT: it needs the table in the natural layout, not the slot-ordered one
+      gtab_nat.need((size_t)K[0] * K[1] * (K[2] / 2 + 1) * sizeof(T));
+      launch_gtab<T>(stream, K, 0, K[1], binv_d.as<double>(), std::fabs(vol), kappa, which, gtab_nat.as<T>(), ref_korder);
+      gt = gtab_nat.as<T>();
+    }
+    { TIMED("kspace"); launch_kspace<T>(stream, K, nyown(), gt, spec.as<T>(), Ed_cur(), slot); }
     fft_inverse(spec.as<T>(), mesh.as<T>());
   }
   int vs_n = 0; const Site<T>* vs_sites = nullptr; RecipGeom<T> vs_g;
@@ -1483,10 +1538,10 @@ struct Engine : EngineBase {
     for (int k = 0; k < 9; ++k) gj.Aop[k] = g.Jac[k];
     const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
     const int nch = (pmax - 4) / 2;
-    if (use_dft && nch > 1) {
+    if ((use_dft || use_pfa) && nch > 1) {
       // direct-DFT meshes are small and dispatch bound: the powers are spread into separate meshes and transformed
       // as ONE batch (5 launches instead of 5 per power); gather per power from its own mesh
-      const size_t nreal = (size_t)K[0] * K[1] * K[2], nspec = 2 * (size_t)K[0] * K[1] * (K[2] / 2 + 1);
+      const size_t nreal = (size_t)K[0] * K[1] * K[2], nspec = 2 * (size_t)K[0] * K[1] * (use_pfa ? pfa.Khp : K[2] / 2 + 1);
       mesh.need(nch * nreal * sizeof(T));
       spec.need(nch * nspec * sizeof(T));
       DftTabs<T> tabs;
@@ -1512,12 +1567,21 @@ struct Engine : EngineBase {
           if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
         }
       }
+      if (use_pfa) {
+        const T* tw = pfa_tw.as<T>();
+        { TIMED("dft_z_r2c"); launch_pfa_z<T>(stream, pfa, tw, mesh.as<T>(), spec.as<T>(), 0, nch, (long)nreal, (long)nspec); }
+        { TIMED("dft_y_fwd"); launch_pfa_y<T>(stream, pfa, tw, spec.as<T>(), 0, nch, (long)nspec); }
+        { TIMED("dft_x_kspace"); launch_pfa_x_conv<T>(stream, pfa, tw, spec.as<T>(), tabs, Ed, E_RECIP, nch, (long)nspec); }
+        { TIMED("dft_y_inv"); launch_pfa_y<T>(stream, pfa, tw, spec.as<T>(), 1, nch, (long)nspec); }
+        { TIMED("dft_z_c2r"); launch_pfa_z<T>(stream, pfa, tw, mesh.as<T>(), spec.as<T>(), 1, nch, (long)nreal, (long)nspec); }
+      } else {
       const T* tw = dft_tw.as<T>();
       { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 0, nch, (long)nreal, (long)nspec); }
       { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 0, nch, (long)nspec); }
       { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec.as<T>(), tabs, Ed, E_RECIP, nch, (long)nspec); }
       { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 1, nch, (long)nspec); }
       { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 1, nch, (long)nreal, (long)nspec); }
+      }
       // the site rows hold the positions (only the charge slot differs per power): one gather over the batch of meshes
       { TIMED("gather_field"); launch_gather_field<T>(stream, na, sites.as<Site<T>>(), gj, mesh.as<T>(), fld_recip.as<T>(), nullptr, nch); }
       { TIMED("scale_add"); launch_scale_add<T>(stream, na, cl, 3, 0, fld_recip.as<T>(), dpos, nch); }

@@ -165,6 +165,25 @@ template <class T>
 void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
                        int slot, int nb = 1, long spec_stride = 0);
 
+// ---- pfa_kernels.hip: two-level (Good-Thomas) direct DFT for mesh dimensions N = N1 * N2 > 160 with a hard prime power N2
+struct PfaAxis { int N, N1, N2; };            // N1 = 1: plain direct lines
+struct PfaPlan {
+  PfaAxis ax[3];
+  int Khp;                                    // stored z columns: ax[2].N1 * (ax[2].N2 / 2 + 1)
+  int tw_off[3];                              // twiddles of axis d at tw + tw_off[d] (complex entries): N2 entries, then N1
+};
+bool pfa_split(int N, PfaAxis* out);          // false: no usable split
+void pfa_freq_of_slot(const PfaAxis& a, int* f);      // f[slot] = frequency stored at that position of the axis
+void pfa_freq_of_zcolumn(const PfaAxis& a, int* f);   // the same for the Khp stored z columns
+template <class T>
+void launch_pfa_z(hipStream_t st, const PfaPlan& p, const T* tw, T* mesh, T* spec, int inverse, int nb = 1, long mesh_stride = 0,
+                  long spec_stride = 0);
+template <class T>
+void launch_pfa_y(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, int inverse, int nb = 1, long spec_stride = 0);
+template <class T>
+void launch_pfa_x_conv(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, const DftTabs<T>& tabs, double* energies, int slot,
+                       int nb = 1, long spec_stride = 0);
+
 // ---- pair_kernels.hip
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
@@ -296,7 +315,10 @@ size_t spread_scan_bytes(int ncell);
 // which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels
 template <class T>
 void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* box_inv, double volume, double kappa,
-                 int which, T* gtab, int ref_order = 0 /* the reference's k-point table, see k_gtab */);
+                 int which, T* gtab, int ref_order = 0 /* the reference's k-point table, see k_gtab */,
+                 const int* fmap = nullptr /* slot-ordered spectrum (pfa_kernels.hip): device table of the frequency stored
+                                              at every x slot (K0), y slot (K1) and z column (nh), back to back */,
+                 int nh = 0 /* with fmap: number of stored z columns */);
 // spec <- spec * gtab ; energies[slot] += sum_k w_k (gtab/2) |S_k|^2
 template <class T>
 void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec /* interleaved complex */,

@@ -1,0 +1,375 @@
+// Two-level direct-DFT mesh convolution for mesh dimensions that rocFFT can only do with Bluestein's algorithm AND that are
+// too long for the plain O(N^2) lines of dft_kernels.hip -- e.g. the 305 = 5 * 61 mesh the reference's
+// setup_ewald_parameters (admp/pme.py:146-172) gives for the 98 304-atom water box.
+//
+// Good-Thomas (prime-factor) split of every axis: N = N1 * N2 with gcd(N1, N2) = 1, N2 = the power of the largest prime in
+// N (the "hard" part, <= 160), N1 the smooth cofactor (<= 32).  With the index maps
+//     position  n  <->  (n1, n2):  n = (N2 n1 + N1 n2) mod N           frequency  k  <->  (k1, k2):  k = k1 (mod N1), k = k2 (mod N2)
+// the length-N transform IS the two-dimensional N1 x N2 transform -- no twiddles between the stages:
+//     X(k1, k2) = sum_n1 W_N1^(n1 k1)  sum_n2 W_N2^(n2 k2)  x(n1, n2)
+// Stage A: N2-point lines (the pair-symmetric direct sums of dft_math.h), stage B: N1-point lines (plain sums), both on a
+// tile of lines held in LDS, one kernel per mesh axis like dft_kernels.hip:
+//     z lines r2c -> y lines -> x lines forward * G (+ energy) x lines inverse -> y lines -> z lines c2r
+// The spectrum is stored in SLOT order: X(k1, k2) of an axis sits where x(n1 = k1, n2 = k2) sat, i.e. at position
+// (N2 k1 + N1 k2) mod N.  Nothing ever needs the natural order: the G table is generated in slot order (launch_gtab with
+// the frequency-of-slot maps), the inverse transform reads slots and writes positions.
+// z axis (real input): stage A is a real N2-point transform (outputs k2 = 0 .. N2/2), stage B complex over n1; the stored
+// half is the N1 x (N2/2 + 1) set of (k1, k2 <= N2/2), column cz = k2 * N1 + k1 -- Khp = N1 (N2/2 + 1) columns instead of
+// N/2 + 1.  The Hermitian partner of (k1, k2) is (-k1, -k2): inside the set only for k2 = 0 (and k2 = N2/2, N2 even), whose
+// columns therefore weigh 1/2 in the energy sum -- the role kz = 0 / Nyquist play in the natural layout (recip.py:400-414).
+#include "dft_math.h"
+#include "launch.h"
+#include "reduce.h"
+
+namespace admp {
+
+constexpr int kPfaBlock = 256;
+extern __shared__ __align__(32) unsigned char pfa_smem[];
+
+__host__ __device__ inline int pfa_pos(const PfaAxis& a, int n1, int n2) { return (a.N2 * n1 + a.N1 * n2) % a.N; }
+
+// sum_n1 y[n1 * stride] w1^(sign n1 k1), k1 fixed: the short stage (N1 <= 32)
+template <class T>
+__device__ __forceinline__ Cx<T> short_dft(int N1, int k1, int sign, const Cx<T>* y, int stride, const Cx<T>* tw1) {
+  Cx<T> acc{T(0), T(0)};
+  int m = 0;
+  for (int n1 = 0; n1 < N1; ++n1) {
+    const Cx<T> v = y[n1 * stride];
+    const T c = tw1[m].re, s = sign < 0 ? -tw1[m].im : tw1[m].im;
+    acc.re += v.re * c - v.im * s;
+    acc.im += v.re * s + v.im * c;
+    m += k1;
+    if (m >= N1) m -= N1;
+  }
+  return acc;
+}
+
+// real line, rows layout (x[j * stride], j = 0..N-1): X[k] = x0 + P - i R (+ xn (-1)^k)
+template <class T>
+__device__ __forceinline__ Cx<T> rdft_rows(int N, int k, int stride, const T* x, const Cx<T>* tw) {
+  const int H = (N - 1) / 2;
+  T P = T(0), R = T(0);
+  int m = k;
+  for (int j = 1; j <= H; ++j) {
+    const T a = x[j * stride], b = x[(N - j) * stride];
+    P += (a + b) * tw[m].re;
+    R += (a - b) * tw[m].im;
+    m += k;
+    if (m >= N) m -= N;
+  }
+  T re = x[0] + P;
+  if ((N & 1) == 0) re += (k & 1) ? -x[(N / 2) * stride] : x[(N / 2) * stride];
+  return Cx<T>{re, -R};
+}
+// Hermitian half line, rows layout (X[k * stride], k = 0 .. N/2): x_j and x_{N-j}
+template <class T>
+__device__ __forceinline__ void irdft_rows(int N, int j, int stride, const Cx<T>* X, const Cx<T>* tw, T& xj, T& xnj) {
+  const int H = (N - 1) / 2;
+  T P = T(0), R = T(0);
+  int m = j;
+  for (int k = 1; k <= H; ++k) {
+    const Cx<T> v = X[k * stride];
+    P += v.re * tw[m].re;
+    R += v.im * tw[m].im;
+    m += j;
+    if (m >= N) m -= N;
+  }
+  T base = X[0].re + T(2) * P;
+  if ((N & 1) == 0) base += (j & 1) ? -X[(N / 2) * stride].re : X[(N / 2) * stride].re;
+  xj = base - T(2) * R;
+  xnj = base + T(2) * R;
+}
+
+// LDS layout of the strided passes: tw2[N2] | tw1[N1] | D[N][NC] | Y[N][NC]   (row index = n1 * N2 + n2, resp. k1 * N2 + k2)
+template <class T>
+struct PfaTile {
+  Cx<T>* tw2; Cx<T>* tw1; Cx<T>* D; Cx<T>* Y;
+};
+template <class T>
+__device__ __forceinline__ PfaTile<T> pfa_tile(const PfaAxis& a, int NC) {
+  PfaTile<T> t;
+  t.tw2 = reinterpret_cast<Cx<T>*>(pfa_smem);
+  t.tw1 = t.tw2 + a.N2;
+  t.D = t.tw1 + a.N1;
+  t.Y = t.D + (size_t)a.N * NC;
+  return t;
+}
+static size_t pfa_tile_bytes(const PfaAxis& a, int NC, size_t w) { return 2 * w * ((size_t)a.N2 + a.N1 + 2 * (size_t)a.N * NC); }
+// columns per block: as many as fit the budget, at most 16 (64-B segments of f32 complex at 8)
+static int pfa_cols(const PfaAxis& a, size_t w, size_t budget = 60 * 1024) {
+  int nc = 16;
+  while (nc > 1 && pfa_tile_bytes(a, nc, w) > budget) nc >>= 1;
+  return nc;
+}
+
+template <class T>
+__device__ __forceinline__ void pfa_load(const PfaAxis& a, const PfaTile<T>& s, int NC, int nca, const Cx<T>* __restrict__ spec,
+                                         long base, long jstride, const Cx<T>* __restrict__ tw2g, const Cx<T>* __restrict__ tw1g) {
+  for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) s.tw2[t] = tw2g[t];
+  for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) s.tw1[t] = tw1g[t];
+#pragma unroll 4
+  for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {
+    const int idx = t / NC, c = t - idx * NC;
+    const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
+    s.D[t] = c < nca ? spec[base + (long)pfa_pos(a, n1, n2) * jstride + c] : Cx<T>{T(0), T(0)};
+  }
+}
+// stage A: N2-point lines over n2 for every (n1, column): in[(n1 N2 + n2) NC + c] -> out[(n1 N2 + k2) NC + c]
+template <class T, int SIGN>
+__device__ __forceinline__ void pfa_stage_a(const PfaAxis& a, int NC, const Cx<T>* in, Cx<T>* out, const Cx<T>* tw2) {
+  constexpr int KQ = 2;
+  const int Kh2 = a.N2 / 2 + 1, TK = (Kh2 + KQ - 1) / KQ;
+  for (int t = threadIdx.x; t < a.N1 * TK * NC; t += kPfaBlock) {
+    const int c = t % NC, g = (t / NC) % TK, n1 = t / (NC * TK);
+    int k[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh2) ? g + q * TK : 0;
+    Cx<T> Xk[KQ], Xnk[KQ];
+    {   // (dft_pair_outputs_rows of dft_math.h wants the pair sums already formed in the rows; these rows hold the values)
+      const Cx<T>* col = in + (size_t)n1 * a.N2 * NC + c;
+      const int N2 = a.N2;
+      const Cx<T> x0 = col[0];
+      const Cx<T> xn = (N2 & 1) ? Cx<T>{T(0), T(0)} : col[(N2 / 2) * NC];
+      dft_pair_core<T, SIGN, KQ>(N2, k, [=](int j) {
+        const Cx<T> u = col[(1 + j) * NC], v = col[(N2 - 1 - j) * NC];
+        return PairCx<T>{u.re + v.re, u.im + v.im, u.re - v.re, u.im - v.im};
+      }, x0, xn, tw2, Xk, Xnk);
+    }
+    Cx<T>* o = out + (size_t)n1 * a.N2 * NC + c;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK;
+      if (kq < Kh2) {
+        o[kq * NC] = Xk[q];
+        if (kq != 0 && 2 * kq != a.N2) o[(a.N2 - kq) * NC] = Xnk[q];
+      }
+    }
+  }
+}
+
+// ---- strided complex lines, in place (y lines)
+template <class T, int SIGN>
+__global__ __launch_bounds__(kPfaBlock) void k_pfa_strided(PfaAxis a, int ncols, int NC, long jstride, long fixstride,
+                                                          Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ tw2g,
+                                                          const Cx<T>* __restrict__ tw1g, long spec_stride) {
+  spec += blockIdx.z * spec_stride;
+  const PfaTile<T> s = pfa_tile<T>(a, NC);
+  const int col0 = blockIdx.x * NC, nca = min(NC, ncols - col0);
+  const long base = (long)blockIdx.y * fixstride + col0;
+  pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g);
+  __syncthreads();
+  pfa_stage_a<T, SIGN>(a, NC, s.D, s.Y, s.tw2);
+  __syncthreads();
+  // stage B straight to memory: X(k1, k2) -> slot (N2 k1 + N1 k2) mod N
+  for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {
+    const int idx = t / NC, c = t - idx * NC;
+    const int k1 = idx / a.N2, k2 = idx - k1 * a.N2;
+    if (c < nca) spec[base + (long)pfa_pos(a, k1, k2) * jstride + c] = short_dft<T>(a.N1, k1, SIGN, s.Y + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
+  }
+}
+
+// ---- x lines: forward, multiply by G (accumulating sum w G |S|^2), inverse; in place.  az = the z axis (column weights)
+template <class T>
+__global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az, int ncols, int NC, long jstride, long fixstride,
+                                                         Cx<T>* __restrict__ spec, DftTabs<T> tabs, const Cx<T>* __restrict__ tw2g,
+                                                         const Cx<T>* __restrict__ tw1g, double* energies, int slot,
+                                                         long spec_stride) {
+  spec += blockIdx.z * spec_stride;
+  const T* __restrict__ gtab = tabs.p[blockIdx.z];
+  const PfaTile<T> s = pfa_tile<T>(a, NC);
+  const int col0 = blockIdx.x * NC, nca = min(NC, ncols - col0);
+  const long base = (long)blockIdx.y * fixstride + col0;
+  pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g);
+  __syncthreads();
+  pfa_stage_a<T, -1>(a, NC, s.D, s.Y, s.tw2);
+  __syncthreads();
+  double e = 0.0;
+  for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {          // stage B, times G: Y -> D
+    const int idx = t / NC, c = t - idx * NC;
+    const int k1 = idx / a.N2, k2 = idx - k1 * a.N2;
+    Cx<T> X{T(0), T(0)};
+    if (c < nca) {
+      X = short_dft<T>(a.N1, k1, -1, s.Y + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
+      const T G = gtab[base + (long)pfa_pos(a, k1, k2) * jstride + c];
+      const int k2z = (col0 + c) / az.N1;
+      const double w = (k2z == 0 || ((az.N2 & 1) == 0 && k2z == az.N2 / 2)) ? 0.5 : 1.0;
+      e += w * (double)G * ((double)X.re * X.re + (double)X.im * X.im);
+      X.re *= G; X.im *= G;
+    }
+    s.D[t] = X;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {          // inverse stage B: D(k1, k2) -> Y(n1, k2)
+    const int idx = t / NC, c = t - idx * NC;
+    const int n1 = idx / a.N2, k2 = idx - n1 * a.N2;
+    s.Y[t] = short_dft<T>(a.N1, n1, +1, s.D + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
+  }
+  __syncthreads();
+  pfa_stage_a<T, +1>(a, NC, s.Y, s.D, s.tw2);                        // inverse stage A: Y(n1, k2) -> D(n1, n2)
+  __syncthreads();
+  for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {
+    const int idx = t / NC, c = t - idx * NC;
+    const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
+    if (c < nca) spec[base + (long)pfa_pos(a, n1, n2) * jstride + c] = s.D[t];
+  }
+  e = block_reduce_sum<kPfaBlock>(e);
+  if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
+}
+
+// ---- z lines (contiguous, real): mesh [nlines][N] -> spec [nlines][Khp], column cz = k2 * N1 + k1, k2 <= N2/2.
+// LDS: tw2[N2] | tw1[N1] | Dr[N][NL] (reals) | Y[N1 * Kh2][NL]
+template <class T>
+__global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, int NL, const T* __restrict__ mesh,
+                                                        Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ tw2g,
+                                                        const Cx<T>* __restrict__ tw1g, long mesh_stride, long spec_stride) {
+  mesh += blockIdx.y * mesh_stride;
+  spec += blockIdx.y * spec_stride;
+  const int Kh2 = a.N2 / 2 + 1, Khp = a.N1 * Kh2;
+  Cx<T>* tw2 = reinterpret_cast<Cx<T>*>(pfa_smem);
+  Cx<T>* tw1 = tw2 + a.N2;
+  Cx<T>* Y = tw1 + a.N1;                                   // [N1 * Kh2][NL]
+  T* Dr = reinterpret_cast<T*>(Y + (size_t)Khp * NL);      // [N][NL]
+  const int line0 = blockIdx.x * NL, nl = min(NL, nlines - line0);
+  for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) tw2[t] = tw2g[t];
+  for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) tw1[t] = tw1g[t];
+#pragma unroll 4
+  for (int t = threadIdx.x; t < a.N * NL; t += kPfaBlock) {
+    const int l = t / a.N, idx = t - l * a.N;
+    const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
+    Dr[idx * NL + l] = l < nl ? mesh[(long)(line0 + l) * a.N + pfa_pos(a, n1, n2)] : T(0);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < a.N1 * Kh2 * NL; t += kPfaBlock) {   // stage A: real N2-point lines
+    const int l = t % NL, k2 = (t / NL) % Kh2, n1 = t / (NL * Kh2);
+    Y[(n1 * Kh2 + k2) * NL + l] = rdft_rows<T>(a.N2, k2, NL, Dr + (size_t)n1 * a.N2 * NL + l, tw2);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {          // stage B over n1, straight to memory
+    const int cz = t % Khp, l = t / Khp;
+    const int k2 = cz / a.N1, k1 = cz - k2 * a.N1;
+    if (l < nl) spec[(long)(line0 + l) * Khp + cz] = short_dft<T>(a.N1, k1, -1, Y + (size_t)k2 * NL + l, Kh2 * NL, tw1);
+  }
+}
+
+// ---- z lines back: spec [nlines][Khp] -> mesh [nlines][N]
+template <class T>
+__global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, int NL, const Cx<T>* __restrict__ spec,
+                                                        T* __restrict__ mesh, const Cx<T>* __restrict__ tw2g,
+                                                        const Cx<T>* __restrict__ tw1g, long mesh_stride, long spec_stride) {
+  mesh += blockIdx.y * mesh_stride;
+  spec += blockIdx.y * spec_stride;
+  const int Kh2 = a.N2 / 2 + 1, Khp = a.N1 * Kh2;
+  Cx<T>* tw2 = reinterpret_cast<Cx<T>*>(pfa_smem);
+  Cx<T>* tw1 = tw2 + a.N2;
+  Cx<T>* X = tw1 + a.N1;                                   // [Khp][NL], row cz = k2 * N1 + k1
+  Cx<T>* Y = X + (size_t)Khp * NL;                         // [N1 * Kh2][NL], row n1 * Kh2 + k2
+  const int line0 = blockIdx.x * NL, nl = min(NL, nlines - line0);
+  for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) tw2[t] = tw2g[t];
+  for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) tw1[t] = tw1g[t];
+#pragma unroll 4
+  for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {
+    const int l = t / Khp, cz = t - l * Khp;
+    X[cz * NL + l] = l < nl ? spec[(long)(line0 + l) * Khp + cz] : Cx<T>{T(0), T(0)};
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {          // inverse stage B: X(k1, k2) -> Y(n1, k2)
+    const int l = t % NL, k2 = (t / NL) % Kh2, n1 = t / (NL * Kh2);
+    Y[(n1 * Kh2 + k2) * NL + l] = short_dft<T>(a.N1, n1, +1, X + (size_t)k2 * a.N1 * NL + l, NL, tw1);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < a.N1 * Kh2 * NL; t += kPfaBlock) {   // inverse stage A: Hermitian N2-point lines -> reals
+    const int l = t % NL, j = (t / NL) % Kh2, n1 = t / (NL * Kh2);
+    if (l >= nl) continue;
+    T xj, xnj;
+    irdft_rows<T>(a.N2, j, NL, Y + (size_t)n1 * Kh2 * NL + l, tw2, xj, xnj);
+    T* x = mesh + (long)(line0 + l) * a.N;
+    x[pfa_pos(a, n1, j)] = xj;
+    if (j != 0 && 2 * j != a.N2) x[pfa_pos(a, n1, a.N2 - j)] = xnj;
+  }
+}
+
+// ---- host side
+// split of one axis; false: this length neither fits the plain lines nor has a usable coprime split
+bool pfa_split(int N, PfaAxis* out) {
+  int p = largest_prime_factor(N), N2 = 1, m = N;
+  while (m % p == 0) { N2 *= p; m /= p; }
+  PfaAxis a;
+  a.N = N;
+  static const int plain_max = [] { const char* e = getenv("ADMP_PFA_MIN"); return e ? atoi(e) : 160; }();   // tests: 0 splits whatever it can
+  if (N <= plain_max || m == 1) { a.N1 = 1; a.N2 = N; }
+  else { a.N1 = m; a.N2 = N2; }
+  if (a.N2 > 160 || a.N1 > 32 || a.N2 < 2) return false;
+  *out = a;
+  return true;
+}
+void pfa_freq_of_slot(const PfaAxis& a, int* f) {      // f[slot] = the frequency stored there
+  for (int k1 = 0; k1 < a.N1; ++k1)
+    for (int k2 = 0; k2 < a.N2; ++k2) {
+      int k = k2;
+      while (k % a.N1 != k1) k += a.N2;               // CRT by search (N1 <= 32 steps)
+      f[pfa_pos(a, k1, k2)] = k;
+    }
+}
+void pfa_freq_of_zcolumn(const PfaAxis& a, int* f) {   // f[cz] for the stored z half, cz = k2 * N1 + k1
+  const int Kh2 = a.N2 / 2 + 1;
+  for (int k2 = 0; k2 < Kh2; ++k2)
+    for (int k1 = 0; k1 < a.N1; ++k1) {
+      int k = k2;
+      while (k % a.N1 != k1) k += a.N2;
+      f[k2 * a.N1 + k1] = k;
+    }
+}
+
+template <class T>
+void launch_pfa_z(hipStream_t st, const PfaPlan& p, const T* tw, T* mesh, T* spec, int inverse, int nb, long mesh_stride,
+                  long spec_stride) {
+  const PfaAxis& a = p.ax[2];
+  const int nlines = p.ax[0].N * p.ax[1].N, Khp = p.Khp;
+  const Cx<T>* tw2 = reinterpret_cast<const Cx<T>*>(tw) + p.tw_off[2];
+  const Cx<T>* tw1 = tw2 + a.N2;
+  // lines per block: LDS = tw + Khp * NL complex + max(N reals, Khp complex) * NL
+  const size_t per_line = sizeof(Cx<T>) * (size_t)Khp + (inverse ? sizeof(Cx<T>) * (size_t)Khp : sizeof(T) * (size_t)a.N);
+  int NL = 8;
+  while (NL > 1 && sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL > 60 * 1024) NL >>= 1;
+  const size_t sh = sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL;
+  const dim3 grid((nlines + NL - 1) / NL, nb);
+  if (inverse)
+    k_pfa_z_c2r<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, reinterpret_cast<const Cx<T>*>(spec), mesh, tw2, tw1, mesh_stride, spec_stride / 2);
+  else
+    k_pfa_z_r2c<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mesh, reinterpret_cast<Cx<T>*>(spec), tw2, tw1, mesh_stride, spec_stride / 2);
+}
+template <class T>
+void launch_pfa_y(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, int inverse, int nb, long spec_stride) {
+  const PfaAxis& a = p.ax[1];
+  const int Khp = p.Khp, NC = pfa_cols(a, sizeof(T));
+  const Cx<T>* tw2 = reinterpret_cast<const Cx<T>*>(tw) + p.tw_off[1];
+  const Cx<T>* tw1 = tw2 + a.N2;
+  const dim3 grid((Khp + NC - 1) / NC, p.ax[0].N, nb);
+  const size_t sh = pfa_tile_bytes(a, NC, sizeof(T));
+  Cx<T>* sp = reinterpret_cast<Cx<T>*>(spec);
+  if (inverse)
+    k_pfa_strided<T, +1><<<grid, kPfaBlock, sh, st>>>(a, Khp, NC, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, spec_stride / 2);
+  else
+    k_pfa_strided<T, -1><<<grid, kPfaBlock, sh, st>>>(a, Khp, NC, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, spec_stride / 2);
+}
+template <class T>
+void launch_pfa_x_conv(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
+                       int slot, int nb, long spec_stride) {
+  const PfaAxis& a = p.ax[0];
+  const int Khp = p.Khp, NC = pfa_cols(a, sizeof(T));
+  const Cx<T>* tw2 = reinterpret_cast<const Cx<T>*>(tw) + p.tw_off[0];
+  const Cx<T>* tw1 = tw2 + a.N2;
+  const dim3 grid((Khp + NC - 1) / NC, p.ax[1].N, nb);
+  const size_t sh = pfa_tile_bytes(a, NC, sizeof(T));
+  k_pfa_x_conv<T><<<grid, kPfaBlock, sh, st>>>(a, p.ax[2], Khp, NC, (long)p.ax[1].N * Khp, (long)Khp, reinterpret_cast<Cx<T>*>(spec),
+                                              tabs, tw2, tw1, energies, slot, spec_stride / 2);
+}
+#define INST(T)                                                                                          \
+  template void launch_pfa_z<T>(hipStream_t, const PfaPlan&, const T*, T*, T*, int, int, long, long);    \
+  template void launch_pfa_y<T>(hipStream_t, const PfaPlan&, const T*, T*, int, int, long);              \
+  template void launch_pfa_x_conv<T>(hipStream_t, const PfaPlan&, const T*, T*, const DftTabs<T>&, double*, int, int, long);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace admp

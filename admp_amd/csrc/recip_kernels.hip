@@ -470,13 +470,14 @@ __device__ inline double gfactor_at(int i0, int i1, int i2, int K0, int K1, int 
 
 template <class T>
 __global__ void k_gtab(int K0, int K1, int K2, int y0, int ny, const double* __restrict__ binv, double volume,
-                       double kappa, int which, int ref_order, T* __restrict__ gtab) {
-  const int nh = K2 / 2 + 1;
+                       double kappa, int which, int ref_order, T* __restrict__ gtab, const int* __restrict__ fmap, int nhmap) {
+  const int nh = fmap ? nhmap : K2 / 2 + 1;
   const long n = (long)K0 * ny * nh;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
-    const int i2 = (int)(t % nh);
-    const int i1 = y0 + (int)((t / nh) % ny);
-    const int i0 = (int)(t / ((long)nh * ny));
+    int i2 = (int)(t % nh);
+    int i1 = y0 + (int)((t / nh) % ny);
+    int i0 = (int)(t / ((long)nh * ny));
+    if (fmap) { i0 = fmap[i0]; i1 = fmap[K0 + i1]; i2 = fmap[K0 + K1 + i2]; }   // slot -> frequency (pfa_kernels.hip)
     double G = gfactor_at(i0, i1, i2, K0, K1, K2, binv, volume, kappa, which, ref_order);
     if (ref_order)
       G = 0.5 * (G + gfactor_at((K0 - i0) % K0, (K1 - i1) % K1, (K2 - i2) % K2, K0, K1, K2, binv, volume, kappa, which, 1));
@@ -788,11 +789,11 @@ size_t spread_scan_bytes(int ncell) {
 }
 template <class T>
 void launch_gtab(hipStream_t st, const int K[3], int y0, int ny, const double* box_inv, double volume, double kappa,
-                 int which, T* gtab, int ref_order) {
-  const long n = (long)K[0] * ny * (K[2] / 2 + 1);
+                 int which, T* gtab, int ref_order, const int* fmap, int nh) {
+  const long n = (long)K[0] * ny * (fmap ? nh : K[2] / 2 + 1);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  k_gtab<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], y0, ny, box_inv, volume, kappa, which, ref_order, gtab);
+  k_gtab<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], y0, ny, box_inv, volume, kappa, which, ref_order, gtab, fmap, nh);
 }
 template <class T>
 void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spec, double* energies, int slot) {
@@ -858,7 +859,8 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
 #define INST(T)                                                                                                       \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
                                 const int*, const int4*, int, int);                                                   \
-  template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*, int);            \
+  template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*, int,             \
+                               const int*, int);                                                                      \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \

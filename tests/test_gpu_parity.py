@@ -222,8 +222,10 @@ print('DFT-RUN-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     # 'dft', 'dft_kq4': the vector forms of dft_kernels.hip (the default); 'dft_mfma': the matrix-core kernels of dft_mfma.hip
+    # 'pfa': the two-level (Good-Thomas) kernels of pfa_kernels.hip forced onto these small meshes, every dimension split
+    # that has a coprime split (34 = 2 * 17, 38 = 2 * 19, 96 = 32 * 3, 100 = 4 * 25, 45 = 9 * 5, 51 = 3 * 17; 31, 97, 64 plain)
     modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'dft_mfma': dict(ADMP_DFT='1', ADMP_DFT_MFMA='1'),
-             'dft_kq4': dict(ADMP_DFT='1', ADMP_DFT_KQ='4')}
+             'dft_kq4': dict(ADMP_DFT='1', ADMP_DFT_KQ='4'), 'pfa': dict(ADMP_DFT='2', ADMP_PFA_MIN='0')}
     for mode, extra in modes.items():
         path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
@@ -232,7 +234,7 @@ print('DFT-RUN-OK')
         res[mode] = dict(np.load(path))
     assert len(res['rocfft']) == 2 * 4 * 5
     for key, a in res['rocfft'].items():
-        for mode in ('dft', 'dft_mfma', 'dft_kq4'):
+        for mode in ('dft', 'dft_mfma', 'dft_kq4', 'pfa'):
             b = res[mode][key]
             tol = 1e-10 if key.startswith('double') else 2e-4
             scale = np.abs(a).max()
@@ -1190,3 +1192,50 @@ def test_charge_only_site_classes_follow_the_parameters(precision, prec, tolE, t
             fn.get_forces(pos, box, pairs, Q0, par['mScales'])      # a call that may take the reduced forms
         E, G, dQ = fn.get_forces_and_dQ(pos, box, pairs, Q0, par['mScales'])
         assert rel(G, ref['grad']) < tolG and rel(dQ, ref['dQ_local']) < tolG
+
+
+@pytest.mark.gpu
+def test_two_level_dft_on_a_bluestein_mesh_above_160(precision):
+    """Mesh dimensions with a prime factor above 13 that are too long for plain O(N^2) lines -- 305 = 5 * 61 is what the
+    reference's setup_ewald_parameters gives for the 98 304-atom box (admp/pme.py:146-172) -- go through the two-level
+    kernels of pfa_kernels.hip by default.  Same numbers as the rocFFT (Bluestein) leg: energy parts, forces, induced
+    dipoles, the dispersion terms, and the box gradient (whose reciprocal passes stay on rocFFT and need the natural-order
+    G table next to the slot-ordered one)."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_parity import water_system
+from admp_amd import settings
+settings.PRECISION = 'double'
+from admp_amd.pme import ADMPPmeForce
+from admp_amd.disp_pme import ADMPDispPmeForce
+pos, box, at, ai, cov, par, pairs = water_system(216, 5, True)
+out = {}
+f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+for o in (f, d):
+    o.K1, o.K2, o.K3 = 305, 170, 183          # 5 * 61, 10 * 17, 3 * 61
+    o.refresh_calculators()
+args = (par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+E, G = f.get_forces(pos, box, pairs, *args)
+out['parts'] = np.asarray(f.energy_parts); out['G'] = np.asarray(G); out['U'] = np.asarray(f.U_ind)
+Ed, Gd = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+out['dparts'] = np.asarray(d.energy_parts); out['Gd'] = np.asarray(Gd)
+Eb, dbox = f.get_energy_and_box_gradient(pos, box, pairs, *args, U_init=f.U_ind)
+out['Eb'] = np.asarray(Eb); out['dbox'] = np.asarray(dbox)
+np.savez(sys.argv[1], **out)
+print('PFA-RUN-OK')
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode, extra in {'rocfft': dict(ADMP_DFT='0'), 'pfa': {}}.items():
+        path = os.path.join('/tmp', 'pfa_%s_%d.npz' % (mode, os.getpid()))
+        r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True, env=dict(os.environ, **extra),
+                           timeout=900)
+        assert r.returncode == 0 and 'PFA-RUN-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        res[mode] = dict(np.load(path))
+        os.remove(path)
+    for key, a in res['rocfft'].items():
+        b = res['pfa'][key]
+        assert np.abs(a - b).max() <= 1e-10 * np.abs(a).max(), (key, np.abs(a - b).max(), np.abs(a).max())
