@@ -15,24 +15,10 @@
 // C/D column = lane & 15, row = (lane >> 4) + 4 r for f64, 4 (lane >> 4) + r for f32, r = 0..3.
 #include "dft_math.h"
 #include "launch.h"
+#include "mfma.h"
 #include "reduce.h"
 
 namespace admp {
-
-template <class T>
-struct Mfma;
-template <>
-struct Mfma<double> {
-  typedef double Acc __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ Acc mma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
-};
-template <>
-struct Mfma<float> {
-  typedef float Acc __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
-};
 
 constexpr int kMfmaMaxTiles = 8;     // H <= 128
 
@@ -46,15 +32,6 @@ __device__ long long* g_dftm_trace;
 
 extern __shared__ __align__(32) unsigned char dftm_smem[];
 
-// twiddle index of a lane: output index i (0-based: k - 1), position kk (0-based: jj); advanced by 4 positions per step
-struct TwIdx {
-  int m, inc, N;
-  __device__ __forceinline__ TwIdx(int i, int kk0, int N_) : N(N_) {
-    m = (int)(((long)(1 + i) * (1 + kk0)) % N_);
-    inc = (4 * (1 + i)) % N_;
-  }
-  __device__ __forceinline__ void step() { m += inc; if (m >= N) m -= N; }
-};
 
 // ---- z lines (contiguous): real mesh [nlines][N] -> half spectrum [nlines][N/2+1].  32 lines per block; A = data, B = twiddle
 template <class T>

@@ -19,6 +19,7 @@
 // columns therefore weigh 1/2 in the energy sum -- the role kz = 0 / Nyquist play in the natural layout (recip.py:400-414).
 #include "dft_math.h"
 #include "launch.h"
+#include "mfma.h"
 #include "reduce.h"
 
 namespace admp {
@@ -84,7 +85,15 @@ __device__ __forceinline__ void irdft_rows(int N, int j, int stride, const Cx<T>
 template <class T>
 struct PfaTile {
   Cx<T>* tw2; Cx<T>* tw1; Cx<T>* D; Cx<T>* Y;
+  int* ptab;        // [N]: row idx = n1 * N2 + n2 -> position (N2 n1 + N1 n2) mod N in the low 16 bits, n1 above
 };
+// the index table spares every element of every sweep two integer divisions and a modulo
+__device__ __forceinline__ void pfa_fill_ptab(const PfaAxis& a, int* ptab) {
+  for (int idx = threadIdx.x; idx < a.N; idx += kPfaBlock) {
+    const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
+    ptab[idx] = ((a.N2 * n1 + a.N1 * n2) % a.N) | (n1 << 16);
+  }
+}
 template <class T>
 __device__ __forceinline__ PfaTile<T> pfa_tile(const PfaAxis& a, int NC) {
   PfaTile<T> t;
@@ -92,13 +101,20 @@ __device__ __forceinline__ PfaTile<T> pfa_tile(const PfaAxis& a, int NC) {
   t.tw1 = t.tw2 + a.N2;
   t.D = t.tw1 + a.N1;
   t.Y = t.D + (size_t)a.N * NC;
+  t.ptab = reinterpret_cast<int*>(t.Y + (size_t)a.N * NC);
   return t;
 }
-static size_t pfa_tile_bytes(const PfaAxis& a, int NC, size_t w) { return 2 * w * ((size_t)a.N2 + a.N1 + 2 * (size_t)a.N * NC); }
+static size_t pfa_tile_bytes(const PfaAxis& a, int NC, size_t w) {
+  return 2 * w * ((size_t)a.N2 + a.N1 + 2 * (size_t)a.N * NC) + sizeof(int) * (size_t)a.N;
+}
 // columns per block: as many as fit the budget, at most 16 (64-B segments of f32 complex at 8)
-static int pfa_cols(const PfaAxis& a, size_t w, size_t budget = 60 * 1024) {
-  int nc = 16;
-  while (nc > 1 && pfa_tile_bytes(a, nc, w) > budget) nc >>= 1;
+static size_t pfa_lds_budget() {
+  static const size_t b = [] { const char* e = getenv("ADMP_PFA_LDS_KB"); return (size_t)(e ? atoi(e) : 60) * 1024; }();
+  return b;
+}
+static int pfa_cols(const PfaAxis& a, size_t w) {
+  int nc = 8;        // 8 complex columns = the 16 words of an MFMA tile row (pfa_stage_a_mfma); 16 measured slower (occupancy)
+  while (nc > 1 && pfa_tile_bytes(a, nc, w) > pfa_lds_budget()) nc >>= 1;
   return nc;
 }
 
@@ -107,12 +123,15 @@ __device__ __forceinline__ void pfa_load(const PfaAxis& a, const PfaTile<T>& s, 
                                          long base, long jstride, const Cx<T>* __restrict__ tw2g, const Cx<T>* __restrict__ tw1g) {
   for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) s.tw2[t] = tw2g[t];
   for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) s.tw1[t] = tw1g[t];
+  // positions straight from the arithmetic here (the table is being filled by the same threads); NC is a power of two
+  const int sh = 31 - __clz(NC);
 #pragma unroll 4
   for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {
-    const int idx = t / NC, c = t - idx * NC;
+    const int idx = t >> sh, c = t & (NC - 1);
     const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
     s.D[t] = c < nca ? spec[base + (long)pfa_pos(a, n1, n2) * jstride + c] : Cx<T>{T(0), T(0)};
   }
+  pfa_fill_ptab(a, s.ptab);
 }
 // stage A: N2-point lines over n2 for every (n1, column): in[(n1 N2 + n2) NC + c] -> out[(n1 N2 + k2) NC + c]
 template <class T, int SIGN>
@@ -147,50 +166,120 @@ __device__ __forceinline__ void pfa_stage_a(const PfaAxis& a, int NC, const Cx<T
   }
 }
 
+// Stage A on the matrix cores (N2 odd, NC = 8): the N2-point sums of a sub-line are products with the H x H cosine / sine
+// matrices of its pair sums (dft_mfma.hip has the derivation), H = (N2 - 1) / 2.  With 8 complex columns per tile the 16
+// data columns of one MFMA tile are exactly the 16 words (re, im of 8 columns) of ONE row of sub-line n1 -- contiguous in
+// LDS, conflict-free.  Work items (16 outputs k, sub-line n1) are dealt round-robin to the four wavefronts; a lane ends
+// up with one component of X[k] and X[N2-k] and takes the partner component of the sine product from lane ^ 1.
+// f32: v_mfma_f32_16x16x4_f32 issues every 20 ns per SIMD (tools/ubench/mfma_f64_rate.hip) -- the vector form of stage A
+// (dft_pair_core) was 3x over the memory time of a pass at 305^3.
+template <class T, int SIGN>
+__device__ __forceinline__ void pfa_stage_a_mfma(const PfaAxis& a, const Cx<T>* in, Cx<T>* out, const Cx<T>* tw2) {
+  typedef typename Mfma<T>::Acc Acc;
+  const int N2 = a.N2, H = (N2 - 1) / 2, MT = (H + 15) / 16, KP = (H + 3) & ~3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 15, hi = lane >> 4;
+  const T* inr = reinterpret_cast<const T*>(in);
+  T* outr = reinterpret_cast<T*>(out);
+  for (int item = wave; item < MT * a.N1; item += kPfaBlock / 64) {
+    const int mt = item % MT, n1 = item / MT;
+    const int i = 16 * mt + lo;
+    TwIdx ti(i < H ? i : 0, hi, N2);
+    const T* col = inr + (size_t)n1 * N2 * 16 + lo;          // word lo of row n2 at col[n2 * 16]
+    Acc P = {0, 0, 0, 0}, R = {0, 0, 0, 0};
+    for (int kk = hi; kk < KP; kk += 4) {
+      const Cx<T> w = tw2[ti.m];
+      ti.step();
+      T u = T(0), v = T(0);
+      if (kk < H) { u = col[(1 + kk) * 16]; v = col[(N2 - 1 - kk) * 16]; }
+      P = Mfma<T>::mma(w.re, u + v, P);
+      R = Mfma<T>::mma(w.im, u - v, R);
+    }
+    const T x0 = col[0];
+    T* o = outr + (size_t)n1 * N2 * 16 + lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 1 + 16 * mt + Mfma<T>::row(lane, r);
+      const T other = __shfl_xor(R[r], 1, 64);               // sgn i R = sgn (-R.im, R.re)
+      if (k <= H) {
+        const T base = x0 + P[r];
+        const T q = (lo & 1) ? T(SIGN) * other : -T(SIGN) * other;
+        o[k * 16] = base + q;
+        o[(N2 - k) * 16] = base - q;
+      }
+    }
+  }
+  for (int t = threadIdx.x; t < a.N1 * 16; t += kPfaBlock) {   // k = 0: plain sums
+    const int n1 = t >> 4, w = t & 15;
+    const T* col = inr + (size_t)n1 * N2 * 16 + w;
+    T sum = T(0);
+    for (int n2 = 0; n2 < N2; ++n2) sum += col[n2 * 16];
+    outr[(size_t)n1 * N2 * 16 + w] = sum;
+  }
+}
+static bool pfa_use_mfma(const PfaAxis& a, int NC) {
+  static const bool off = [] { const char* e = getenv("ADMP_PFA_MFMA"); return e && atoi(e) == 0; }();
+  return !off && NC == 8 && (a.N2 & 1) && (a.N2 - 1) / 2 <= 128;
+}
+template <class T, int SIGN>
+__device__ __forceinline__ void pfa_stage_a_any(const PfaAxis& a, int NC, int mfma, const Cx<T>* in, Cx<T>* out, const Cx<T>* tw2) {
+  if (mfma) pfa_stage_a_mfma<T, SIGN>(a, in, out, tw2);
+  else pfa_stage_a<T, SIGN>(a, NC, in, out, tw2);
+}
+
 // ---- strided complex lines, in place (y lines)
 template <class T, int SIGN>
-__global__ __launch_bounds__(kPfaBlock) void k_pfa_strided(PfaAxis a, int ncols, int NC, long jstride, long fixstride,
+__global__ __launch_bounds__(kPfaBlock) void k_pfa_strided(PfaAxis a, int ncols, int nfix, int NC, int mfma, long jstride, long fixstride,
                                                           Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ tw2g,
                                                           const Cx<T>* __restrict__ tw1g, long spec_stride) {
-  spec += blockIdx.z * spec_stride;
+  spec += blockIdx.y * spec_stride;
   const PfaTile<T> s = pfa_tile<T>(a, NC);
-  const int col0 = blockIdx.x * NC, nca = min(NC, ncols - col0);
-  const long base = (long)blockIdx.y * fixstride + col0;
+  // tiles of one row of columns share their 128-B lines (8 f32 complex columns = 64 B): the XCD remap puts neighbours on
+  // the same XCD, i.e. behind the same L2
+  const int ntile = (ncols + NC - 1) / NC;
+  const long L = xcd_block(blockIdx.x, (unsigned)(ntile * nfix));
+  if (L < 0) return;
+  const int col0 = (int)(L % ntile) * NC, nca = min(NC, ncols - col0);
+  const long base = (L / ntile) * fixstride + col0;
   pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g);
   __syncthreads();
-  pfa_stage_a<T, SIGN>(a, NC, s.D, s.Y, s.tw2);
+  pfa_stage_a_any<T, SIGN>(a, NC, mfma, s.D, s.Y, s.tw2);
   __syncthreads();
   // stage B straight to memory: X(k1, k2) -> slot (N2 k1 + N1 k2) mod N
+  const int sh = 31 - __clz(NC);
   for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {
-    const int idx = t / NC, c = t - idx * NC;
-    const int k1 = idx / a.N2, k2 = idx - k1 * a.N2;
-    if (c < nca) spec[base + (long)pfa_pos(a, k1, k2) * jstride + c] = short_dft<T>(a.N1, k1, SIGN, s.Y + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
+    const int idx = t >> sh, c = t & (NC - 1);
+    const int pk = s.ptab[idx], k1 = pk >> 16, k2 = idx - k1 * a.N2;
+    if (c < nca) spec[base + (long)(pk & 0xffff) * jstride + c] = short_dft<T>(a.N1, k1, SIGN, s.Y + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
   }
 }
 
 // ---- x lines: forward, multiply by G (accumulating sum w G |S|^2), inverse; in place.  az = the z axis (column weights)
 template <class T>
-__global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az, int ncols, int NC, long jstride, long fixstride,
+__global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az, int ncols, int nfix, int NC, int mfma, long jstride, long fixstride,
                                                          Cx<T>* __restrict__ spec, DftTabs<T> tabs, const Cx<T>* __restrict__ tw2g,
                                                          const Cx<T>* __restrict__ tw1g, double* energies, int slot,
                                                          long spec_stride) {
-  spec += blockIdx.z * spec_stride;
-  const T* __restrict__ gtab = tabs.p[blockIdx.z];
+  spec += blockIdx.y * spec_stride;
+  const T* __restrict__ gtab = tabs.p[blockIdx.y];
   const PfaTile<T> s = pfa_tile<T>(a, NC);
-  const int col0 = blockIdx.x * NC, nca = min(NC, ncols - col0);
-  const long base = (long)blockIdx.y * fixstride + col0;
+  const int ntile = (ncols + NC - 1) / NC;
+  const long L = xcd_block(blockIdx.x, (unsigned)(ntile * nfix));   // (see k_pfa_strided)
+  if (L < 0) return;
+  const int col0 = (int)(L % ntile) * NC, nca = min(NC, ncols - col0);
+  const long base = (L / ntile) * fixstride + col0;
   pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g);
   __syncthreads();
-  pfa_stage_a<T, -1>(a, NC, s.D, s.Y, s.tw2);
+  pfa_stage_a_any<T, -1>(a, NC, mfma, s.D, s.Y, s.tw2);
   __syncthreads();
   double e = 0.0;
+  const int sh = 31 - __clz(NC);
   for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {          // stage B, times G: Y -> D
-    const int idx = t / NC, c = t - idx * NC;
-    const int k1 = idx / a.N2, k2 = idx - k1 * a.N2;
+    const int idx = t >> sh, c = t & (NC - 1);
+    const int pk = s.ptab[idx], k1 = pk >> 16, k2 = idx - k1 * a.N2;
     Cx<T> X{T(0), T(0)};
     if (c < nca) {
+      const T G = gtab[base + (long)(pk & 0xffff) * jstride + c];
       X = short_dft<T>(a.N1, k1, -1, s.Y + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
-      const T G = gtab[base + (long)pfa_pos(a, k1, k2) * jstride + c];
       const int k2z = (col0 + c) / az.N1;
       const double w = (k2z == 0 || ((az.N2 & 1) == 0 && k2z == az.N2 / 2)) ? 0.5 : 1.0;
       e += w * (double)G * ((double)X.re * X.re + (double)X.im * X.im);
@@ -200,17 +289,16 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az,
   }
   __syncthreads();
   for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {          // inverse stage B: D(k1, k2) -> Y(n1, k2)
-    const int idx = t / NC, c = t - idx * NC;
-    const int n1 = idx / a.N2, k2 = idx - n1 * a.N2;
+    const int idx = t >> sh, c = t & (NC - 1);
+    const int n1 = s.ptab[idx] >> 16, k2 = idx - n1 * a.N2;
     s.Y[t] = short_dft<T>(a.N1, n1, +1, s.D + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
   }
   __syncthreads();
-  pfa_stage_a<T, +1>(a, NC, s.Y, s.D, s.tw2);                        // inverse stage A: Y(n1, k2) -> D(n1, n2)
+  pfa_stage_a_any<T, +1>(a, NC, mfma, s.Y, s.D, s.tw2);              // inverse stage A: Y(n1, k2) -> D(n1, n2)
   __syncthreads();
   for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {
-    const int idx = t / NC, c = t - idx * NC;
-    const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
-    if (c < nca) spec[base + (long)pfa_pos(a, n1, n2) * jstride + c] = s.D[t];
+    const int idx = t >> sh, c = t & (NC - 1);
+    if (c < nca) spec[base + (long)(s.ptab[idx] & 0xffff) * jstride + c] = s.D[t];
   }
   e = block_reduce_sum<kPfaBlock>(e);
   if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
@@ -219,7 +307,7 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az,
 // ---- z lines (contiguous, real): mesh [nlines][N] -> spec [nlines][Khp], column cz = k2 * N1 + k1, k2 <= N2/2.
 // LDS: tw2[N2] | tw1[N1] | Dr[N][NL] (reals) | Y[N1 * Kh2][NL]
 template <class T>
-__global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, int NL, const T* __restrict__ mesh,
+__global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, int NL, int mfma, const T* __restrict__ mesh,
                                                         Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ tw2g,
                                                         const Cx<T>* __restrict__ tw1g, long mesh_stride, long spec_stride) {
   mesh += blockIdx.y * mesh_stride;
@@ -233,15 +321,50 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, 
   for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) tw2[t] = tw2g[t];
   for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) tw1[t] = tw1g[t];
 #pragma unroll 4
-  for (int t = threadIdx.x; t < a.N * NL; t += kPfaBlock) {
-    const int l = t / a.N, idx = t - l * a.N;
+  for (int t = threadIdx.x; t < a.N * NL; t += kPfaBlock) {          // line index fastest: conflict-free LDS writes; the
+    const int idx = t / NL, l = t - idx * NL;                        // NL lines of the block stay in L1 while it sweeps them
     const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
-    Dr[idx * NL + l] = l < nl ? mesh[(long)(line0 + l) * a.N + pfa_pos(a, n1, n2)] : T(0);
+    Dr[t] = l < nl ? mesh[(long)(line0 + l) * a.N + pfa_pos(a, n1, n2)] : T(0);
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < a.N1 * Kh2 * NL; t += kPfaBlock) {   // stage A: real N2-point lines
-    const int l = t % NL, k2 = (t / NL) % Kh2, n1 = t / (NL * Kh2);
-    Y[(n1 * Kh2 + k2) * NL + l] = rdft_rows<T>(a.N2, k2, NL, Dr + (size_t)n1 * a.N2 * NL + l, tw2);
+  if (mfma) {
+    // stage A on the matrix cores (NL = 16: the 16 data columns of a tile are the 16 lines of ONE sub-line n1)
+    typedef typename Mfma<T>::Acc Acc;
+    const int N2 = a.N2, H = (N2 - 1) / 2, MT = (H + 15) / 16, KP = (H + 3) & ~3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 15, hi = lane >> 4;
+    for (int item = wave; item < MT * a.N1; item += kPfaBlock / 64) {
+      const int mt = item % MT, n1 = item / MT;
+      const int i = 16 * mt + lo;
+      TwIdx ti(i < H ? i : 0, hi, N2);
+      const T* col = Dr + (size_t)n1 * N2 * 16 + lo;
+      Acc P = {0, 0, 0, 0}, R = {0, 0, 0, 0};
+      for (int kk = hi; kk < KP; kk += 4) {
+        const Cx<T> w = tw2[ti.m];
+        ti.step();
+        T u = T(0), v = T(0);
+        if (kk < H) { u = col[(1 + kk) * 16]; v = col[(N2 - 1 - kk) * 16]; }
+        P = Mfma<T>::mma(w.re, u + v, P);
+        R = Mfma<T>::mma(w.im, u - v, R);
+      }
+      const T x0 = col[0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 1 + 16 * mt + Mfma<T>::row(lane, r);
+        if (k <= H) Y[(n1 * Kh2 + k) * 16 + lo] = Cx<T>{x0 + P[r], -R[r]};
+      }
+    }
+    for (int t = threadIdx.x; t < a.N1 * 16; t += kPfaBlock) {        // k2 = 0: plain sums
+      const int n1 = t >> 4, l = t & 15;
+      const T* col = Dr + (size_t)n1 * N2 * 16 + l;
+      T sum = T(0);
+      for (int n2 = 0; n2 < N2; ++n2) sum += col[n2 * 16];
+      Y[(n1 * Kh2) * 16 + l] = Cx<T>{sum, T(0)};
+    }
+  } else {
+    for (int t = threadIdx.x; t < a.N1 * Kh2 * NL; t += kPfaBlock) {   // stage A: real N2-point lines
+      const int l = t % NL, k2 = (t / NL) % Kh2, n1 = t / (NL * Kh2);
+      Y[(n1 * Kh2 + k2) * NL + l] = rdft_rows<T>(a.N2, k2, NL, Dr + (size_t)n1 * a.N2 * NL + l, tw2);
+    }
   }
   __syncthreads();
   for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {          // stage B over n1, straight to memory
@@ -253,7 +376,7 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, 
 
 // ---- z lines back: spec [nlines][Khp] -> mesh [nlines][N]
 template <class T>
-__global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, int NL, const Cx<T>* __restrict__ spec,
+__global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, int NL, int mfma, const Cx<T>* __restrict__ spec,
                                                         T* __restrict__ mesh, const Cx<T>* __restrict__ tw2g,
                                                         const Cx<T>* __restrict__ tw1g, long mesh_stride, long spec_stride) {
   mesh += blockIdx.y * mesh_stride;
@@ -277,6 +400,51 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, 
     Y[(n1 * Kh2 + k2) * NL + l] = short_dft<T>(a.N1, n1, +1, X + (size_t)k2 * a.N1 * NL + l, NL, tw1);
   }
   __syncthreads();
+  if (mfma) {
+    // inverse stage A on the matrix cores (NL = 16): x_j, x_{N2-j} = Y0.re + 2 (P -+ R), P = sum Re Y_k cos, R = sum Im Y_k sin;
+    // the reals go to LDS first (X is free now) so that the lines leave in order
+    typedef typename Mfma<T>::Acc Acc;
+    T* Dr = reinterpret_cast<T*>(X);                         // [N][16]
+    const int N2 = a.N2, H = (N2 - 1) / 2, MT = (H + 15) / 16, KP = (H + 3) & ~3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lo = lane & 15, hi = lane >> 4;
+    for (int item = wave; item < MT * a.N1; item += kPfaBlock / 64) {
+      const int mt = item % MT, n1 = item / MT;
+      const int i = 16 * mt + lo;
+      TwIdx ti(i < H ? i : 0, hi, N2);
+      const Cx<T>* col = Y + (size_t)n1 * Kh2 * 16 + lo;
+      Acc P = {0, 0, 0, 0}, R = {0, 0, 0, 0};
+      for (int kk = hi; kk < KP; kk += 4) {
+        const Cx<T> w = tw2[ti.m];
+        ti.step();
+        const Cx<T> v = kk < H ? col[(1 + kk) * 16] : Cx<T>{T(0), T(0)};
+        P = Mfma<T>::mma(w.re, v.re, P);
+        R = Mfma<T>::mma(w.im, v.im, R);
+      }
+      const T y0 = col[0].re;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 1 + 16 * mt + Mfma<T>::row(lane, r);
+        if (j <= H) {
+          Dr[(n1 * N2 + j) * 16 + lo] = y0 + T(2) * (P[r] - R[r]);
+          Dr[(n1 * N2 + N2 - j) * 16 + lo] = y0 + T(2) * (P[r] + R[r]);
+        }
+      }
+    }
+    for (int t = threadIdx.x; t < a.N1 * 16; t += kPfaBlock) {        // j = 0
+      const int n1 = t >> 4, l = t & 15;
+      const Cx<T>* col = Y + (size_t)n1 * Kh2 * 16 + l;
+      T sum = T(0);
+      for (int k = 1; k <= H; ++k) sum += col[k * 16].re;
+      Dr[(n1 * N2) * 16 + l] = col[0].re + T(2) * sum;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.N * NL; t += kPfaBlock) {
+      const int idx = t / NL, l = t - idx * NL;
+      const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
+      if (l < nl) mesh[(long)(line0 + l) * a.N + pfa_pos(a, n1, n2)] = Dr[t];
+    }
+    return;
+  }
   for (int t = threadIdx.x; t < a.N1 * Kh2 * NL; t += kPfaBlock) {   // inverse stage A: Hermitian N2-point lines -> reals
     const int l = t % NL, j = (t / NL) % Kh2, n1 = t / (NL * Kh2);
     if (l >= nl) continue;
@@ -329,39 +497,42 @@ void launch_pfa_z(hipStream_t st, const PfaPlan& p, const T* tw, T* mesh, T* spe
   const Cx<T>* tw1 = tw2 + a.N2;
   // lines per block: LDS = tw + Khp * NL complex + max(N reals, Khp complex) * NL
   const size_t per_line = sizeof(Cx<T>) * (size_t)Khp + (inverse ? sizeof(Cx<T>) * (size_t)Khp : sizeof(T) * (size_t)a.N);
-  int NL = 8;
-  while (NL > 1 && sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL > 60 * 1024) NL >>= 1;
+  int NL = 16;        // 16 lines = the 16 data columns of an MFMA tile (one sub-line n1)
+  while (NL > 1 && sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL > pfa_lds_budget()) NL >>= 1;
+  const int mf = (NL == 16 && pfa_use_mfma(a, 8)) ? 1 : 0;
   const size_t sh = sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL;
   const dim3 grid((nlines + NL - 1) / NL, nb);
   if (inverse)
-    k_pfa_z_c2r<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, reinterpret_cast<const Cx<T>*>(spec), mesh, tw2, tw1, mesh_stride, spec_stride / 2);
+    k_pfa_z_c2r<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mf, reinterpret_cast<const Cx<T>*>(spec), mesh, tw2, tw1, mesh_stride, spec_stride / 2);
   else
-    k_pfa_z_r2c<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mesh, reinterpret_cast<Cx<T>*>(spec), tw2, tw1, mesh_stride, spec_stride / 2);
+    k_pfa_z_r2c<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mf, mesh, reinterpret_cast<Cx<T>*>(spec), tw2, tw1, mesh_stride, spec_stride / 2);
 }
 template <class T>
 void launch_pfa_y(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, int inverse, int nb, long spec_stride) {
   const PfaAxis& a = p.ax[1];
-  const int Khp = p.Khp, NC = pfa_cols(a, sizeof(T));
+  const int Khp = p.Khp, NC = pfa_cols(a, sizeof(T)), mf = pfa_use_mfma(a, NC) ? 1 : 0;
   const Cx<T>* tw2 = reinterpret_cast<const Cx<T>*>(tw) + p.tw_off[1];
   const Cx<T>* tw1 = tw2 + a.N2;
-  const dim3 grid((Khp + NC - 1) / NC, p.ax[0].N, nb);
+  const int nfix = p.ax[0].N;
+  const dim3 grid(xcd_grid((unsigned)(((Khp + NC - 1) / NC) * nfix)), nb);
   const size_t sh = pfa_tile_bytes(a, NC, sizeof(T));
   Cx<T>* sp = reinterpret_cast<Cx<T>*>(spec);
   if (inverse)
-    k_pfa_strided<T, +1><<<grid, kPfaBlock, sh, st>>>(a, Khp, NC, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, spec_stride / 2);
+    k_pfa_strided<T, +1><<<grid, kPfaBlock, sh, st>>>(a, Khp, nfix, NC, mf, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, spec_stride / 2);
   else
-    k_pfa_strided<T, -1><<<grid, kPfaBlock, sh, st>>>(a, Khp, NC, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, spec_stride / 2);
+    k_pfa_strided<T, -1><<<grid, kPfaBlock, sh, st>>>(a, Khp, nfix, NC, mf, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, spec_stride / 2);
 }
 template <class T>
 void launch_pfa_x_conv(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
                        int slot, int nb, long spec_stride) {
   const PfaAxis& a = p.ax[0];
-  const int Khp = p.Khp, NC = pfa_cols(a, sizeof(T));
+  const int Khp = p.Khp, NC = pfa_cols(a, sizeof(T)), mf = pfa_use_mfma(a, NC) ? 1 : 0;
   const Cx<T>* tw2 = reinterpret_cast<const Cx<T>*>(tw) + p.tw_off[0];
   const Cx<T>* tw1 = tw2 + a.N2;
-  const dim3 grid((Khp + NC - 1) / NC, p.ax[1].N, nb);
+  const int nfix = p.ax[1].N;
+  const dim3 grid(xcd_grid((unsigned)(((Khp + NC - 1) / NC) * nfix)), nb);
   const size_t sh = pfa_tile_bytes(a, NC, sizeof(T));
-  k_pfa_x_conv<T><<<grid, kPfaBlock, sh, st>>>(a, p.ax[2], Khp, NC, (long)p.ax[1].N * Khp, (long)Khp, reinterpret_cast<Cx<T>*>(spec),
+  k_pfa_x_conv<T><<<grid, kPfaBlock, sh, st>>>(a, p.ax[2], Khp, nfix, NC, mf, (long)p.ax[1].N * Khp, (long)Khp, reinterpret_cast<Cx<T>*>(spec),
                                               tabs, tw2, tw1, energies, slot, spec_stride / 2);
 }
 #define INST(T)                                                                                          \

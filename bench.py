@@ -52,6 +52,8 @@ WORKLOADS = {
     'S1': (1024, 'double', None, 'water_pol_1024 (BASELINE configs[1]): 1024 polarizable MPID waters = 3072 atoms, '
                                  'seeded liquid box L=31.289 A, rc 4 A, f64'),
     'S2': (32768, 'single', 128, '98 304-atom polarizable water box (configs[2] size), K=128, rc 4 A, f32'),
+    'S2ref': (32768, 'single', None, '98 304-atom polarizable water box with the mesh of the reference rule '
+                                     '(admp/pme.py:146-172: K = 305 = 5 * 61, a Bluestein size), rc 4 A, f32'),
     'S3': (349525, 'single', 256, '1 048 575-atom polarizable water box (configs[3] size), K=256, rc 4 A, f32'),
 }
 
