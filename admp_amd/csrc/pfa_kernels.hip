@@ -29,11 +29,20 @@ extern __shared__ __align__(32) unsigned char pfa_smem[];
 
 __host__ __device__ inline int pfa_pos(const PfaAxis& a, int n1, int n2) { return (a.N2 * n1 + a.N1 * n2) % a.N; }
 
+// t / d for 0 <= t < 2^22 with inv = 1.0f / d: an integer division costs ~40 instructions, and the flat sweeps do two per element
+__device__ __forceinline__ int fast_div(int t, int d, float inv) {
+  int q = (int)((float)t * inv);
+  if (q * d > t) --q;
+  else if ((q + 1) * d <= t) ++q;
+  return q;
+}
+
 // sum_n1 y[n1 * stride] w1^(sign n1 k1), k1 fixed: the short stage (N1 <= 32)
 template <class T>
 __device__ __forceinline__ Cx<T> short_dft(int N1, int k1, int sign, const Cx<T>* y, int stride, const Cx<T>* tw1) {
   Cx<T> acc{T(0), T(0)};
   int m = 0;
+#pragma unroll 4
   for (int n1 = 0; n1 < N1; ++n1) {
     const Cx<T> v = y[n1 * stride];
     const T c = tw1[m].re, s = sign < 0 ? -tw1[m].im : tw1[m].im;
@@ -123,15 +132,14 @@ __device__ __forceinline__ void pfa_load(const PfaAxis& a, const PfaTile<T>& s, 
                                          long base, long jstride, const Cx<T>* __restrict__ tw2g, const Cx<T>* __restrict__ tw1g) {
   for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) s.tw2[t] = tw2g[t];
   for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) s.tw1[t] = tw1g[t];
-  // positions straight from the arithmetic here (the table is being filled by the same threads); NC is a power of two
-  const int sh = 31 - __clz(NC);
+  pfa_fill_ptab(a, s.ptab);
+  __syncthreads();
+  const int sh = 31 - __clz(NC);                         // NC is a power of two
 #pragma unroll 4
   for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {
     const int idx = t >> sh, c = t & (NC - 1);
-    const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
-    s.D[t] = c < nca ? spec[base + (long)pfa_pos(a, n1, n2) * jstride + c] : Cx<T>{T(0), T(0)};
+    s.D[t] = c < nca ? spec[base + (long)(s.ptab[idx] & 0xffff) * jstride + c] : Cx<T>{T(0), T(0)};
   }
-  pfa_fill_ptab(a, s.ptab);
 }
 // stage A: N2-point lines over n2 for every (n1, column): in[(n1 N2 + n2) NC + c] -> out[(n1 N2 + k2) NC + c]
 template <class T, int SIGN>
@@ -186,13 +194,28 @@ __device__ __forceinline__ void pfa_stage_a_mfma(const PfaAxis& a, const Cx<T>* 
     TwIdx ti(i < H ? i : 0, hi, N2);
     const T* col = inr + (size_t)n1 * N2 * 16 + lo;          // word lo of row n2 at col[n2 * 16]
     Acc P = {0, 0, 0, 0}, R = {0, 0, 0, 0};
-    for (int kk = hi; kk < KP; kk += 4) {
-      const Cx<T> w = tw2[ti.m];
+    // two operand sets in flight: the LDS reads of a step are issued before the products of the step before it
+    struct Ops { Cx<T> w; T u, v; };
+    auto fetch = [&](Ops& o, int kk) {
+      o.w = tw2[ti.m];
       ti.step();
-      T u = T(0), v = T(0);
-      if (kk < H) { u = col[(1 + kk) * 16]; v = col[(N2 - 1 - kk) * 16]; }
-      P = Mfma<T>::mma(w.re, u + v, P);
-      R = Mfma<T>::mma(w.im, u - v, R);
+      o.u = kk < H ? col[(1 + kk) * 16] : T(0);
+      o.v = kk < H ? col[(N2 - 1 - kk) * 16] : T(0);
+    };
+    auto mul = [&](const Ops& o) {
+      P = Mfma<T>::mma(o.w.re, o.u + o.v, P);
+      R = Mfma<T>::mma(o.w.im, o.u - o.v, R);
+    };
+    {
+      Ops A, B;
+      fetch(A, hi);
+      for (int kk = hi; kk < KP; kk += 8) {
+        const bool two = kk + 4 < KP;
+        if (two) fetch(B, kk + 4);
+        mul(A);
+        if (kk + 8 < KP) fetch(A, kk + 8);
+        if (two) mul(B);
+      }
     }
     const T x0 = col[0];
     T* o = outr + (size_t)n1 * N2 * 16 + lo;
@@ -212,6 +235,7 @@ __device__ __forceinline__ void pfa_stage_a_mfma(const PfaAxis& a, const Cx<T>* 
     const int n1 = t >> 4, w = t & 15;
     const T* col = inr + (size_t)n1 * N2 * 16 + w;
     T sum = T(0);
+#pragma unroll 8
     for (int n2 = 0; n2 < N2; ++n2) sum += col[n2 * 16];
     outr[(size_t)n1 * N2 * 16 + w] = sum;
   }
@@ -317,14 +341,17 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, 
   Cx<T>* tw1 = tw2 + a.N2;
   Cx<T>* Y = tw1 + a.N1;                                   // [N1 * Kh2][NL]
   T* Dr = reinterpret_cast<T*>(Y + (size_t)Khp * NL);      // [N][NL]
+  int* ptab = reinterpret_cast<int*>(Dr + (size_t)a.N * NL);   // [N] (pfa_fill_ptab)
   const int line0 = blockIdx.x * NL, nl = min(NL, nlines - line0);
   for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) tw2[t] = tw2g[t];
   for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) tw1[t] = tw1g[t];
+  pfa_fill_ptab(a, ptab);
+  __syncthreads();
+  const int shl = 31 - __clz(NL);                          // NL is a power of two
 #pragma unroll 4
   for (int t = threadIdx.x; t < a.N * NL; t += kPfaBlock) {          // line index fastest: conflict-free LDS writes; the
-    const int idx = t / NL, l = t - idx * NL;                        // NL lines of the block stay in L1 while it sweeps them
-    const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
-    Dr[t] = l < nl ? mesh[(long)(line0 + l) * a.N + pfa_pos(a, n1, n2)] : T(0);
+    const int idx = t >> shl, l = t & (NL - 1);                      // NL lines of the block stay in L1 while it sweeps them
+    Dr[t] = l < nl ? mesh[(long)(line0 + l) * a.N + (ptab[idx] & 0xffff)] : T(0);
   }
   __syncthreads();
   if (mfma) {
@@ -357,6 +384,7 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, 
       const int n1 = t >> 4, l = t & 15;
       const T* col = Dr + (size_t)n1 * N2 * 16 + l;
       T sum = T(0);
+#pragma unroll 8
       for (int n2 = 0; n2 < N2; ++n2) sum += col[n2 * 16];
       Y[(n1 * Kh2) * 16 + l] = Cx<T>{sum, T(0)};
     }
@@ -367,9 +395,10 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, 
     }
   }
   __syncthreads();
+  const float invK = 1.0f / (float)Khp, inv1 = 1.0f / (float)a.N1;
   for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {          // stage B over n1, straight to memory
-    const int cz = t % Khp, l = t / Khp;
-    const int k2 = cz / a.N1, k1 = cz - k2 * a.N1;
+    const int l = fast_div(t, Khp, invK), cz = t - l * Khp;
+    const int k2 = fast_div(cz, a.N1, inv1), k1 = cz - k2 * a.N1;
     if (l < nl) spec[(long)(line0 + l) * Khp + cz] = short_dft<T>(a.N1, k1, -1, Y + (size_t)k2 * NL + l, Kh2 * NL, tw1);
   }
 }
@@ -384,20 +413,26 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, 
   const int Kh2 = a.N2 / 2 + 1, Khp = a.N1 * Kh2;
   Cx<T>* tw2 = reinterpret_cast<Cx<T>*>(pfa_smem);
   Cx<T>* tw1 = tw2 + a.N2;
-  Cx<T>* X = tw1 + a.N1;                                   // [Khp][NL], row cz = k2 * N1 + k1
-  Cx<T>* Y = X + (size_t)Khp * NL;                         // [N1 * Kh2][NL], row n1 * Kh2 + k2
+  const int KhpP = Khp | 1;                                // odd pitch: conflict-free both ways
+  Cx<T>* X = tw1 + a.N1;                                   // [NL][KhpP], column cz = k2 * N1 + k1
+  Cx<T>* Y = X + (size_t)KhpP * NL;                        // [N1 * Kh2][NL], row n1 * Kh2 + k2
+  int* ptab = reinterpret_cast<int*>(Y + (size_t)Khp * NL);    // [N] (pfa_fill_ptab)
   const int line0 = blockIdx.x * NL, nl = min(NL, nlines - line0);
   for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) tw2[t] = tw2g[t];
   for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) tw1[t] = tw1g[t];
+  pfa_fill_ptab(a, ptab);
+  const float invK = 1.0f / (float)Khp;
 #pragma unroll 4
   for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {
-    const int l = t / Khp, cz = t - l * Khp;
-    X[cz * NL + l] = l < nl ? spec[(long)(line0 + l) * Khp + cz] : Cx<T>{T(0), T(0)};
+    const int l = fast_div(t, Khp, invK), cz = t - l * Khp;
+    X[l * KhpP + cz] = l < nl ? spec[(long)(line0 + l) * Khp + cz] : Cx<T>{T(0), T(0)};
   }
   __syncthreads();
+  const int shl = 31 - __clz(NL);                          // NL is a power of two
+  const float invH = 1.0f / (float)Kh2;
   for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {          // inverse stage B: X(k1, k2) -> Y(n1, k2)
-    const int l = t % NL, k2 = (t / NL) % Kh2, n1 = t / (NL * Kh2);
-    Y[(n1 * Kh2 + k2) * NL + l] = short_dft<T>(a.N1, n1, +1, X + (size_t)k2 * a.N1 * NL + l, NL, tw1);
+    const int l = t & (NL - 1), r = t >> shl, n1 = fast_div(r, Kh2, invH), k2 = r - n1 * Kh2;
+    Y[(n1 * Kh2 + k2) * NL + l] = short_dft<T>(a.N1, n1, +1, X + (size_t)l * KhpP + k2 * a.N1, 1, tw1);
   }
   __syncthreads();
   if (mfma) {
@@ -434,14 +469,14 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, 
       const int n1 = t >> 4, l = t & 15;
       const Cx<T>* col = Y + (size_t)n1 * Kh2 * 16 + l;
       T sum = T(0);
+#pragma unroll 8
       for (int k = 1; k <= H; ++k) sum += col[k * 16].re;
       Dr[(n1 * N2) * 16 + l] = col[0].re + T(2) * sum;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < a.N * NL; t += kPfaBlock) {
-      const int idx = t / NL, l = t - idx * NL;
-      const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
-      if (l < nl) mesh[(long)(line0 + l) * a.N + pfa_pos(a, n1, n2)] = Dr[t];
+      const int idx = t >> 4, l = t & 15;
+      if (l < nl) mesh[(long)(line0 + l) * a.N + (ptab[idx] & 0xffff)] = Dr[t];
     }
     return;
   }
@@ -496,11 +531,11 @@ void launch_pfa_z(hipStream_t st, const PfaPlan& p, const T* tw, T* mesh, T* spe
   const Cx<T>* tw2 = reinterpret_cast<const Cx<T>*>(tw) + p.tw_off[2];
   const Cx<T>* tw1 = tw2 + a.N2;
   // lines per block: LDS = tw + Khp * NL complex + max(N reals, Khp complex) * NL
-  const size_t per_line = sizeof(Cx<T>) * (size_t)Khp + (inverse ? sizeof(Cx<T>) * (size_t)Khp : sizeof(T) * (size_t)a.N);
+  const size_t per_line = sizeof(Cx<T>) * (size_t)Khp + (inverse ? sizeof(Cx<T>) * (size_t)(Khp | 1) : sizeof(T) * (size_t)a.N);
   int NL = 16;        // 16 lines = the 16 data columns of an MFMA tile (one sub-line n1)
-  while (NL > 1 && sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL > pfa_lds_budget()) NL >>= 1;
+  while (NL > 1 && sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL + sizeof(int) * (size_t)a.N > pfa_lds_budget()) NL >>= 1;
   const int mf = (NL == 16 && pfa_use_mfma(a, 8)) ? 1 : 0;
-  const size_t sh = sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL;
+  const size_t sh = sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL + sizeof(int) * (size_t)a.N;
   const dim3 grid((nlines + NL - 1) / NL, nb);
   if (inverse)
     k_pfa_z_c2r<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mf, reinterpret_cast<const Cx<T>*>(spec), mesh, tw2, tw1, mesh_stride, spec_stride / 2);
