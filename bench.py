@@ -642,6 +642,23 @@ def main():
                 out['at_scale'] = sc
             except Exception as e:      # the headline line must still be printed
                 out['at_scale'] = {'error': repr(e)}
+            if not opt.no_extras:
+                try:      # configs[2] size with the mesh the reference's own rule gives (K = 305: a Bluestein size for rocFFT)
+                    f3 = a3 = fr3 = None
+                    torch.cuda.empty_cache()
+                    w2 = make_workload('S2ref')
+                    f2, a2 = make_force(w2)
+                    fr2 = ThermalFrames(w2, dev)
+                    dtm, _, cycm = run_timed(f2, a2, 10, 3, fr2, only=False)
+                    dts, _, _ = run_timed(f2, a2, 10, 3, None, only=False)
+                    out['reference_rule_mesh'] = dict(
+                        workload=w2['desc'], pme_grid=[f2.K1, f2.K2, f2.K3],
+                        convolution='two-level (Good-Thomas) direct DFT, admp_amd/csrc/pfa_kernels.hip; the rocFFT (Bluestein) '
+                                    'leg of the same step: ADMP_PFA=0, see profiles/README.md',
+                        ms_per_step=round(dtm / 10 * 1e3, 3), ns_per_day=round(0.0864 / (dtm / 10), 3),
+                        static_geometry_ms_per_step=round(dts / 10 * 1e3, 3), **cycm)
+                except Exception as e:
+                    out['reference_rule_mesh'] = {'error': repr(e)}
         print(json.dumps(out))
     if dist is not None:
         try:
