@@ -76,6 +76,15 @@ def toy():
                         K=np.array([K1, K2, K3]), parts=np.array(r['parts']), grad=r['grad'], U_ind=r['U_ind'],
                         n_cycle=r['n_cycle'])
     print('toy', r['E'], r['parts'], r['n_cycle'], r['U_ind'][0], r['U_ind'][3])
+    # The one reference-held number of the hot path that belongs to a shipped geometry: examples/water_pol_1024/dipole_2,
+    # the induced dipoles of this 2-water toy from the MPID OpenMM plugin (nm e; what the commented loop of run_admp.py:142-145
+    # compared U_ind with).  Stored as data next to the positions it belongs to.
+    import json
+    mpid = np.loadtxt(os.path.join(REF, 'examples', 'water_pol_1024', 'dipole_2'))
+    with open(os.path.join(HERE, 'ref_water2_mpid_dipoles.json'), 'w') as fh:
+        json.dump({'source': 'examples/water_pol_1024/dipole_2 + water2.pdb of the reference (data files)',
+                   'unit': 'nm e (x10 -> e A)', 'positions_A': pos.tolist(), 'box_A': box.tolist(),
+                   'induced_dipoles_nm_e': mpid.tolist()}, fh, indent=1)
 
 
 if __name__ == '__main__':

@@ -1239,3 +1239,30 @@ print('PFA-RUN-OK')
     for key, a in res['rocfft'].items():
         b = res['pfa'][key]
         assert np.abs(a - b).max() <= 1e-10 * np.abs(a).max(), (key, np.abs(a - b).max(), np.abs(a).max())
+
+
+@pytest.mark.gpu
+def test_toy_two_waters_vs_reference_held_mpid_dipoles(precision):
+    """The HIP path against the reference-held induced dipoles of the 2-water toy (`examples/water_pol_1024/dipole_2`, MPID
+    OpenMM plugin; see tests/test_oracle_physics.py for what this number is and is not): tight SCF, percent-level bar."""
+    import json
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    g = json.load(open(os.path.join(GOLD, 'ref_water2_mpid_dipoles.json')))
+    pos, box = np.array(g['positions_A']), np.array(g['box_A'])
+    ref = np.array(g['induced_dipoles_nm_e']) * 10.0
+    at, ai, cov = S.water_topology(2)
+    par = S.water_parameters(2, True)
+    old = settings.POL_CONV
+    settings.POL_CONV = 1e-8
+    try:
+        f = ADMPPmeForce(box, at, ai, cov.toarray(), 4.0, 1e-4, 2, lpol=True)
+        pairs = S.build_pairs(pos, box, 4.0)
+        f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+        U = np.asarray(f.U_ind)
+        assert f.lconverg
+        assert np.linalg.norm(U - ref) / np.linalg.norm(ref) < 0.035
+        big = np.unravel_index(np.abs(ref).argmax(), ref.shape)
+        assert abs(U[big] - ref[big]) < 5e-3 * abs(ref[big])
+    finally:
+        settings.POL_CONV = old
