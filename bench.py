@@ -186,10 +186,13 @@ def step(f, a, U, positions=None, pairs='fixed'):
                         a['pScales'], a['dScales'], U_init=U)
 
 
-def run_timed(f, a, steps, warmup, frames=None, barrier=None, only='pair_full', thresh=None):
+def run_timed(f, a, steps, warmup, frames=None, barrier=None, only='pair_full', thresh=None, predictor=False):
     """Timed region.  frames = ThermalFrames: step k evaluates frame k of the moving trajectory (None: the same geometry
     every step).  Only the roofline kernel is bracketed by HIP events (two event records per launch); the full
-    per-kernel breakdown comes from `kernel_breakdown` afterwards, outside the timed region."""
+    per-kernel breakdown comes from `kernel_breakdown` afterwards, outside the timed region.
+    predictor: start the SCF of step n from 2 U(n-1) - U(n-2) instead of U(n-1) (a labelled extra, not the headline: the
+    reference's drivers pass the previous step's dipoles, examples/water_pol_1024/run_admp.py:139); the two small tensor
+    operations are inside the timed region."""
     import torch
     from admp_amd import settings
     old = settings.POL_CONV
@@ -198,9 +201,15 @@ def run_timed(f, a, steps, warmup, frames=None, barrier=None, only='pair_full', 
     try:
         seq = [frames.step_frame(k) if frames is not None else None for k in range(warmup + steps)]   # resident in HBM
         U = None
+        U1 = U0 = None            # predictor: the converged dipoles of the two previous steps
+
+        def start():
+            return (2.0 * U1 - U0) if (predictor and U0 is not None) else U
         for k in range(warmup):
-            step(f, a, U, seq[k])
+            step(f, a, start(), seq[k])
             U = f.U_ind
+            if predictor:
+                U0, U1 = U1, U.clone()
         f.profile(only is not False, only=only if only else None)
         f.profile_reset()
         torch.cuda.synchronize()
@@ -209,9 +218,11 @@ def run_timed(f, a, steps, warmup, frames=None, barrier=None, only='pair_full', 
         t0 = time.perf_counter()
         updates = 0
         for k in range(warmup, warmup + steps):
-            step(f, a, U, seq[k])
+            step(f, a, start(), seq[k])
             U = f.U_ind
             updates += f.n_cycle
+            if predictor:
+                U0, U1 = U1, U.clone()
         torch.cuda.synchronize()
         if barrier:
             barrier()
@@ -584,6 +595,13 @@ def main():
                 dt2, _, cyc2 = run_timed(f, a, k2, opt.warmup, frames, only=False, thresh=1e-2)
                 out['scf_tight'] = dict(thresh=1e-2, ms_per_step=round(dt2 / k2 * 1e3, 5),
                                         ns_per_day=round(0.0864 / (dt2 / k2), 3), steps=k2, **cyc2)
+                dtp, _, cycp = run_timed(f, a, k2, opt.warmup, frames, only=False, predictor=True)
+                dtq, _, cycq = run_timed(f, a, k2, opt.warmup, frames, only=False, thresh=1e-2, predictor=True)
+                out['scf_predictor'] = dict(note='EXTRA, not the metric: SCF started from the linear extrapolation 2 U(n-1) - U(n-2) '
+                                            'of the two previous steps instead of U(n-1)',
+                                            ms_per_step=round(dtp / k2 * 1e3, 5), ns_per_day=round(0.0864 / (dtp / k2), 3),
+                                            steps=k2, **cycp,
+                                            thresh_1e_2=dict(ms_per_step=round(dtq / k2 * 1e3, 5), **cycq))
                 dt0, _, cyc0 = run_timed(f, a, k2, opt.warmup, None, only=False)
                 out['static_geometry'] = dict(note='UPPER BOUND, not the metric: identical positions every step, the first SCF '
                                               'check always passes (what round 1 reported as the headline)',
@@ -637,6 +655,11 @@ def main():
                     dt2, _, cyc2 = run_timed(f3, a3, 5, 2, fr3, only=False, thresh=1e-2)
                     sc['scf_tight'] = dict(thresh=1e-2, ms_per_step=round(dt2 / 5 * 1e3, 3),
                                            ns_per_day=round(0.0864 / (dt2 / 5), 3), **cyc2)
+                    dtp, _, cycp = run_timed(f3, a3, 5, 3, fr3, only=False, predictor=True)
+                    dtq, _, cycq = run_timed(f3, a3, 5, 3, fr3, only=False, thresh=1e-2, predictor=True)
+                    sc['scf_predictor'] = dict(note='extra: SCF started from 2 U(n-1) - U(n-2)',
+                                               ms_per_step=round(dtp / 5 * 1e3, 3), ns_per_day=round(0.0864 / (dtp / 5), 3), **cycp,
+                                               thresh_1e_2=dict(ms_per_step=round(dtq / 5 * 1e3, 3), **cycq))
                     sc['precision_check'] = f32_vs_f64_force_error(w3, f3, a3, fr3.frame(3))
                     out.setdefault('md_all_terms', {})[w3['name']] = md_all_terms(w3, f3, a3, fr3, 5, 2)
                 out['at_scale'] = sc
