@@ -455,6 +455,10 @@ struct Engine : EngineBase {
   T* gtab_cur = nullptr;
   BinScratch bins;
   rocfft_plan plan_f = nullptr, plan_b = nullptr, plan_xf = nullptr, plan_xb = nullptr;
+  // power-of-two x dimension on one rank: batched 2-D plans of the y-z planes around the fused x pass (fftx_kernels.hip)
+  rocfft_plan plan2_f = nullptr, plan2_b = nullptr;
+  bool use_fx = false;
+  DevBuf fx_tw;
   rocfft_execution_info info_f = nullptr;
   int planK[3] = {0, 0, 0}, planR = 0, planRank = 0;
   DevBuf home_list;
@@ -482,7 +486,7 @@ struct Engine : EngineBase {
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
                       &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp,
-                      &rq_d, &pfa_tw, &pfa_fmap, &gtab_nat})
+                      &rq_d, &pfa_tw, &pfa_fmap, &gtab_nat, &fx_tw})
       b->release();
     free_topology();
     if (ind.rowptr) (void)hipFree(ind.rowptr);
@@ -499,8 +503,11 @@ struct Engine : EngineBase {
     if (plan_b) rocfft_plan_destroy(plan_b);
     if (plan_xf) rocfft_plan_destroy(plan_xf);
     if (plan_xb) rocfft_plan_destroy(plan_xb);
+    if (plan2_f) rocfft_plan_destroy(plan2_f);
+    if (plan2_b) rocfft_plan_destroy(plan2_b);
     if (info_f) rocfft_execution_info_destroy(info_f);
-    plan_f = plan_b = plan_xf = plan_xb = nullptr;
+    plan_f = plan_b = plan_xf = plan_xb = plan2_f = plan2_b = nullptr;
+    use_fx = false;
     info_f = nullptr;
     planK[0] = planK[1] = planK[2] = 0;
   }
@@ -553,6 +560,23 @@ struct Engine : EngineBase {
       const size_t len[3] = {(size_t)K[2], (size_t)K[1], (size_t)K[0]};   // rocFFT: fastest dimension first
       FFT_TRY(rocfft_plan_create(&plan_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 3, len, 1, nullptr));
       FFT_TRY(rocfft_plan_create(&plan_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 3, len, 1, nullptr));
+      static const bool fx_off = [] { const char* e = getenv("ADMP_FUSED_X"); return e && atoi(e) == 0; }();
+      if (!fx_off && fftx_usable(K[0])) {
+        const size_t len2[2] = {(size_t)K[2], (size_t)K[1]};
+        FFT_TRY(rocfft_plan_create(&plan2_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 2, len2, (size_t)K[0], nullptr));
+        FFT_TRY(rocfft_plan_create(&plan2_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 2, len2, (size_t)K[0], nullptr));
+        FFT_TRY(rocfft_plan_get_work_buffer_size(plan2_f, &w)); if (w > wmax) wmax = w;
+        FFT_TRY(rocfft_plan_get_work_buffer_size(plan2_b, &w)); if (w > wmax) wmax = w;
+        std::vector<T> tw((size_t)K[0]);
+        for (int m = 0; m < K[0] / 2; ++m) {
+          const double th = 2.0 * M_PI * (double)m / (double)K[0];
+          tw[2 * m] = (T)std::cos(th);
+          tw[2 * m + 1] = (T)std::sin(th);
+        }
+        fx_tw.need(tw.size() * sizeof(T));
+        HIP_TRY(hipMemcpy(fx_tw.p, tw.data(), tw.size() * sizeof(T), hipMemcpyHostToDevice));
+        use_fx = true;
+      }
     } else {
       // distributed transform = batched 2-D r2c over the owned planes, all-to-all transpose (done by the caller over
       // RCCL), batched strided 1-D c2c along x
@@ -668,6 +692,12 @@ struct Engine : EngineBase {
       { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec_p, tabs, Ed, slot); }
       { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec_p, 1); }
       { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 1); }
+      return;
+    }
+    if (use_fx) {      // rocFFT for the y-z planes, one fused kernel for x forward * G * x inverse
+      run_plan("rocfft_r2c_yz", plan2_f, mesh_p, spec_p);
+      { TIMED("fftx_kspace"); launch_fftx_conv<T>(stream, K, fx_tw.as<T>(), spec_p, gtab, Ed, slot); }
+      run_plan("rocfft_c2r_yz", plan2_b, spec_p, mesh_p);
       return;
     }
     fft_forward(mesh_p, spec_p);

@@ -1,0 +1,158 @@
+// Fused x pass of the mesh convolution for power-of-two meshes: x lines forward, times G (+ the reciprocal energy), x lines
+// inverse -- ONE sweep over the half spectrum where rocFFT's 3-D plans + k_kspace make three (the x pass of the r2c plan,
+// the G multiply, the x pass of the c2r plan; 58 + 43 + 58 us at 256^3 f32).  rocFFT keeps the y-z planes (batched 2-D
+// r2c / c2r plans, engine.hip); replaces fftn / ifftn + the k-space product of admp/recip.py:395-426 exactly like they do
+// (unnormalised both ways).
+//
+// A workgroup holds NC neighbouring columns (y, kz) of all N x positions in LDS.  Forward: radix-2 decimation in frequency,
+// natural order in, bit-reversed order out; the G multiply works on that order (row p holds frequency bitrev(p));
+// inverse: radix-2 decimation in time, bit-reversed in, natural out -- in place, no reordering pass, one twiddle table.
+#include "dft_math.h"
+#include "launch.h"
+#include "reduce.h"
+
+namespace admp {
+
+constexpr int kFftxBlock = 256;
+extern __shared__ __align__(32) unsigned char fftx_smem[];
+
+template <class T>
+__global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int ncols, int nfix, int NC, long jstride, long fixstride,
+                                                          int K3, Cx<T>* __restrict__ spec, const T* __restrict__ gtab,
+                                                          const Cx<T>* __restrict__ twg, double* energies, int slot) {
+  Cx<T>* tw = reinterpret_cast<Cx<T>*>(fftx_smem);      // [N / 2]: (cos, sin)(2 pi k / N)
+  Cx<T>* D = tw + N / 2;                                 // [N][NC]
+  // tiles of one row of columns share their 128-B lines: neighbours on the same XCD (same L2)
+  const int ntile = (ncols + NC - 1) / NC;
+  const long L = xcd_block(blockIdx.x, (unsigned)(ntile * nfix));
+  if (L < 0) return;
+  const int col0 = (int)(L % ntile) * NC, nca = min(NC, ncols - col0);
+  const long base = (L / ntile) * fixstride + col0;
+  const int sh = 31 - __clz(NC);                         // NC is a power of two
+  for (int t = threadIdx.x; t < N / 2; t += kFftxBlock) tw[t] = twg[t];
+#pragma unroll 4
+  for (int t = threadIdx.x; t < N * NC; t += kFftxBlock) {
+    const int j = t >> sh, c = t & (NC - 1);
+    D[t] = c < nca ? spec[base + (long)j * jstride + c] : Cx<T>{T(0), T(0)};
+  }
+  __syncthreads();
+  const int nbf = (N / 2) * NC, nbq = (N / 4) * NC;
+  auto cmul = [](Cx<T> a, Cx<T> b) { return Cx<T>{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; };
+  auto cmulc = [](Cx<T> a, Cx<T> b) { return Cx<T>{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; };   // a conj(b)
+  // forward, decimation in frequency: spans N/2, N/4, .. 1; W = exp(-2 pi i / N).  Two stages (spans 2q, q) per LDS round
+  // trip: same arithmetic and data order as two radix-2 stages, half the LDS traffic and barriers.
+  int s = logN - 1;
+  for (; s >= 1; s -= 2) {
+    const int q = 1 << (s - 1);                     // spans 2q (stage s) and q (stage s - 1)
+    for (int t = threadIdx.x; t < nbq; t += kFftxBlock) {
+      const int b = t >> sh, c = t & (NC - 1);
+      const int k = b & (q - 1), i0 = ((b >> (s - 1)) << (s + 1)) | k;
+      const Cx<T> w1 = tw[k << (logN - 1 - s)], w2 = tw[k << (logN - s)];      // W_{4q}^k, W_{2q}^k
+      Cx<T>* p = D + ((size_t)i0 << sh) + c;
+      const int st = q << sh;
+      const Cx<T> x0 = p[0], x1 = p[st], x2 = p[2 * st], x3 = p[3 * st];
+      const Cx<T> t0{x0.re + x2.re, x0.im + x2.im}, t1{x1.re + x3.re, x1.im + x3.im};
+      const Cx<T> t2 = cmulc(Cx<T>{x0.re - x2.re, x0.im - x2.im}, w1);
+      const Cx<T> d13 = cmulc(Cx<T>{x1.re - x3.re, x1.im - x3.im}, w1);
+      const Cx<T> t3{d13.im, -d13.re};                                            // times -i (W_{4q}^q)
+      p[0] = Cx<T>{t0.re + t1.re, t0.im + t1.im};
+      p[st] = cmulc(Cx<T>{t0.re - t1.re, t0.im - t1.im}, w2);
+      p[2 * st] = Cx<T>{t2.re + t3.re, t2.im + t3.im};
+      p[3 * st] = cmulc(Cx<T>{t2.re - t3.re, t2.im - t3.im}, w2);
+    }
+    __syncthreads();
+  }
+  for (; s >= 0; --s) {                             // odd log2 N: one plain stage (span 1) is left
+    const int half = 1 << s;
+    for (int t = threadIdx.x; t < nbf; t += kFftxBlock) {
+      const int b = t >> sh, c = t & (NC - 1);
+      const int k = b & (half - 1), i = ((b >> s) << (s + 1)) | k;
+      const Cx<T> w = tw[k << (logN - 1 - s)];
+      const Cx<T> u = D[(i << sh) + c], v = D[((i + half) << sh) + c];
+      const T dr = u.re - v.re, di = u.im - v.im;
+      D[(i << sh) + c] = Cx<T>{u.re + v.re, u.im + v.im};
+      D[((i + half) << sh) + c] = Cx<T>{dr * w.re + di * w.im, di * w.re - dr * w.im};      // (u - v) conj(w)
+    }
+    __syncthreads();
+  }
+  // times G; row p holds frequency bitrev(p)
+  double e = 0.0;
+  for (int t = threadIdx.x; t < N * NC; t += kFftxBlock) {
+    const int p = t >> sh, c = t & (NC - 1);
+    if (c < nca) {
+      const int k = (int)(__brev((unsigned)p) >> (32 - logN));
+      const T G = gtab[base + (long)k * jstride + c];
+      const Cx<T> X = D[t];
+      const int kz = col0 + c;
+      const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
+      e += w * (double)G * ((double)X.re * X.re + (double)X.im * X.im);
+      D[t] = Cx<T>{G * X.re, G * X.im};
+    }
+  }
+  __syncthreads();
+  // inverse, decimation in time: spans 1, 2, .. N/2; W = exp(+2 pi i / N); again two stages (spans q, 2q) per round trip,
+  // after the single plain stage of an odd log2 N (the mirror image of the forward order)
+  s = 0;
+  for (; s < (logN & 1); ++s) {
+    const int half = 1 << s;
+    for (int t = threadIdx.x; t < nbf; t += kFftxBlock) {
+      const int b = t >> sh, c = t & (NC - 1);
+      const int k = b & (half - 1), i = ((b >> s) << (s + 1)) | k;
+      const Cx<T> w = tw[k << (logN - 1 - s)];
+      const Cx<T> u = D[(i << sh) + c], y = D[((i + half) << sh) + c];
+      const Cx<T> v{y.re * w.re - y.im * w.im, y.re * w.im + y.im * w.re};                    // y w
+      D[(i << sh) + c] = Cx<T>{u.re + v.re, u.im + v.im};
+      D[((i + half) << sh) + c] = Cx<T>{u.re - v.re, u.im - v.im};
+    }
+    __syncthreads();
+  }
+  for (; s + 1 < logN; s += 2) {
+    const int q = 1 << s;                           // spans q (stage s) and 2q (stage s + 1)
+    for (int t = threadIdx.x; t < nbq; t += kFftxBlock) {
+      const int b = t >> sh, c = t & (NC - 1);
+      const int k = b & (q - 1), i0 = ((b >> s) << (s + 2)) | k;
+      const Cx<T> w1 = tw[k << (logN - 2 - s)], w2 = tw[k << (logN - 1 - s)];  // W_{4q}^k, W_{2q}^k
+      Cx<T>* p = D + ((size_t)i0 << sh) + c;
+      const int st = q << sh;
+      const Cx<T> x0 = p[0], x2 = p[2 * st];
+      const Cx<T> y1 = cmul(p[st], w2), y3 = cmul(p[3 * st], w2);
+      const Cx<T> t0{x0.re + y1.re, x0.im + y1.im}, t1{x0.re - y1.re, x0.im - y1.im};
+      const Cx<T> t2{x2.re + y3.re, x2.im + y3.im}, t3{x2.re - y3.re, x2.im - y3.im};
+      const Cx<T> z2 = cmul(t2, w1), z3w = cmul(t3, w1);
+      const Cx<T> z3{-z3w.im, z3w.re};                                            // times +i (conj W_{4q}^q)
+      p[0] = Cx<T>{t0.re + z2.re, t0.im + z2.im};
+      p[2 * st] = Cx<T>{t0.re - z2.re, t0.im - z2.im};
+      p[st] = Cx<T>{t1.re + z3.re, t1.im + z3.im};
+      p[3 * st] = Cx<T>{t1.re - z3.re, t1.im - z3.im};
+    }
+    __syncthreads();
+  }
+#pragma unroll 4
+  for (int t = threadIdx.x; t < N * NC; t += kFftxBlock) {
+    const int j = t >> sh, c = t & (NC - 1);
+    if (c < nca) spec[base + (long)j * jstride + c] = D[t];
+  }
+  e = block_reduce_sum<kFftxBlock>(e);
+  if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
+}
+
+bool fftx_usable(int N) { return N >= 32 && N <= 1024 && (N & (N - 1)) == 0; }
+
+// spec = [K0][K1][K2/2+1] complex after the batched 2-D r2c of the y-z planes; tw = (cos, sin)(2 pi k / K0), k < K0 / 2
+template <class T>
+void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot) {
+  const int N = K[0], Kh = K[2] / 2 + 1;
+  int logN = 0;
+  while ((1 << logN) < N) ++logN;
+  int NC = (int)(128 / (2 * sizeof(T)));                 // one 128-B line of columns
+  while (NC > 1 && sizeof(Cx<T>) * ((size_t)N / 2 + (size_t)N * NC) > 60 * 1024) NC >>= 1;
+  const size_t sh = sizeof(Cx<T>) * ((size_t)N / 2 + (size_t)N * NC);
+  const int ntile = (Kh + NC - 1) / NC;
+  k_fftx_conv<T><<<xcd_grid((unsigned)(ntile * K[1])), kFftxBlock, sh, st>>>(N, logN, Kh, K[1], NC, (long)K[1] * Kh, (long)Kh, K[2],
+                                                                          reinterpret_cast<Cx<T>*>(spec), gtab,
+                                                                          reinterpret_cast<const Cx<T>*>(tw), energies, slot);
+}
+template void launch_fftx_conv<float>(hipStream_t, const int*, const float*, float*, const float*, double*, int);
+template void launch_fftx_conv<double>(hipStream_t, const int*, const double*, double*, const double*, double*, int);
+
+}  // namespace admp

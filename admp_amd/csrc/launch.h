@@ -184,6 +184,11 @@ template <class T>
 void launch_pfa_x_conv(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, const DftTabs<T>& tabs, double* energies, int slot,
                        int nb = 1, long spec_stride = 0);
 
+// ---- fftx_kernels.hip: x lines forward * G (+ energy) * x lines inverse in one sweep, power-of-two K[0]
+bool fftx_usable(int N);
+template <class T>
+void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot);
+
 // ---- pair_kernels.hip
 template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,

@@ -1266,3 +1266,49 @@ def test_toy_two_waters_vs_reference_held_mpid_dipoles(precision):
         assert abs(U[big] - ref[big]) < 5e-3 * abs(ref[big])
     finally:
         settings.POL_CONV = old
+
+
+@pytest.mark.gpu
+def test_fused_x_pass_vs_rocfft_3d(tmp_path):
+    """Power-of-two K1: the k-space leg is rocFFT on the y-z planes + ONE kernel doing x forward * G (+ energy) * x inverse
+    (fftx_kernels.hip) instead of 3-D rocFFT plans + k_kspace.  Same numbers to round-off: polarizable PME and dispersion PME,
+    both precisions, x lengths 32 / 64 / 128 with other (even, odd) dimensions."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_parity import water_system
+from admp_amd import settings
+out = {}
+pos, box, at, ai, cov, par, pairs = water_system(216, 5, True)
+for prec in ('double', 'single'):
+    settings.PRECISION = prec
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    for K in ((32, 30, 36), (64, 48, 45), (128, 64, 50)):
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+        d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+        for o in (f, d):
+            o.K1, o.K2, o.K3 = K
+            o.refresh_calculators()
+        E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+        Ed, Gd = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+        key = '%%s_%%d_%%d_%%d' %% ((prec,) + K)
+        out[key + '_parts'] = np.asarray(f.energy_parts); out[key + '_G'] = np.asarray(G); out[key + '_U'] = np.asarray(f.U_ind)
+        out[key + '_dparts'] = np.asarray(d.energy_parts); out[key + '_Gd'] = np.asarray(Gd)
+np.savez(sys.argv[1], **out)
+print('FX-RUN-OK')
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode, extra in {'rocfft3d': dict(ADMP_FUSED_X='0'), 'fused_x': {}}.items():
+        path = str(tmp_path / ('%s.npz' % mode))
+        r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True, env=dict(os.environ, **extra),
+                           timeout=900)
+        assert r.returncode == 0 and 'FX-RUN-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        res[mode] = dict(np.load(path))
+    assert len(res['rocfft3d']) == 2 * 3 * 5
+    for key, a in res['rocfft3d'].items():
+        b = res['fused_x'][key]
+        tol = 1e-10 if key.startswith('double') else 2e-4
+        assert np.abs(a - b).max() <= tol * np.abs(a).max(), (key, np.abs(a - b).max(), np.abs(a).max())
