@@ -16,6 +16,7 @@ namespace admp {
 constexpr int kFftxBlock = 256;
 extern __shared__ __align__(32) unsigned char fftx_smem[];
 
+constexpr int kFftxGMax = 16;      // G values a thread keeps in registers: N * NC / kFftxBlock <= 16 (else fetched late)
 template <class T>
 __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int ncols, int nfix, int NC, long jstride, long fixstride,
                                                           int K3, Cx<T>* __restrict__ spec, const T* __restrict__ gtab,
@@ -34,6 +35,15 @@ __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int n
   for (int t = threadIdx.x; t < N * NC; t += kFftxBlock) {
     const int j = t >> sh, c = t & (NC - 1);
     D[t] = c < nca ? spec[base + (long)j * jstride + c] : Cx<T>{T(0), T(0)};
+  }
+  // the G factors this thread applies after the forward transform: fetched now, their latency hides behind the transform
+  const bool gpre = N * NC <= kFftxGMax * kFftxBlock;
+  T Gr[kFftxGMax];
+#pragma unroll
+  for (int u = 0; u < kFftxGMax; ++u) {
+    const int t = threadIdx.x + u * kFftxBlock;
+    const int p = t >> sh, c = t & (NC - 1);
+    Gr[u] = (gpre && t < N * NC && c < nca) ? gtab[base + (long)(__brev((unsigned)p) >> (32 - logN)) * jstride + c] : T(0);
   }
   __syncthreads();
   const int nbf = (N / 2) * NC, nbq = (N / 4) * NC;
@@ -77,7 +87,21 @@ __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int n
   }
   // times G; row p holds frequency bitrev(p)
   double e = 0.0;
-  for (int t = threadIdx.x; t < N * NC; t += kFftxBlock) {
+#pragma unroll
+  for (int u = 0; u < kFftxGMax; ++u) {
+    const int t = threadIdx.x + u * kFftxBlock;
+    if (!gpre || t >= N * NC) break;
+    const int c = t & (NC - 1);
+    if (c < nca) {
+      const T G = Gr[u];
+      const Cx<T> X = D[t];
+      const int kz = col0 + c;
+      const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
+      e += w * (double)G * ((double)X.re * X.re + (double)X.im * X.im);
+      D[t] = Cx<T>{G * X.re, G * X.im};
+    }
+  }
+  for (int t = threadIdx.x; !gpre && t < N * NC; t += kFftxBlock) {
     const int p = t >> sh, c = t & (NC - 1);
     if (c < nca) {
       const int k = (int)(__brev((unsigned)p) >> (32 - logN));
