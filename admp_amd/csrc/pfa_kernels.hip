@@ -292,17 +292,28 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az,
   const int col0 = (int)(L % ntile) * NC, nca = min(NC, ncols - col0);
   const long base = (L / ntile) * fixstride + col0;
   pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g);
+  // the G factors this thread applies in stage B: fetched now (the index table is complete after pfa_load's barrier), so
+  // that their latency hides behind stage A
+  constexpr int kGMax = 16;
+  const int sh = 31 - __clz(NC);
+  const bool gpre = a.N * NC <= kGMax * kPfaBlock;
+  T Gr[kGMax];
+#pragma unroll
+  for (int u = 0; u < kGMax; ++u) {
+    const int t = threadIdx.x + u * kPfaBlock;
+    const int idx = t >> sh, c = t & (NC - 1);
+    Gr[u] = (gpre && t < a.N * NC && c < nca) ? gtab[base + (long)(s.ptab[idx] & 0xffff) * jstride + c] : T(0);
+  }
   __syncthreads();
   pfa_stage_a_any<T, -1>(a, NC, mfma, s.D, s.Y, s.tw2);
   __syncthreads();
   double e = 0.0;
-  const int sh = 31 - __clz(NC);
-  for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {          // stage B, times G: Y -> D
+  auto stage_b_g = [&](int t, T Gpre, bool have) {                    // stage B, times G: Y -> D
     const int idx = t >> sh, c = t & (NC - 1);
     const int pk = s.ptab[idx], k1 = pk >> 16, k2 = idx - k1 * a.N2;
     Cx<T> X{T(0), T(0)};
     if (c < nca) {
-      const T G = gtab[base + (long)(pk & 0xffff) * jstride + c];
+      const T G = have ? Gpre : gtab[base + (long)(pk & 0xffff) * jstride + c];
       X = short_dft<T>(a.N1, k1, -1, s.Y + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
       const int k2z = (col0 + c) / az.N1;
       const double w = (k2z == 0 || ((az.N2 & 1) == 0 && k2z == az.N2 / 2)) ? 0.5 : 1.0;
@@ -310,6 +321,15 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az,
       X.re *= G; X.im *= G;
     }
     s.D[t] = X;
+  };
+  if (gpre) {
+#pragma unroll
+    for (int u = 0; u < kGMax; ++u) {
+      const int t = threadIdx.x + u * kPfaBlock;
+      if (t < a.N * NC) stage_b_g(t, Gr[u], true);
+    }
+  } else {
+    for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) stage_b_g(t, T(0), false);
   }
   __syncthreads();
   for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {          // inverse stage B: D(k1, k2) -> Y(n1, k2)
