@@ -17,6 +17,8 @@
 // half is the N1 x (N2/2 + 1) set of (k1, k2 <= N2/2), column cz = k2 * N1 + k1 -- Khp = N1 (N2/2 + 1) columns instead of
 // N/2 + 1.  The Hermitian partner of (k1, k2) is (-k1, -k2): inside the set only for k2 = 0 (and k2 = N2/2, N2 even), whose
 // columns therefore weigh 1/2 in the energy sum -- the role kz = 0 / Nyquist play in the natural layout (recip.py:400-414).
+#include <type_traits>
+
 #include "dft_math.h"
 #include "launch.h"
 #include "mfma.h"
@@ -52,6 +54,43 @@ __device__ __forceinline__ Cx<T> short_dft(int N1, int k1, int sign, const Cx<T>
     if (m >= N1) m -= N1;
   }
   return acc;
+}
+
+// The short stage for a whole column at once, N1 known at compile time: the N1 inputs and the N1 twiddles are read once
+// (not once per output), the index arithmetic folds away.  out[k1] = sum_n1 y[n1 * stride] w1^(sign n1 k1).
+template <class T, int N1>
+__device__ __forceinline__ void short_dft_col(int sign, const Cx<T>* y, int stride, const Cx<T>* tw1, Cx<T> (&out)[N1]) {
+  Cx<T> v[N1], w[N1];
+#pragma unroll
+  for (int n = 0; n < N1; ++n) {
+    v[n] = y[n * stride];
+    w[n] = Cx<T>{tw1[n].re, sign < 0 ? -tw1[n].im : tw1[n].im};
+  }
+#pragma unroll
+  for (int k = 0; k < N1; ++k) {
+    Cx<T> acc = v[0];
+#pragma unroll
+    for (int n = 1; n < N1; ++n) {
+      const int m = (n * k) % N1;                    // compile time after unrolling
+      acc.re += v[n].re * w[m].re - v[n].im * w[m].im;
+      acc.im += v[n].re * w[m].im + v[n].im * w[m].re;
+    }
+    out[k] = acc;
+  }
+}
+// run `body(std::integral_constant<int, N1>)` for the compiled short lengths; false: not one of them (generic loops instead)
+template <class F>
+__device__ __forceinline__ bool pfa_n1_dispatch(int N1, F&& body) {
+  switch (N1) {
+    case 1: body(std::integral_constant<int, 1>()); return true;
+    case 2: body(std::integral_constant<int, 2>()); return true;
+    case 3: body(std::integral_constant<int, 3>()); return true;
+    case 4: body(std::integral_constant<int, 4>()); return true;
+    case 5: body(std::integral_constant<int, 5>()); return true;
+    case 6: body(std::integral_constant<int, 6>()); return true;
+    case 8: body(std::integral_constant<int, 8>()); return true;
+    default: return false;
+  }
 }
 
 // real line, rows layout (x[j * stride], j = 0..N-1): X[k] = x0 + P - i R (+ xn (-1)^k)
@@ -270,6 +309,18 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_strided(PfaAxis a, int ncols,
   __syncthreads();
   // stage B straight to memory: X(k1, k2) -> slot (N2 k1 + N1 k2) mod N
   const int sh = 31 - __clz(NC);
+  const bool done = pfa_n1_dispatch(a.N1, [&](auto n1c) {
+    constexpr int N1 = decltype(n1c)::value;
+    for (int t = threadIdx.x; t < a.N2 * NC; t += kPfaBlock) {       // one column (k2, c) per task
+      const int k2 = t >> sh, c = t & (NC - 1);
+      if (c >= nca) continue;
+      Cx<T> X[N1];
+      short_dft_col<T, N1>(SIGN, s.Y + (size_t)k2 * NC + c, a.N2 * NC, s.tw1, X);
+#pragma unroll
+      for (int k1 = 0; k1 < N1; ++k1) spec[base + (long)(s.ptab[k1 * a.N2 + k2] & 0xffff) * jstride + c] = X[k1];
+    }
+  });
+  if (done) return;
   for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {
     const int idx = t >> sh, c = t & (NC - 1);
     const int pk = s.ptab[idx], k1 = pk >> 16, k2 = idx - k1 * a.N2;
@@ -296,7 +347,8 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az,
   // that their latency hides behind stage A
   constexpr int kGMax = 16;
   const int sh = 31 - __clz(NC);
-  const bool gpre = a.N * NC <= kGMax * kPfaBlock;
+  const bool n1_compiled = a.N1 <= 6 || a.N1 == 8;      // pfa_n1_dispatch: those read G inside the fused short stage
+  const bool gpre = !n1_compiled && a.N * NC <= kGMax * kPfaBlock;
   T Gr[kGMax];
 #pragma unroll
   for (int u = 0; u < kGMax; ++u) {
@@ -322,20 +374,44 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az,
     }
     s.D[t] = X;
   };
-  if (gpre) {
+  // compiled short lengths: a column (k2, c) per task -- forward short stage, G, inverse short stage all in registers
+  // (Y -> Y; the LDS round trip through D and one barrier fall away)
+  const bool fused_b = pfa_n1_dispatch(a.N1, [&](auto n1c) {
+    constexpr int N1 = decltype(n1c)::value;
+    for (int t = threadIdx.x; t < a.N2 * NC; t += kPfaBlock) {
+      const int k2 = t >> sh, c = t & (NC - 1);
+      if (c >= nca) continue;
+      Cx<T> X[N1], Z[N1];
+      short_dft_col<T, N1>(-1, s.Y + (size_t)k2 * NC + c, a.N2 * NC, s.tw1, X);
+      const int k2z = (col0 + c) / az.N1;
+      const double w = (k2z == 0 || ((az.N2 & 1) == 0 && k2z == az.N2 / 2)) ? 0.5 : 1.0;
 #pragma unroll
-    for (int u = 0; u < kGMax; ++u) {
-      const int t = threadIdx.x + u * kPfaBlock;
-      if (t < a.N * NC) stage_b_g(t, Gr[u], true);
+      for (int k1 = 0; k1 < N1; ++k1) {
+        const T G = gtab[base + (long)(s.ptab[k1 * a.N2 + k2] & 0xffff) * jstride + c];
+        e += w * (double)G * ((double)X[k1].re * X[k1].re + (double)X[k1].im * X[k1].im);
+        X[k1].re *= G; X[k1].im *= G;
+      }
+      short_dft_col<T, N1>(+1, X, 1, s.tw1, Z);
+#pragma unroll
+      for (int n1 = 0; n1 < N1; ++n1) s.Y[((size_t)n1 * a.N2 + k2) * NC + c] = Z[n1];
     }
-  } else {
-    for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) stage_b_g(t, T(0), false);
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {          // inverse stage B: D(k1, k2) -> Y(n1, k2)
-    const int idx = t >> sh, c = t & (NC - 1);
-    const int n1 = s.ptab[idx] >> 16, k2 = idx - n1 * a.N2;
-    s.Y[t] = short_dft<T>(a.N1, n1, +1, s.D + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
+  });
+  if (!fused_b) {
+    if (gpre) {
+#pragma unroll
+      for (int u = 0; u < kGMax; ++u) {
+        const int t = threadIdx.x + u * kPfaBlock;
+        if (t < a.N * NC) stage_b_g(t, Gr[u], true);
+      }
+    } else {
+      for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) stage_b_g(t, T(0), false);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.N * NC; t += kPfaBlock) {          // inverse stage B: D(k1, k2) -> Y(n1, k2)
+      const int idx = t >> sh, c = t & (NC - 1);
+      const int n1 = s.ptab[idx] >> 16, k2 = idx - n1 * a.N2;
+      s.Y[t] = short_dft<T>(a.N1, n1, +1, s.D + (size_t)k2 * NC + c, a.N2 * NC, s.tw1);
+    }
   }
   __syncthreads();
   pfa_stage_a_any<T, +1>(a, NC, mfma, s.Y, s.D, s.tw2);              // inverse stage A: Y(n1, k2) -> D(n1, n2)
@@ -415,6 +491,20 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, 
     }
   }
   __syncthreads();
+  const bool done = pfa_n1_dispatch(a.N1, [&](auto n1c) {          // compiled short lengths: a column (k2, line) per task
+    constexpr int N1 = decltype(n1c)::value;
+    const int shl = 31 - __clz(NL);
+    for (int t = threadIdx.x; t < Kh2 * NL; t += kPfaBlock) {
+      const int k2 = t >> shl, l = t & (NL - 1);
+      if (l >= nl) continue;
+      Cx<T> X[N1];
+      short_dft_col<T, N1>(-1, Y + (size_t)k2 * NL + l, Kh2 * NL, tw1, X);
+      Cx<T>* o = spec + (long)(line0 + l) * Khp + k2 * N1;
+#pragma unroll
+      for (int k1 = 0; k1 < N1; ++k1) o[k1] = X[k1];
+    }
+  });
+  if (done) return;
   const float invK = 1.0f / (float)Khp, inv1 = 1.0f / (float)a.N1;
   for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {          // stage B over n1, straight to memory
     const int l = fast_div(t, Khp, invK), cz = t - l * Khp;
@@ -449,10 +539,22 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, 
   }
   __syncthreads();
   const int shl = 31 - __clz(NL);                          // NL is a power of two
-  const float invH = 1.0f / (float)Kh2;
-  for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {          // inverse stage B: X(k1, k2) -> Y(n1, k2)
-    const int l = t & (NL - 1), r = t >> shl, n1 = fast_div(r, Kh2, invH), k2 = r - n1 * Kh2;
-    Y[(n1 * Kh2 + k2) * NL + l] = short_dft<T>(a.N1, n1, +1, X + (size_t)l * KhpP + k2 * a.N1, 1, tw1);
+  const bool done_b = pfa_n1_dispatch(a.N1, [&](auto n1c) {
+    constexpr int N1 = decltype(n1c)::value;
+    for (int t = threadIdx.x; t < Kh2 * NL; t += kPfaBlock) {        // a column (k2, line) per task
+      const int k2 = t >> shl, l = t & (NL - 1);
+      Cx<T> Z[N1];
+      short_dft_col<T, N1>(+1, X + (size_t)l * KhpP + k2 * N1, 1, tw1, Z);
+#pragma unroll
+      for (int n1 = 0; n1 < N1; ++n1) Y[(n1 * Kh2 + k2) * NL + l] = Z[n1];
+    }
+  });
+  if (!done_b) {
+    const float invH = 1.0f / (float)Kh2;
+    for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {          // inverse stage B: X(k1, k2) -> Y(n1, k2)
+      const int l = t & (NL - 1), r = t >> shl, n1 = fast_div(r, Kh2, invH), k2 = r - n1 * Kh2;
+      Y[(n1 * Kh2 + k2) * NL + l] = short_dft<T>(a.N1, n1, +1, X + (size_t)l * KhpP + k2 * a.N1, 1, tw1);
+    }
   }
   __syncthreads();
   if (mfma) {
