@@ -180,7 +180,8 @@ struct EngineBase {
     if (!nbr_src) return;
     if (!is_live(nbr_src)) { nbr = NbrTable(); nbr_src = nullptr; have_pairs = false; throw Err{ADMP_E_ARG, "the handle the neighbour table was borrowed from has been destroyed"}; }
     if (!nbr_src->have_pairs || nbr_src->top.na != top.na) { nbr = NbrTable(); have_pairs = false; return; }
-    if (nbr_src_gen != nbr_src->nbr_gen || nbr.col != nbr_src->nbr.col || nbr.order != nbr_src->nbr.order) {
+    if (nbr_src_gen != nbr_src->nbr_gen || nbr.col != nbr_src->nbr.col || nbr.order != nbr_src->nbr.order ||
+        nbr.order_plain != nbr_src->nbr.order_plain) {
       if (nbr_src->stream != stream) HIP_TRY(hipStreamSynchronize(nbr_src->stream));   // built / ordered on the lender's stream
       nbr = nbr_src->nbr;
       nbr_src_gen = nbr_src->nbr_gen;
@@ -198,6 +199,7 @@ struct EngineBase {
       if (nbr.col) (void)hipFree(nbr.col);
       if (nbr.order) (void)hipFree(nbr.order);
       if (nbr.cls) (void)hipFree(nbr.cls);
+      if (nbr.order_plain) (void)hipFree(nbr.order_plain);
     }
     nbr = NbrTable();
     nbr_src = src; nbr_src_gen = -1;
@@ -292,6 +294,7 @@ struct EngineBase {
       if (nbr.col) (void)hipFree(nbr.col);
       if (nbr.order) (void)hipFree(nbr.order);
       if (nbr.cls) (void)hipFree(nbr.cls);
+      if (nbr.order_plain) (void)hipFree(nbr.order_plain);
     }
     nbr_src = nullptr; nbr_src_gen = -1;
     nbr = NbrTable();
@@ -303,9 +306,17 @@ struct EngineBase {
   // row order of the freshly built table (see launch_row_order); ADMP_PAIR_SORT=0 keeps the natural order
   void order_rows() {
     static const bool off = [] { const char* e = getenv("ADMP_PAIR_SORT"); return e && atoi(e) == 0; }();
-    if (off || snranks != 1) { if (nbr.order) { (void)hipFree(nbr.order); nbr.order = nullptr; } return; }
+    if (off || snranks != 1) {
+      if (nbr.order) { (void)hipFree(nbr.order); nbr.order = nullptr; }
+      if (nbr.order_plain) { (void)hipFree(nbr.order_plain); nbr.order_plain = nullptr; }
+      return;
+    }
     if (!nbr.order) HIP_TRY(hipMalloc(&nbr.order, sizeof(int) * (size_t)top.na));
     launch_row_order(stream, top.na, nbr.rowptr, nbr.order, nbr.cls);
+    if (nbr.cls) {
+      if (!nbr.order_plain) HIP_TRY(hipMalloc(&nbr.order_plain, sizeof(int) * (size_t)top.na));
+      launch_row_order(stream, top.na, nbr.rowptr, nbr.order_plain, nullptr);
+    }
   }
   // Site classes of the neighbour table (NbrTable::cls).  k_prepare_sites compares them with the sites of every evaluation
   // and leaves CLS_STALE / CLS_BETTER next to E_NACT; read_energies hands the word to cls_seen, and the next evaluation

@@ -628,7 +628,7 @@ void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, 
   const int lpr = pair_lanes_per_row(na);
 #define CALL(L)                                                                                                        \
   k_pair_scalar<T, L, false><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, clist, box, tab, kappa, \
-                                                                     pmax, grad, energies, nb.order)
+                                                                     pmax, grad, energies, nb.order_plain ? nb.order_plain : nb.order)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
@@ -638,7 +638,7 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
   const int lpr = pair_lanes_per_row(na);
 #define CALL(L)                                                                                                       \
   k_pair_scalar<T, L, true><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, abqc, box, tab, T(0), 0, \
-                                                                    grad, energies, nb.order)
+                                                                    grad, energies, nb.order_plain ? nb.order_plain : nb.order)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }

@@ -341,7 +341,9 @@ def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10):
     import torch
     from admp_amd.disp_pme import ADMPDispPmeForce
     from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
-    dt = torch.float32 if w['prec'] == 'single' else torch.float64
+    from admp_amd import settings
+    settings.PRECISION = w['prec']      # the calculators built here take it from the module global (make_force of another
+    dt = torch.float32 if w['prec'] == 'single' else torch.float64      # workload may have left it at the other precision)
     par = w['par']
     cl = torch.as_tensor(par['c_list'], dtype=dt, device='cuda')
     disp = ADMPDispPmeForce(w['box'], w['cov'], RC, 1e-4, 10)
