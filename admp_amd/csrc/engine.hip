@@ -485,7 +485,7 @@ struct Engine : EngineBase {
   bool use_dft = false;   // mesh convolution through dft_kernels.hip instead of rocFFT (single rank, a Bluestein dimension)
   bool use_pfa = false;   // ... through pfa_kernels.hip: a Bluestein dimension too long for plain lines, split N = N1 * N2;
   PfaPlan pfa;            //     spectrum and G tables then live in slot order with pfa.Khp z columns
-  DevBuf pfa_tw, pfa_fmap, gtab_nat;
+  DevBuf pfa_tw, pfa_fmap, pfa_ptab, gtab_nat;
   // validity of the cached G table
   struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0, ref = 0; bool pfa = false; } tabkey[4];
   static int tab_slot(int which) { return which == 1 ? 0 : (which == 6 ? 1 : (which == 8 ? 2 : 3)); }
@@ -497,7 +497,7 @@ struct Engine : EngineBase {
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
                       &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp,
-                      &rq_d, &pfa_tw, &pfa_fmap, &gtab_nat, &fx_tw})
+                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw})
       b->release();
     free_topology();
     if (ind.rowptr) (void)hipFree(ind.rowptr);
@@ -676,6 +676,13 @@ struct Engine : EngineBase {
     pfa_freq_of_zcolumn(pfa.ax[2], fm.data() + K[0] + K[1]);
     pfa_fmap.need(fm.size() * sizeof(int));
     HIP_TRY(hipMemcpy(pfa_fmap.p, fm.data(), fm.size() * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int> pt((size_t)K[0] + K[1] + K[2]);
+    pfa_index_table(pfa.ax[0], pt.data());
+    pfa_index_table(pfa.ax[1], pt.data() + K[0]);
+    pfa_index_table(pfa.ax[2], pt.data() + K[0] + K[1]);
+    pfa_ptab.need(pt.size() * sizeof(int));
+    HIP_TRY(hipMemcpy(pfa_ptab.p, pt.data(), pt.size() * sizeof(int), hipMemcpyHostToDevice));
+    pfa.ptab[0] = pfa_ptab.as<int>(); pfa.ptab[1] = pfa.ptab[0] + K[0]; pfa.ptab[2] = pfa.ptab[1] + K[1];
     spec.need((size_t)K[0] * K[1] * pfa.Khp * 2 * sizeof(T));
     use_pfa = true;
     return true;

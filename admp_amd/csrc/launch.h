@@ -174,8 +174,10 @@ struct PfaPlan {
   PfaAxis ax[3];
   int Khp;                                    // stored z columns: ax[2].N1 * (ax[2].N2 / 2 + 1)
   int tw_off[3];                              // twiddles of axis d at tw + tw_off[d] (complex entries): N2 entries, then N1
+  const int* ptab[3];                         // device: index table of axis d (pfa_index_table)
 };
 bool pfa_split(int N, PfaAxis* out);          // false: no usable split
+void pfa_index_table(const PfaAxis& a, int* t);       // t[n1 * N2 + n2] = position | n1 << 16
 void pfa_freq_of_slot(const PfaAxis& a, int* f);      // f[slot] = frequency stored at that position of the axis
 void pfa_freq_of_zcolumn(const PfaAxis& a, int* f);   // the same for the Khp stored z columns
 template <class T>

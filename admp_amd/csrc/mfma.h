@@ -25,9 +25,13 @@ struct Mfma<float> {
 // output index i (0-based: k - 1), position kk (0-based: jj) -> (1 + i)(1 + kk) mod N; advanced by 4 positions per step
 struct TwIdx {
   int m, inc, N;
+  // i < (N - 1) / 2 and kk0 < 4: both products stay below 2 N -- reduced by subtraction (a 64-bit modulo is ~300 VALU
+  // instructions, and this constructor runs once per work item of the matrix-core stages)
   __device__ __forceinline__ TwIdx(int i, int kk0, int N_) : N(N_) {
-    m = (int)(((long)(1 + i) * (1 + kk0)) % N_);
-    inc = (4 * (1 + i)) % N_;
+    m = (1 + i) * (1 + kk0);
+    while (m >= N_) m -= N_;
+    inc = 4 * (1 + i);
+    while (inc >= N_) inc -= N_;
   }
   __device__ __forceinline__ void step() { m += inc; if (m >= N) m -= N; }
 };

@@ -135,12 +135,10 @@ struct PfaTile {
   Cx<T>* tw2; Cx<T>* tw1; Cx<T>* D; Cx<T>* Y;
   int* ptab;        // [N]: row idx = n1 * N2 + n2 -> position (N2 n1 + N1 n2) mod N in the low 16 bits, n1 above
 };
-// the index table spares every element of every sweep two integer divisions and a modulo
-__device__ __forceinline__ void pfa_fill_ptab(const PfaAxis& a, int* ptab) {
-  for (int idx = threadIdx.x; idx < a.N; idx += kPfaBlock) {
-    const int n1 = idx / a.N2, n2 = idx - n1 * a.N2;
-    ptab[idx] = ((a.N2 * n1 + a.N1 * n2) % a.N) | (n1 << 16);
-  }
+// the index table spares every element of every sweep two integer divisions and a modulo; it is built once on the host
+// (pfa_index_table) -- computing it per workgroup cost ~300 VALU instructions per thread, a sixth of a kernel's issue time
+__device__ __forceinline__ void pfa_fill_ptab(const PfaAxis& a, int* ptab, const int* __restrict__ ptabg) {
+  for (int idx = threadIdx.x; idx < a.N; idx += kPfaBlock) ptab[idx] = ptabg[idx];
 }
 template <class T>
 __device__ __forceinline__ PfaTile<T> pfa_tile(const PfaAxis& a, int NC) {
@@ -168,10 +166,11 @@ static int pfa_cols(const PfaAxis& a, size_t w) {
 
 template <class T>
 __device__ __forceinline__ void pfa_load(const PfaAxis& a, const PfaTile<T>& s, int NC, int nca, const Cx<T>* __restrict__ spec,
-                                         long base, long jstride, const Cx<T>* __restrict__ tw2g, const Cx<T>* __restrict__ tw1g) {
+                                         long base, long jstride, const Cx<T>* __restrict__ tw2g, const Cx<T>* __restrict__ tw1g,
+                                         const int* __restrict__ ptabg) {
   for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) s.tw2[t] = tw2g[t];
   for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) s.tw1[t] = tw1g[t];
-  pfa_fill_ptab(a, s.ptab);
+  pfa_fill_ptab(a, s.ptab, ptabg);
   __syncthreads();
   const int sh = 31 - __clz(NC);                         // NC is a power of two
 #pragma unroll 4
@@ -293,7 +292,8 @@ __device__ __forceinline__ void pfa_stage_a_any(const PfaAxis& a, int NC, int mf
 template <class T, int SIGN>
 __global__ __launch_bounds__(kPfaBlock) void k_pfa_strided(PfaAxis a, int ncols, int nfix, int NC, int mfma, long jstride, long fixstride,
                                                           Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ tw2g,
-                                                          const Cx<T>* __restrict__ tw1g, long spec_stride) {
+                                                          const Cx<T>* __restrict__ tw1g, const int* __restrict__ ptabg,
+                                                          long spec_stride) {
   spec += blockIdx.y * spec_stride;
   const PfaTile<T> s = pfa_tile<T>(a, NC);
   // tiles of one row of columns share their 128-B lines (8 f32 complex columns = 64 B): the XCD remap puts neighbours on
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_strided(PfaAxis a, int ncols,
   if (L < 0) return;
   const int col0 = (int)(L % ntile) * NC, nca = min(NC, ncols - col0);
   const long base = (L / ntile) * fixstride + col0;
-  pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g);
+  pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g, ptabg);
   __syncthreads();
   pfa_stage_a_any<T, SIGN>(a, NC, mfma, s.D, s.Y, s.tw2);
   __syncthreads();
@@ -332,8 +332,8 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_strided(PfaAxis a, int ncols,
 template <class T>
 __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az, int ncols, int nfix, int NC, int mfma, long jstride, long fixstride,
                                                          Cx<T>* __restrict__ spec, DftTabs<T> tabs, const Cx<T>* __restrict__ tw2g,
-                                                         const Cx<T>* __restrict__ tw1g, double* energies, int slot,
-                                                         long spec_stride) {
+                                                         const Cx<T>* __restrict__ tw1g, const int* __restrict__ ptabg,
+                                                         double* energies, int slot, long spec_stride) {
   spec += blockIdx.y * spec_stride;
   const T* __restrict__ gtab = tabs.p[blockIdx.y];
   const PfaTile<T> s = pfa_tile<T>(a, NC);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az,
   if (L < 0) return;
   const int col0 = (int)(L % ntile) * NC, nca = min(NC, ncols - col0);
   const long base = (L / ntile) * fixstride + col0;
-  pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g);
+  pfa_load<T>(a, s, NC, nca, spec, base, jstride, tw2g, tw1g, ptabg);
   // the G factors this thread applies in stage B: fetched now (the index table is complete after pfa_load's barrier), so
   // that their latency hides behind stage A
   constexpr int kGMax = 16;
@@ -429,7 +429,8 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_x_conv(PfaAxis a, PfaAxis az,
 template <class T>
 __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, int NL, int mfma, const T* __restrict__ mesh,
                                                         Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ tw2g,
-                                                        const Cx<T>* __restrict__ tw1g, long mesh_stride, long spec_stride) {
+                                                        const Cx<T>* __restrict__ tw1g, const int* __restrict__ ptabg,
+                                                        long mesh_stride, long spec_stride) {
   mesh += blockIdx.y * mesh_stride;
   spec += blockIdx.y * spec_stride;
   const int Kh2 = a.N2 / 2 + 1, Khp = a.N1 * Kh2;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, 
   const int line0 = blockIdx.x * NL, nl = min(NL, nlines - line0);
   for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) tw2[t] = tw2g[t];
   for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) tw1[t] = tw1g[t];
-  pfa_fill_ptab(a, ptab);
+  pfa_fill_ptab(a, ptab, ptabg);
   __syncthreads();
   const int shl = 31 - __clz(NL);                          // NL is a power of two
 #pragma unroll 4
@@ -517,7 +518,8 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_r2c(PfaAxis a, int nlines, 
 template <class T>
 __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, int NL, int mfma, const Cx<T>* __restrict__ spec,
                                                         T* __restrict__ mesh, const Cx<T>* __restrict__ tw2g,
-                                                        const Cx<T>* __restrict__ tw1g, long mesh_stride, long spec_stride) {
+                                                        const Cx<T>* __restrict__ tw1g, const int* __restrict__ ptabg,
+                                                        long mesh_stride, long spec_stride) {
   mesh += blockIdx.y * mesh_stride;
   spec += blockIdx.y * spec_stride;
   const int Kh2 = a.N2 / 2 + 1, Khp = a.N1 * Kh2;
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(kPfaBlock) void k_pfa_z_c2r(PfaAxis a, int nlines, 
   const int line0 = blockIdx.x * NL, nl = min(NL, nlines - line0);
   for (int t = threadIdx.x; t < a.N2; t += kPfaBlock) tw2[t] = tw2g[t];
   for (int t = threadIdx.x; t < a.N1; t += kPfaBlock) tw1[t] = tw1g[t];
-  pfa_fill_ptab(a, ptab);
+  pfa_fill_ptab(a, ptab, ptabg);
   const float invK = 1.0f / (float)Khp;
 #pragma unroll 4
   for (int t = threadIdx.x; t < Khp * NL; t += kPfaBlock) {
@@ -627,6 +629,10 @@ bool pfa_split(int N, PfaAxis* out) {
   *out = a;
   return true;
 }
+void pfa_index_table(const PfaAxis& a, int* t) {      // t[n1 * N2 + n2] = position (low 16 bits) | n1 << 16
+  for (int n1 = 0; n1 < a.N1; ++n1)
+    for (int n2 = 0; n2 < a.N2; ++n2) t[n1 * a.N2 + n2] = pfa_pos(a, n1, n2) | (n1 << 16);
+}
 void pfa_freq_of_slot(const PfaAxis& a, int* f) {      // f[slot] = the frequency stored there
   for (int k1 = 0; k1 < a.N1; ++k1)
     for (int k2 = 0; k2 < a.N2; ++k2) {
@@ -660,9 +666,9 @@ void launch_pfa_z(hipStream_t st, const PfaPlan& p, const T* tw, T* mesh, T* spe
   const size_t sh = sizeof(Cx<T>) * (size_t)(a.N1 + a.N2) + per_line * NL + sizeof(int) * (size_t)a.N;
   const dim3 grid((nlines + NL - 1) / NL, nb);
   if (inverse)
-    k_pfa_z_c2r<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mf, reinterpret_cast<const Cx<T>*>(spec), mesh, tw2, tw1, mesh_stride, spec_stride / 2);
+    k_pfa_z_c2r<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mf, reinterpret_cast<const Cx<T>*>(spec), mesh, tw2, tw1, p.ptab[2], mesh_stride, spec_stride / 2);
   else
-    k_pfa_z_r2c<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mf, mesh, reinterpret_cast<Cx<T>*>(spec), tw2, tw1, mesh_stride, spec_stride / 2);
+    k_pfa_z_r2c<T><<<grid, kPfaBlock, sh, st>>>(a, nlines, NL, mf, mesh, reinterpret_cast<Cx<T>*>(spec), tw2, tw1, p.ptab[2], mesh_stride, spec_stride / 2);
 }
 template <class T>
 void launch_pfa_y(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, int inverse, int nb, long spec_stride) {
@@ -675,9 +681,9 @@ void launch_pfa_y(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, int in
   const size_t sh = pfa_tile_bytes(a, NC, sizeof(T));
   Cx<T>* sp = reinterpret_cast<Cx<T>*>(spec);
   if (inverse)
-    k_pfa_strided<T, +1><<<grid, kPfaBlock, sh, st>>>(a, Khp, nfix, NC, mf, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, spec_stride / 2);
+    k_pfa_strided<T, +1><<<grid, kPfaBlock, sh, st>>>(a, Khp, nfix, NC, mf, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, p.ptab[1], spec_stride / 2);
   else
-    k_pfa_strided<T, -1><<<grid, kPfaBlock, sh, st>>>(a, Khp, nfix, NC, mf, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, spec_stride / 2);
+    k_pfa_strided<T, -1><<<grid, kPfaBlock, sh, st>>>(a, Khp, nfix, NC, mf, (long)Khp, (long)a.N * Khp, sp, tw2, tw1, p.ptab[1], spec_stride / 2);
 }
 template <class T>
 void launch_pfa_x_conv(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
@@ -690,7 +696,7 @@ void launch_pfa_x_conv(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, c
   const dim3 grid(xcd_grid((unsigned)(((Khp + NC - 1) / NC) * nfix)), nb);
   const size_t sh = pfa_tile_bytes(a, NC, sizeof(T));
   k_pfa_x_conv<T><<<grid, kPfaBlock, sh, st>>>(a, p.ax[2], Khp, nfix, NC, mf, (long)p.ax[1].N * Khp, (long)Khp, reinterpret_cast<Cx<T>*>(spec),
-                                              tabs, tw2, tw1, energies, slot, spec_stride / 2);
+                                              tabs, tw2, tw1, p.ptab[0], energies, slot, spec_stride / 2);
 }
 #define INST(T)                                                                                          \
   template void launch_pfa_z<T>(hipStream_t, const PfaPlan&, const T*, T*, T*, int, int, long, long);    \
