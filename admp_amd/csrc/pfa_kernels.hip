@@ -31,14 +31,6 @@ extern __shared__ __align__(32) unsigned char pfa_smem[];
 
 __host__ __device__ inline int pfa_pos(const PfaAxis& a, int n1, int n2) { return (a.N2 * n1 + a.N1 * n2) % a.N; }
 
-// t / d for 0 <= t < 2^22 with inv = 1.0f / d: an integer division costs ~40 instructions, and the flat sweeps do two per element
-__device__ __forceinline__ int fast_div(int t, int d, float inv) {
-  int q = (int)((float)t * inv);
-  if (q * d > t) --q;
-  else if ((q + 1) * d <= t) ++q;
-  return q;
-}
-
 // sum_n1 y[n1 * stride] w1^(sign n1 k1), k1 fixed: the short stage (N1 <= 32)
 template <class T>
 __device__ __forceinline__ Cx<T> short_dft(int N1, int k1, int sign, const Cx<T>* y, int stride, const Cx<T>* tw1) {

@@ -256,10 +256,19 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   }
   __syncthreads();
   const int nyz = n[1] * n[2], ntot = n[0] * nyz;
-  for (int t = threadIdx.x; t < ntot; t += 256) {
-    const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
-    mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] =
-        (T)((double)(long long)tile[(ja * 16 + jb) * kBrickRow + jc] * inv_scale);
+  if (n[1] == 16 && n[2] == 16) {       // whole 16 x 16 rows (mesh sizes divisible by 16): shifts instead of two divisions per word
+    for (int t = threadIdx.x; t < ntot; t += 256) {
+      const int ja = t >> 8, jb = (t >> 4) & 15, jc = t & 15;
+      mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] =
+          (T)((double)(long long)tile[(ja * 16 + jb) * kBrickRow + jc] * inv_scale);
+    }
+  } else {
+    const float inv_yz = 1.0f / (float)nyz, inv_z = 1.0f / (float)n[2];
+    for (int t = threadIdx.x; t < ntot; t += 256) {
+      const int ja = fast_div(t, nyz, inv_yz), rem = t - ja * nyz, jb = fast_div(rem, n[2], inv_z), jc = rem - jb * n[2];
+      mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] =
+          (T)((double)(long long)tile[(ja * 16 + jb) * kBrickRow + jc] * inv_scale);
+    }
   }
   // this brick's binning counters are consumed: clear them for the next binning (no memset dispatches per step)
   if (threadIdx.x == 0 && clear_a) { clear_a[blockIdx.x] = 0; clear_b[blockIdx.x] = 0; }
@@ -347,8 +356,9 @@ template <class T>
 __device__ __forceinline__ void store_tile(const double* tile, const RecipGeom<T>& g, const int lo[3], const int n[3],
                                            T* __restrict__ mesh) {
   const int nyz = n[1] * n[2], ntot = n[0] * nyz;
+  const float inv_yz = 1.0f / (float)nyz, inv_z = 1.0f / (float)n[2];
   for (int t = threadIdx.x; t < ntot; t += 256) {
-    const int ja = t / nyz, rem = t - ja * nyz, jb = rem / n[2], jc = rem - jb * n[2];
+    const int ja = fast_div(t, nyz, inv_yz), rem = t - ja * nyz, jb = fast_div(rem, n[2], inv_z), jc = rem - jb * n[2];
     mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] = (T)tile[(ja * 16 + jb) * kTileRow + jc];
   }
 }
@@ -575,14 +585,19 @@ __global__ __launch_bounds__(256) void k_kspace(int K0, int ny, int K2, const T*
   const int nh = K2 / 2 + 1;
   const long n = (long)K0 * ny * nh;
   double e = 0.0;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
-    const int i2 = (int)(t % nh);
+  // the z index advances with the stride: ONE (64-bit) modulo per thread instead of one per element
+  const long t0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+  int i2 = (int)(t0 % nh);
+  const int di = (int)(stride % nh);
+  for (long t = t0; t < n; t += stride) {
     const T G = gtab[t];
     T re = spec[2 * t], im = spec[2 * t + 1];
     const double w = (i2 == 0 || ((K2 & 1) == 0 && i2 == K2 / 2)) ? 0.5 : 1.0;
     e += w * (double)G * ((double)re * re + (double)im * im);
     spec[2 * t] = re * G;
     spec[2 * t + 1] = im * G;
+    i2 += di;
+    if (i2 >= nh) i2 -= nh;
   }
   e = block_reduce_sum<256>(e);
   if (threadIdx.x == 0) atomicAdd(&energies[slot], e);

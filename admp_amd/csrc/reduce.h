@@ -58,4 +58,13 @@ __device__ __forceinline__ long xcd_block(unsigned b, unsigned n) {
 }
 static inline unsigned xcd_grid(unsigned n) { return ((n + 7u) / 8u) * 8u; }
 
+// t / d for 0 <= t < 2^22 with inv = 1.0f / d: an integer division by a run-time divisor costs ~40 VALU instructions (a
+// 64-bit one ~300), which adds up in per-element sweeps
+__device__ __forceinline__ int fast_div(int t, int d, float inv) {
+  int q = (int)((float)t * inv);
+  if (q * d > t) --q;
+  else if ((q + 1) * d <= t) ++q;
+  return q;
+}
+
 }  // namespace admp
