@@ -51,7 +51,7 @@ class _PairInteraction(HipForceBase):
             raise TypeError('%s takes %d atomic parameter lists' % (self.kernel.name, self.kernel.n_params))
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
-        par = torch.stack([self._real(p, (na,)) for p in atomic_params], dim=1).contiguous()
+        par = self._packed_params(atomic_params)
         mS = self._host64(mScales)
         E = (ctypes.c_double * 1)()
         grad = torch.empty((na, 3), dtype=self._dtype, device=self._device) if want_grad else None
@@ -59,6 +59,19 @@ class _PairInteraction(HipForceBase):
                                          len(mS), _lib.darr(mS), E, self._ptr(grad), 1)
         _lib.check(self._h, rc, 'admp_tt_energy_grad')
         return np.float64(E[0]), grad
+
+    def _packed_params(self, atomic_params):
+        """(Na, n_params) device rows of the per-atom parameter lists.  Repacking them is a stack + copy per call; the
+        packed tensor is kept while every list is the same torch tensor, not written since (same test as the pair list)."""
+        key = None
+        if all(isinstance(p, torch.Tensor) for p in atomic_params):
+            key = tuple((id(p), p.data_ptr(), p._version) for p in atomic_params)
+            c = getattr(self, '_par_cache', None)
+            if c is not None and c[0] == key:
+                return c[1]
+        par = torch.stack([self._real(p, (self.n_atoms,)) for p in atomic_params], dim=1).contiguous()
+        self._par_cache = (key, par, tuple(atomic_params)) if key is not None else None    # (the lists stay alive: ids unique)
+        return par
 
     def get_mscale_gradient(self, positions, box, pairs, mScales, *atomic_params):
         """dE/dmScales (len(mScales),) of this pair interaction."""
