@@ -381,3 +381,33 @@ def test_calculators_share_one_neighbour_table():
             d.get_forces(pos, box, None, par['c_list'], mS)
     finally:
         settings.PRECISION = old
+
+
+@pytest.mark.gpu
+def test_pair_parameter_cache_follows_in_place_writes():
+    """The packed per-atom parameter rows of a pair interaction are cached while the lists are the same, unwritten torch
+    tensors: an in-place write (version counter) or a new tensor must be seen."""
+    import torch
+    from admp_amd import settings
+    from admp_amd import systems as S
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel
+    old = settings.PRECISION
+    settings.PRECISION = 'double'
+    try:
+        n_mol = 64
+        pos, box = S.synthetic_water_box(n_mol, seed=9)
+        at, ai, cov = S.water_topology(n_mol)
+        par = S.water_parameters(n_mol, polarizable=False)
+        pairs = S.build_pairs(pos, box, 4.0)
+        t = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+        dev = 'cuda'
+        a_, b_, q_, c_ = (torch.as_tensor(par[k] if k != 'c' else par['c_list'][:, 0].copy(), dtype=torch.float64, device=dev)
+                          for k in ('a_list', 'b_list', 'q_list', 'c'))
+        E0 = float(t(pos, box, pairs, par['mScales'], a_, b_, q_, c_))
+        assert abs(float(t(pos, box, pairs, par['mScales'], a_, b_, q_, c_)) - E0) <= 1e-12 * abs(E0)    # cached rows (atomic sums: order-dependent last bits)
+        a_.mul_(1.1)                                                                     # in-place write
+        E1 = float(t(pos, box, pairs, par['mScales'], a_, b_, q_, c_))
+        E1_fresh = float(t(pos, box, pairs, par['mScales'], a_.clone(), b_, q_, c_))     # a new tensor
+        assert abs(E1 - E0) > 1e-6 * abs(E0) and abs(E1 - E1_fresh) <= 1e-12 * abs(E1)
+    finally:
+        settings.PRECISION = old
