@@ -3,6 +3,7 @@
 // gather that produces dE/dQ and dE/dr from phi = c2r(G S) (the adjoint the reference leaves to jax.grad).
 // The 3-D transforms themselves are rocFFT r2c / c2r plans driven from engine.hip.
 #include <cstdlib>
+#include <cstring>
 #include <hipcub/hipcub.hpp>
 
 #include "disp_math.h"
@@ -724,6 +725,165 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Sit
   }
 }
 
+// ---- staged gather ---------------------------------------------------------------------------------------------------
+// Of the ~1100 instructions a wave of k_gather issues only a quarter are the 36 loads and their sums: every lane of an atom's
+// group evaluates the same three splines (~420 instructions with the index arithmetic), the 20 sums are folded with 60
+// shuffles, and the conversion to dE/dQ, dE/dr runs with one lane in eight.  Here a workgroup takes 32 atoms with SIX lanes
+// each (192 threads: no idle lanes in the load loop) and
+//   0. wave d evaluates the dimension-d spline of the 32 atoms once and leaves the weights in LDS (W4 rows),
+//   1. every lane sums its z-index over the 36 (x, y) with weights read from LDS,
+//   2. the partial sums go to LDS (over the weight rows, after a barrier) and are folded by 192 threads, 6 words each,
+//   3. 32 lanes of one wave convert the sums of the 32 atoms.
+constexpr int kGsAtoms = 32, kGsBlock = 6 * kGsAtoms, kGsRow = 19 /* 18 W4 rows + 1: conflict-free 16-byte reads */;
+
+template <class T>
+struct GatherStage {
+  union {
+    W4<T> w[kGsAtoms][kGsRow];
+    T part[NF][kGsBlock];
+  };
+  int base[kGsAtoms][4];
+  T sum[kGsAtoms][NF + 1];
+};
+
+// step 0; every thread of the workgroup calls it (ends with a barrier)
+template <class T, int NORD>
+__device__ __forceinline__ void stage_splines(const RecipGeom<T>& g, const Site<T>* __restrict__ sites,
+                                              const int* __restrict__ list, int slot0, int na, W4<T> (*w)[kGsRow],
+                                              int (*base)[4]) {
+  const int d = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), s = threadIdx.x & 63;
+  if (d < 3 && s < kGsAtoms && slot0 + s < na) {
+    const int i = list ? list[slot0 + s] : slot0 + s;
+    const T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
+    int b;
+    const T f = grid_ref(g, r, d, b);
+    T M[6], D1[6], D2[6], D3[6];
+    bspline6(f, M, D1, D2, D3);
+    base[s][d] = b;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      W4<T> o;
+      o.m = M[p]; o.d1 = D1[p];
+      o.d2 = NORD > 2 ? D2[p] : T(0); o.d3 = NORD > 2 ? D3[p] : T(0);
+      w[s][6 * d + p] = o;
+    }
+  }
+  __syncthreads();
+}
+
+template <class T, bool ERECIP>
+__global__ __launch_bounds__(kGsBlock) void k_gather_staged(int na, const Site<T>* __restrict__ sites, int lpol,
+                                                            RecipGeom<T> g, const T* __restrict__ phi,
+                                                            T* __restrict__ pot, T* __restrict__ grad,
+                                                            const int* __restrict__ list, T* __restrict__ fld,
+                                                            FieldFin<T> ff, double* e_recip) {
+  __shared__ GatherStage<T> L;
+  const long blk = xcd_block(blockIdx.x, (unsigned)((na + kGsAtoms - 1) / kGsAtoms));
+  if (blk < 0) return;                                   // workgroup-uniform
+  const int slot0 = (int)blk * kGsAtoms;
+  stage_splines<T, 4>(g, sites, list, slot0, na, L.w, L.base);
+  const int s = threadIdx.x / 6, c = threadIdx.x - 6 * s;
+  T F[NF];
+#pragma unroll
+  for (int k = 0; k < NF; ++k) F[k] = T(0);
+  if (slot0 + s < na) {
+    const int base[3] = {L.base[s][0], L.base[s][1], L.base[s][2]};
+    const W4<T> wz = L.w[s][12 + c];
+    gather_zcol_w(g, base, &L.w[s][0], &L.w[s][6], wz, wrap_add(base[2], c, g.K[2]), [&](long idx) { return phi[idx]; }, F);
+  }
+  __syncthreads();                                       // the weight rows are dead: the partial sums take their place
+#pragma unroll
+  for (int k = 0; k < NF; ++k) L.part[k][threadIdx.x] = F[k];
+  __syncthreads();
+  for (int t = threadIdx.x; t < NF * kGsAtoms; t += kGsBlock) {
+    const int k = t >> 5, a = t & 31;
+    const T* q = &L.part[k][6 * a];
+    L.sum[a][k] = ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]);
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;                          // step 3: one wave, lanes 0..31
+  const int slot = slot0 + (int)threadIdx.x;
+  const bool on = threadIdx.x < kGsAtoms && slot < na;
+  const int i = on ? (list ? list[slot] : slot) : 0;
+  T er = T(0);
+  T P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gr[3] = {0, 0, 0};
+  if (on) {
+    T r[3], Q[9], S[NF];
+    site_qtot(sites[i], lpol, r, Q);
+#pragma unroll
+    for (int k = 0; k < NF; ++k) S[k] = L.sum[threadIdx.x][k];
+    unfold_potential(g, Q, S, P, gr);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pot[9 * i + k] += P[k];
+    if (fld) { fld[3 * i] = P[2]; fld[3 * i + 1] = P[3]; fld[3 * i + 2] = P[1]; }   // harmonic (z,x,y) -> cartesian
+    if (grad) {
+      grad[3 * i] += gr[0]; grad[3 * i + 1] += gr[1]; grad[3 * i + 2] += gr[2];
+    }
+    if (ERECIP) {       // the mesh energy is a quadratic form of the multipoles: E = 1/2 sum_h Q_h dE/dQ_h
+#pragma unroll
+      for (int k = 0; k < 9; ++k) er += Q[k] * P[k];
+    }
+  }
+  if (ERECIP) {
+    const double e = wave_reduce_sum((double)er);
+    if (threadIdx.x == 0) atomicAdd(&e_recip[(blockIdx.x >> 3) & (E_PARTS - 1)], 0.5 * e);
+  }
+  if (ff.fmax_bits) {   // kernel-uniform
+    double fm = 0.0;
+    if (on) {
+      const T al = ff.pol[i];
+      T fx, fy, fz;
+      total_field(sites[i], al, ff.Ucart + 3 * i, ff.fld_pair + 3 * i, fld + 3 * i, ff.kappa, fx, fy, fz);
+      ff.field[3 * i] = fx; ff.field[3 * i + 1] = fy; ff.field[3 * i + 2] = fz;
+      if (al > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
+    }
+    fm = wave_reduce_max(fm);
+    if (threadIdx.x == 0 && fm > 0.0) atomicMax(ff.fmax_bits, nonneg_bits(fm));
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kGsBlock) void k_gather_field_staged(int na, const Site<T>* __restrict__ sites,
+                                                                  RecipGeom<T> g, const T* __restrict__ phi,
+                                                                  T* __restrict__ fld, const int* __restrict__ list,
+                                                                  const int* __restrict__ n_dev,
+                                                                  const int* __restrict__ add_to) {
+  __shared__ W4<T> w[kGsAtoms][kGsRow];
+  __shared__ int sbase[kGsAtoms][4];
+  __shared__ T part[3][kGsBlock];
+  phi += (size_t)blockIdx.y * ((size_t)g.nloc0 * g.K[1] * g.K[2]);            // batch: same atoms, another mesh
+  fld += (size_t)blockIdx.y * 3 * na;
+  if (n_dev) na = min(na, *n_dev);
+  const long blk = xcd_block(blockIdx.x, (unsigned)((na + kGsAtoms - 1) / kGsAtoms));
+  if (blk < 0) return;
+  const int slot0 = (int)blk * kGsAtoms;
+  stage_splines<T, 2>(g, sites, list, slot0, na, w, sbase);
+  const int s = threadIdx.x / 6, c = threadIdx.x - 6 * s;
+  T f[3] = {0, 0, 0};
+  if (slot0 + s < na) {
+    const int base[3] = {sbase[s][0], sbase[s][1], sbase[s][2]};
+    const W4<T> wz = w[s][12 + c];
+    gather_zcol_field_w(g, base, &w[s][0], &w[s][6], wz, wrap_add(base[2], c, g.K[2]), [&](long idx) { return phi[idx]; }, f);
+  }
+  part[0][threadIdx.x] = f[0]; part[1][threadIdx.x] = f[1]; part[2][threadIdx.x] = f[2];
+  __syncthreads();
+  const int slot = slot0 + (int)threadIdx.x;
+  if (threadIdx.x >= kGsAtoms || slot >= na) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const T* q = &part[k][6 * threadIdx.x];
+    f[k] = ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]);
+  }
+  const T* A = g.Aop;
+  const int i = list ? list[slot] : slot;
+  T* o = add_to ? fld + 3 * (size_t)add_to[slot] : fld + 3 * (size_t)i;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const T v = A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
+    o[k] = add_to ? o[k] + v : v;       // compact rows (incremental SCF): accumulate into the owning atom's entry
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_mesh_add(long n, T* __restrict__ a, const T* __restrict__ b) {
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) a[t] += b[t];
@@ -855,9 +1015,22 @@ void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipG
                       int* count) {
   k_home_list<T><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, width, list, count);
 }
+// ADMP_GATHER=lanes8 keeps the 8-lane form above (A/B measurements)
+static bool gather_staged() {
+  static const bool on = [] { const char* e = getenv("ADMP_GATHER"); return !(e && !strcmp(e, "lanes8")); }();
+  return on;
+}
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
                    T* grad, const int* list, T* fld, const FieldFin<T>& ff, double* e_recip) {
+  if (gather_staged()) {
+    const unsigned gs = xcd_grid((unsigned)nblk(na, kGsAtoms));
+    if (e_recip)
+      k_gather_staged<T, true><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
+    else
+      k_gather_staged<T, false><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
+    return;
+  }
   const unsigned grid = xcd_grid((unsigned)nblk(na * 8, kGatherBlock));
   if (e_recip)
     k_gather<T, true><<<grid, kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
@@ -868,6 +1041,11 @@ template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
                          const int* list, int nb, const int* n_dev, const int* add_to) {
   if (na <= 0) return;
+  if (gather_staged()) {
+    k_gather_field_staged<T><<<dim3(xcd_grid((unsigned)nblk(na, kGsAtoms)), nb), kGsBlock, 0, st>>>(na, sites, g, phi, fld, list,
+                                                                                                  n_dev, add_to);
+    return;
+  }
   k_gather_field<T><<<dim3(xcd_grid((unsigned)nblk(na * 8, kGatherBlock)), nb), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list,
                                                                                                       n_dev, add_to);
 }

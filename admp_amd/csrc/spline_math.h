@@ -346,6 +346,118 @@ ADMP_HD void gather_zcol(const RecipGeom<T>& g, const Stencil<T>& st, int ic, co
   F[F012] = e2 * u01;
   F[F003] = g2 * u00;
 }
+// The same z-index sums with the spline weights taken from staged rows (the gather's workgroups evaluate every spline once
+// and keep it in LDS: W4 = the four orders of one stencil index side by side, one 16-byte read).  wx / wy: the six rows of
+// dimensions 0 / 1, wz: the lane's own row of dimension 2.  Mesh offsets advance by additions (no multiplies in the loops).
+template <class T>
+struct alignas(4 * sizeof(T)) W4 {
+  T m, d1, d2, d3;
+};
+
+template <class T, class LoadF>
+ADMP_HD void gather_zcol_w(const RecipGeom<T>& g, const int base[3], const W4<T>* wx, const W4<T>* wy, const W4<T>& wz, int ic,
+                           LoadF phi, T* F) {
+  T u00 = 0, u10 = 0, u20 = 0, u30 = 0, u01 = 0, u11 = 0, u21 = 0, u02 = 0, u12 = 0, u03 = 0;   // u[i along x][j along y]
+  W4<T> y[6];
+  long rb[6];
+  {
+    int ib = base[1];
+    long r = (long)ib * g.K[2] + ic;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 6; ++b) {
+      y[b] = wy[b];
+      rb[b] = r;
+      r += g.K[2];
+      if (++ib == g.K[1]) { ib = 0; r = ic; }
+    }
+  }
+  const long k12 = (long)g.K[1] * g.K[2];
+  int ia = base[0];
+  long ra = (long)ia * k12;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int a = 0; a < 6; ++a) {
+    T t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 6; ++b) {
+      const T v = phi(ra + rb[b]);
+      t0 += v * y[b].m;
+      t1 += v * y[b].d1;
+      t2 += v * y[b].d2;
+      t3 += v * y[b].d3;
+    }
+    const W4<T> x = wx[a];
+    u00 += x.m * t0; u10 += x.d1 * t0; u20 += x.d2 * t0; u30 += x.d3 * t0;
+    u01 += x.m * t1; u11 += x.d1 * t1; u21 += x.d2 * t1;
+    u02 += x.m * t2; u12 += x.d1 * t2;
+    u03 += x.m * t3;
+    ra += k12;
+    if (++ia == g.wrap0) { ia = 0; ra = 0; }
+  }
+  const T m2 = wz.m, d2 = wz.d1, e2 = wz.d2, g2 = wz.d3;
+  F[F000] = m2 * u00; F[F100] = m2 * u10; F[F200] = m2 * u20; F[F300] = m2 * u30;
+  F[F010] = m2 * u01; F[F110] = m2 * u11; F[F210] = m2 * u21;
+  F[F020] = m2 * u02; F[F120] = m2 * u12;
+  F[F030] = m2 * u03;
+  F[F001] = d2 * u00; F[F101] = d2 * u10; F[F201] = d2 * u20;
+  F[F011] = d2 * u01; F[F111] = d2 * u11;
+  F[F021] = d2 * u02;
+  F[F002] = e2 * u00; F[F102] = e2 * u10;
+  F[F012] = e2 * u01;
+  F[F003] = g2 * u00;
+}
+// ... and its first-derivative part (SCF field, scalar dispersion channels)
+template <class T, class LoadF>
+ADMP_HD void gather_zcol_field_w(const RecipGeom<T>& g, const int base[3], const W4<T>* wx, const W4<T>* wy, const W4<T>& wz,
+                                 int ic, LoadF phi, T f[3]) {
+  T u00 = 0, u10 = 0, u01 = 0;
+  T ym[6], yd[6];
+  long rb[6];
+  {
+    int ib = base[1];
+    long r = (long)ib * g.K[2] + ic;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 6; ++b) {
+      ym[b] = wy[b].m; yd[b] = wy[b].d1;
+      rb[b] = r;
+      r += g.K[2];
+      if (++ib == g.K[1]) { ib = 0; r = ic; }
+    }
+  }
+  const long k12 = (long)g.K[1] * g.K[2];
+  int ia = base[0];
+  long ra = (long)ia * k12;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int a = 0; a < 6; ++a) {
+    T t0 = 0, t1 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 6; ++b) {
+      const T v = phi(ra + rb[b]);
+      t0 += v * ym[b];
+      t1 += v * yd[b];
+    }
+    const T xm = wx[a].m, xd = wx[a].d1;
+    u00 += xm * t0;
+    u10 += xd * t0;
+    u01 += xm * t1;
+    ra += k12;
+    if (++ia == g.wrap0) { ia = 0; ra = 0; }
+  }
+  f[0] = wz.m * u10;
+  f[1] = wz.m * u01;
+  f[2] = wz.d1 * u00;
+}
 // first-derivative part of one z-index: f[3] = (F100, F010, F001) contributions
 template <class T, class LoadF>
 ADMP_HD void gather_zcol_field(const RecipGeom<T>& g, const Stencil<T>& st, int ic, T m2, T d2, LoadF phi, T f[3]) {
