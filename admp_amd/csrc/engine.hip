@@ -462,9 +462,10 @@ struct Engine : EngineBase {
   // staging for host-pointer calls
   DevBuf s_pos, s_Q, s_pol, s_thole, s_U, s_out, s_dQ, s_par;
   // mesh
-  DevBuf mesh, spec, gtabs[4], fft_work, binv_d, bin_cells, bin_sorted, bin_scan;   // gtabs: Ck_1, Ck_6, Ck_8, Ck_10
+  DevBuf mesh, spec, gtabs[4], fft_work, binv_d, bin_cells, bin_sorted, bin_scan, bin_cells_ind, bin_sorted_ind;   // gtabs: Ck_1, Ck_6, Ck_8, Ck_10
   T* gtab_cur = nullptr;
-  BinScratch bins;
+  BinScratch bins, bins_ind;   // brick lists of the site rows / of the compact rows of the SCF increments
+  bool bins_main = false;      // `bins` holds the lists of this evaluation's site rows (the closing gather reuses them)
   rocfft_plan plan_f = nullptr, plan_b = nullptr, plan_xf = nullptr, plan_xb = nullptr;
   // power-of-two x dimension on one rank: batched 2-D plans of the y-z planes around the fused x pass (fftx_kernels.hip)
   rocfft_plan plan2_f = nullptr, plan2_b = nullptr;
@@ -480,6 +481,9 @@ struct Engine : EngineBase {
   int act_n = -1;                // its length once the host has seen it (-1: not yet)
   bool act_fresh = false;        // this evaluation rebuilt the list (count still on the device)
   long ind_nbr_gen = -1, ind_act_gen = -1;
+  long eval_seq = 0, ind_bins_eval = -1, ind_bins_gen = -1;   // evaluation counter; the evaluation / active set bins_ind was built for
+  int ind_bins_n = -1;
+  const int* ind_bins_at = nullptr;
   DevBuf dft_tw;          // twiddle tables of the direct-DFT path
   DevBuf bases_d;         // int4 per atom: lowest stencil index on each mesh axis
   bool use_dft = false;   // mesh convolution through dft_kernels.hip instead of rocFFT (single rank, a Bluestein dimension)
@@ -497,7 +501,7 @@ struct Engine : EngineBase {
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
                       &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp,
-                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw})
+                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw, &bin_cells_ind, &bin_sorted_ind})
       b->release();
     free_topology();
     if (ind.rowptr) (void)hipFree(ind.rowptr);
@@ -801,20 +805,21 @@ struct Engine : EngineBase {
     return b.as<T>();
   }
 
-  void ensure_bins(int na) {
+  void ensure_bins(int na) { ensure_bins(na, bins, bin_cells, bin_sorted); bins_main = false; }
+  void ensure_bins(int na, BinScratch& b, DevBuf& cells, DevBuf& sorted) {
     const int dims[3] = {nloc0(), K[1], K[2]};
     const BrickGrid bg = make_bricks(dims);
-    bin_cells.need(sizeof(int) * 3 * (size_t)(bg.ncell + 1));
-    bin_sorted.need(sizeof(int) * 8 * (size_t)na);
+    cells.need(sizeof(int) * 3 * (size_t)(bg.ncell + 1));
+    sorted.need(sizeof(int) * 8 * (size_t)na);
     bin_scan.need(spread_scan_bytes(bg.ncell));
-    if (bins.cell_start != bin_cells.as<int>() || bins.cursor != bin_cells.as<int>() + (bg.ncell + 1))
-      bins.counters_zero = false;                  // fresh or re-laid-out storage
-    bins.cell_start = bin_cells.as<int>();
-    bins.cursor = bin_cells.as<int>() + (bg.ncell + 1);
-    bins.fillcur = bin_cells.as<int>() + 2 * (size_t)(bg.ncell + 1);
-    bins.sorted = bin_sorted.as<int>();
-    bins.scan_tmp = bin_scan.p;
-    bins.scan_bytes = bin_scan.bytes;
+    if (b.cell_start != cells.as<int>() || b.cursor != cells.as<int>() + (bg.ncell + 1))
+      b.counters_zero = false;                     // fresh or re-laid-out storage
+    b.cell_start = cells.as<int>();
+    b.cursor = cells.as<int>() + (bg.ncell + 1);
+    b.fillcur = cells.as<int>() + 2 * (size_t)(bg.ncell + 1);
+    b.sorted = sorted.as<int>();
+    b.scan_tmp = bin_scan.p;
+    b.scan_bytes = bin_scan.bytes;
   }
 
   // ---- one evaluation, stage by stage -------------------------------------------------------------------
@@ -836,6 +841,7 @@ struct Engine : EngineBase {
     if (lpol) ARG_CHECK(pol_ && thole_ && U_ && pS, "polarizable handle needs pol, tholes, pScales and U_inout");
     const int na = top.na;
     double inv[9], vol;
+    ++eval_seq;
     ensure_mesh();
     ev.bx = make_box(box, inv, &vol);
     ev.g = make_geom(inv);
@@ -943,6 +949,7 @@ struct Engine : EngineBase {
     TIMED("spread");
     int rc = launch_spread<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, bins, mesh_p, ev.home, ev.bases);
     if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+    bins_main = !ev.home && snranks == 1 && spread_uses_bricks(ev.n_home, ev.g);
   }
   // spectrum buffer in the k-space layout [K0][ny][K2/2+1]: energy into `slot`, multiply by G
   void stage_kspace(T* spec_p, int slot) {
@@ -1008,7 +1015,7 @@ struct Engine : EngineBase {
     }
     TIMED("gather");
     launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff,
-                     e_recip);
+                     e_recip, bins_main ? &bins : nullptr, ev.bases);
   }
   // closes the evaluation: E_out = (real, recip[slot], self, penalty) of THIS rank's share
   // with_field_finish (single rank, pull kernel): the SCF residual and its maximum are formed by this kernel too
@@ -1094,7 +1101,14 @@ struct Engine : EngineBase {
     const size_t nreal = (size_t)K[0] * K[1] * K[2];
     mesh2.need(nreal * sizeof(T));
     { TIMED("spread_ind");
-      int rc = launch_spread<T>(stream, n_act, isites.as<Site<T>>(), 1, ev.g, bins, mesh2.as<T>(), nullptr, nullptr);
+      // the compact rows keep their positions and their order through the SCF cycles of one evaluation: the brick lists of
+      // its first increment serve the later ones (two binning passes and a scan less per cycle)
+      ensure_bins(n_act, bins_ind, bin_cells_ind, bin_sorted_ind);
+      const bool reuse = ind_bins_eval == eval_seq && ind_bins_n == n_act && ind_bins_gen == act_gen &&
+                         ind_bins_at == bins_ind.cell_start;
+      int rc = launch_spread<T>(stream, n_act, isites.as<Site<T>>(), 1, ev.g, bins_ind, mesh2.as<T>(), nullptr, nullptr, 1,
+                                reuse ? 1 : 0);
+      ind_bins_eval = eval_seq; ind_bins_n = n_act; ind_bins_gen = act_gen; ind_bins_at = bins_ind.cell_start;
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)}; }
     convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH);
     { TIMED("gather_field_ind");
@@ -1328,6 +1342,7 @@ struct Engine : EngineBase {
     need_eval_or_disp();
     {
       TIMED("spread");
+      bins_main = false;
       int rc = launch_spread<T>(stream, vs_n, vs_sites, lpol_sites < 0 ? lpol : lpol_sites, vs_g, bins, mesh.as<T>(), nullptr,
                                 nullptr, 1, reuse_bins);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};

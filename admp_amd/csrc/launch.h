@@ -300,6 +300,9 @@ __host__ __device__ inline int brick_code(const int base[3], const int dims[3], 
 // below this atom count the spread uses global atomics (8 lanes per atom) instead of binned LDS bricks
 // (default 20000; env ADMP_SPREAD_BRICK_MIN overrides, 0 forces the brick path -- used by the parity tests)
 int spread_brick_min_atoms();
+// launch_spread(na atoms, this mesh) takes the binned brick kernel and leaves its lists in the BinScratch
+template <class T>
+bool spread_uses_bricks(int na, const RecipGeom<T>& g);
 // scratch for the per-call binning: brick offsets cell_start[ncell+1] (+cursor copy) and the
 // (atom, brick) entry list sorted[<= 8 na] (a stencil touches at most 2 bricks per axis)
 struct BinScratch {
@@ -337,7 +340,10 @@ template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
                    T* grad, const int* list, T* fld_recip /* optional: cartesian reciprocal dE/dU */,
                    const FieldFin<T>& ff = FieldFin<T>(),
-                   double* e_recip = nullptr /* optional: += 1/2 sum_i Q_tot,i . dE_recip/dQ_i = the reciprocal energy */);
+                   double* e_recip = nullptr /* optional: += 1/2 sum_i Q_tot,i . dE_recip/dQ_i = the reciprocal energy */,
+                   const BinScratch* bins = nullptr /* the brick lists launch_spread built from these sites at these positions
+                                                       (whole-mesh, list == nullptr): one workgroup per brick, phi from LDS */,
+                   const int4* bases = nullptr /* with bins: the stencil records launch_spread was given */);
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
                          T* fld_recip, const int* list, int nb = 1 /* batch: phi of b at phi + b * mesh size, fld + b * 3 * na */,

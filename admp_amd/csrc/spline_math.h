@@ -354,6 +354,48 @@ struct alignas(4 * sizeof(T)) W4 {
   T m, d1, d2, d3;
 };
 
+// load(a, b) returns the mesh word of stencil point (a, b) at the lane's z index
+template <class T, class LoadAB>
+ADMP_HD void gather_zcol_core(const W4<T>* wx, const W4<T>* wy, const W4<T>& wz, LoadAB load, T* F) {
+  T u00 = 0, u10 = 0, u20 = 0, u30 = 0, u01 = 0, u11 = 0, u21 = 0, u02 = 0, u12 = 0, u03 = 0;   // u[i along x][j along y]
+  W4<T> y[6];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int b = 0; b < 6; ++b) y[b] = wy[b];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int a = 0; a < 6; ++a) {
+    T t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 6; ++b) {
+      const T v = load(a, b);
+      t0 += v * y[b].m;
+      t1 += v * y[b].d1;
+      t2 += v * y[b].d2;
+      t3 += v * y[b].d3;
+    }
+    const W4<T> x = wx[a];
+    u00 += x.m * t0; u10 += x.d1 * t0; u20 += x.d2 * t0; u30 += x.d3 * t0;
+    u01 += x.m * t1; u11 += x.d1 * t1; u21 += x.d2 * t1;
+    u02 += x.m * t2; u12 += x.d1 * t2;
+    u03 += x.m * t3;
+  }
+  const T m2 = wz.m, d2 = wz.d1, e2 = wz.d2, g2 = wz.d3;
+  F[F000] = m2 * u00; F[F100] = m2 * u10; F[F200] = m2 * u20; F[F300] = m2 * u30;
+  F[F010] = m2 * u01; F[F110] = m2 * u11; F[F210] = m2 * u21;
+  F[F020] = m2 * u02; F[F120] = m2 * u12;
+  F[F030] = m2 * u03;
+  F[F001] = d2 * u00; F[F101] = d2 * u10; F[F201] = d2 * u20;
+  F[F011] = d2 * u01; F[F111] = d2 * u11;
+  F[F021] = d2 * u02;
+  F[F002] = e2 * u00; F[F102] = e2 * u10;
+  F[F012] = e2 * u01;
+  F[F003] = g2 * u00;
+}
 template <class T, class LoadF>
 ADMP_HD void gather_zcol_w(const RecipGeom<T>& g, const int base[3], const W4<T>* wx, const W4<T>* wy, const W4<T>& wz, int ic,
                            LoadF phi, T* F) {

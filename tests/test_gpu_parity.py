@@ -183,9 +183,12 @@ for prec, tol in (('double', 1e-9), ('single', 5e-4)):
         assert abs(E - dref['E']) < tol * max(abs(p) for p in dref['parts']) and rel(G, dref['grad']) < max(tol, 1e-8), (prec, K)
 print('BRICK-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ADMP_SPREAD_BRICK_MIN='0')
-    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and 'BRICK-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    # the three forms of the gather (recip_kernels.hip launch_gather): staged (default), one workgroup per quarter brick reading
+    # phi from LDS (takes the lists of the brick spread), and the 8-lane form of round 1
+    for gather in ('staged', 'bricks', 'lanes8'):
+        env = dict(os.environ, ADMP_SPREAD_BRICK_MIN='0', ADMP_GATHER=gather)
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and 'BRICK-OK' in r.stdout, gather + r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_direct_dft_convolution_vs_rocfft(tmp_path):
