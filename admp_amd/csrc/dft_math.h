@@ -34,6 +34,37 @@ ADMP_HD Cx<T> cx_mul(Cx<T> a, Cx<T> b) {
   return Cx<T>{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
 
+// Twiddle of output k carried from line position j to j + 1.  f32: the rotation w <- w * w^k (4 operations).  f64, where an
+// operation costs twice as much and the 97^3 headline mesh spends 40 % of its step in these loops: the three-term recurrence
+// w_{j+1} = 2 cos(theta) w_j - w_{j-1}, one FMA per component; its error grows with j^2, which the re-seeding from the exact
+// table every kDftReseed steps bounds at ~64 ulp of f64 (in f32 that would show, so f32 keeps the rotation).
+template <class T>
+struct TwStep {
+  Cx<T> w, aux;     // f32: aux = w^k (the rotation); f64: aux = w_{j-1}
+  T t;              // f64: 2 cos(theta)
+  ADMP_HD void seed(const Cx<T>* tw, int m, int k, int N) {
+    w = tw[m];
+    if (sizeof(T) == 8) {
+      int mp = m - k;
+      if (mp < 0) mp += N;
+      aux = tw[mp];
+      t = T(2) * tw[k].re;
+    } else {
+      aux = tw[k];
+      t = T(0);
+    }
+  }
+  ADMP_HD void next() {
+    if (sizeof(T) == 8) {
+      const Cx<T> n{t * w.re - aux.re, t * w.im - aux.im};
+      aux = w;
+      w = n;
+    } else {
+      w = cx_mul(w, aux);
+    }
+  }
+};
+
 // complex line, direction SIGN (-1 forward, +1 inverse): outputs X[k] and X[N-k] (k = 0 .. N/2)
 //   load(j), j = 0..H-1, returns the pair sums of line positions j+1 / N-1-j;  x0 = x_0;  xn = x_{N/2} (used when N is
 //   even);  tw[m] = (cos, sin)(2 pi m / N)
@@ -41,18 +72,17 @@ template <class T, int SIGN, int KQ, class LoadAB>
 ADMP_HD void dft_pair_core(int N, const int* k, LoadAB load, Cx<T> x0, Cx<T> xn, const Cx<T>* tw, Cx<T>* Xk, Cx<T>* Xnk) {
   const int H = (N - 1) / 2;
   T Are[KQ], Aim[KQ], Bre[KQ], Bim[KQ];
-  Cx<T> rot[KQ], w[KQ];
+  TwStep<T> w[KQ];
   int m[KQ], step[KQ];
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
     Are[q] = Aim[q] = Bre[q] = Bim[q] = T(0);
-    rot[q] = tw[k[q]];
     m[q] = k[q];
     step[q] = (kDftReseed * k[q]) % N;
   }
   for (int jb = 0; jb < H; jb += kDftReseed) {
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) w[q] = tw[m[q]];
+    for (int q = 0; q < KQ; ++q) w[q].seed(tw, m[q], k[q], N);
     const int je = (H - jb) < kDftReseed ? (H - jb) : kDftReseed;
     if (je == kDftReseed) {
 #pragma unroll
@@ -60,11 +90,11 @@ ADMP_HD void dft_pair_core(int N, const int* k, LoadAB load, Cx<T> x0, Cx<T> xn,
         const PairCx<T> p = load(jb + jj);
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
-          Are[q] += p.are * w[q].re;
-          Aim[q] += p.aim * w[q].re;
-          Bre[q] += p.bre * w[q].im;
-          Bim[q] += p.bim * w[q].im;
-          w[q] = cx_mul(w[q], rot[q]);
+          Are[q] += p.are * w[q].w.re;
+          Aim[q] += p.aim * w[q].w.re;
+          Bre[q] += p.bre * w[q].w.im;
+          Bim[q] += p.bim * w[q].w.im;
+          w[q].next();
         }
       }
     } else {
@@ -72,11 +102,11 @@ ADMP_HD void dft_pair_core(int N, const int* k, LoadAB load, Cx<T> x0, Cx<T> xn,
         const PairCx<T> p = load(jb + jj);
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
-          Are[q] += p.are * w[q].re;
-          Aim[q] += p.aim * w[q].re;
-          Bre[q] += p.bre * w[q].im;
-          Bim[q] += p.bim * w[q].im;
-          w[q] = cx_mul(w[q], rot[q]);
+          Are[q] += p.are * w[q].w.re;
+          Aim[q] += p.aim * w[q].w.re;
+          Bre[q] += p.bre * w[q].w.im;
+          Bim[q] += p.bim * w[q].w.im;
+          w[q].next();
         }
       }
     }
@@ -123,18 +153,17 @@ ADMP_HD void dft_pair_outputs_rows(int N, const int* k, int stride, const Cx<T>*
 template <class T, int KQ>
 ADMP_HD void real_pair_sums(int N, const int* k, int stride, const Cx<T>* p, const Cx<T>* tw, T* P, T* R) {
   const int H = (N - 1) / 2;
-  Cx<T> rot[KQ], w[KQ];
+  TwStep<T> w[KQ];
   int m[KQ], step[KQ];
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
     P[q] = R[q] = T(0);
-    rot[q] = tw[k[q]];
     m[q] = k[q];
     step[q] = (kDftReseed * k[q]) % N;
   }
   for (int jb = 0; jb < H; jb += kDftReseed) {
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) w[q] = tw[m[q]];
+    for (int q = 0; q < KQ; ++q) w[q].seed(tw, m[q], k[q], N);
     const int je = (H - jb) < kDftReseed ? (H - jb) : kDftReseed;
     if (je == kDftReseed) {
 #pragma unroll
@@ -142,9 +171,9 @@ ADMP_HD void real_pair_sums(int N, const int* k, int stride, const Cx<T>* p, con
         const Cx<T> v = p[(jb + jj) * stride];
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
-          P[q] += v.re * w[q].re;
-          R[q] += v.im * w[q].im;
-          w[q] = cx_mul(w[q], rot[q]);
+          P[q] += v.re * w[q].w.re;
+          R[q] += v.im * w[q].w.im;
+          w[q].next();
         }
       }
     } else {
@@ -152,9 +181,9 @@ ADMP_HD void real_pair_sums(int N, const int* k, int stride, const Cx<T>* p, con
         const Cx<T> v = p[(jb + jj) * stride];
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
-          P[q] += v.re * w[q].re;
-          R[q] += v.im * w[q].im;
-          w[q] = cx_mul(w[q], rot[q]);
+          P[q] += v.re * w[q].w.re;
+          R[q] += v.im * w[q].w.im;
+          w[q].next();
         }
       }
     }
