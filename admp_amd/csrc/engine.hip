@@ -494,6 +494,11 @@ struct Engine : EngineBase {
   struct TabKey { double box[9] = {0}, kappa = -1; int K[3] = {0, 0, 0}, Y0 = 0, ref = 0; bool pfa = false; } tabkey[4];
   static int tab_slot(int which) { return which == 1 ? 0 : (which == 6 ? 1 : (which == 8 ? 2 : 3)); }
   bool warm_regime = false;   // previous polarizable call converged at its first SCF check
+  // Residual history of consecutive polarizable calls (MD: every call starts from the previous call's dipoles): the residual
+  // of a call's first check is the previous call's last residual plus what one step of motion adds.  scf_growth = that
+  // increase as last observed, scf_last = the residual the previous call ended with (< 0: no history).  The first cycle is
+  // evaluated speculatively with the full kernels only when scf_last + scf_growth predicts that its check will pass.
+  double scf_last = -1.0, scf_growth = 0.0;
   bool mono_ok = false;       // this evaluation may use the charge-only pair forms (no dE/dQ_local requested)
 
   ~Engine() override {
@@ -1194,7 +1199,11 @@ struct Engine : EngineBase {
       ARG_CHECK(max_cycle >= 1, "max_cycle must be >= 1");
       int i = 0, n_act = 0;
       bool have_base = false;    // fld_pair / fld_recip / phi belong to the dipoles before the last Jacobi step
-      if (warm_regime) {
+      // which form of the first cycle: ADMP_SPECULATE=0 / 1 forces the plain / the speculative one (A/B, tests)
+      static const int spec_mode = [] { const char* e = getenv("ADMP_SPECULATE"); return e ? atoi(e) : -1; }();
+      const bool speculate = spec_mode >= 0 ? spec_mode != 0 : (scf_last >= 0.0 ? scf_last + scf_growth < thresh : warm_regime);
+      double f_first = -1.0, f_final = -1.0;
+      if (speculate) {
         // Steady-state MD regime (the previous call converged at its first check): evaluate the FIRST SCF cycle
         // with the full kernels -- they produce dE/dU alongside the gradient -- so that, when the check passes
         // again, the step is already finished (no separate field kernels, no second pass).  Same arithmetic and
@@ -1211,6 +1220,7 @@ struct Engine : EngineBase {
         if (!fuse_ff && !pull) launch_field_finish_only();
         launch_finish_only(dpos ? gbuf : nullptr, dQl, !fuse_ff && pull);
         const double fmax = read_energies(E_SCF_RECIP, E);
+        f_first = f_final = fmax;
         nact_seen();
         n_act = act_n;
         if (fmax < thresh) {
@@ -1238,6 +1248,8 @@ struct Engine : EngineBase {
           phi_accum = true;
         }
         const double fmax = scf_check(&n_act);
+        if (f_first < 0.0) f_first = fmax;
+        f_final = fmax;
         if (fmax < thresh) { phi_valid = true; break; }
         scf_jacobi(n_act);
       }
@@ -1245,6 +1257,10 @@ struct Engine : EngineBase {
       cyc = i;
       flag = (i != max_cycle - 1);             // admp/pme.py:139-143
       warm_regime = (cyc == 0);
+      if (f_first >= 0.0) {
+        if (scf_last >= 0.0) scf_growth = f_first - scf_last;
+        scf_last = f_final;
+      }
     }
 
     const bool atoms_energy = phi_valid && phi_accum;
@@ -1290,6 +1306,7 @@ struct Engine : EngineBase {
     }
     stage_finish(dpos_ ? gbuf : nullptr, reinterpret_cast<T*>(dQl_), E_RECIP, E);
     warm_regime = false;
+    scf_last = -1.0;
   }
 
   void local_frames(const void* pos, const double* box, void* out) override {
@@ -1393,6 +1410,7 @@ struct Engine : EngineBase {
     vs_sites = nullptr;
     vir_assemble(inv, E[1], dbox);
     warm_regime = false;
+    scf_last = -1.0;
   }
 
   void disp_box_grad(const void* pos_, const double* box, const void* clist_, int pmax, int ns, const double* mS, double* E,

@@ -1315,3 +1315,56 @@ print('FX-RUN-OK')
         b = res['fused_x'][key]
         tol = 1e-10 if key.startswith('double') else 2e-4
         assert np.abs(a - b).max() <= tol * np.abs(a).max(), (key, np.abs(a - b).max(), np.abs(a).max())
+
+
+def test_first_cycle_forms_agree_on_a_moving_sequence(tmp_path):
+    """engine.hip pme(): the first SCF cycle of a call runs either as field kernels followed by the closing pass, or
+    speculatively with the full kernels (one host synchronisation when its check passes); which one is chosen from the residual
+    history of the previous calls (scf_last + scf_growth < threshold).  Every choice must give the same step: energies,
+    gradient, dipoles, cycle count and flag on a sequence of displaced frames, warm-started like an MD run."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_parity import water_system
+from admp_amd import settings
+from admp_amd.pme import ADMPPmeForce
+pos, box, at, ai, cov, par, pairs = water_system(216, 5, True)
+rng = np.random.default_rng(3)
+vel = rng.normal(size=pos.shape) * 0.012
+out = {}
+for prec in ('double', 'single'):
+    settings.PRECISION = prec
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    U = None
+    for k in range(8):
+        p = pos + vel * k
+        E, G = f.get_forces(p, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
+                            par['dScales'], U_init=U)
+        U = np.asarray(f.U_ind).copy()
+        out['%%s_%%d_E' %% (prec, k)] = np.asarray(f.energy_parts)
+        out['%%s_%%d_G' %% (prec, k)] = np.asarray(G)
+        out['%%s_%%d_U' %% (prec, k)] = U
+        out['%%s_%%d_c' %% (prec, k)] = np.array([f.n_cycle, int(f.lconverg)])
+np.savez(sys.argv[1], **out)
+print('SEQ-OK', [int(out['double_%%d_c' %% k][0]) for k in range(8)])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode, extra in {'auto': {}, 'plain': dict(ADMP_SPECULATE='0'), 'speculative': dict(ADMP_SPECULATE='1')}.items():
+        path = str(tmp_path / ('%s.npz' % mode))
+        r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
+                           env=dict(os.environ, **extra), timeout=600)
+        assert r.returncode == 0 and 'SEQ-OK' in r.stdout, mode + r.stdout[-2000:] + r.stderr[-3000:]
+        res[mode] = dict(np.load(path))
+    cycles = [int(res['plain']['double_%d_c' % k][0]) for k in range(8)]
+    assert min(cycles) == 0 and max(cycles) >= 1, cycles          # the sequence exercises both outcomes of the first check
+    for key, a in res['plain'].items():
+        for mode in ('auto', 'speculative'):
+            b = res[mode][key]
+            if key.endswith('_c'):
+                assert (a == b).all(), (mode, key, a, b)
+            else:
+                tol = 1e-10 if key.startswith('double') else 2e-4
+                scale = np.abs(a).max()
+                assert np.abs(a - b).max() <= tol * scale, (mode, key, np.abs(a - b).max(), scale)
