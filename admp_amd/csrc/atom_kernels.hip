@@ -6,6 +6,8 @@
 // One thread per atom; 20-real site rows are written as whole 16/32-byte vectors.
 #include <cstdlib>
 
+#include <cstring>
+
 #include "launch.h"
 #include "reduce.h"
 
@@ -118,11 +120,17 @@ template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_jacobi_delta(int n_act, const int* __restrict__ act,
                                                              const T* __restrict__ pol, const T* __restrict__ field,
                                                              T* __restrict__ Ucart, Site<T>* __restrict__ sites,
-                                                             Site<T>* __restrict__ isites) {
+                                                             Site<T>* __restrict__ isites,
+                                                             const unsigned long long* __restrict__ gate,
+                                                             unsigned long long gate_bits) {
   const int slot = blockIdx.x * kAtomBlock + threadIdx.x;
   if (slot >= n_act) return;
   const int i = act[slot];
-  const T s = -pol[i] * T(1.0 / kDielectric);
+  // gate (chained SCF, engine.hip): the step is enqueued before the host has seen the residual of the check it follows; when
+  // that check passed (bit patterns of non-negative doubles order like the numbers) the step is a zero step: U keeps its
+  // bits and every kernel of the increment that follows adds exact zeros
+  const bool on = !gate || *gate >= gate_bits;
+  const T s = on ? -pol[i] * T(1.0 / kDielectric) : T(0);
   const T dx = field[3 * i] * s, dy = field[3 * i + 1] * s, dz = field[3 * i + 2] * s;     // admp/pme.py:138
   Ucart[3 * i] += dx; Ucart[3 * i + 1] += dy; Ucart[3 * i + 2] += dz;
   Site<T> r = sites[i];
@@ -587,8 +595,11 @@ void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* 
 }
 template <class T>
 void launch_jacobi_delta(hipStream_t st, int n_act, const int* act, const T* pol, const T* field, T* Ucart, Site<T>* sites,
-                         Site<T>* isites) {
-  if (n_act > 0) k_jacobi_delta<T><<<nblk(n_act), kAtomBlock, 0, st>>>(n_act, act, pol, field, Ucart, sites, isites);
+                         Site<T>* isites, const unsigned long long* gate, double gate_min) {
+  unsigned long long bits;
+  std::memcpy(&bits, &gate_min, sizeof(bits));
+  if (n_act > 0)
+    k_jacobi_delta<T><<<nblk(n_act), kAtomBlock, 0, st>>>(n_act, act, pol, field, Ucart, sites, isites, gate, bits);
 }
 template <class T>
 void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, const T* Ucart, T* Unew,
@@ -664,7 +675,8 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
   template void launch_site_classes<T>(hipStream_t, int, const Site<T>*, int*);                                         \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
                                        unsigned long long*, const int*, const int*);                                    \
-  template void launch_jacobi_delta<T>(hipStream_t, int, const int*, const T*, const T*, T*, Site<T>*, Site<T>*);       \
+  template void launch_jacobi_delta<T>(hipStream_t, int, const int*, const T*, const T*, T*, Site<T>*, Site<T>*,        \
+                                       const unsigned long long*, double);                                            \
   template void launch_jacobi_update<T>(hipStream_t, int, const T*, const T*, const T*, T*, Site<T>*, const int*);       \
   template void launch_finish<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const Site<T>*, const T*,        \
                                  const T*, int, T, T*, T*, T*, double*, const int*, int, const FieldFin<T>&);

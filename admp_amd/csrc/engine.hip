@@ -496,9 +496,12 @@ struct Engine : EngineBase {
   bool warm_regime = false;   // previous polarizable call converged at its first SCF check
   // Residual history of consecutive polarizable calls (MD: every call starts from the previous call's dipoles): the residual
   // of a call's first check is the previous call's last residual plus what one step of motion adds.  scf_growth = that
-  // increase as last observed, scf_last = the residual the previous call ended with (< 0: no history).  The first cycle is
+  // increase as last observed after a call of the same kind, scf_last = the residual the previous call ended with (< 0: no history).  The first cycle is
   // evaluated speculatively with the full kernels only when scf_last + scf_growth predicts that its check will pass.
-  double scf_last = -1.0, scf_growth = 0.0;
+  double scf_last = -1.0, scf_growth[2] = {0.0, 0.0};   // growth after a call without / with a Jacobi step (they differ: the
+  int scf_state = 0;                                     // residual is a maximum norm, not additive)
+  double scf_contract = -1.0;   // factor by which one Jacobi step shrank the residual in the last call that took steps
+                                // ((last / first residual)^(1 / steps); < 0: never observed)
   bool mono_ok = false;       // this evaluation may use the charge-only pair forms (no dE/dQ_local requested)
 
   ~Engine() override {
@@ -1085,12 +1088,18 @@ struct Engine : EngineBase {
     *n_act = act_n;
     return fmax;
   }
-  void scf_jacobi(int n_act) {
+  void scf_jacobi(int n_act, const unsigned long long* gate = nullptr, double gate_min = 0.0) {
     if (n_act <= 0) return;
     isites.need(sizeof(Site<T>) * (size_t)n_act);
     TIMED("jacobi_update");
     launch_jacobi_delta<T>(stream, n_act, act_d.as<int>(), ev.pol, field.as<T>(), ev.U, sites.as<Site<T>>(),
-                           isites.as<Site<T>>());
+                           isites.as<Site<T>>(), gate, gate_min);
+  }
+  // total field of the polarizable rows and its maximum into `word` (a zero word of this evaluation's energy block); no read
+  void launch_field_check(unsigned long long* word) {
+    TIMED("field_finish");
+    launch_field_finish<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
+                           (T)kappa, field.as<T>(), word, act_d.as<int>(), nact_arg());
   }
   void scf_increment(int n_act) {         // fld_pair / fld_recip / phi <- their values for the dipoles after scf_jacobi
     if (n_act <= 0) return;
@@ -1201,8 +1210,73 @@ struct Engine : EngineBase {
       bool have_base = false;    // fld_pair / fld_recip / phi belong to the dipoles before the last Jacobi step
       // which form of the first cycle: ADMP_SPECULATE=0 / 1 forces the plain / the speculative one (A/B, tests)
       static const int spec_mode = [] { const char* e = getenv("ADMP_SPECULATE"); return e ? atoi(e) : -1; }();
-      const bool speculate = spec_mode >= 0 ? spec_mode != 0 : (scf_last >= 0.0 ? scf_last + scf_growth < thresh : warm_regime);
-      double f_first = -1.0, f_final = -1.0;
+      const bool speculate = spec_mode >= 0 ? spec_mode != 0 : (scf_last >= 0.0 ? scf_last + scf_growth[scf_state] < thresh : warm_regime);
+      double f_first = -1.0, f_final = -1.0, f_second = -1.0;
+      // Chained form (small systems, where a host synchronisation costs as much as three kernels): when the history says the
+      // first check will fail and n Jacobi steps will do, the whole call is enqueued at once -- first field evaluation and its
+      // check, then n times (Jacobi step GATED on the previous check's residual on the device: a zero step once a check has
+      // passed, after which every later residual repeats the passing one; increment; check), the closing pass -- and read back
+      // with one synchronisation.  The host then replays the reference's decisions on the n + 1 residuals: same dipoles,
+      // cycle count and flag as the plain loop; a wrong guess costs the kernels that ran for nothing (closing pass when more
+      // cycles are needed, increments after the check that passed).
+      static const int chain_max = [] { const char* e = getenv("ADMP_SCF_CHAIN_MAX"); return e ? atoi(e) : 20000; }();
+      const double pred = scf_last >= 0.0 ? scf_last + scf_growth[scf_state] : -1.0;
+      // number of Jacobi steps the history predicts: the residual contracts by scf_contract per step
+      int nhat = 0;
+      if (pred >= 1.1 * thresh && scf_contract > 0.0 && scf_contract < 0.95 && thresh > 0.0) {
+        double r = pred;
+        while (nhat <= E_CHAIN && r >= thresh) { r *= scf_contract; ++nhat; }
+      }
+      const bool chain = spec_mode < 0 && !speculate && top.na <= chain_max && nhat >= 1 && nhat <= E_CHAIN &&
+                         nhat + 2 <= max_cycle && !act_fresh && act_n > 0;
+      static const bool scf_trace = getenv("ADMP_SCF_TRACE") != nullptr;     // one line per call: which form ran
+      if (scf_trace) fprintf(stderr, "[admp scf] %s (predicted residual %.4g, threshold %.4g, %d steps)\n",
+                             chain ? "chained" : (speculate ? "speculative" : "plain"), pred, thresh, chain ? nhat : 0);
+      if (chain) {
+        n_act = act_n;
+        { TIMED("pair_field");
+          launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
+                               act_d.as<int>(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole); }
+        recip_pass(E_SCF_RECIP);
+        { TIMED("gather_field");
+          launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(),
+                                 act_d.as<int>(), 1, nact_arg()); }
+        if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
+        fmax_clean = false;
+        auto word = [&](int k) {      // residual of check k: E_FMAX, then the (still zero) chain words of this evaluation
+          return k == 0 ? fmax_word() : reinterpret_cast<unsigned long long*>(Ed_cur() + E_FMAX1 + (k - 1));
+        };
+        launch_field_check(word(0));
+        for (int c = 0; c < nhat; ++c) {
+          scf_jacobi(n_act, word(c), thresh);        // a zero step once a check has passed: later residuals repeat it
+          scf_increment(n_act);
+          launch_field_check(word(c + 1));
+        }
+        stage_pair_full(gbuf);
+        stage_gather(mesh.as<T>(), gbuf, nullptr, false, Ed_cur() + E_SLOTS);
+        launch_finish_only(dpos ? gbuf : nullptr, dQl);
+        read_energies(E_PARTS_SUM, E);
+        nact_seen();
+        f_first = Eh[E_FMAX];
+        f_second = Eh[E_FMAX1];
+        have_base = true;
+        phi_accum = true;
+        int hit = -1;
+        for (int k = 0; k <= nhat && hit < 0; ++k)
+          if ((k == 0 ? Eh[E_FMAX] : Eh[E_FMAX1 + k - 1]) < thresh) hit = k;
+        if (hit >= 0) {
+          i = hit;
+          f_final = hit == 0 ? Eh[E_FMAX] : Eh[E_FMAX1 + hit - 1];
+          phi_valid = done = finished = true;
+          ev.active = false;
+        } else {   // more cycles are needed: undo the energy sums of the closing pass, go on like the plain loop
+          HIP_TRY(hipMemsetAsync(Ed_cur() + E_SELF, 0, 2 * sizeof(double), stream));
+          HIP_TRY(hipMemsetAsync(Ed_cur() + E_SLOTS, 0, E_PARTS * sizeof(double), stream));
+          f_final = Eh[E_FMAX1 + nhat - 1];
+          scf_jacobi(n_act);
+          i = nhat + 1;
+        }
+      }
       if (speculate) {
         // Steady-state MD regime (the previous call converged at its first check): evaluate the FIRST SCF cycle
         // with the full kernels -- they produce dE/dU alongside the gradient -- so that, when the check passes
@@ -1249,6 +1323,7 @@ struct Engine : EngineBase {
         }
         const double fmax = scf_check(&n_act);
         if (f_first < 0.0) f_first = fmax;
+        else if (f_second < 0.0) f_second = fmax;
         f_final = fmax;
         if (fmax < thresh) { phi_valid = true; break; }
         scf_jacobi(n_act);
@@ -1258,8 +1333,10 @@ struct Engine : EngineBase {
       flag = (i != max_cycle - 1);             // admp/pme.py:139-143
       warm_regime = (cyc == 0);
       if (f_first >= 0.0) {
-        if (scf_last >= 0.0) scf_growth = f_first - scf_last;
+        if (scf_last >= 0.0) scf_growth[scf_state] = f_first - scf_last;
         scf_last = f_final;
+        scf_state = cyc > 0 ? 1 : 0;
+        if (cyc >= 1 && f_first > 0.0 && f_final > 0.0 && f_final < f_first) scf_contract = std::pow(f_final / f_first, 1.0 / cyc);
       }
     }
 

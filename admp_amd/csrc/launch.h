@@ -64,7 +64,8 @@ constexpr int kMaxGroup = 4;
 // energies[] slots on the device
 enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_NACT = 4 /* int: number of polarizable sites (k_prepare_sites) */,
        E_SCRATCH = 5 /* energy of passes whose energy nobody reads */, E_SCF_RECIP = 6, E_FMAX = 7 /* bit pattern */,
-       E_SLOTS = 8,
+       E_FMAX1 = 8 /* bit patterns: residuals of checks 1 .. E_CHAIN of a chained SCF (engine.hip) */, E_CHAIN = 6,
+       E_SLOTS = E_FMAX1 + E_CHAIN,
        E_PARTS = 64 /* partial sums of the atom-side reciprocal energy (k_gather<.., true>): 32k workgroups adding into ONE
                        word serialise at the memory side (0.2 ms at 1M atoms); 64 words take them in parallel */,
        E_WORDS = E_SLOTS + E_PARTS /* one half of the double-buffered energy block */ };
@@ -111,7 +112,8 @@ void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* 
 // that the increment's spread / gather read
 template <class T>
 void launch_jacobi_delta(hipStream_t st, int n_act, const int* act, const T* pol, const T* field, T* Ucart, Site<T>* sites,
-                         Site<T>* isites);
+                         Site<T>* isites, const unsigned long long* gate = nullptr /* device word: bit pattern of the residual */,
+                         double gate_min = 0.0 /* with gate: a zero step unless residual >= gate_min */);
 // Unew <- U - field * pol / DIELECTRIC (admp/pme.py:138), refreshing the packed harmonic copy (Unew may be U)
 template <class T>
 void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, const T* Ucart, T* Unew,

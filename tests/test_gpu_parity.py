@@ -1351,16 +1351,21 @@ np.savez(sys.argv[1], **out)
 print('SEQ-OK', [int(out['double_%%d_c' %% k][0]) for k in range(8)])
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode, extra in {'auto': {}, 'plain': dict(ADMP_SPECULATE='0'), 'speculative': dict(ADMP_SPECULATE='1')}.items():
+    # auto: the form is chosen per call from the residual history, incl. the chained form (whole step enqueued at once, the
+    # Jacobi step gated on the device); nochain: auto without the chained form
+    for mode, extra in {'auto': dict(ADMP_SCF_TRACE='1'), 'nochain': dict(ADMP_SCF_CHAIN_MAX='0'), 'plain': dict(ADMP_SPECULATE='0'),
+                        'speculative': dict(ADMP_SPECULATE='1')}.items():
         path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
                            env=dict(os.environ, **extra), timeout=600)
         assert r.returncode == 0 and 'SEQ-OK' in r.stdout, mode + r.stdout[-2000:] + r.stderr[-3000:]
         res[mode] = dict(np.load(path))
+        if mode == 'auto':
+            assert 'chained' in r.stderr and 'speculative' in r.stderr and 'plain' in r.stderr, r.stderr[-2000:]
     cycles = [int(res['plain']['double_%d_c' % k][0]) for k in range(8)]
     assert min(cycles) == 0 and max(cycles) >= 1, cycles          # the sequence exercises both outcomes of the first check
     for key, a in res['plain'].items():
-        for mode in ('auto', 'speculative'):
+        for mode in ('auto', 'nochain', 'speculative'):
             b = res[mode][key]
             if key.endswith('_c'):
                 assert (a == b).all(), (mode, key, a, b)

@@ -4,6 +4,7 @@
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import time
 import torch
 import bench as B
 
@@ -13,9 +14,15 @@ w = B.make_workload(name)
 f, a = B.make_force(w)
 frames = B.ThermalFrames(w, torch.device('cuda', 0))
 U = None
-seq = []
+seq, ms = [], []
+fr = [frames.step_frame(k) for k in range(steps)]
+torch.cuda.synchronize()
 for k in range(steps):
-    B.step(f, a, U, frames.step_frame(k))
+    t0 = time.perf_counter()
+    B.step(f, a, U, fr[k])
     U = f.U_ind
+    torch.cuda.synchronize()
+    ms.append((time.perf_counter() - t0) * 1e3)
     seq.append(int(f.n_cycle))
+print('ms per step (synchronised):', ' '.join('%.3f' % m for m in ms[-12:]))
 print(name, 'updates per step:', ''.join(str(min(s, 9)) for s in seq), 'mean %.2f' % (sum(seq[5:]) / float(len(seq) - 5)))
