@@ -55,15 +55,7 @@ class ADMPDispPmeForce(HipForceBase):
         na = self.n_atoms
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
-        if isinstance(c_list, torch.Tensor):
-            c = c_list.detach().to(device=self._device, dtype=self._dtype)
-        else:
-            c = torch.as_tensor(np.asarray(c_list, dtype=np.float64), dtype=self._dtype).to(self._device)
-        nc = (self.pmax - 4) // 2
-        if c.dim() != 2 or c.shape[0] != na or c.shape[1] < nc:
-            raise ValueError('c_list must be (Na, >= (pmax-4)/2)')
-        c3 = torch.zeros((na, 3), dtype=self._dtype, device=self._device)
-        c3[:, :nc] = c[:, :nc]
+        c3 = self._packed_c(c_list)
         mS = self._host64(mScales)
         E = (ctypes.c_double * 3)()
         grad = torch.empty((na, 3), dtype=self._dtype, device=self._device) if want_grad else None
@@ -73,16 +65,34 @@ class ADMPDispPmeForce(HipForceBase):
         self.energy_parts = tuple(E)
         return np.float64(E[0] + E[1] + E[2]), grad
 
+    def _packed_c(self, c_list):
+        """(Na, 3) device rows (C6, C8, C10; unused powers zero) in the handle's precision.  Packing is a fill + a copy per call:
+        the packed tensor is kept while c_list is the same torch tensor, not written since (as pairwise._packed_params does)."""
+        na = self.n_atoms
+        nc = (self.pmax - 4) // 2
+        key = None
+        if isinstance(c_list, torch.Tensor):
+            key = (id(c_list), c_list.data_ptr(), c_list._version)
+            hit = getattr(self, '_c_cache', None)
+            if hit is not None and hit[0] == key:
+                return hit[1]
+            c = c_list.detach().to(device=self._device, dtype=self._dtype)
+        else:
+            c = torch.as_tensor(np.asarray(c_list, dtype=np.float64), dtype=self._dtype).to(self._device)
+        if c.dim() != 2 or c.shape[0] != na or c.shape[1] < nc:
+            raise ValueError('c_list must be (Na, >= (pmax-4)/2)')
+        c3 = torch.zeros((na, 3), dtype=self._dtype, device=self._device)
+        c3[:, :nc] = c[:, :nc]
+        self._c_cache = (key, c3, c_list) if key is not None else None      # (the tensor stays alive: its id stays unique)
+        return c3
+
     def get_energy_and_box_gradient(self, positions, box, pairs, c_list, mScales):
         """(E, dE/dbox (3,3)) at fixed Cartesian positions: `value_and_grad(get_energy, argnums=1)` of the reference."""
         with self._on_stream():
             na = self.n_atoms
             self.set_pairs(pairs)
             pos = self._real(positions, (na, 3))
-            nc = (self.pmax - 4) // 2
-            c = c_list.detach() if isinstance(c_list, torch.Tensor) else torch.as_tensor(np.asarray(c_list, dtype=np.float64))
-            c3 = torch.zeros((na, 3), dtype=self._dtype, device=self._device)
-            c3[:, :nc] = c.to(device=self._device, dtype=self._dtype)[:, :nc]
+            c3 = self._packed_c(c_list)
             mS = self._host64(mScales)
             E = (ctypes.c_double * 3)()
             dbox = (ctypes.c_double * 9)()
