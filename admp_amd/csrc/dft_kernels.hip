@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int 
 template <class T, int KQ>
 __global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int NL, int TK, const Cx<T>* __restrict__ spec,
                                                         T* __restrict__ mesh, const Cx<T>* __restrict__ twg,
-                                                        long mesh_stride, long spec_stride) {
+                                                        long mesh_stride, long spec_stride, T* __restrict__ accum) {
   mesh += blockIdx.y * mesh_stride;
   spec += blockIdx.y * spec_stride;
   const int H = (N - 1) / 2, Kh = N / 2 + 1;
@@ -109,12 +109,17 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int 
     T xj[KQ], xnj[KQ];
     irdft_pair_outputs<T, KQ>(N, j, NL, p + l, X0[l], Xn[l], tw, xj, xnj);
     T* x = mesh + (long)(line0 + l) * N;
+    T* acc = accum ? accum + (long)(line0 + l) * N : nullptr;   // SCF increment: phi += this mesh in the same pass
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const int jq = g + q * TK;
       if (jq < Kh) {
         x[jq] = xj[q];
-        if (jq != 0 && 2 * jq != N) x[N - jq] = xnj[q];
+        if (acc) acc[jq] += xj[q];
+        if (jq != 0 && 2 * jq != N) {
+          x[N - jq] = xnj[q];
+          if (acc) acc[N - jq] += xnj[q];
+        }
       }
     }
   }
@@ -310,9 +315,12 @@ template <class T>
 void launch_dftm_x_conv(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long);
 
 template <class T>
-void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb, long mesh_stride,
-                  long spec_stride) {
-  if (dftm_enabled(K[2])) return launch_dftm_z<T>(st, K, tw, mesh, spec, inverse, nb, mesh_stride, spec_stride);
+bool launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb, long mesh_stride,
+                  long spec_stride, T* accum) {
+  if (dftm_enabled(K[2])) {
+    launch_dftm_z<T>(st, K, tw, mesh, spec, inverse, nb, mesh_stride, spec_stride);
+    return false;
+  }
   const int N = K[2], nlines = K[0] * K[1], H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NL = dft_cols(N, dft_kq(), sizeof(Cx<T>) * (size_t)H + 2 * sizeof(T), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(Cx<T>) * (size_t)(N + H * NL) + sizeof(T) * 2 * (size_t)NL;
@@ -320,10 +328,12 @@ void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec,
   const dim3 grid((nlines + NL - 1) / NL, nb);
   const long ss = spec_stride / 2;       // strides are given in reals; the kernels index complex numbers
   if (inverse) {
-    KQ_SWITCH((k_dft_z_c2r<T, KQ><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, reinterpret_cast<const Cx<T>*>(spec), mesh, t2, mesh_stride, ss)))
-  } else {
-    KQ_SWITCH((k_dft_z_r2c<T, KQ><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, mesh, reinterpret_cast<Cx<T>*>(spec), t2, mesh_stride, ss)))
+    KQ_SWITCH((k_dft_z_c2r<T, KQ><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, reinterpret_cast<const Cx<T>*>(spec), mesh, t2, mesh_stride, ss,
+                                                              nb == 1 ? accum : nullptr)))
+    return accum != nullptr && nb == 1;
   }
+  KQ_SWITCH((k_dft_z_r2c<T, KQ><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, mesh, reinterpret_cast<Cx<T>*>(spec), t2, mesh_stride, ss)))
+  return false;
 }
 template <class T>
 void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse, int nb, long spec_stride) {
@@ -356,7 +366,7 @@ void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, con
 }
 #undef KQ_SWITCH
 #define INST(T)                                                                                   \
-  template void launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long); \
+  template bool launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*); \
   template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int, int, long);           \
   template void launch_dft_x_conv<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long);
 INST(float)

@@ -702,7 +702,9 @@ struct Engine : EngineBase {
     return true;
   }
   // mesh <- IFFT( G * FFT(mesh) ), energies[slot] += sum w G |S|^2 : the whole k-space leg of one reciprocal pass
-  void convolve(T* mesh_p, T* spec_p, const T* gtab, int slot) {
+  // accum (optional): a second mesh the result is to be ADDED to; returns true when the last pass did that itself (the direct
+  // DFT writes every word once anyway), false when the caller still has to add
+  bool convolve(T* mesh_p, T* spec_p, const T* gtab, int slot, T* accum = nullptr) {
     double* Ed = Ed_cur();
     if (use_pfa) {
       const T* tw = pfa_tw.as<T>();
@@ -713,7 +715,7 @@ struct Engine : EngineBase {
       { TIMED("dft_x_kspace"); launch_pfa_x_conv<T>(stream, pfa, tw, spec_p, tabs, Ed, slot); }
       { TIMED("dft_y_inv"); launch_pfa_y<T>(stream, pfa, tw, spec_p, 1); }
       { TIMED("dft_z_c2r"); launch_pfa_z<T>(stream, pfa, tw, mesh_p, spec_p, 1); }
-      return;
+      return false;
     }
     if (use_dft) {
       const T* tw = dft_tw.as<T>();
@@ -723,18 +725,20 @@ struct Engine : EngineBase {
       tabs.p[0] = gtab;
       { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec_p, tabs, Ed, slot); }
       { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec_p, 1); }
-      { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 1); }
-      return;
+      bool added;
+      { TIMED("dft_z_c2r"); added = launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 1, 1, 0, 0, accum); }
+      return added;
     }
     if (use_fx) {      // rocFFT for the y-z planes, one fused kernel for x forward * G * x inverse
       run_plan("rocfft_r2c_yz", plan2_f, mesh_p, spec_p);
       { TIMED("fftx_kspace"); launch_fftx_conv<T>(stream, K, fx_tw.as<T>(), spec_p, gtab, Ed, slot); }
       run_plan("rocfft_c2r_yz", plan2_b, spec_p, mesh_p);
-      return;
+      return false;
     }
     fft_forward(mesh_p, spec_p);
     { TIMED("kspace"); launch_kspace<T>(stream, K, nyown(), gtab, spec_p, Ed, slot); }
     fft_inverse(spec_p, mesh_p);
+    return false;
   }
 
   void run_plan(const char* label, rocfft_plan plan, void* in, void* out) {
@@ -1126,11 +1130,11 @@ struct Engine : EngineBase {
                                 reuse ? 1 : 0);
       ind_bins_eval = eval_seq; ind_bins_n = n_act; ind_bins_gen = act_gen; ind_bins_at = bins_ind.cell_start;
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)}; }
-    convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH);
+    const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>());
     { TIMED("gather_field_ind");
       launch_gather_field<T>(stream, n_act, isites.as<Site<T>>(), ev.g, mesh2.as<T>(), fld_recip.as<T>(), nullptr, 1, nullptr,
                              act_d.as<int>()); }
-    { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)nreal, mesh.as<T>(), mesh2.as<T>()); }
+    if (!added) { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)nreal, mesh.as<T>(), mesh2.as<T>()); }
   }
 
   // one device->host copy + sync: energies (and the max|field| word, returned)

@@ -160,8 +160,9 @@ struct DftTabs {
   const T* p[3] = {nullptr, nullptr, nullptr};
 };
 template <class T>
-void launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb = 1,
-                  long mesh_stride = 0, long spec_stride = 0);                                    // r2c / c2r along z
+bool launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb = 1,
+                  long mesh_stride = 0, long spec_stride = 0,                                     // r2c / c2r along z
+                  T* accum = nullptr /* c2r of one mesh: accum += result as well; returns whether that was done */);
 template <class T>
 void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse, int nb = 1,
                   long spec_stride = 0);                                                          // in place along y
