@@ -856,6 +856,7 @@ struct Engine : EngineBase {
     const int na = top.na;
     double inv[9], vol;
     ++eval_seq;
+    ff_done = nullptr;
     ensure_mesh();
     ev.bx = make_box(box, inv, &vol);
     ev.g = make_geom(inv);
@@ -1081,13 +1082,8 @@ struct Engine : EngineBase {
     if (rc != 0) throw Err{ADMP_E_HIP, std::string("sort_ints: ") + hipGetErrorString((hipError_t)rc)};
   }
   double scf_check(int* n_act) {          // total field + its maximum over the polarizable sites; one host read
-    if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
-    fmax_clean = false;
-    {
-      TIMED("field_finish");
-      launch_field_finish<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
-                             (T)kappa, field.as<T>(), fmax_word(), act_d.as<int>(), nact_arg());
-    }
+    if (ff_done == fmax_word()) ff_done = nullptr;            // formed by the field gather before this check
+    else launch_field_check(next_check_word());
     double dummy[4];
     const double fmax = read_energies(E_SCF_RECIP, dummy);
     nact_seen();
@@ -1101,13 +1097,37 @@ struct Engine : EngineBase {
     launch_jacobi_delta<T>(stream, n_act, act_d.as<int>(), ev.pol, field.as<T>(), ev.U, sites.as<Site<T>>(),
                            isites.as<Site<T>>(), gate, gate_min);
   }
+  // Small systems are dispatch-bound: the SCF residual rides in the epilogue of the field gather that precedes a check
+  // (field_epilogue(word) describes it; the check's own kernel is then skipped).  word: a zero word of the energy block.
+  const unsigned long long* ff_done = nullptr;
+  bool fuse_ok() const {
+    static const int fuse_max = [] { const char* e = getenv("ADMP_FUSE_FF_MAX"); return e ? atoi(e) : 16384; }();
+    return top.na <= fuse_max && snranks == 1 && !ev.home;
+  }
+  FieldFin<T> field_epilogue(unsigned long long* word) {
+    FieldFin<T> ff;
+    if (!word || !fuse_ok()) return ff;
+    ff.pol = ev.pol; ff.Ucart = ev.U; ff.fld_pair = fld_pair.as<T>(); ff.kappa = (T)kappa;
+    ff.field = field.as<T>(); ff.fmax_bits = word; ff.sites = sites.as<Site<T>>();
+    ff_done = word;
+    return ff;
+  }
+  // the word the next plain check writes: fmax_word(), cleared if this evaluation has used it
+  unsigned long long* next_check_word() {
+    if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
+    fmax_clean = false;
+    return fmax_word();
+  }
   // total field of the polarizable rows and its maximum into `word` (a zero word of this evaluation's energy block); no read
   void launch_field_check(unsigned long long* word) {
+    if (ff_done == word) { ff_done = nullptr; return; }     // the field gather before it has done this
+    ff_done = nullptr;
     TIMED("field_finish");
     launch_field_finish<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
                            (T)kappa, field.as<T>(), word, act_d.as<int>(), nact_arg());
   }
-  void scf_increment(int n_act) {         // fld_pair / fld_recip / phi <- their values for the dipoles after scf_jacobi
+  // check_word: the zero word the check after this increment writes (its residual then rides in the field gather)
+  void scf_increment(int n_act, unsigned long long* check_word = nullptr) {   // fld_pair / fld_recip / phi <- their values for the dipoles after scf_jacobi
     if (n_act <= 0) return;
     if (ind_nbr_gen != nbr_gen || ind_act_gen != act_gen) {      // neighbour table or polarizable set changed
       TIMED("ind_table");
@@ -1133,7 +1153,7 @@ struct Engine : EngineBase {
     const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>());
     { TIMED("gather_field_ind");
       launch_gather_field<T>(stream, n_act, isites.as<Site<T>>(), ev.g, mesh2.as<T>(), fld_recip.as<T>(), nullptr, 1, nullptr,
-                             act_d.as<int>()); }
+                             act_d.as<int>(), check_word ? field_epilogue(check_word) : FieldFin<T>()); }
     if (!added) { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)nreal, mesh.as<T>(), mesh2.as<T>()); }
   }
 
@@ -1252,18 +1272,17 @@ struct Engine : EngineBase {
           launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
                                act_d.as<int>(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole); }
         recip_pass(E_SCF_RECIP);
-        { TIMED("gather_field");
-          launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(),
-                                 act_d.as<int>(), 1, nact_arg()); }
-        if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
-        fmax_clean = false;
         auto word = [&](int k) {      // residual of check k: E_FMAX, then the (still zero) chain words of this evaluation
           return k == 0 ? fmax_word() : reinterpret_cast<unsigned long long*>(Ed_cur() + E_FMAX1 + (k - 1));
         };
+        next_check_word();
+        { TIMED("gather_field");
+          launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(),
+                                 act_d.as<int>(), 1, nact_arg(), nullptr, field_epilogue(word(0))); }
         launch_field_check(word(0));
         for (int c = 0; c < nhat; ++c) {
           scf_jacobi(n_act, word(c), thresh);        // a zero step once a check has passed: later residuals repeat it
-          scf_increment(n_act);
+          scf_increment(n_act, word(c + 1));
           launch_field_check(word(c + 1));
         }
         stage_pair_full(gbuf);
@@ -1327,12 +1346,13 @@ struct Engine : EngineBase {
             launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
                                  act_d.as<int>(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole); }
           recip_pass(E_SCF_RECIP);
+          unsigned long long* w = fuse_ok() ? next_check_word() : nullptr;
           { TIMED("gather_field");
             launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(),
-                                   act_d.as<int>(), 1, nact_arg()); }
+                                   act_d.as<int>(), 1, nact_arg(), nullptr, field_epilogue(w)); }
           have_base = true;
         } else {
-          scf_increment(n_act);
+          scf_increment(n_act, fuse_ok() ? next_check_word() : nullptr);
           phi_accum = true;
         }
         const double fmax = scf_check(&n_act);

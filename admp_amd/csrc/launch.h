@@ -81,6 +81,7 @@ struct FieldFin {
   T kappa = 0;
   T* field = nullptr;
   unsigned long long* fmax_bits = nullptr;   // nullptr = epilogue off
+  const Site<T>* sites = nullptr;            // field-gather variant only: the full site rows (its own rows may be compact)
 };
 // ---- atom_kernels.hip
 template <class T>
@@ -351,7 +352,9 @@ template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
                          T* fld_recip, const int* list, int nb = 1 /* batch: phi of b at phi + b * mesh size, fld + b * 3 * na */,
                          const int* n_dev = nullptr /* atom count on the device (na = grid bound) */,
-                         const int* add_to = nullptr /* rows are compact: ADD the result to fld_recip[3 * add_to[slot]] */);
+                         const int* add_to = nullptr /* rows are compact: ADD the result to fld_recip[3 * add_to[slot]] */,
+                         const FieldFin<T>& ff = FieldFin<T>() /* small systems: total dE/dU and its maximum of the rows' atoms
+                                                                 ride along (launch_field_finish's work; nb = 1) */);
 // a += b over n mesh points
 template <class T>
 void launch_mesh_add(hipStream_t st, long n, T* a, const T* b);

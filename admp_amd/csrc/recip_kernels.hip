@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(kGsBlock) void k_gather_field_staged(int na, const 
                                                                   RecipGeom<T> g, const T* __restrict__ phi,
                                                                   T* __restrict__ fld, const int* __restrict__ list,
                                                                   const int* __restrict__ n_dev,
-                                                                  const int* __restrict__ add_to) {
+                                                                  const int* __restrict__ add_to, FieldFin<T> ff) {
   __shared__ W4<T> w[kGsAtoms][kGsRow];
   __shared__ int sbase[kGsAtoms][4];
   __shared__ T part[3][kGsBlock];
@@ -1075,20 +1075,38 @@ __global__ __launch_bounds__(kGsBlock) void k_gather_field_staged(int na, const 
   }
   part[0][threadIdx.x] = f[0]; part[1][threadIdx.x] = f[1]; part[2][threadIdx.x] = f[2];
   __syncthreads();
+  if (threadIdx.x >= 64) return;                         // one wave converts the 32 atoms
   const int slot = slot0 + (int)threadIdx.x;
-  if (threadIdx.x >= kGsAtoms || slot >= na) return;
+  const bool on = threadIdx.x < kGsAtoms && slot < na;
+  double fm = 0.0;
+  if (on) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const T* q = &part[k][6 * threadIdx.x];
-    f[k] = ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]);
+    for (int k = 0; k < 3; ++k) {
+      const T* q = &part[k][6 * threadIdx.x];
+      f[k] = ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]);
+    }
+    const T* A = g.Aop;
+    const int i = list ? list[slot] : slot;
+    const int owner = add_to ? add_to[slot] : i;
+    T* o = fld + 3 * (size_t)owner;
+    T r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const T v = A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
+      r[k] = add_to ? o[k] + v : v;     // compact rows (incremental SCF): accumulate into the owning atom's entry
+      o[k] = r[k];
+    }
+    if (ff.fmax_bits) {   // kernel-uniform: the SCF residual of these atoms and its maximum (k_field_finish's work)
+      const T al = ff.pol[owner];
+      T fx, fy, fz;
+      total_field(ff.sites[owner], al, ff.Ucart + 3 * owner, ff.fld_pair + 3 * owner, r, ff.kappa, fx, fy, fz);
+      ff.field[3 * owner] = fx; ff.field[3 * owner + 1] = fy; ff.field[3 * owner + 2] = fz;
+      if (al > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
+    }
   }
-  const T* A = g.Aop;
-  const int i = list ? list[slot] : slot;
-  T* o = add_to ? fld + 3 * (size_t)add_to[slot] : fld + 3 * (size_t)i;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const T v = A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
-    o[k] = add_to ? o[k] + v : v;       // compact rows (incremental SCF): accumulate into the owning atom's entry
+  if (ff.fmax_bits) {
+    fm = wave_reduce_max(fm);
+    if (threadIdx.x == 0 && fm > 0.0) atomicMax(ff.fmax_bits, nonneg_bits(fm));
   }
 }
 
@@ -1277,11 +1295,11 @@ void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const
 }
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
-                         const int* list, int nb, const int* n_dev, const int* add_to) {
+                         const int* list, int nb, const int* n_dev, const int* add_to, const FieldFin<T>& ff) {
   if (na <= 0) return;
-  if (gather_staged()) {
+  if (gather_staged() || ff.fmax_bits) {
     k_gather_field_staged<T><<<dim3(xcd_grid((unsigned)nblk(na, kGsAtoms)), nb), kGsBlock, 0, st>>>(na, sites, g, phi, fld, list,
-                                                                                                  n_dev, add_to);
+                                                                                                  n_dev, add_to, ff);
     return;
   }
   k_gather_field<T><<<dim3(xcd_grid((unsigned)nblk(na * 8, kGatherBlock)), nb), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list,
@@ -1297,7 +1315,7 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
                                  const int*, T*, const FieldFin<T>&, double*, const BinScratch*, const int4*);          \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
-                                       const int*, int, const int*, const int*);                                      \
+                                       const int*, int, const int*, const int*, const FieldFin<T>&);                  \
   template void launch_kspace_virial<T>(hipStream_t, const int*, const double*, double, double, int, int, const T*,   \
                                         double*);                                                                     \
   template void launch_gather_virial<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, double*, \
