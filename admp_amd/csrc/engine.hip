@@ -1237,23 +1237,23 @@ struct Engine : EngineBase {
       // which form of the first cycle: ADMP_SPECULATE=0 / 1 forces the plain / the speculative one (A/B, tests)
       static const int spec_mode = [] { const char* e = getenv("ADMP_SPECULATE"); return e ? atoi(e) : -1; }();
       // a failed speculation wastes the full pair kernel, the gather and the closing kernel; a successful one saves the field
-      // kernels and one synchronisation: at 3072 atoms that is 30 against 45 us, at 1M atoms 0.55 against 0.18 ms -- large
-      // systems speculate only on a clear prediction
-      const double spec_infl = top.na <= 20000 ? 1.0 : 1.5;     // weight of the observed growth (0 on a static geometry)
+      // kernels and one synchronisation: at 3072 atoms that is 30 against 45 us, at 98k atoms about even, at 1M atoms 0.55
+      // against 0.18 ms -- very large systems speculate only on a clear prediction
+      const double spec_infl = top.na <= 200000 ? 1.0 : 1.5;    // weight of the observed growth (0 on a static geometry)
       const bool have_pred = scf_last >= 0.0 && scf_nobs[scf_state] >= 2;
       const double g_hi = std::max(scf_growth[scf_state][0], scf_growth[scf_state][1]);
       const double g_lo = std::min(scf_growth[scf_state][0], scf_growth[scf_state][1]);
       const bool speculate = spec_mode >= 0 ? spec_mode != 0
                                             : (have_pred ? scf_last + spec_infl * g_hi < thresh : (scf_last < 0.0 && warm_regime));
       double f_first = -1.0, f_final = -1.0, f_second = -1.0;
-      // Chained form (small systems, where a host synchronisation costs as much as three kernels): when the history says the
+      // Chained form (up to 200k atoms; at 3072 atoms a host synchronisation costs as much as three kernels): when the history says the
       // first check will fail and n Jacobi steps will do, the whole call is enqueued at once -- first field evaluation and its
       // check, then n times (Jacobi step GATED on the previous check's residual on the device: a zero step once a check has
       // passed, after which every later residual repeats the passing one; increment; check), the closing pass -- and read back
       // with one synchronisation.  The host then replays the reference's decisions on the n + 1 residuals: same dipoles,
       // cycle count and flag as the plain loop; a wrong guess costs the kernels that ran for nothing (closing pass when more
       // cycles are needed, increments after the check that passed).
-      static const int chain_max = [] { const char* e = getenv("ADMP_SCF_CHAIN_MAX"); return e ? atoi(e) : 20000; }();
+      static const int chain_max = [] { const char* e = getenv("ADMP_SCF_CHAIN_MAX"); return e ? atoi(e) : 200000; }();
       const double pred = have_pred ? scf_last + 0.5 * (g_hi + g_lo) : -1.0;
       // number of Jacobi steps the history predicts: the residual contracts by scf_contract per step
       int nhat = 0;
