@@ -25,10 +25,19 @@ static int dft_kq() {
   }
   return v;
 }
+// threads per output set: ADMP_DFT_JS = 1 (default) | 2.  With 2, a pair of neighbouring lanes shares one task -- each sums half
+// of the pair positions, the halves are combined with one lane exchange: twice the waves, half the dependent chain.  Measured
+// on the 97^3 f64 mesh (< 2 waves per SIMD with one thread per task): SLOWER, x pass 36.8 -> 44.4 us with 256-thread blocks
+// (half the columns per tile: 80-byte instead of 160-byte runs in memory), 38.2 us with 512-thread blocks (same tiles) -- like
+// KQ = 1, more and thinner threads do not help these passes.  Kept for A/B.
+static int dft_js() {
+  static const int v = [] { const char* e = getenv("ADMP_DFT_JS"); return e && atoi(e) == 2 ? 2 : 1; }();
+  return v;
+}
 // thread-tasks per line and lines (columns) per block
 static int dft_tasks(int N, int KQ) { return (N / 2 + 1 + KQ - 1) / KQ; }
 static int dft_cols(int N, int KQ, size_t bytes_per_col, size_t fixed_bytes) {
-  int nc = kDftBlock / dft_tasks(N, KQ);
+  int nc = (kDftBlock / dft_js()) / dft_tasks(N, KQ);
   if (nc < 1) nc = 1;
   while (nc > 1 && fixed_bytes + bytes_per_col * nc > kDftLdsBudget) --nc;
   return nc;
@@ -37,8 +46,48 @@ int dft_tile_cols(int N) { return dft_cols(N, dft_kq(), 0, 0); }
 
 extern __shared__ __align__(32) unsigned char dft_smem[];
 
+// task index of a thread and which half of the pair positions it sums (JS = 2: lanes 2i, 2i+1 share task i)
+template <int JS>
+__device__ __forceinline__ void dft_task_of_thread(int& tid, int& half) {
+  tid = JS == 2 ? (int)(threadIdx.x >> 1) : (int)threadIdx.x;
+  half = JS == 2 ? (int)(threadIdx.x & 1) : 0;
+}
+template <class T>
+__device__ __forceinline__ T pair_lane_sum(T v) { return v + __shfl_xor(v, 1, 64); }
+
+// dft_pair_core / real_pair_sums over this thread's share of the positions, shares combined: every lane gets the full outputs
+template <class T, int SIGN, int KQ, int JS>
+__device__ __forceinline__ void dft_pair_outputs_js(int N, const int* k, int stride, const PairCx<T>* ab, Cx<T> x0, Cx<T> xn,
+                                                    const Cx<T>* tw, int half, Cx<T>* Xk, Cx<T>* Xnk) {
+  T Are[KQ], Aim[KQ], Bre[KQ], Bim[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) Are[q] = Aim[q] = Bre[q] = Bim[q] = T(0);
+  const int H = (N - 1) / 2, mid = JS == 2 ? dft_split(N) : H;
+  dft_pair_partial<T, KQ>(N, k, [=](int j) { return ab[j * stride]; }, tw, half ? mid : 0, half ? H : mid, Are, Aim, Bre, Bim);
+  if (JS == 2) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      Are[q] = pair_lane_sum(Are[q]); Aim[q] = pair_lane_sum(Aim[q]);
+      Bre[q] = pair_lane_sum(Bre[q]); Bim[q] = pair_lane_sum(Bim[q]);
+    }
+  }
+  dft_pair_finish<T, SIGN, KQ>(N, k, x0, xn, Are, Aim, Bre, Bim, Xk, Xnk);
+}
+template <class T, int KQ, int JS>
+__device__ __forceinline__ void real_pair_sums_js(int N, const int* k, int stride, const Cx<T>* p, const Cx<T>* tw, int half,
+                                                  T* P, T* R) {
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) P[q] = R[q] = T(0);
+  const int H = (N - 1) / 2, mid = JS == 2 ? dft_split(N) : H;
+  real_pair_partial<T, KQ>(N, k, stride, p, tw, half ? mid : 0, half ? H : mid, P, R);
+  if (JS == 2) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) { P[q] = pair_lane_sum(P[q]); R[q] = pair_lane_sum(R[q]); }
+  }
+}
+
 // ---- z lines (contiguous): real mesh [nlines][N] -> half spectrum [nlines][N/2+1]
-template <class T, int KQ>
+template <class T, int KQ, int JS>
 __global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int NL, int TK, const T* __restrict__ mesh,
                                                         Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg,
                                                         long mesh_stride, long spec_stride) {
@@ -64,21 +113,30 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_z_r2c(int N, int nlines, int 
     xn[threadIdx.x] = (N & 1) ? T(0) : x[N / 2];
   }
   __syncthreads();
-  const int l = threadIdx.x / TK, g = threadIdx.x - l * TK;
+  int tid, half;
+  dft_task_of_thread<JS>(tid, half);
+  const int l = tid / TK, g = tid - l * TK;
   if (l < nl) {
     int k[KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
-    Cx<T> X[KQ];
-    rdft_outputs<T, KQ>(N, k, NL, p + l, x0[l], xn[l], tw, X);
+    T P[KQ], R[KQ];
+    real_pair_sums_js<T, KQ, JS>(N, k, NL, p + l, tw, half, P, R);
 #pragma unroll
-    for (int q = 0; q < KQ; ++q)
-      if (g + q * TK < Kh) spec[(long)(line0 + l) * Kh + g + q * TK] = X[q];
+    for (int q = 0; q < KQ; ++q) {
+      if (g + q * TK < Kh && (JS == 1 || half == (q & 1))) {        // the two lanes of a task share the stores
+        Cx<T> X;
+        X.re = x0[l] + P[q];
+        if ((N & 1) == 0) X.re += (k[q] & 1) ? -xn[l] : xn[l];
+        X.im = -R[q];
+        spec[(long)(line0 + l) * Kh + g + q * TK] = X;
+      }
+    }
   }
 }
 
 // ---- z lines back: half spectrum -> real mesh
-template <class T, int KQ>
+template <class T, int KQ, int JS>
 __global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int NL, int TK, const Cx<T>* __restrict__ spec,
                                                         T* __restrict__ mesh, const Cx<T>* __restrict__ twg,
                                                         long mesh_stride, long spec_stride, T* __restrict__ accum) {
@@ -101,24 +159,32 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_z_c2r(int N, int nlines, int 
   }
   if ((N & 1) && threadIdx.x < nl) Xn[threadIdx.x] = T(0);
   __syncthreads();
-  const int l = threadIdx.x / TK, g = threadIdx.x - l * TK;
+  int tid, half;
+  dft_task_of_thread<JS>(tid, half);
+  const int l = tid / TK, g = tid - l * TK;
   if (l < nl) {
     int j[KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q) j[q] = (g + q * TK < Kh) ? g + q * TK : 0;
-    T xj[KQ], xnj[KQ];
-    irdft_pair_outputs<T, KQ>(N, j, NL, p + l, X0[l], Xn[l], tw, xj, xnj);
+    T P[KQ], R[KQ];
+    real_pair_sums_js<T, KQ, JS>(N, j, NL, p + l, tw, half, P, R);
     T* x = mesh + (long)(line0 + l) * N;
     T* acc = accum ? accum + (long)(line0 + l) * N : nullptr;   // SCF increment: phi += this mesh in the same pass
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const int jq = g + q * TK;
       if (jq < Kh) {
-        x[jq] = xj[q];
-        if (acc) acc[jq] += xj[q];
-        if (jq != 0 && 2 * jq != N) {
-          x[N - jq] = xnj[q];
-          if (acc) acc[N - jq] += xnj[q];
+        T base = X0[l] + T(2) * P[q];
+        if ((N & 1) == 0) base += (j[q] & 1) ? -Xn[l] : Xn[l];
+        if (JS == 1 || half == 0) {                                  // lane 0 of the task stores x_j, lane 1 x_{N-j}
+          const T v = base - T(2) * R[q];
+          x[jq] = v;
+          if (acc) acc[jq] += v;
+        }
+        if ((JS == 1 || half == 1) && jq != 0 && 2 * jq != N) {
+          const T v = base + T(2) * R[q];
+          x[N - jq] = v;
+          if (acc) acc[N - jq] += v;
         }
       }
     }
@@ -152,7 +218,7 @@ __device__ __forceinline__ void load_pairs(int N, int NC, int nca, const Cx<T>* 
 }
 
 // ---- strided complex lines, in place (y lines: fix = x plane; x lines: fix = y row)
-template <class T, int SIGN, int KQ>
+template <class T, int SIGN, int KQ, int JS>
 __global__ __launch_bounds__(kDftBlock) void k_dft_strided(int N, int ncols, int NC, int TK, long jstride, long fixstride,
                                                           Cx<T>* __restrict__ spec, const Cx<T>* __restrict__ twg,
                                                           long spec_stride) {
@@ -168,26 +234,28 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_strided(int N, int ncols, int
   for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
   load_pairs<T>(N, NC, nca, spec, base, jstride, ab, x0, xn);
   __syncthreads();
-  const int g = threadIdx.x / NC, c = threadIdx.x - g * NC;
+  int tid, half;
+  dft_task_of_thread<JS>(tid, half);
+  const int g = tid / NC, c = tid - g * NC;
   if (g < TK && c < nca) {
     int k[KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
     Cx<T> Xk[KQ], Xnk[KQ];
-    dft_pair_outputs<T, SIGN, KQ>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+    dft_pair_outputs_js<T, SIGN, KQ, JS>(N, k, NC, ab + c, x0[c], xn[c], tw, half, Xk, Xnk);
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const int kq = g + q * TK;
       if (kq < Kh) {
-        spec[base + (long)kq * jstride + c] = Xk[q];
-        if (kq != 0 && 2 * kq != N) spec[base + (long)(N - kq) * jstride + c] = Xnk[q];
+        if (JS == 1 || half == 0) spec[base + (long)kq * jstride + c] = Xk[q];
+        if ((JS == 1 || half == 1) && kq != 0 && 2 * kq != N) spec[base + (long)(N - kq) * jstride + c] = Xnk[q];
       }
     }
   }
 }
 
 // ---- x lines: forward, multiply by G (accumulating sum w G |S|^2, recip.py:400-414 / pme.py:240), inverse; in place
-template <class T, int KQ>
+template <class T, int KQ, int JS>
 __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int NC, int TK, long jstride, long fixstride,
                                                          int K3, Cx<T>* __restrict__ spec, DftTabs<T> tabs,
                                                          const Cx<T>* __restrict__ twg, double* energies, int slot,
@@ -225,20 +293,22 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   }
   load_pairs<T>(N, NC, nca, spec, base, jstride, ab, x0, xn);
   __syncthreads();
-  const int g = threadIdx.x / NC, c = threadIdx.x - g * NC;
+  int tid, half;
+  dft_task_of_thread<JS>(tid, half);
+  const int g = tid / NC, c = tid - g * NC;
   const bool task = g < TK && c < nca;
   int k[KQ];
 #pragma unroll
   for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
   if (task) {
     Cx<T> Xk[KQ], Xnk[KQ];
-    dft_pair_outputs<T, -1, KQ>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+    dft_pair_outputs_js<T, -1, KQ, JS>(N, k, NC, ab + c, x0[c], xn[c], tw, half, Xk, Xnk);
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const int kq = g + q * TK;
       if (kq < Kh) {
-        S[kq * NC + c] = Xk[q];
-        if (kq != 0 && 2 * kq != N) S[(N - kq) * NC + c] = Xnk[q];
+        if (JS == 1 || half == 0) S[kq * NC + c] = Xk[q];
+        if ((JS == 1 || half == 1) && kq != 0 && 2 * kq != N) S[(N - kq) * NC + c] = Xnk[q];
       }
     }
   }
@@ -283,13 +353,13 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   __syncthreads();
   if (task) {
     Cx<T> Xk[KQ], Xnk[KQ];
-    dft_pair_outputs<T, +1, KQ>(N, k, NC, ab + c, x0[c], xn[c], tw, Xk, Xnk);
+    dft_pair_outputs_js<T, +1, KQ, JS>(N, k, NC, ab + c, x0[c], xn[c], tw, half, Xk, Xnk);
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const int kq = g + q * TK;
       if (kq < Kh) {
-        spec[base + (long)kq * jstride + c] = Xk[q];
-        if (kq != 0 && 2 * kq != N) spec[base + (long)(N - kq) * jstride + c] = Xnk[q];
+        if (JS == 1 || half == 0) spec[base + (long)kq * jstride + c] = Xk[q];
+        if ((JS == 1 || half == 1) && kq != 0 && 2 * kq != N) spec[base + (long)(N - kq) * jstride + c] = Xnk[q];
       }
     }
   }
@@ -298,12 +368,15 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
 }
 
 // ---- launchers.  K = mesh dimensions, tw = (cos, sin) tables of K[0], K[1], K[2] back to back.
-#define KQ_SWITCH(CALL)            \
+#define KQ_SWITCH_JS(CALL)         \
   switch (dft_kq()) {              \
     case 1: { constexpr int KQ = 1; CALL; } break; \
     case 4: { constexpr int KQ = 4; CALL; } break; \
     default: { constexpr int KQ = 2; CALL; } break; \
   }
+#define KQ_SWITCH(CALL)                                          \
+  if (dft_js() == 2) { constexpr int JS = 2; KQ_SWITCH_JS(CALL) } \
+  else { constexpr int JS = 1; KQ_SWITCH_JS(CALL) }
 
 // matrix-core forms (dft_mfma.hip), opt-in with ADMP_DFT_MFMA=1: measured no faster than the vector forms below
 bool dftm_enabled(int N);
@@ -328,11 +401,11 @@ bool launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec,
   const dim3 grid((nlines + NL - 1) / NL, nb);
   const long ss = spec_stride / 2;       // strides are given in reals; the kernels index complex numbers
   if (inverse) {
-    KQ_SWITCH((k_dft_z_c2r<T, KQ><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, reinterpret_cast<const Cx<T>*>(spec), mesh, t2, mesh_stride, ss,
+    KQ_SWITCH((k_dft_z_c2r<T, KQ, JS><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, reinterpret_cast<const Cx<T>*>(spec), mesh, t2, mesh_stride, ss,
                                                               nb == 1 ? accum : nullptr)))
     return accum != nullptr && nb == 1;
   }
-  KQ_SWITCH((k_dft_z_r2c<T, KQ><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, mesh, reinterpret_cast<Cx<T>*>(spec), t2, mesh_stride, ss)))
+  KQ_SWITCH((k_dft_z_r2c<T, KQ, JS><<<grid, kDftBlock, sh, st>>>(N, nlines, NL, TK, mesh, reinterpret_cast<Cx<T>*>(spec), t2, mesh_stride, ss)))
   return false;
 }
 template <class T>
@@ -346,9 +419,9 @@ void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inve
   Cx<T>* sp = reinterpret_cast<Cx<T>*>(spec);
   const long ss = spec_stride / 2;
   if (inverse) {
-    KQ_SWITCH((k_dft_strided<T, +1, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1, ss)))
+    KQ_SWITCH((k_dft_strided<T, +1, KQ, JS><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1, ss)))
   } else {
-    KQ_SWITCH((k_dft_strided<T, -1, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1, ss)))
+    KQ_SWITCH((k_dft_strided<T, -1, KQ, JS><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)Kh, (long)K[1] * Kh, sp, t1, ss)))
   }
 }
 template <class T>
@@ -359,12 +432,13 @@ void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, con
   const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + sizeof(Cx<T>) * (size_t)(2 + N), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC + N * NC);
   const dim3 grid((Kh + NC - 1) / NC, K[1], nb);
-  KQ_SWITCH((k_dft_x_conv<T, KQ><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)K[1] * Kh, (long)Kh, K[2],
+  KQ_SWITCH((k_dft_x_conv<T, KQ, JS><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)K[1] * Kh, (long)Kh, K[2],
                                                              reinterpret_cast<Cx<T>*>(spec), tabs,
                                                              reinterpret_cast<const Cx<T>*>(tw), energies, slot,
                                                              spec_stride / 2)))
 }
 #undef KQ_SWITCH
+#undef KQ_SWITCH_JS
 #define INST(T)                                                                                   \
   template bool launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*); \
   template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int, int, long);           \

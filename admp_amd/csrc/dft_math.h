@@ -68,22 +68,22 @@ struct TwStep {
 // complex line, direction SIGN (-1 forward, +1 inverse): outputs X[k] and X[N-k] (k = 0 .. N/2)
 //   load(j), j = 0..H-1, returns the pair sums of line positions j+1 / N-1-j;  x0 = x_0;  xn = x_{N/2} (used when N is
 //   even);  tw[m] = (cos, sin)(2 pi m / N)
-template <class T, int SIGN, int KQ, class LoadAB>
-ADMP_HD void dft_pair_core(int N, const int* k, LoadAB load, Cx<T> x0, Cx<T> xn, const Cx<T>* tw, Cx<T>* Xk, Cx<T>* Xnk) {
-  const int H = (N - 1) / 2;
-  T Are[KQ], Aim[KQ], Bre[KQ], Bim[KQ];
+// partial sums over the pair positions j = jb0 .. je0-1 (0-based: line positions j+1 / N-1-j), ADDED to Are .. Bim;
+// jb0 must be a multiple of kDftReseed steps away from nothing in particular: the twiddle is seeded exactly at jb0
+template <class T, int KQ, class LoadAB>
+ADMP_HD void dft_pair_partial(int N, const int* k, LoadAB load, const Cx<T>* tw, int jb0, int je0, T* Are, T* Aim, T* Bre,
+                              T* Bim) {
   TwStep<T> w[KQ];
   int m[KQ], step[KQ];
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
-    Are[q] = Aim[q] = Bre[q] = Bim[q] = T(0);
-    m[q] = k[q];
+    m[q] = jb0 == 0 ? k[q] : (int)(((long)k[q] * (jb0 + 1)) % N);
     step[q] = (kDftReseed * k[q]) % N;
   }
-  for (int jb = 0; jb < H; jb += kDftReseed) {
+  for (int jb = jb0; jb < je0; jb += kDftReseed) {
 #pragma unroll
     for (int q = 0; q < KQ; ++q) w[q].seed(tw, m[q], k[q], N);
-    const int je = (H - jb) < kDftReseed ? (H - jb) : kDftReseed;
+    const int je = (je0 - jb) < kDftReseed ? (je0 - jb) : kDftReseed;
     if (je == kDftReseed) {
 #pragma unroll
       for (int jj = 0; jj < kDftReseed; ++jj) {
@@ -116,6 +116,11 @@ ADMP_HD void dft_pair_core(int N, const int* k, LoadAB load, Cx<T> x0, Cx<T> xn,
       if (m[q] >= N) m[q] -= N;
     }
   }
+}
+// outputs from the complete sums
+template <class T, int SIGN, int KQ>
+ADMP_HD void dft_pair_finish(int N, const int* k, Cx<T> x0, Cx<T> xn, const T* Are, const T* Aim, const T* Bre, const T* Bim,
+                             Cx<T>* Xk, Cx<T>* Xnk) {
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
     T bre = x0.re + Are[q], bim = x0.im + Aim[q];
@@ -130,6 +135,19 @@ ADMP_HD void dft_pair_core(int N, const int* k, LoadAB load, Cx<T> x0, Cx<T> xn,
     Xnk[q].re = bre + T(SIGN) * Bim[q];
     Xnk[q].im = bim - T(SIGN) * Bre[q];
   }
+}
+template <class T, int SIGN, int KQ, class LoadAB>
+ADMP_HD void dft_pair_core(int N, const int* k, LoadAB load, Cx<T> x0, Cx<T> xn, const Cx<T>* tw, Cx<T>* Xk, Cx<T>* Xnk) {
+  T Are[KQ], Aim[KQ], Bre[KQ], Bim[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) Are[q] = Aim[q] = Bre[q] = Bim[q] = T(0);
+  dft_pair_partial<T, KQ>(N, k, load, tw, 0, (N - 1) / 2, Are, Aim, Bre, Bim);
+  dft_pair_finish<T, SIGN, KQ>(N, k, x0, xn, Are, Aim, Bre, Bim, Xk, Xnk);
+}
+// where a line is split between two threads: the first takes positions 0 .. dft_split(N)-1 (whole re-seed blocks)
+ADMP_HD int dft_split(int N) {
+  const int H = (N - 1) / 2, mid = ((H / 2 + kDftReseed - 1) / kDftReseed) * kDftReseed;
+  return mid < H ? mid : H;
 }
 // pair sums stored as one record per position: ab[(j-1)*stride], j = 1..H
 template <class T, int SIGN, int KQ>
@@ -151,20 +169,18 @@ ADMP_HD void dft_pair_outputs_rows(int N, const int* k, int stride, const Cx<T>*
 
 // real pair sums shared by the r2c and c2r lines: P = sum_j p_j.re c_jk, R = sum_j p_j.im s_jk
 template <class T, int KQ>
-ADMP_HD void real_pair_sums(int N, const int* k, int stride, const Cx<T>* p, const Cx<T>* tw, T* P, T* R) {
-  const int H = (N - 1) / 2;
+ADMP_HD void real_pair_partial(int N, const int* k, int stride, const Cx<T>* p, const Cx<T>* tw, int jb0, int je0, T* P, T* R) {
   TwStep<T> w[KQ];
   int m[KQ], step[KQ];
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
-    P[q] = R[q] = T(0);
-    m[q] = k[q];
+    m[q] = jb0 == 0 ? k[q] : (int)(((long)k[q] * (jb0 + 1)) % N);
     step[q] = (kDftReseed * k[q]) % N;
   }
-  for (int jb = 0; jb < H; jb += kDftReseed) {
+  for (int jb = jb0; jb < je0; jb += kDftReseed) {
 #pragma unroll
     for (int q = 0; q < KQ; ++q) w[q].seed(tw, m[q], k[q], N);
-    const int je = (H - jb) < kDftReseed ? (H - jb) : kDftReseed;
+    const int je = (je0 - jb) < kDftReseed ? (je0 - jb) : kDftReseed;
     if (je == kDftReseed) {
 #pragma unroll
       for (int jj = 0; jj < kDftReseed; ++jj) {
@@ -193,6 +209,12 @@ ADMP_HD void real_pair_sums(int N, const int* k, int stride, const Cx<T>* p, con
       if (m[q] >= N) m[q] -= N;
     }
   }
+}
+template <class T, int KQ>
+ADMP_HD void real_pair_sums(int N, const int* k, int stride, const Cx<T>* p, const Cx<T>* tw, T* P, T* R) {
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) P[q] = R[q] = T(0);
+  real_pair_partial<T, KQ>(N, k, stride, p, tw, 0, (N - 1) / 2, P, R);
 }
 
 // r2c line: p_j = (x_j + x_{N-j}, x_j - x_{N-j}) real pair sums; X[k] = x0 + P - i R  (+ xn (-1)^k), k = 0 .. N/2

@@ -224,11 +224,13 @@ np.savez(sys.argv[1], **out)
 print('DFT-RUN-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    # 'dft', 'dft_kq4': the vector forms of dft_kernels.hip (the default); 'dft_mfma': the matrix-core kernels of dft_mfma.hip
+    # 'dft', 'dft_kq4', 'dft_js2': the vector forms of dft_kernels.hip (the default; 4 outputs per thread; two lanes per task);
+    # 'dft_mfma': the matrix-core kernels of dft_mfma.hip
     # 'pfa': the two-level (Good-Thomas) kernels of pfa_kernels.hip forced onto these small meshes, every dimension split
     # that has a coprime split (34 = 2 * 17, 38 = 2 * 19, 96 = 32 * 3, 100 = 4 * 25, 45 = 9 * 5, 51 = 3 * 17; 31, 97, 64 plain)
     modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'dft_mfma': dict(ADMP_DFT='1', ADMP_DFT_MFMA='1'),
-             'dft_kq4': dict(ADMP_DFT='1', ADMP_DFT_KQ='4'), 'pfa': dict(ADMP_DFT='2', ADMP_PFA_MIN='0')}
+             'dft_kq4': dict(ADMP_DFT='1', ADMP_DFT_KQ='4'), 'dft_js2': dict(ADMP_DFT='1', ADMP_DFT_JS='2'),
+             'pfa': dict(ADMP_DFT='2', ADMP_PFA_MIN='0')}
     for mode, extra in modes.items():
         path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
@@ -237,7 +239,7 @@ print('DFT-RUN-OK')
         res[mode] = dict(np.load(path))
     assert len(res['rocfft']) == 2 * 4 * 5
     for key, a in res['rocfft'].items():
-        for mode in ('dft', 'dft_mfma', 'dft_kq4', 'pfa'):
+        for mode in ('dft', 'dft_mfma', 'dft_kq4', 'dft_js2', 'pfa'):
             b = res[mode][key]
             tol = 1e-10 if key.startswith('double') else 2e-4
             scale = np.abs(a).max()
