@@ -368,7 +368,8 @@ __device__ __forceinline__ void store_tile(const double* tile, const RecipGeom<T
 // run at ~20 G/s (the mesh is shared by the 8 XCDs), so each brick's workgroup scans the stencil records of ALL atoms
 // itself, keeps the ones whose stencil touches the brick, and spreads them as above.  One launch, no memset, no
 // global atomics.
-constexpr int kScanChunk = 2048;   // atoms scanned per round (bounds the LDS entry list)
+constexpr int kScanChunk = 3072;   // atoms scanned per round (bounds the LDS entry list; with the tile and the staged weights
+                                   // just under the 64 KB a workgroup may declare: 1024 waters take one round)
 constexpr int kScanSub = 32;       // entries whose weights are staged at a time
 
 template <class T>
@@ -389,20 +390,30 @@ __global__ __launch_bounds__(256) void k_spread_scan(int na, const Site<T>* __re
     if (threadIdx.x == 0) nent = 0;
     __syncthreads();
     const int cend = min(na, c0 + kScanChunk);
-    for (int s = c0 + threadIdx.x; s < cend; s += 256) {
-      const int i = list ? list[s] : s;
+    // all records of the round are fetched before the first test (12 independent loads per thread in flight)
+    constexpr int kPer = kScanChunk / 256;
+    int idx[kPer];
+    int4 rec[kPer];
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int s = c0 + (int)threadIdx.x + 256 * r;
+      idx[r] = s < cend ? (list ? list[s] : s) : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) rec[r] = idx[r] >= 0 ? atom_bases(sites, bases, g, bg, idx[r]) : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
       // the stencil [base, base+5] (periodic) meets this brick's [lo, lo+n) iff, with u = base - lo (mod dim),
       // u < n or u + 5 >= dim -- no integer division in the scan
-      const int4 v = atom_bases(sites, bases, g, bg, i);
-      const int base[3] = {v.x, v.y, v.z};
-      bool hit = true;
+      const int base[3] = {rec[r].x, rec[r].y, rec[r].z};
+      bool hit = idx[r] >= 0;
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         int u = base[d] - lo[d];
         if (u < 0) u += g.dim(d);
         hit = hit && (u < n[d] || u + 5 >= g.dim(d));
       }
-      if (hit) ents[atomicAdd(&nent, 1)] = i;
+      if (hit) ents[atomicAdd(&nent, 1)] = idx[r];
     }
     __syncthreads();
     spread_entry_list<T, kScanSub>(tile, wts, ebase, nent, [&](int k) { return ents[k]; }, sites, lpol, g, lo, n);
