@@ -1336,21 +1336,24 @@ pos, box, at, ai, cov, par, pairs = water_system(216, 5, True)
 rng = np.random.default_rng(3)
 vel = rng.normal(size=pos.shape) * 0.012
 out = {}
-for prec in ('double', 'single'):
-    settings.PRECISION = prec
-    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
-    U = None
-    for k in range(8):
-        p = pos + vel * k
-        E, G = f.get_forces(p, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
-                            par['dScales'], U_init=U)
-        U = np.asarray(f.U_ind).copy()
-        out['%%s_%%d_E' %% (prec, k)] = np.asarray(f.energy_parts)
-        out['%%s_%%d_G' %% (prec, k)] = np.asarray(G)
-        out['%%s_%%d_U' %% (prec, k)] = U
-        out['%%s_%%d_c' %% (prec, k)] = np.array([f.n_cycle, int(f.lconverg)])
+for conv in (10.0, 0.01):          # the reference's threshold (0 / 1 Jacobi steps per call) and a tight one (5 per call)
+    settings.POL_CONV = conv
+    for prec in ('double', 'single'):
+        settings.PRECISION = prec
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+        U = None
+        for k in range(8):
+            p = pos + vel * k
+            E, G = f.get_forces(p, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
+                                par['dScales'], U_init=U)
+            U = np.asarray(f.U_ind).copy()
+            tag = '%%s_%%g_%%d' %% (prec, conv, k)
+            out[tag + '_E'] = np.asarray(f.energy_parts)
+            out[tag + '_G'] = np.asarray(G)
+            out[tag + '_U'] = U
+            out[tag + '_c'] = np.array([f.n_cycle, int(f.lconverg)])
 np.savez(sys.argv[1], **out)
-print('SEQ-OK', [int(out['double_%%d_c' %% k][0]) for k in range(8)])
+print('SEQ-OK', [int(out['double_10_%%d_c' %% k][0]) for k in range(8)], [int(out['double_0.01_%%d_c' %% k][0]) for k in range(8)])
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     # auto: the form is chosen per call from the residual history, incl. the chained form (whole step enqueued at once, the
@@ -1364,8 +1367,10 @@ print('SEQ-OK', [int(out['double_%%d_c' %% k][0]) for k in range(8)])
         res[mode] = dict(np.load(path))
         if mode == 'auto':
             assert 'chained' in r.stderr and 'speculative' in r.stderr and 'plain' in r.stderr, r.stderr[-2000:]
-    cycles = [int(res['plain']['double_%d_c' % k][0]) for k in range(8)]
+            assert any('chained' in line and not line.rstrip().endswith(', 1 steps)') for line in r.stderr.splitlines()), r.stderr[-2000:]
+    cycles = [int(res['plain']['double_10_%d_c' % k][0]) for k in range(8)]
     assert min(cycles) == 0 and max(cycles) >= 1, cycles          # the sequence exercises both outcomes of the first check
+    assert min(int(res['plain']['double_0.01_%d_c' % k][0]) for k in range(8)) >= 3      # ... and chains of several steps
     for key, a in res['plain'].items():
         for mode in ('auto', 'nochain', 'speculative'):
             b = res[mode][key]
