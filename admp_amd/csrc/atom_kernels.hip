@@ -530,7 +530,8 @@ __global__ __launch_bounds__(kAtomBlock) void k_frame_virial(Topology top, const
 template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_scalar_sites(int na, const T* __restrict__ pos, const T* __restrict__ vals,
                                                              int stride, int chan, SelfCoefs self_coefs,
-                                                             Site<T>* __restrict__ sites, double* energies) {
+                                                             Site<T>* __restrict__ sites, double* energies, RecipGeom<T> g,
+                                                             int4* __restrict__ bases) {
   // blockIdx.y = channel of a batch (the site rows of channel b follow those of channel b-1)
   chan += blockIdx.y;
   sites += (size_t)blockIdx.y * na;
@@ -549,6 +550,13 @@ __global__ __launch_bounds__(kAtomBlock) void k_scalar_sites(int na, const T* __
     s.pad[0] = s.pad[1] = s.pad[2] = T(0);
     sites[i] = s;
     s2 = (double)c * (double)c;
+    if (bases && blockIdx.y == 0) {   // stencil records for the spread (as k_prepare_sites writes them): one set for the batch
+      int b[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) grid_ref(g, s.r, d, b[d]);
+      const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
+      bases[i] = make_int4(b[0], b[1], b[2], brick_code(b, dims, make_bricks(dims)));
+    }
   }
   s2 = block_reduce_sum<kAtomBlock>(s2);
   if (threadIdx.x == 0) atomicAdd(&energies[E_SELF], self_coef * s2);
@@ -649,14 +657,15 @@ void launch_scalar_sites(hipStream_t st, int na, const T* pos, const T* vals, in
                          Site<T>* sites, double* energies) {
   SelfCoefs sc;
   sc.c[0] = self_coef;
-  k_scalar_sites<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pos, vals, stride, chan, sc, sites, energies);
+  k_scalar_sites<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pos, vals, stride, chan, sc, sites, energies, RecipGeom<T>(), nullptr);
 }
 template <class T>
 void launch_scalar_sites_batch(hipStream_t st, int na, const T* pos, const T* vals, int stride, int nch,
-                               const double* self_coefs, Site<T>* sites, double* energies) {
+                               const double* self_coefs, Site<T>* sites, double* energies, const RecipGeom<T>* g, int4* bases) {
   SelfCoefs sc;
   for (int b = 0; b < nch && b < 3; ++b) sc.c[b] = self_coefs[b];
-  k_scalar_sites<T><<<dim3(nblk(na), nch), kAtomBlock, 0, st>>>(na, pos, vals, stride, 0, sc, sites, energies);
+  k_scalar_sites<T><<<dim3(nblk(na), nch), kAtomBlock, 0, st>>>(na, pos, vals, stride, 0, sc, sites, energies,
+                                                                 g ? *g : RecipGeom<T>(), g ? bases : nullptr);
 }
 template <class T>
 void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int chan, const T* v, T* grad, int nch) {
@@ -667,7 +676,7 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
   template void launch_scalar_sites<T>(hipStream_t, int, const T*, const T*, int, int, double, Site<T>*, double*);      \
   template void launch_scale_add<T>(hipStream_t, int, const T*, int, int, const T*, T*, int);                           \
   template void launch_scalar_sites_batch<T>(hipStream_t, int, const T*, const T*, int, int, const double*, Site<T>*,   \
-                                             double*);                                                                  \
+                                             double*, const RecipGeom<T>*, int4*);                                      \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
                                         const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*, int*, int*,       \
                                         const int*, int*, RQ4<T>*);                                                     \

@@ -1752,9 +1752,13 @@ struct Engine : EngineBase {
       fld_recip.need(3 * (size_t)na * sizeof(T) * nch);
       const bool batch_spread = na < spread_brick_min_atoms();     // the scan-spread regime takes the channels as a batch
       if (batch_spread) {
-        { TIMED("scalar_sites"); launch_scalar_sites_batch<T>(stream, na, pos, cl, 3, nch, kp, sites.as<Site<T>>(), Ed); }
+        // the stencil records ride along: every (brick, channel) workgroup of the scan spread reads them instead of
+        // redoing three grid_ref per atom (3072 atoms x 1029 workgroups at 97^3)
+        bases_d.need(sizeof(int4) * (size_t)na);
+        { TIMED("scalar_sites"); launch_scalar_sites_batch<T>(stream, na, pos, cl, 3, nch, kp, sites.as<Site<T>>(), Ed, &g,
+                                                              bases_d.as<int4>()); }
         TIMED("spread");
-        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr, nullptr, nch);
+        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr, bases_d.as<int4>(), nch);
         if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
       } else {
         for (int c = 0; c < nch; ++c) {

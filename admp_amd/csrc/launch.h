@@ -140,7 +140,9 @@ struct SelfCoefs {
 // channels 0..nch-1 of vals at once: site rows of channel b at sites + b * na
 template <class T>
 void launch_scalar_sites_batch(hipStream_t st, int na, const T* pos, const T* vals, int stride, int nch,
-                               const double* self_coefs, Site<T>* sites, double* energies);
+                               const double* self_coefs, Site<T>* sites, double* energies,
+                               const RecipGeom<T>* g = nullptr /* with bases: the mesh the rows will be spread on */,
+                               int4* bases = nullptr /* optional: stencil base indices per atom, as launch_prepare_sites */);
 // atoms whose lowest stencil plane lies in the local slab (local base index < width): appended to `list`
 template <class T>
 void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
