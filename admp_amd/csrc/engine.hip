@@ -1245,7 +1245,7 @@ struct Engine : EngineBase {
       const double g_lo = std::min(scf_growth[scf_state][0], scf_growth[scf_state][1]);
       const bool speculate = spec_mode >= 0 ? spec_mode != 0
                                             : (have_pred ? scf_last + spec_infl * g_hi < thresh : (scf_last < 0.0 && warm_regime));
-      double f_first = -1.0, f_final = -1.0, f_second = -1.0;
+      double f_first = -1.0, f_final = -1.0;     // residuals of the first and of the last check of this call
       // Chained form (up to 200k atoms; at 3072 atoms a host synchronisation costs as much as three kernels): when the history says the
       // first check will fail and n Jacobi steps will do, the whole call is enqueued at once -- first field evaluation and its
       // check, then n times (Jacobi step GATED on the previous check's residual on the device: a zero step once a check has
@@ -1291,7 +1291,6 @@ struct Engine : EngineBase {
         read_energies(E_PARTS_SUM, E);
         nact_seen();
         f_first = Eh[E_FMAX];
-        f_second = Eh[E_FMAX1];
         have_base = true;
         phi_accum = true;
         int hit = -1;
@@ -1357,7 +1356,6 @@ struct Engine : EngineBase {
         }
         const double fmax = scf_check(&n_act);
         if (f_first < 0.0) f_first = fmax;
-        else if (f_second < 0.0) f_second = fmax;
         f_final = fmax;
         if (fmax < thresh) { phi_valid = true; break; }
         scf_jacobi(n_act);
