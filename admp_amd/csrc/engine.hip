@@ -469,6 +469,7 @@ struct Engine : EngineBase {
   rocfft_plan plan_f = nullptr, plan_b = nullptr, plan_xf = nullptr, plan_xb = nullptr;
   // power-of-two x dimension on one rank: batched 2-D plans of the y-z planes around the fused x pass (fftx_kernels.hip)
   rocfft_plan plan2_f = nullptr, plan2_b = nullptr;
+  int fx_khp = 0;              // row pitch (complex numbers) of the spectrum those plans write: K2/2+1 padded to whole lines
   bool use_fx = false;
   DevBuf fx_tw;
   rocfft_execution_info info_f = nullptr;
@@ -573,10 +574,20 @@ struct Engine : EngineBase {
     size_t nspec = (size_t)nxown() * K[1] * K2h;
     const size_t nspec_t = (size_t)K[0] * nyown() * K2h;
     if (nspec_t > nspec) nspec = nspec_t;
+    // fused-x path: the kz rows of the spectrum are padded to whole 128-byte lines.  With K2/2+1 = 129 complex numbers per row
+    // every row of a tile straddles two lines; padded to 144, rocFFT's batched 2-D r2c / c2r of the 256^3 f32 mesh take
+    // 61 / 64 us instead of 88 / 91 (tools/ubench/rocfft_yz_layouts.cpp).  ADMP_FX_PAD=0: unpadded.
+    static const bool fx_off = [] { const char* e = getenv("ADMP_FUSED_X"); return e && atoi(e) == 0; }();
+    static const bool fx_pad = [] { const char* e = getenv("ADMP_FX_PAD"); return !(e && atoi(e) == 0); }();
+    const bool want_fx = snranks == 1 && !fx_off && fftx_usable(K[0]);
+    const size_t per_line = 128 / (2 * sizeof(T));
+    const int khp = want_fx && fx_pad ? (int)((K2h + per_line - 1) / per_line * per_line) : (int)K2h;
+    if (want_fx && (size_t)K[0] * K[1] * khp > nspec) nspec = (size_t)K[0] * K[1] * khp;
     mesh.need(nreal * sizeof(T));
     spec.need(nspec * 2 * sizeof(T));
     binv_d.need(9 * sizeof(double));
     if (planK[0] == K[0] && planK[1] == K[1] && planK[2] == K[2] && planR == snranks && planRank == srank && plan_f) return;
+    fx_khp = khp;
     destroy_plans();
     std::call_once(g_fft_once, [] { rocfft_setup(); });
     const rocfft_precision pr = sizeof(T) == 4 ? rocfft_precision_single : rocfft_precision_double;
@@ -585,11 +596,21 @@ struct Engine : EngineBase {
       const size_t len[3] = {(size_t)K[2], (size_t)K[1], (size_t)K[0]};   // rocFFT: fastest dimension first
       FFT_TRY(rocfft_plan_create(&plan_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 3, len, 1, nullptr));
       FFT_TRY(rocfft_plan_create(&plan_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 3, len, 1, nullptr));
-      static const bool fx_off = [] { const char* e = getenv("ADMP_FUSED_X"); return e && atoi(e) == 0; }();
-      if (!fx_off && fftx_usable(K[0])) {
+      if (want_fx) {
         const size_t len2[2] = {(size_t)K[2], (size_t)K[1]};
-        FFT_TRY(rocfft_plan_create(&plan2_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 2, len2, (size_t)K[0], nullptr));
-        FFT_TRY(rocfft_plan_create(&plan2_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 2, len2, (size_t)K[0], nullptr));
+        const size_t rs[2] = {1, (size_t)K[2]}, cs[2] = {1, (size_t)khp};
+        const size_t rdist = (size_t)K[1] * K[2], cdist = (size_t)K[1] * khp;
+        rocfft_plan_description df = nullptr, db = nullptr;
+        FFT_TRY(rocfft_plan_description_create(&df));
+        FFT_TRY(rocfft_plan_description_set_data_layout(df, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr,
+                                                        nullptr, 2, rs, rdist, 2, cs, cdist));
+        FFT_TRY(rocfft_plan_description_create(&db));
+        FFT_TRY(rocfft_plan_description_set_data_layout(db, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr,
+                                                        nullptr, 2, cs, cdist, 2, rs, rdist));
+        FFT_TRY(rocfft_plan_create(&plan2_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 2, len2, (size_t)K[0], df));
+        FFT_TRY(rocfft_plan_create(&plan2_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 2, len2, (size_t)K[0], db));
+        rocfft_plan_description_destroy(df);
+        rocfft_plan_description_destroy(db);
         FFT_TRY(rocfft_plan_get_work_buffer_size(plan2_f, &w)); if (w > wmax) wmax = w;
         FFT_TRY(rocfft_plan_get_work_buffer_size(plan2_b, &w)); if (w > wmax) wmax = w;
         std::vector<T> tw((size_t)K[0]);
@@ -731,7 +752,7 @@ struct Engine : EngineBase {
     }
     if (use_fx) {      // rocFFT for the y-z planes, one fused kernel for x forward * G * x inverse
       run_plan("rocfft_r2c_yz", plan2_f, mesh_p, spec_p);
-      { TIMED("fftx_kspace"); launch_fftx_conv<T>(stream, K, fx_tw.as<T>(), spec_p, gtab, Ed, slot); }
+      { TIMED("fftx_kspace"); launch_fftx_conv<T>(stream, K, fx_tw.as<T>(), spec_p, gtab, Ed, slot, fx_khp); }
       run_plan("rocfft_c2r_yz", plan2_b, spec_p, mesh_p);
       return false;
     }

@@ -19,8 +19,9 @@ extern __shared__ __align__(32) unsigned char fftx_smem[];
 constexpr int kFftxGMax = 16;      // G values a thread keeps in registers: N * NC / kFftxBlock <= 16 (else fetched late)
 template <class T>
 __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int ncols, int nfix, int NC, long jstride, long fixstride,
-                                                          int K3, Cx<T>* __restrict__ spec, const T* __restrict__ gtab,
-                                                          const Cx<T>* __restrict__ twg, double* energies, int slot) {
+                                                          long gjstride, long gfixstride, int K3, Cx<T>* __restrict__ spec,
+                                                          const T* __restrict__ gtab, const Cx<T>* __restrict__ twg,
+                                                          double* energies, int slot) {
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(fftx_smem);      // [N / 2]: (cos, sin)(2 pi k / N)
   Cx<T>* D = tw + N / 2;                                 // [N][NC]
   // tiles of one row of columns share their 128-B lines: neighbours on the same XCD (same L2)
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int n
   if (L < 0) return;
   const int col0 = (int)(L % ntile) * NC, nca = min(NC, ncols - col0);
   const long base = (L / ntile) * fixstride + col0;
+  const long gbase = (L / ntile) * gfixstride + col0;      // the G table keeps the unpadded rows
   const int sh = 31 - __clz(NC);                         // NC is a power of two
   for (int t = threadIdx.x; t < N / 2; t += kFftxBlock) tw[t] = twg[t];
 #pragma unroll 4
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int n
   for (int u = 0; u < kFftxGMax; ++u) {
     const int t = threadIdx.x + u * kFftxBlock;
     const int p = t >> sh, c = t & (NC - 1);
-    Gr[u] = (gpre && t < N * NC && c < nca) ? gtab[base + (long)(__brev((unsigned)p) >> (32 - logN)) * jstride + c] : T(0);
+    Gr[u] = (gpre && t < N * NC && c < nca) ? gtab[gbase + (long)(__brev((unsigned)p) >> (32 - logN)) * gjstride + c] : T(0);
   }
   __syncthreads();
   const int nbf = (N / 2) * NC, nbq = (N / 4) * NC;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int n
     const int p = t >> sh, c = t & (NC - 1);
     if (c < nca) {
       const int k = (int)(__brev((unsigned)p) >> (32 - logN));
-      const T G = gtab[base + (long)k * jstride + c];
+      const T G = gtab[gbase + (long)k * gjstride + c];
       const Cx<T> X = D[t];
       const int kz = col0 + c;
       const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
@@ -162,21 +164,24 @@ __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int n
 
 bool fftx_usable(int N) { return N >= 32 && N <= 1024 && (N & (N - 1)) == 0; }
 
-// spec = [K0][K1][K2/2+1] complex after the batched 2-D r2c of the y-z planes; tw = (cos, sin)(2 pi k / K0), k < K0 / 2
+// spec = [K0][K1][khp] complex (khp >= K2/2+1: rows padded to whole 128-byte lines, engine.hip) after the batched 2-D r2c of
+// the y-z planes; gtab = [K0][K1][K2/2+1]; tw = (cos, sin)(2 pi k / K0), k < K0 / 2
 template <class T>
-void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot) {
+void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot, int khp) {
   const int N = K[0], Kh = K[2] / 2 + 1;
+  if (khp < Kh) khp = Kh;
   int logN = 0;
   while ((1 << logN) < N) ++logN;
   int NC = (int)(128 / (2 * sizeof(T)));                 // one 128-B line of columns
   while (NC > 1 && sizeof(Cx<T>) * ((size_t)N / 2 + (size_t)N * NC) > 60 * 1024) NC >>= 1;
   const size_t sh = sizeof(Cx<T>) * ((size_t)N / 2 + (size_t)N * NC);
   const int ntile = (Kh + NC - 1) / NC;
-  k_fftx_conv<T><<<xcd_grid((unsigned)(ntile * K[1])), kFftxBlock, sh, st>>>(N, logN, Kh, K[1], NC, (long)K[1] * Kh, (long)Kh, K[2],
+  k_fftx_conv<T><<<xcd_grid((unsigned)(ntile * K[1])), kFftxBlock, sh, st>>>(N, logN, Kh, K[1], NC, (long)K[1] * khp, (long)khp,
+                                                                          (long)K[1] * Kh, (long)Kh, K[2],
                                                                           reinterpret_cast<Cx<T>*>(spec), gtab,
                                                                           reinterpret_cast<const Cx<T>*>(tw), energies, slot);
 }
-template void launch_fftx_conv<float>(hipStream_t, const int*, const float*, float*, const float*, double*, int);
-template void launch_fftx_conv<double>(hipStream_t, const int*, const double*, double*, const double*, double*, int);
+template void launch_fftx_conv<float>(hipStream_t, const int*, const float*, float*, const float*, double*, int, int);
+template void launch_fftx_conv<double>(hipStream_t, const int*, const double*, double*, const double*, double*, int, int);
 
 }  // namespace admp

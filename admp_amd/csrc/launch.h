@@ -198,7 +198,8 @@ void launch_pfa_x_conv(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, c
 // ---- fftx_kernels.hip: x lines forward * G (+ energy) * x lines inverse in one sweep, power-of-two K[0]
 bool fftx_usable(int N);
 template <class T>
-void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot);
+void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot,
+                      int khp = 0 /* row pitch of spec in complex numbers (0: K[2]/2+1) */);
 
 // ---- pair_kernels.hip
 template <class T>

@@ -2,6 +2,7 @@
 // one plane per x; the fused x pass that follows only needs a fixed stride between x planes.)
 //   A: default -- spectrum [x][y][kz], kz fastest
 //   C: transposed -- spectrum [x][kz][y], y fastest (out strides {K1, 1})
+//   P: default order with the kz rows padded to a multiple of 16 complex (128-byte aligned rows)
 // hipcc -O2 tools/ubench/rocfft_yz_layouts.cpp -lrocfft -o tools/ubench/rocfft_yz_layouts.bin
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
@@ -38,22 +39,25 @@ int main(int argc, char** argv) {
   void* work;
   const size_t wcap = 512u << 20;
   CK(hipMalloc(&mesh, K * K * K * sizeof(float)));
-  CK(hipMalloc(&spec, K * K * Kh * 2 * sizeof(float)));
+  CK(hipMalloc(&spec, K * K * ((Kh + 15) / 16 * 16) * 2 * sizeof(float)));
   CK(hipMalloc(&work, wcap));
   CK(hipMemset(mesh, 0, K * K * K * sizeof(float)));
-  CK(hipMemset(spec, 0, K * K * Kh * 2 * sizeof(float)));
+  CK(hipMemset(spec, 0, K * K * ((Kh + 15) / 16 * 16) * 2 * sizeof(float)));
   const size_t len2[2] = {K, K};
-  for (int variant = 0; variant < 2; ++variant) {
+  const size_t Kp = (Kh + 15) / 16 * 16;
+  for (int variant = 0; variant < 3; ++variant) {
     rocfft_plan pf, pb;
     rocfft_plan_description df = nullptr, db = nullptr;
-    if (variant == 1) {
-      const size_t rs[2] = {1, K}, cs[2] = {K, 1};
+    if (variant >= 1) {
+      const size_t rs[2] = {1, K};
+      const size_t cs[2] = {variant == 1 ? K : 1, variant == 1 ? 1 : Kp};
+      const size_t cdist = variant == 1 ? K * Kh : K * Kp;
       CK(rocfft_plan_description_create(&df));
       CK(rocfft_plan_description_set_data_layout(df, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr, nullptr,
-                                                 2, rs, K * K, 2, cs, K * Kh));
+                                                 2, rs, K * K, 2, cs, cdist));
       CK(rocfft_plan_description_create(&db));
       CK(rocfft_plan_description_set_data_layout(db, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr, nullptr,
-                                                 2, cs, K * Kh, 2, rs, K * K));
+                                                 2, cs, cdist, 2, rs, K * K));
     }
     CK(rocfft_plan_create(&pf, rocfft_placement_notinplace, rocfft_transform_type_real_forward, rocfft_precision_single, 2, len2, K, df));
     CK(rocfft_plan_create(&pb, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, rocfft_precision_single, 2, len2, K, db));
@@ -62,7 +66,7 @@ int main(int argc, char** argv) {
     CK(rocfft_plan_get_work_buffer_size(pb, &wb));
     if (wf > wcap || wb > wcap) { printf("variant %d: work buffer too large\n", variant); continue; }
     const float tf = time_plan(pf, mesh, spec, work, wf, 20), tb = time_plan(pb, spec, mesh, work, wb, 20);
-    printf("K=%zu variant %s: r2c %.1f us (work %zu MB), c2r %.1f us (work %zu MB)\n", K, variant ? "C [x][kz][y]" : "A [x][y][kz]", tf,
+    printf("K=%zu variant %s: r2c %.1f us (work %zu MB), c2r %.1f us (work %zu MB)\n", K, variant == 0 ? "A [x][y][kz]" : (variant == 1 ? "C [x][kz][y]" : "P [x][y][kz pad 16]"), tf,
            wf >> 20, tb, wb >> 20);
     rocfft_plan_destroy(pf); rocfft_plan_destroy(pb);
   }
