@@ -1306,7 +1306,8 @@ np.savez(sys.argv[1], **out)
 print('FX-RUN-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode, extra in {'rocfft3d': dict(ADMP_FUSED_X='0'), 'fused_x': {}}.items():
+    # fused_x: spectrum rows padded to whole 128-byte lines (the default); fused_x_unpadded: K3/2+1 complex numbers per row
+    for mode, extra in {'rocfft3d': dict(ADMP_FUSED_X='0'), 'fused_x': {}, 'fused_x_unpadded': dict(ADMP_FX_PAD='0')}.items():
         path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True, env=dict(os.environ, **extra),
                            timeout=900)
@@ -1314,9 +1315,10 @@ print('FX-RUN-OK')
         res[mode] = dict(np.load(path))
     assert len(res['rocfft3d']) == 2 * 3 * 5
     for key, a in res['rocfft3d'].items():
-        b = res['fused_x'][key]
-        tol = 1e-10 if key.startswith('double') else 2e-4
-        assert np.abs(a - b).max() <= tol * np.abs(a).max(), (key, np.abs(a - b).max(), np.abs(a).max())
+        for mode in ('fused_x', 'fused_x_unpadded'):
+            b = res[mode][key]
+            tol = 1e-10 if key.startswith('double') else 2e-4
+            assert np.abs(a - b).max() <= tol * np.abs(a).max(), (mode, key, np.abs(a - b).max(), np.abs(a).max())
 
 
 def test_first_cycle_forms_agree_on_a_moving_sequence(tmp_path):
