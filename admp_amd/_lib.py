@@ -50,8 +50,8 @@ PROTOTYPES = {
     'admp_set_pairs_from_positions': (_i32, [_vp, _vp, _dp, _dbl]),
     'admp_slab_configure': (_i32, [_vp, _i32, _i32]),
     'admp_slab_info': (_i32, [_vp, _c.POINTER(_i64)]),
-    'admp_stage_begin': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _ip]),
-    'admp_stage': (_i32, [_vp, _i32, _vp, _vp, _i32, _dp]),
+    'admp_set_comm': (_i32, [_vp, _vp]),
+    'admp_slab_home': (_i32, [_vp, _vp, _ip, _ip]),
     'admp_profile_enable': (_i32, [_vp, _i32]),
     'admp_profile_filter': (_i32, [_vp, _c.c_char_p]),
     'admp_profile_reset': (_i32, [_vp]),
@@ -59,9 +59,19 @@ PROTOTYPES = {
     'admp_profile_entry': (_i32, [_vp, _i32, _c.POINTER(_c.c_char_p), _dp, _c.POINTER(_i64)]),
 }
 
-# stage codes of admp_stage (include/admp_hip.h)
-ST_SET_U, ST_PAIR_FIELD, ST_SPREAD, ST_FFT_YZ, ST_FFT_X, ST_KSPACE, ST_GATHER_FIELD, ST_FIELD_FINISH, ST_JACOBI, \
-    ST_PAIR_FULL, ST_GATHER, ST_FINISH, ST_MARK_IMPORTS, ST_HOME_LIST, ST_FIELD_MAX_DEV, ST_FINISH_DEV = range(1, 17)
+# communicator of a slab-decomposed handle (include/admp_hip.h: admp_comm)
+T_I32, T_F32, T_F64 = 0, 1, 2
+OP_SUM, OP_MAX = 0, 1
+TAGS = {1: 'ghost_planes', 2: 'transpose', 3: 'halo_dipoles', 4: 'halo_gradient', 5: 'scf_max', 6: 'energies'}
+_i64p = _c.POINTER(_i64)
+ALL_REDUCE_FN = _c.CFUNCTYPE(_i32, _vp, _vp, _i64, _i32, _i32, _i32)
+ALL_TO_ALL_V_FN = _c.CFUNCTYPE(_i32, _vp, _vp, _i64p, _vp, _i64p, _i32, _i32)
+SHIFT_FN = _c.CFUNCTYPE(_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32)
+
+
+class AdmpComm(_c.Structure):
+    _fields_ = [('ctx', _vp), ('all_reduce', ALL_REDUCE_FN), ('all_to_all_v', ALL_TO_ALL_V_FN), ('shift', SHIFT_FN)]
+
 
 OPT_REFERENCE_KPOINTS = 1
 OPT_KEEP_POL_SITES = 2

@@ -163,17 +163,6 @@ template void launch_local_frames<float>(hipStream_t, const Topology&, const flo
 template void launch_local_frames<double>(hipStream_t, const Topology&, const double*, const Box<double>&, double*);
 
 template <class T>
-__global__ __launch_bounds__(kAtomBlock) void k_update_U(int na, const T* __restrict__ Ucart,
-                                                         Site<T>* __restrict__ sites) {
-  int i = blockIdx.x * kAtomBlock + threadIdx.x;
-  if (i >= na) return;
-  sites[i].U[0] = Ucart[3 * i + 2];
-  sites[i].U[1] = Ucart[3 * i];
-  sites[i].U[2] = Ucart[3 * i + 1];
-}
-
-
-template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_field_finish(int na, const Site<T>* __restrict__ sites,
                                                              const T* __restrict__ pol, const T* __restrict__ Ucart,
                                                              const T* __restrict__ fld_pair,
@@ -193,24 +182,6 @@ __global__ __launch_bounds__(kAtomBlock) void k_field_finish(int na, const Site<
   }
   fm = block_reduce_max<kAtomBlock>(fm);
   if (threadIdx.x == 0 && fm > 0.0) atomicMax(fmax_bits, nonneg_bits(fm));
-}
-
-// Unew may alias Ucart (single GPU); with a home list only the listed atoms are written (the other ranks'
-// entries of Unew stay zero so that a sum all-reduce assembles the full array).
-template <class T>
-__global__ __launch_bounds__(kAtomBlock) void k_jacobi_update(int na, const T* __restrict__ pol,
-                                                              const T* __restrict__ field, const T* Ucart, T* Unew,
-                                                              Site<T>* __restrict__ sites,
-                                                              const int* __restrict__ list) {
-  const int slot = blockIdx.x * kAtomBlock + threadIdx.x;
-  if (slot >= na) return;
-  const int i = list ? list[slot] : slot;
-  T s = pol[i] * T(1.0 / kDielectric);
-  T ux = Ucart[3 * i] - field[3 * i] * s;
-  T uy = Ucart[3 * i + 1] - field[3 * i + 1] * s;
-  T uz = Ucart[3 * i + 2] - field[3 * i + 2] * s;
-  Unew[3 * i] = ux; Unew[3 * i + 1] = uy; Unew[3 * i + 2] = uz;
-  sites[i].U[0] = uz; sites[i].U[1] = ux; sites[i].U[2] = uy;
 }
 
 template <class T>
@@ -591,10 +562,6 @@ void launch_site_classes(hipStream_t st, int na, const Site<T>* sites, int* cls)
   if (na > 0) k_site_classes<T><<<nblk(na), kAtomBlock, 0, st>>>(na, sites, cls);
 }
 template <class T>
-void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites) {
-  k_update_U<T><<<nblk(na), kAtomBlock, 0, st>>>(na, Ucart, sites);
-}
-template <class T>
 void launch_field_finish(hipStream_t st, int na, const Site<T>* sites, const T* pol, const T* Ucart, const T* fld_pair,
                          const T* fld_recip, T kappa, T* field, unsigned long long* fmax_bits, const int* list,
                          const int* n_dev) {
@@ -608,11 +575,6 @@ void launch_jacobi_delta(hipStream_t st, int n_act, const int* act, const T* pol
   std::memcpy(&bits, &gate_min, sizeof(bits));
   if (n_act > 0)
     k_jacobi_delta<T><<<nblk(n_act), kAtomBlock, 0, st>>>(n_act, act, pol, field, Ucart, sites, isites, gate, bits);
-}
-template <class T>
-void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, const T* Ucart, T* Unew,
-                          Site<T>* sites, const int* list) {
-  k_jacobi_update<T><<<nblk(na), kAtomBlock, 0, st>>>(na, pol, field, Ucart, Unew, sites, list);
 }
 template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
@@ -680,13 +642,11 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
                                         const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*, int*, int*,       \
                                         const int*, int*, RQ4<T>*);                                                     \
-  template void launch_update_U<T>(hipStream_t, int, const T*, Site<T>*);                                               \
   template void launch_site_classes<T>(hipStream_t, int, const Site<T>*, int*);                                         \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
                                        unsigned long long*, const int*, const int*);                                    \
   template void launch_jacobi_delta<T>(hipStream_t, int, const int*, const T*, const T*, T*, Site<T>*, Site<T>*,        \
                                        const unsigned long long*, double);                                            \
-  template void launch_jacobi_update<T>(hipStream_t, int, const T*, const T*, const T*, T*, Site<T>*, const int*);       \
   template void launch_finish<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const Site<T>*, const T*,        \
                                  const T*, int, T, T*, T*, T*, double*, const int*, int, const FieldFin<T>&);
 INST(float)

@@ -158,6 +158,22 @@ struct EngineBase {
   int K[3] = {0, 0, 0};
   int lmax = 2, lpol = 0;
   int srank = 0, snranks = 1;   // x-slab decomposition (admp_slab_configure)
+  admp_comm comm{};             // ... and the caller's communicator (admp_set_comm); unused with one rank
+  bool have_comm = false;
+  // collectives of a decomposed evaluation: every rank makes the same calls in the same order
+  void comm_fail(const char* what, int rc) { throw Err{ADMP_E_COMM, std::string("communicator callback ") + what + " returned " + std::to_string(rc)}; }
+  void c_all_reduce(void* buf, int64_t n, int dtype, int op, int tag) {
+    const int rc = comm.all_reduce(comm.ctx, buf, n, dtype, op, tag);
+    if (rc != 0) comm_fail("all_reduce", rc);
+  }
+  void c_all_to_all_v(const void* send, const int64_t* sc, void* recv, const int64_t* rc_, int dtype, int tag) {
+    const int rc = comm.all_to_all_v(comm.ctx, send, sc, recv, rc_, dtype, tag);
+    if (rc != 0) comm_fail("all_to_all_v", rc);
+  }
+  void c_shift(const void* send, void* recv, int64_t n, int dtype, int to_next, int tag) {
+    const int rc = comm.shift(comm.ctx, send, recv, n, dtype, to_next, tag);
+    if (rc != 0) comm_fail("shift", rc);
+  }
   int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
   int keep_pol_sites = 0;       // ADMP_OPT_KEEP_POL_SITES: the caller vouches that the set {i : pol_i > 0} has not changed
   long nbr_gen = 0;             // bumped whenever the neighbour table is rebuilt
@@ -194,13 +210,7 @@ struct EngineBase {
     if (!src) { detach_shared(); return; }
     ARG_CHECK(src != this && !src->nbr_src, "the lender must own its neighbour table");
     ARG_CHECK(src->have_top && src->top.na == top.na && src->device == device, "handles of different systems / devices");
-    if (!nbr_src) {              // drop the table this handle owns
-      if (nbr.rowptr) (void)hipFree(nbr.rowptr);
-      if (nbr.col) (void)hipFree(nbr.col);
-      if (nbr.order) (void)hipFree(nbr.order);
-      if (nbr.cls) (void)hipFree(nbr.cls);
-      if (nbr.order_plain) (void)hipFree(nbr.order_plain);
-    }
+    if (!nbr_src) nbr.free_all();   // drop the table this handle owns
     nbr = NbrTable();
     nbr_src = src; nbr_src_gen = -1;
     have_pairs = false;
@@ -270,14 +280,11 @@ struct EngineBase {
                            const double* mS, const double* pS, const void* U, double* out) = 0;
   virtual void mscale_grad(int kind, const void* pos, const double* box, const void* par, int pmax, int ns, double* out,
                            int on_device) = 0;
-  // staged evaluation (device pointers only)
   virtual void nbr_count(int na, const void* pos, const double* box, double rc, int64_t* n_pairs) = 0;
   virtual void nbr_fill(int32_t* pairs) = 0;
   virtual void nbr_table(const void* pos, const double* box, double rc) = 0;
   virtual void slab_info(int64_t* out) = 0;
-  virtual int v_stage_begin(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole,
-                            int ns, const double* mS, const double* pS, void* U) = 0;
-  virtual void v_stage(int what, void* a, void* b, int iarg, double* dout) = 0;
+  virtual void slab_home(int32_t* out, int* n_home, int* n_import) = 0;
 
   void free_topology() {
     if (top.axis_type) (void)hipFree(top.axis_type);
@@ -289,13 +296,7 @@ struct EngineBase {
     if (top.inv_idx) (void)hipFree(top.inv_idx);
     if (top.grp_ptr) (void)hipFree(top.grp_ptr);
     top = Topology();
-    if (!nbr_src) {
-      if (nbr.rowptr) (void)hipFree(nbr.rowptr);
-      if (nbr.col) (void)hipFree(nbr.col);
-      if (nbr.order) (void)hipFree(nbr.order);
-      if (nbr.cls) (void)hipFree(nbr.cls);
-      if (nbr.order_plain) (void)hipFree(nbr.order_plain);
-    }
+    if (!nbr_src) nbr.free_all();
     nbr_src = nullptr; nbr_src_gen = -1;
     nbr = NbrTable();
     cls_pending = false; cls_quiet = 1 << 20;
@@ -306,7 +307,7 @@ struct EngineBase {
   // row order of the freshly built table (see launch_row_order); ADMP_PAIR_SORT=0 keeps the natural order
   void order_rows() {
     static const bool off = [] { const char* e = getenv("ADMP_PAIR_SORT"); return e && atoi(e) == 0; }();
-    if (off || snranks != 1) {
+    if (off) {
       if (nbr.order) { (void)hipFree(nbr.order); nbr.order = nullptr; }
       if (nbr.order_plain) { (void)hipFree(nbr.order_plain); nbr.order_plain = nullptr; }
       return;
@@ -326,7 +327,6 @@ struct EngineBase {
   bool cls_pending = false;
   int cls_quiet = 1 << 20;      // evaluations since the last CLS_STALE
   void cls_seen(int flags) {
-    if (snranks != 1) return;
     if (flags & CLS_STALE) { cls_pending = true; cls_quiet = 0; }
     else if ((flags & CLS_BETTER) && cls_quiet > 8) cls_pending = true;
   }
@@ -446,6 +446,18 @@ struct EngineBase {
   }
 };
 
+// decomposition state of one evaluation on a slab rank (snranks > 1; slab_kernels.hip)
+struct SlabState {
+  DevBuf owner, bits, counts, totals, lists, imp, exp, sendb, recvb, ghost, pack, tbuf;
+  int64_t tr_send[kSlabMaxRanks], tr_recv[kSlabMaxRanks];
+  int64_t imp_cnt[kSlabMaxRanks], exp_cnt[kSlabMaxRanks];     // atoms imported from / exported to every rank
+  int n_home = 0, n_act = 0, n_imp = 0, n_exp = 0;
+  const int* home = nullptr;    // home atoms, ascending
+  const int* rows = nullptr;    // home rows in the pair kernels' order (the table's class-grouped order, filtered)
+  const int* act = nullptr;     // polarizable home atoms, ascending
+  void release() { for (DevBuf* b : {&owner, &bits, &counts, &totals, &lists, &imp, &exp, &sendb, &recvb, &ghost, &pack, &tbuf}) b->release(); }
+};
+
 template <class T>
 struct Engine : EngineBase {
   // per-atom
@@ -465,7 +477,6 @@ struct Engine : EngineBase {
   DevBuf mesh, spec, gtabs[4], fft_work, binv_d, bin_cells, bin_sorted, bin_scan, bin_cells_ind, bin_sorted_ind;   // gtabs: Ck_1, Ck_6, Ck_8, Ck_10
   T* gtab_cur = nullptr;
   BinScratch bins, bins_ind;   // brick lists of the site rows / of the compact rows of the SCF increments
-  bool bins_main = false;      // `bins` holds the lists of this evaluation's site rows (the closing gather reuses them)
   rocfft_plan plan_f = nullptr, plan_b = nullptr, plan_xf = nullptr, plan_xb = nullptr;
   // power-of-two x dimension on one rank: batched 2-D plans of the y-z planes around the fused x pass (fftx_kernels.hip)
   rocfft_plan plan2_f = nullptr, plan2_b = nullptr;
@@ -518,6 +529,7 @@ struct Engine : EngineBase {
     if (ind.rowptr) (void)hipFree(ind.rowptr);
     if (ind.col) (void)hipFree(ind.col);
     cells.release();
+    sl.release();
     free_programs();
     if (Eh) (void)hipHostFree(Eh);
     prof.destroy();
@@ -555,13 +567,116 @@ struct Engine : EngineBase {
     X0 = (int)((long)srank * K[0] / snranks); X1 = (int)((long)(srank + 1) * K[0] / snranks);
     Y0 = (int)((long)srank * K[1] / snranks); Y1 = (int)((long)(srank + 1) * K[1] / snranks);
     if (snranks > 1) {
+      ARG_CHECK(have_comm, "slab-decomposed handle without a communicator (admp_set_comm)");
+      const int64_t nh = K[2] / 2 + 1;
       for (int s = 0; s < snranks; ++s) {
         int w = (int)((long)(s + 1) * K[0] / snranks) - (int)((long)s * K[0] / snranks);
         ARG_CHECK(w >= 6, "slab decomposition needs at least 6 mesh planes per rank along x");
         int wy = (int)((long)(s + 1) * K[1] / snranks) - (int)((long)s * K[1] / snranks);
         ARG_CHECK(wy >= 1, "slab decomposition needs at least 1 mesh row per rank along y");
+        // transposes: block (x in my slab) x (y in slab s) travels to rank s, block (x in slab s) x (my y rows) comes back
+        sl.tr_send[s] = (int64_t)(X1 - X0) * wy * nh * 2;
+        sl.tr_recv[s] = (int64_t)w * (Y1 - Y0) * nh * 2;
       }
     }
+  }
+  // ---- decomposition state of one evaluation (snranks > 1; slab_kernels.hip) ------------------------------------------
+  SlabState sl;
+  static constexpr int real_dtype() { return sizeof(T) == 4 ? ADMP_T_F32 : ADMP_T_F64; }
+  // Who owns what in this evaluation, derived by every rank from the replicated inputs (no communication): home atoms, home
+  // rows in pair-kernel order, polarizable home atoms, imports per owner, exports per reader.  One host read (the counts).
+  void decompose() {
+    const int na = top.na, N = snranks, me = srank;
+    ARG_CHECK(N <= kSlabMaxRanks, "at most 28 slab ranks");
+    sl.owner.need(sizeof(int) * (size_t)na);
+    sl.bits.need(sizeof(int) * (size_t)na);
+    SlabCols cs;
+    auto col = [&](const int* seq, int len, int mask, int want) {
+      cs.seq[cs.ncols] = seq; cs.len[cs.ncols] = len; cs.mask[cs.ncols] = mask; cs.want[cs.ncols] = want;
+      return cs.ncols++;
+    };
+    const int c_home = col(nullptr, na, kSlabHome, kSlabHome);
+    const int c_rows = col(nbr.order, na, kSlabHome, kSlabHome);          // nbr.order == nullptr: natural order
+    const int c_act = col(nullptr, na, kSlabHome | kSlabPolar, kSlabHome | kSlabPolar);
+    int c_imp[kSlabMaxRanks], c_exp[kSlabMaxRanks];
+    for (int t = 0; t < N; ++t) {
+      c_imp[t] = c_exp[t] = -1;
+      if (t == me) continue;
+      c_imp[t] = col(nullptr, na, kSlabHome | (1 << t), 1 << t);
+      c_exp[t] = col(nullptr, na, kSlabHome | (1 << t), kSlabHome | (1 << t));
+    }
+    sl.counts.need(sizeof(int) * (size_t)cs.ncols * (size_t)std::max(1, slab_compact_blocks(na)));
+    sl.totals.need(sizeof(int) * kSlabMaxCols);
+    sl.lists.need(sizeof(int) * (size_t)cs.ncols * (size_t)na);
+    {
+      TIMED("slab_decompose");
+      int rc = launch_slab_decompose(stream, na, nbr, top, ev.bases, ev.pol, (int)sizeof(T), X1 - X0, K[0], X0, N, me,
+                                     sl.owner.as<int>(), sl.bits.as<int>(), cs, sl.counts.as<int>(), sl.totals.as<int>(),
+                                     sl.lists.as<int>());
+      if (rc != 0) throw Err{ADMP_E_HIP, std::string("slab decomposition: ") + hipGetErrorString((hipError_t)rc)};
+    }
+    int tot[kSlabMaxCols];
+    HIP_TRY(hipMemcpyAsync(tot, sl.totals.p, sizeof(int) * cs.ncols, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const int* L = sl.lists.as<int>();
+    sl.n_home = tot[c_home]; sl.home = L + (size_t)c_home * na;
+    sl.rows = L + (size_t)c_rows * na;
+    sl.n_act = tot[c_act]; sl.act = L + (size_t)c_act * na;
+    if (tot[c_rows] != sl.n_home) throw Err{ADMP_E_STATE, "slab decomposition: row order and home list disagree"};
+    SlabSegs si, se;
+    si.off[0] = se.off[0] = 0;
+    for (int t = 0; t < N; ++t) {
+      sl.imp_cnt[t] = t == me ? 0 : tot[c_imp[t]];
+      sl.exp_cnt[t] = t == me ? 0 : tot[c_exp[t]];
+      if (t == me) continue;
+      si.col[si.n] = c_imp[t]; si.off[si.n + 1] = si.off[si.n] + tot[c_imp[t]]; ++si.n;
+      se.col[se.n] = c_exp[t]; se.off[se.n + 1] = se.off[se.n] + tot[c_exp[t]]; ++se.n;
+    }
+    sl.n_imp = si.off[si.n]; sl.n_exp = se.off[se.n];
+    sl.imp.need(sizeof(int) * (size_t)std::max(1, sl.n_imp));
+    sl.exp.need(sizeof(int) * (size_t)std::max(1, sl.n_exp));
+    launch_slab_concat(stream, si, L, (long)na, sl.imp.as<int>());
+    launch_slab_concat(stream, se, L, (long)na, sl.exp.as<int>());
+    const size_t w = 9 * sizeof(T) * (size_t)std::max(1, std::max(sl.n_imp, sl.n_exp));
+    sl.sendb.need(w); sl.recvb.need(w);
+    ev.n_home = sl.n_home;
+    ev.home = sl.home;
+  }
+  // rows of width w of the halo atoms: owners -> readers (to_readers: exports out, imports in) or back (gradient contributions)
+  void halo_counts(int w, bool to_readers, int64_t* sc, int64_t* rc) const {
+    for (int t = 0; t < snranks; ++t) {
+      sc[t] = (to_readers ? sl.exp_cnt[t] : sl.imp_cnt[t]) * w;
+      rc[t] = (to_readers ? sl.imp_cnt[t] : sl.exp_cnt[t]) * w;
+    }
+  }
+  // what 0: the Cartesian dipoles of the atoms this rank reads <- their owners' values (start of an evaluation: the result
+  // must not depend on rows of U the rank does not own); what 1: the last Jacobi step's change of those dipoles
+  void exchange_U(int what) {
+    TIMED("comm_halo_dipoles");
+    int64_t sc[kSlabMaxRanks], rc[kSlabMaxRanks];
+    halo_counts(3, true, sc, rc);
+    launch_halo_u_pack<T>(stream, sl.n_exp, what, sl.exp.as<int>(), ev.U, sites.as<Site<T>>(), sl.sendb.as<T>());
+    c_all_to_all_v(sl.sendb.p, sc, sl.recvb.p, rc, real_dtype(), ADMP_TAG_HALO_DIPOLES);
+    launch_halo_u_unpack<T>(stream, sl.n_imp, what, sl.imp.as<int>(), sl.recvb.as<T>(), ev.U, sites.as<Site<T>>());
+  }
+  // what the closing kernel added to atoms of other ranks (frame adjoint of molecules across a slab face) goes to the owners
+  void exchange_grad(T* grad_p) {
+    TIMED("comm_halo_gradient");
+    int64_t sc[kSlabMaxRanks], rc[kSlabMaxRanks];
+    halo_counts(3, false, sc, rc);
+    launch_rows_gather<T>(stream, sl.n_imp, 3, sl.imp.as<int>(), grad_p, sl.sendb.as<T>());
+    c_all_to_all_v(sl.sendb.p, sc, sl.recvb.p, rc, real_dtype(), ADMP_TAG_HALO_GRADIENT);
+    launch_rows_scatter<T>(stream, 1, sl.n_exp, 3, sl.exp.as<int>(), sl.recvb.as<T>(), grad_p);
+  }
+  void slab_home(int32_t* out, int* n_home, int* n_import) override {
+    ARG_CHECK(snranks > 1 && sl.home, "no decomposed evaluation has run on this handle");
+    if (out) HIP_TRY(hipMemcpyAsync(out, sl.home, sizeof(int) * (size_t)sl.n_home, hipMemcpyDeviceToDevice, stream));
+    if (n_home) *n_home = sl.n_home;
+    if (n_import) *n_import = sl.n_imp;
+  }
+  // the residual word of an SCF check: maximum over the ranks (bit patterns of non-negative doubles are doubles)
+  void reduce_check_word(unsigned long long* word) {
+    if (snranks > 1) { TIMED("comm_scf_max"); c_all_reduce(word, 1, ADMP_T_F64, ADMP_OP_MAX, ADMP_TAG_SCF_MAX); }
   }
   int nloc0() const { return snranks > 1 ? (X1 - X0) + kGhost : K[0]; }
   int nxown() const { return snranks > 1 ? (X1 - X0) : K[0]; }
@@ -645,6 +760,17 @@ struct Engine : EngineBase {
       }
       FFT_TRY(rocfft_plan_get_work_buffer_size(plan_xf, &w)); if (w > wmax) wmax = w;
       FFT_TRY(rocfft_plan_get_work_buffer_size(plan_xb, &w)); if (w > wmax) wmax = w;
+      if (!fx_off && fftx_usable(K[0])) {   // the fused x pass works on the transposed layout [K0][ny][K2/2+1] as well
+        std::vector<T> tw((size_t)K[0]);
+        for (int m = 0; m < K[0] / 2; ++m) {
+          const double th = 2.0 * M_PI * (double)m / (double)K[0];
+          tw[2 * m] = (T)std::cos(th);
+          tw[2 * m + 1] = (T)std::sin(th);
+        }
+        fx_tw.need(tw.size() * sizeof(T));
+        HIP_TRY(hipMemcpy(fx_tw.p, tw.data(), tw.size() * sizeof(T), hipMemcpyHostToDevice));
+        use_fx = true;
+      }
     }
     FFT_TRY(rocfft_plan_get_work_buffer_size(plan_f, &w)); if (w > wmax) wmax = w;
     FFT_TRY(rocfft_plan_get_work_buffer_size(plan_b, &w)); if (w > wmax) wmax = w;
@@ -727,6 +853,36 @@ struct Engine : EngineBase {
   // DFT writes every word once anyway), false when the caller still has to add
   bool convolve(T* mesh_p, T* spec_p, const T* gtab, int slot, T* accum = nullptr) {
     double* Ed = Ed_cur();
+    if (snranks > 1) {
+      // x-slab ranks: the stencils of the home atoms overhang into kGhost planes of the next rank (added there before the
+      // transform), the 3-D transform is batched 2-D r2c on the owned planes -> transpose (all-to-all over the ranks: every
+      // GPU exchanges a block with each of the others) -> x lines forward * G * inverse on the y rows this rank owns ->
+      // transpose back -> 2-D c2r, and the gather needs the next rank's first planes of phi as its ghost planes
+      const size_t plane = (size_t)K[1] * K[2];
+      const int nx = nxown(), ny = nyown(), nh = K[2] / 2 + 1;
+      sl.ghost.need(kGhost * plane * sizeof(T));
+      sl.pack.need((size_t)nx * K[1] * nh * 2 * sizeof(T));
+      sl.tbuf.need((size_t)K[0] * ny * nh * 2 * sizeof(T));
+      { TIMED("comm_ghost"); c_shift(mesh_p + (size_t)nx * plane, sl.ghost.p, (int64_t)(kGhost * plane), real_dtype(), 1, ADMP_TAG_GHOST); }
+      { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)(kGhost * plane), mesh_p, sl.ghost.as<T>()); }
+      fft_forward(mesh_p, spec_p);
+      { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, snranks, 0, spec_p, sl.pack.as<T>()); }
+      { TIMED("comm_transpose"); c_all_to_all_v(sl.pack.p, sl.tr_send, sl.tbuf.p, sl.tr_recv, real_dtype(), ADMP_TAG_TRANSPOSE); }
+      if (use_fx) {
+        TIMED("fftx_kspace");
+        launch_fftx_conv<T>(stream, K, fx_tw.as<T>(), sl.tbuf.as<T>(), gtab, Ed, slot, nh, ny);
+      } else {
+        fft_x(sl.tbuf.as<T>(), 0);
+        { TIMED("kspace"); launch_kspace<T>(stream, K, ny, gtab, sl.tbuf.as<T>(), Ed, slot); }
+        fft_x(sl.tbuf.as<T>(), 1);
+      }
+      { TIMED("comm_transpose"); c_all_to_all_v(sl.tbuf.p, sl.tr_recv, sl.pack.p, sl.tr_send, real_dtype(), ADMP_TAG_TRANSPOSE); }
+      { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, snranks, 1, spec_p, sl.pack.as<T>()); }
+      fft_inverse(spec_p, mesh_p);
+      { TIMED("comm_ghost"); c_shift(mesh_p, mesh_p + (size_t)nx * plane, (int64_t)(kGhost * plane), real_dtype(), 0, ADMP_TAG_GHOST); }
+      (void)accum;
+      return false;
+    }
     if (use_pfa) {
       const T* tw = pfa_tw.as<T>();
       { TIMED("dft_z_r2c"); launch_pfa_z<T>(stream, pfa, tw, mesh_p, spec_p, 0); }
@@ -840,7 +996,7 @@ struct Engine : EngineBase {
     return b.as<T>();
   }
 
-  void ensure_bins(int na) { ensure_bins(na, bins, bin_cells, bin_sorted); bins_main = false; }
+  void ensure_bins(int na) { ensure_bins(na, bins, bin_cells, bin_sorted); }
   void ensure_bins(int na, BinScratch& b, DevBuf& cells, DevBuf& sorted) {
     const int dims[3] = {nloc0(), K[1], K[2]};
     const BrickGrid bg = make_bricks(dims);
@@ -857,9 +1013,9 @@ struct Engine : EngineBase {
     b.scan_bytes = bin_scan.bytes;
   }
 
-  // ---- one evaluation, stage by stage -------------------------------------------------------------------
-  // The single-GPU entry point pme() runs the stages back to back; with a slab decomposition the caller
-  // (admp_amd/parallel.py) runs them itself and puts RCCL collectives in between (stage_* C ABI).
+  // ---- one evaluation, step by step --------------------------------------------------------------------------
+  // pme() runs the steps back to back.  On a slab-decomposed handle the same steps work on the rank's home atoms and the
+  // collectives of the caller's communicator (admp_set_comm) sit between them: same kernels, same SCF forms.
   struct Eval {
     const T* pos = nullptr; const T* Ql = nullptr; const T* pol = nullptr; const T* thole = nullptr;
     T* U = nullptr;
@@ -868,6 +1024,7 @@ struct Engine : EngineBase {
     const int4* bases = nullptr;                 // stencil base indices per atom (written by prepare_sites)
     bool active = false;
   } ev;
+  const int* pair_rows() const { return snranks > 1 ? sl.rows : nbr.order; }      // row order of the pair kernels
 
   int stage_begin(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
                   const double* mS, const double* pS, void* U_) {
@@ -911,12 +1068,13 @@ struct Engine : EngineBase {
     {
       TIMED("prepare_sites");
       // list of the polarizable sites for the incremental SCF: rebuilt by this kernel unless the caller vouches that the
-      // set is the one of the previous call (ADMP_OPT_KEEP_POL_SITES; the Python wrapper sets it while `pol` is unchanged)
+      // set is the one of the previous call (ADMP_OPT_KEEP_POL_SITES; the Python wrapper sets it while `pol` is unchanged).
+      // A slab rank takes its list (the polarizable HOME atoms of this evaluation) from the decomposition instead.
       const bool have_list = act_n >= 0 && act_top_na == na && act_d.p;
       const bool want_act = lpol && snranks == 1 && !(keep_pol_sites && have_list);
       act_fresh = want_act;
       if (want_act) { act_d.need(sizeof(int) * (size_t)na); act_n = -1; act_top_na = na; ++act_gen; }
-      if (cls_pending && snranks == 1 && have_pairs && cls_sites_na == na && !nbr_src) {   // `sites` still holds the last evaluation's
+      if (cls_pending && have_pairs && cls_sites_na == na && !nbr_src) {   // `sites` still holds the last evaluation's
         if (!nbr.cls) HIP_TRY(hipMalloc(&nbr.cls, sizeof(int) * (size_t)na));
         launch_site_classes<T>(stream, na, sites.as<Site<T>>(), nbr.cls);
         apply_classes();
@@ -932,7 +1090,7 @@ struct Engine : EngineBase {
       ev.bases = bases_d.as<int4>();
       // First evaluation on a table compiled without classes: look at the flags right away (one extra host read, once) so
       // that this call already walks the parted rows -- a caller who evaluates once gets the reduced forms too.
-      if (!nbr.cls && snranks == 1 && have_pairs && !nbr_src && !cls_first_done) {
+      if (!nbr.cls && have_pairs && !nbr_src && !cls_first_done) {
         cls_first_done = true;
         int flags = 0;
         HIP_TRY(hipMemcpyAsync(&flags, cls_flags_dev(), sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -948,15 +1106,8 @@ struct Engine : EngineBase {
     }
     other_clean = true;
     if (snranks > 1) {
-      home_list.need(sizeof(int) * (size_t)na + sizeof(int));
-      int* cnt = home_list.as<int>() + na;
-      HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), stream));
-      { TIMED("home_list"); launch_home_list<T>(stream, na, sites.as<Site<T>>(), ev.g, X1 - X0, home_list.as<int>(), cnt); }
-      int n = 0;
-      HIP_TRY(hipMemcpyAsync(&n, cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      ev.n_home = n;
-      ev.home = home_list.as<int>();
+      decompose();
+      if (lpol) exchange_U(0);
     } else {
       ev.n_home = na;
       ev.home = nullptr;
@@ -965,78 +1116,42 @@ struct Engine : EngineBase {
     return ev.n_home;
   }
 
-  void need_eval() { ARG_CHECK(ev.active, "admp_stage_begin has not been called"); }
+  void need_eval() { ARG_CHECK(ev.active, "internal: no evaluation in progress"); }
 
-  void stage_set_U(const void* U_) {   // refresh the packed harmonic dipoles of ALL atoms from a full U array
-    need_eval();
-    ev.U = reinterpret_cast<T*>(const_cast<void*>(U_));
-    TIMED("update_U");
-    launch_update_U<T>(stream, top.na, ev.U, sites.as<Site<T>>());
-  }
-  void stage_pair_field() {
-    need_eval();
-    TIMED("pair_field");
-    launch_pair_field<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                         ev.home ? ev.home : nbr.order, nullptr, snranks == 1 && !ev.home ? cls_flags_dev() : nullptr,
-                         rq_d.as<RQ4<T>>(), ev.thole);
-  }
   void stage_spread(T* mesh_p) {
     need_eval();
     TIMED("spread");
     int rc = launch_spread<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, bins, mesh_p, ev.home, ev.bases);
     if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
-    bins_main = !ev.home && snranks == 1 && spread_uses_bricks(ev.n_home, ev.g);
-  }
-  // spectrum buffer in the k-space layout [K0][ny][K2/2+1]: energy into `slot`, multiply by G
-  void stage_kspace(T* spec_p, int slot) {
-    need_eval();
-    if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(Ed_cur() + slot, 0, sizeof(double), stream));
-    slot_clean[slot] = false;
-    TIMED("kspace");
-    launch_kspace<T>(stream, K, nyown(), gtab_cur, spec_p, Ed_cur(), slot);
-  }
-  void stage_gather_field(const T* mesh_p) {
-    need_eval();
-    TIMED("gather_field");
-    launch_gather_field<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.g, mesh_p, fld_recip.as<T>(), ev.home);
   }
   // max|field| lives in the last word of the energies buffer (bit pattern of a non-negative double), so that one
   // device->host copy can fetch it together with the energies
   unsigned long long* fmax_word() { return reinterpret_cast<unsigned long long*>(Ed_cur() + E_FMAX); }
-  void launch_field_finish_only() {
+  void launch_field_finish_only() {      // total dE/dU of every home atom and its maximum (over all ranks) into fmax_word()
     need_eval();
     if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
     fmax_clean = false;
-    TIMED("field_finish");
-    launch_field_finish<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
-                           (T)kappa, field.as<T>(), fmax_word(), ev.home);
+    { TIMED("field_finish");
+      launch_field_finish<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
+                             (T)kappa, field.as<T>(), fmax_word(), ev.home); }
+    reduce_check_word(fmax_word());
   }
-  double stage_field_finish() {
-    launch_field_finish_only();
-    unsigned long long bits = 0;
-    HIP_TRY(hipMemcpyAsync(&bits, fmax_word(), sizeof(bits), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    double fmax;
-    std::memcpy(&fmax, &bits, sizeof(fmax));
-    return fmax;
-  }
-  void stage_jacobi(T* Unew) {   // Unew == U: in place (single rank); else only the home entries of Unew are written
-    need_eval();
-    TIMED("jacobi_update");
-    launch_jacobi_update<T>(stream, ev.n_home, ev.pol, field.as<T>(), ev.U, Unew, sites.as<Site<T>>(), ev.home);
+  // The charge-only pair forms read the compact rq rows and the class marks of the table: asking for them without those is
+  // a bug of the caller, not something to paper over (round 2: a slab handle passed the flag word but no rq rows, and the
+  // kernels' prefetch `rq[0]` read address 0 -- DESIGN.md section 7a).
+  void check_mono_inputs(bool use_mono) {
+    if (use_mono && !rq_d.p) throw Err{ADMP_E_STATE, "charge-only pair forms requested without the compact site rows"};
   }
   void stage_pair_full(T* grad_p, T* fld_out = nullptr) {
     need_eval();
-    if (ev.home) {   // rows of other ranks stay zero so that a sum all-reduce assembles the gradient
-      HIP_TRY(hipMemsetAsync(grad_p, 0, 3 * (size_t)top.na * sizeof(T), stream));
-      HIP_TRY(hipMemsetAsync(pot.p, 0, 9 * (size_t)top.na * sizeof(T), stream));
-    }
+    if (snranks > 1)   // the closing kernel ADDS frame-adjoint contributions to atoms of other ranks: those rows start at zero
+      launch_rows_scatter<T>(stream, 2, sl.n_imp, 3, sl.imp.as<int>(), nullptr, grad_p);
     if (!slot_clean[E_REAL]) HIP_TRY(hipMemsetAsync(Ed_cur() + E_REAL, 0, sizeof(double), stream));
     slot_clean[E_REAL] = false;
+    check_mono_inputs(mono_ok);
     TIMED("pair_full");
     launch_pair_full<T>(stream, ev.n_home, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, lpol, grad_p, pot.as<T>(),
-                        Ed_cur(), ev.home ? ev.home : nbr.order, fld_out, mono_ok && !ev.home && snranks == 1 ? 1 : 0,
-                        cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole);
+                        Ed_cur(), pair_rows(), fld_out, mono_ok ? 1 : 0, cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole);
   }
   // with_field_finish: the gather also forms the total dE/dU and its maximum (launch_field_finish's work, fused)
   void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr, bool with_field_finish = false,
@@ -1051,7 +1166,7 @@ struct Engine : EngineBase {
     }
     TIMED("gather");
     launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff,
-                     e_recip, bins_main ? &bins : nullptr, ev.bases);
+                     e_recip);
   }
   // closes the evaluation: E_out = (real, recip[slot], self, penalty) of THIS rank's share
   // with_field_finish (single rank, pull kernel): the SCF residual and its maximum are formed by this kernel too
@@ -1064,33 +1179,37 @@ struct Engine : EngineBase {
       ff.pol = ev.pol; ff.Ucart = ev.U; ff.fld_pair = fld_pair.as<T>(); ff.fld_recip = fld_recip.as<T>();
       ff.kappa = (T)kappa; ff.field = field.as<T>(); ff.fmax_bits = fmax_word();
     }
-    TIMED("finish");
-    launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
-                     dQl, Ed_cur(), ev.home, ev.n_home, ff);
+    { TIMED("finish");
+      launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
+                       dQl, Ed_cur(), ev.home, ev.n_home, ff); }
+    if (snranks > 1 && grad_p) exchange_grad(grad_p);
   }
-  // ---- incremental SCF (single rank) --------------------------------------------------------------------------
+  // ---- incremental SCF ------------------------------------------------------------------------------------------
   // The field dE/dU is LINEAR in the induced dipoles and only sites with pol > 0 ever change theirs.  So after the first
   // (full) field evaluation of a call, every further SCF cycle evaluates only the field of the Jacobi step's dipole CHANGE
   // dU: real space over polarizable-polarizable pairs (k_pair_field_ind), reciprocal space by spreading the dU of the
   // polarizable sites alone, and adds it to the stored field; phi is kept current by adding the increment's mesh.  For
   // water that is 1/9 of the pairs and 1/3 of the spread / gather work per cycle; the arithmetic is the reference's
-  // (admp/pme.py:130-138) regrouped, same dipoles and cycle count to round-off.
+  // (admp/pme.py:130-138) regrouped, same dipoles and cycle count to round-off.  On a slab rank the rows are the polarizable
+  // HOME atoms and the dU of the imported atoms arrive by one all-to-all-v per Jacobi step (exchange_U).
   enum { E_PARTS_SUM = -1 };   // read_energies: the reciprocal energy is the sum of the E_PARTS partial words
   int* nact_dev() { return reinterpret_cast<int*>(Ed_cur() + E_NACT); }
   DevBuf rq_d;                                      // compact (position, charge) rows: what the pair kernels read of a
   RQ4<T>* rq_p() {                                  // charge-only partner
-    if (snranks != 1) return nullptr;
     rq_d.need(sizeof(RQ4<T>) * (size_t)top.na);
     return rq_d.as<RQ4<T>>();
   }
   int* cls_flags_dev() { return nact_dev() + 1; }   // the other half of that word: CLS_* of this evaluation (k_prepare_sites)
   int cls_sites_na = -1;                            // `sites` holds an evaluation of this many atoms
   bool cls_first_done = false;                      // the flags of the first evaluation have been looked at
-  // device-side count for the kernels of the first cycle when the list is fresh (nullptr: the host knows it: act_n)
-  const int* nact_arg() { return act_fresh ? nact_dev() : nullptr; }
-  int nact_rows() const { return act_fresh ? top.na : act_n; }      // grid bound of those kernels
+  // the polarizable rows of this evaluation: all polarizable atoms (one rank), or the rank's polarizable home atoms
+  const int* act_list() const { return snranks > 1 ? sl.act : act_d.as<int>(); }
+  // device-side count for the kernels of the first cycle when the list is fresh (nullptr: the host knows it)
+  const int* nact_arg() { return snranks == 1 && act_fresh ? nact_dev() : nullptr; }
+  int nact_rows() const { return snranks > 1 ? sl.n_act : (act_fresh ? top.na : act_n); }      // grid bound of those kernels
+  int nact_known() const { return snranks > 1 ? sl.n_act : act_n; }
   void nact_seen() {                                                 // after a read_energies of this evaluation
-    if (!act_fresh) return;
+    if (snranks > 1 || !act_fresh) return;
     int n = 0;
     std::memcpy(&n, &Eh[E_NACT], sizeof(n));
     act_n = n;
@@ -1102,21 +1221,33 @@ struct Engine : EngineBase {
     int rc = sort_ints(stream, act_d.as<int>(), act_tmp.as<int>(), n, &scan_scratch.p, &scan_bytes);
     if (rc != 0) throw Err{ADMP_E_HIP, std::string("sort_ints: ") + hipGetErrorString((hipError_t)rc)};
   }
+  void first_pair_field() {          // real-space dE/dU of the polarizable rows, all partners
+    TIMED("pair_field");
+    launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
+                         act_list(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole);
+  }
+  void first_gather_field(const FieldFin<T>& ff) {   // reciprocal dE/dU of the polarizable rows from phi
+    TIMED("gather_field");
+    launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(), act_list(), 1,
+                           nact_arg(), nullptr, ff);
+  }
   double scf_check(int* n_act) {          // total field + its maximum over the polarizable sites; one host read
     if (ff_done == fmax_word()) ff_done = nullptr;            // formed by the field gather before this check
     else launch_field_check(next_check_word());
     double dummy[4];
-    const double fmax = read_energies(E_SCF_RECIP, dummy);
+    const double fmax = read_energies(E_SCF_RECIP, dummy, false);
     nact_seen();
-    *n_act = act_n;
+    *n_act = nact_known();
     return fmax;
   }
   void scf_jacobi(int n_act, const unsigned long long* gate = nullptr, double gate_min = 0.0) {
-    if (n_act <= 0) return;
-    isites.need(sizeof(Site<T>) * (size_t)n_act);
-    TIMED("jacobi_update");
-    launch_jacobi_delta<T>(stream, n_act, act_d.as<int>(), ev.pol, field.as<T>(), ev.U, sites.as<Site<T>>(),
-                           isites.as<Site<T>>(), gate, gate_min);
+    if (n_act > 0) {
+      isites.need(sizeof(Site<T>) * (size_t)n_act);
+      TIMED("jacobi_update");
+      launch_jacobi_delta<T>(stream, n_act, act_list(), ev.pol, field.as<T>(), ev.U, sites.as<Site<T>>(),
+                             isites.as<Site<T>>(), gate, gate_min);
+    }
+    if (snranks > 1) exchange_U(1);       // every rank takes part, whatever its own count
   }
   // Small systems are dispatch-bound: the SCF residual rides in the epilogue of the field gather that precedes a check
   // (field_epilogue(word) describes it; the check's own kernel is then skipped).  word: a zero word of the energy block.
@@ -1139,17 +1270,22 @@ struct Engine : EngineBase {
     fmax_clean = false;
     return fmax_word();
   }
-  // total field of the polarizable rows and its maximum into `word` (a zero word of this evaluation's energy block); no read
+  // total field of the polarizable rows and its maximum (over all ranks) into `word` (a zero word of this evaluation's
+  // energy block); no host read
   void launch_field_check(unsigned long long* word) {
-    if (ff_done == word) { ff_done = nullptr; return; }     // the field gather before it has done this
+    if (ff_done == word) { ff_done = nullptr; return; }     // the field gather before it has done this (one rank only)
     ff_done = nullptr;
-    TIMED("field_finish");
-    launch_field_finish<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
-                           (T)kappa, field.as<T>(), word, act_d.as<int>(), nact_arg());
+    if (nact_rows() > 0) {
+      TIMED("field_finish");
+      launch_field_finish<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
+                             (T)kappa, field.as<T>(), word, act_list(), nact_arg());
+    }
+    reduce_check_word(word);
   }
+  size_t nreal_local() const { return (size_t)nloc0() * K[1] * K[2]; }
   // check_word: the zero word the check after this increment writes (its residual then rides in the field gather)
   void scf_increment(int n_act, unsigned long long* check_word = nullptr) {   // fld_pair / fld_recip / phi <- their values for the dipoles after scf_jacobi
-    if (n_act <= 0) return;
+    if (n_act <= 0 && snranks == 1) return;
     if (ind_nbr_gen != nbr_gen || ind_act_gen != act_gen) {      // neighbour table or polarizable set changed
       TIMED("ind_table");
       int rc = build_ind_table<T>(stream, top.na, nbr, sites.as<Site<T>>(), ind, &scan_scratch.p, &scan_bytes);
@@ -1158,13 +1294,13 @@ struct Engine : EngineBase {
     }
     { TIMED("pair_field_ind");
       launch_pair_field_ind<T>(stream, n_act, ind, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                               act_d.as<int>()); }
-    const size_t nreal = (size_t)K[0] * K[1] * K[2];
+                               act_list()); }
+    const size_t nreal = nreal_local();
     mesh2.need(nreal * sizeof(T));
     { TIMED("spread_ind");
       // the compact rows keep their positions and their order through the SCF cycles of one evaluation: the brick lists of
       // its first increment serve the later ones (two binning passes and a scan less per cycle)
-      ensure_bins(n_act, bins_ind, bin_cells_ind, bin_sorted_ind);
+      ensure_bins(std::max(n_act, 1), bins_ind, bin_cells_ind, bin_sorted_ind);
       const bool reuse = ind_bins_eval == eval_seq && ind_bins_n == n_act && ind_bins_gen == act_gen &&
                          ind_bins_at == bins_ind.cell_start;
       int rc = launch_spread<T>(stream, n_act, isites.as<Site<T>>(), 1, ev.g, bins_ind, mesh2.as<T>(), nullptr, nullptr, 1,
@@ -1174,19 +1310,30 @@ struct Engine : EngineBase {
     const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>());
     { TIMED("gather_field_ind");
       launch_gather_field<T>(stream, n_act, isites.as<Site<T>>(), ev.g, mesh2.as<T>(), fld_recip.as<T>(), nullptr, 1, nullptr,
-                             act_d.as<int>(), check_word ? field_epilogue(check_word) : FieldFin<T>()); }
+                             act_list(), check_word ? field_epilogue(check_word) : FieldFin<T>()); }
     if (!added) { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)nreal, mesh.as<T>(), mesh2.as<T>()); }
   }
 
-  // one device->host copy + sync: energies (and the max|field| word, returned)
-  double read_energies(int recip_slot, double* E) {
+  // one device->host copy + sync: energies (and the max|field| word, returned).  On a slab rank the four parts are first
+  // summed over the ranks (want_sum; the SCF checks only need the residual word, which is already the global maximum).
+  double read_energies(int recip_slot, double* E, bool want_sum = true) {
     if (!Eh) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&Eh), E_WORDS * sizeof(double), hipHostMallocDefault));
+    const bool summed = snranks > 1 && want_sum;
+    if (summed) {
+      TIMED("comm_energies");
+      launch_energy_pack(stream, Ed_cur(), recip_slot, Ed_cur() + E_RED);
+      c_all_reduce(Ed_cur() + E_RED, 4, ADMP_T_F64, ADMP_OP_SUM, ADMP_TAG_ENERGIES);
+    }
     HIP_TRY(hipMemcpyAsync(Eh, Ed_cur(), E_WORDS * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     {
       int w[2];
       std::memcpy(w, &Eh[E_NACT], sizeof(w));
       cls_seen(w[1]);
+    }
+    if (summed) {
+      for (int k = 0; k < 4; ++k) E[k] = Eh[E_RED + k];
+      return Eh[E_FMAX];
     }
     E[0] = Eh[E_REAL]; E[1] = recip_slot >= 0 ? Eh[recip_slot] : 0.0; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
     if (recip_slot == E_PARTS_SUM) {         // atom-side reciprocal energy: the partial words of k_gather<.., true>
@@ -1214,7 +1361,7 @@ struct Engine : EngineBase {
   void pme(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
            const double* mS, const double* pS, void* U_, int max_cycle, double thresh, double* E, void* dpos_,
            void* dQl_, int* ncyc, int* conv, int on_device) override {
-    ARG_CHECK(snranks == 1, "this handle is slab-decomposed: drive it through the admp_stage_* entry points");
+    ARG_CHECK(snranks == 1 || on_device, "a slab-decomposed handle takes device pointers");
     ARG_CHECK(pos_ && box && Ql_ && E, "null argument");
     const int na = top.na;
     HIP_TRY(hipSetDevice(device));
@@ -1282,24 +1429,21 @@ struct Engine : EngineBase {
         double r = pred;
         while (nhat <= E_CHAIN && r >= thresh) { r *= scf_contract; ++nhat; }
       }
+      // (every input of these decisions is the same on every rank of a decomposed handle: the residuals are global maxima)
       const bool chain = spec_mode < 0 && !speculate && top.na <= chain_max && nhat >= 1 && nhat <= E_CHAIN &&
-                         nhat + 2 <= max_cycle && !act_fresh && act_n > 0;
+                         nhat + 2 <= max_cycle && (snranks > 1 || (!act_fresh && act_n > 0));
       static const bool scf_trace = getenv("ADMP_SCF_TRACE") != nullptr;     // one line per call: which form ran
       if (scf_trace) fprintf(stderr, "[admp scf] %s (predicted residual %.4g, threshold %.4g, %d steps)\n",
                              chain ? "chained" : (speculate ? "speculative" : "plain"), pred, thresh, chain ? nhat : 0);
       if (chain) {
-        n_act = act_n;
-        { TIMED("pair_field");
-          launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                               act_d.as<int>(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole); }
+        n_act = nact_known();
+        first_pair_field();
         recip_pass(E_SCF_RECIP);
         auto word = [&](int k) {      // residual of check k: E_FMAX, then the (still zero) chain words of this evaluation
           return k == 0 ? fmax_word() : reinterpret_cast<unsigned long long*>(Ed_cur() + E_FMAX1 + (k - 1));
         };
         next_check_word();
-        { TIMED("gather_field");
-          launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(),
-                                 act_d.as<int>(), 1, nact_arg(), nullptr, field_epilogue(word(0))); }
+        first_gather_field(field_epilogue(word(0)));
         launch_field_check(word(0));
         for (int c = 0; c < nhat; ++c) {
           scf_jacobi(n_act, word(c), thresh);        // a zero step once a check has passed: later residuals repeat it
@@ -1342,14 +1486,15 @@ struct Engine : EngineBase {
         // kernels (98k atoms: gather 26 -> 47 us fused against 9 us saved; 1M atoms: 0.40 vs 0.31 + 0.056 ms)
         static const int fuse_max = [] { const char* e = getenv("ADMP_FUSE_FF_MAX"); return e ? atoi(e) : 16384; }();
         const bool fuse_ff = top.na <= fuse_max;
-        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), fuse_ff);
+        const bool fuse_g = fuse_ff && snranks == 1;
+        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), fuse_g);
         const bool pull = !ev.home && top.inv_ptr;          // the atomics-free closing kernel can carry the field finish
-        if (!fuse_ff && !pull) launch_field_finish_only();
-        launch_finish_only(dpos ? gbuf : nullptr, dQl, !fuse_ff && pull);
+        if (!fuse_g && !pull) launch_field_finish_only();
+        launch_finish_only(dpos ? gbuf : nullptr, dQl, !fuse_g && pull);
         const double fmax = read_energies(E_SCF_RECIP, E);
         f_first = f_final = fmax;
         nact_seen();
-        n_act = act_n;
+        n_act = nact_known();
         if (fmax < thresh) {
           phi_valid = done = finished = true;
           ev.active = false;
@@ -1362,14 +1507,10 @@ struct Engine : EngineBase {
       }
       for (; !done && i < max_cycle; ++i) {     // admp/pme.py:132-138
         if (!have_base) {        // first field evaluation of the call: everything, at the polarizable sites
-          { TIMED("pair_field");
-            launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                                 act_d.as<int>(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole); }
+          first_pair_field();
           recip_pass(E_SCF_RECIP);
           unsigned long long* w = fuse_ok() ? next_check_word() : nullptr;
-          { TIMED("gather_field");
-            launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(),
-                                   act_d.as<int>(), 1, nact_arg(), nullptr, field_epilogue(w)); }
+          first_gather_field(field_epilogue(w));
           have_base = true;
         } else {
           scf_increment(n_act, fuse_ok() ? next_check_word() : nullptr);
@@ -1421,7 +1562,7 @@ struct Engine : EngineBase {
   // CALLER supplies -- no SCF.  Device pointers only.  dU = dE/dUind_global (Cartesian, incl. the self and penalty terms).
   void pme_at_U(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
                 const double* mS, const double* pS, const void* U_, double* E, void* dpos_, void* dU_, void* dQl_) override {
-    ARG_CHECK(snranks == 1, "this handle is slab-decomposed: drive it through the admp_stage_* entry points");
+    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
     ARG_CHECK(lpol, "polarizable handle required (the non-polarizable energy is admp_pme_energy_grad)");
     ARG_CHECK(pos_ && box && Ql_ && U_ && E, "null argument");
     ARG_CHECK(!dQl_ || dpos_, "dE_dQlocal requires dE_dpos");
@@ -1494,7 +1635,6 @@ struct Engine : EngineBase {
     need_eval_or_disp();
     {
       TIMED("spread");
-      bins_main = false;
       int rc = launch_spread<T>(stream, vs_n, vs_sites, lpol_sites < 0 ? lpol : lpol_sites, vs_g, bins, mesh.as<T>(), nullptr,
                                 nullptr, 1, reuse_bins);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
@@ -1668,58 +1808,6 @@ struct Engine : EngineBase {
     o[0] = X0; o[1] = X1; o[2] = Y0; o[3] = Y1; o[4] = nloc0(); o[5] = kGhost; o[6] = K[0]; o[7] = K[1]; o[8] = K[2] / 2 + 1;
     o[9] = srank; o[10] = snranks;
   }
-  int v_stage_begin(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
-                    const double* mS, const double* pS, void* U) override {
-    mono_ok = false;            // the staged caller may still ask for dE/dQ_local at ADMP_ST_FINISH
-    return stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, U);
-  }
-  void v_stage(int what, void* a, void* b, int iarg, double* dout) override {
-    switch (what) {
-      case ADMP_ST_SET_U: stage_set_U(a); break;
-      case ADMP_ST_PAIR_FIELD: stage_pair_field(); break;
-      case ADMP_ST_SPREAD: stage_spread((T*)a); break;
-      case ADMP_ST_FFT_YZ: if (iarg) fft_inverse((T*)b, (T*)a); else fft_forward((T*)a, (T*)b); break;
-      case ADMP_ST_FFT_X: ARG_CHECK(snranks > 1, "FFT_X is a slab stage"); fft_x((T*)a, iarg); break;
-      case ADMP_ST_KSPACE: stage_kspace((T*)a, iarg ? E_SCF_RECIP : E_RECIP); break;
-      case ADMP_ST_GATHER_FIELD: stage_gather_field((const T*)a); break;
-      case ADMP_ST_FIELD_FINISH: ARG_CHECK(dout, "null"); dout[0] = stage_field_finish(); break;
-      case ADMP_ST_JACOBI: stage_jacobi((T*)a); break;
-      case ADMP_ST_PAIR_FULL: stage_pair_full((T*)a, (iarg && lpol) ? fld_pair.as<T>() : nullptr); break;
-      case ADMP_ST_GATHER: stage_gather((const T*)a, (T*)b, (iarg && lpol) ? fld_recip.as<T>() : nullptr); break;
-      case ADMP_ST_FINISH: ARG_CHECK(dout, "null"); stage_finish((T*)a, (T*)b, iarg ? E_SCF_RECIP : E_RECIP, dout); break;
-      case ADMP_ST_MARK_IMPORTS:
-        need_eval();
-        ARG_CHECK(a && snranks > 1 && ev.home, "MARK_IMPORTS is a slab stage");
-        launch_mark_imports(stream, ev.n_home, ev.home, nbr, top, ev.bases, X1 - X0, K[0], X0, snranks, (int*)a);
-        break;
-      case ADMP_ST_HOME_LIST:
-        need_eval();
-        ARG_CHECK(a && ev.home, "HOME_LIST is a slab stage");
-        HIP_TRY(hipMemcpyAsync(a, ev.home, sizeof(int) * (size_t)ev.n_home, hipMemcpyDeviceToDevice, stream));
-        break;
-      case ADMP_ST_FIELD_MAX_DEV: {
-        need_eval();
-        ARG_CHECK(a, "null");
-        TIMED("field_finish");
-        launch_field_finish<T>(stream, ev.n_home, sites.as<Site<T>>(), ev.pol, ev.U, fld_pair.as<T>(), fld_recip.as<T>(),
-                               (T)kappa, field.as<T>(), (unsigned long long*)a, ev.home);
-        break;
-      }
-      case ADMP_ST_FINISH_DEV: {
-        ARG_CHECK(b, "null");
-        launch_finish_only((T*)a, nullptr);
-        const int slot = iarg ? E_SCF_RECIP : E_RECIP;
-        double* o = (double*)b;
-        HIP_TRY(hipMemcpyAsync(o, Ed_cur() + E_REAL, sizeof(double), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(o + 1, Ed_cur() + slot, sizeof(double), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(o + 2, Ed_cur() + E_SELF, 2 * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        ev.active = false;
-        break;
-      }
-      default: throw Err{ADMP_E_ARG, "unknown stage"};
-    }
-  }
-
   // dispersion PME (admp/disp_pme.py:80-123): real-space pairs + one scalar reciprocal pass per power
   void disp(const void* pos_, const double* box, const void* clist_, int pmax, int ns, const double* mS, double* E,
             void* dpos_, int on_device) override {
@@ -2184,23 +2272,23 @@ int admp_set_pairs_from_positions(admp_handle* h, const void* positions, const d
 
 int admp_slab_configure(admp_handle* h, int rank, int nranks) {
   return guarded(h, [&](EngineBase& e) {
-    ARG_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    ARG_CHECK(nranks >= 1 && nranks <= kSlabMaxRanks && rank >= 0 && rank < nranks, "bad rank / nranks (at most 28 ranks)");
     e.srank = rank; e.snranks = nranks;
   });
 }
 int admp_slab_info(admp_handle* h, int64_t* out11) {
   return guarded(h, [&](EngineBase& e) { ARG_CHECK(out11, "null"); e.slab_info(out11); });
 }
-int admp_stage_begin(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
-                     const void* tholes, int n_scales, const double* mScales, const double* pScales, void* U,
-                     int* n_home) {
+int admp_set_comm(admp_handle* h, const admp_comm* comm) {
   return guarded(h, [&](EngineBase& e) {
-    int n = e.v_stage_begin(positions, box, Q_local, pol, tholes, n_scales, mScales, pScales, U);
-    if (n_home) *n_home = n;
+    if (!comm) { e.have_comm = false; e.comm = admp_comm{}; return; }
+    ARG_CHECK(comm->all_reduce && comm->all_to_all_v && comm->shift, "communicator with a missing callback");
+    e.comm = *comm;
+    e.have_comm = true;
   });
 }
-int admp_stage(admp_handle* h, int what, void* a, void* b, int iarg, double* dout) {
-  return guarded(h, [&](EngineBase& e) { e.v_stage(what, a, b, iarg, dout); });
+int admp_slab_home(admp_handle* h, int32_t* home_out, int* n_home, int* n_import) {
+  return guarded(h, [&](EngineBase& e) { e.slab_home(home_out, n_home, n_import); });
 }
 
 int admp_profile_enable(admp_handle* h, int on) {

@@ -167,21 +167,23 @@ bool fftx_usable(int N) { return N >= 32 && N <= 1024 && (N & (N - 1)) == 0; }
 // spec = [K0][K1][khp] complex (khp >= K2/2+1: rows padded to whole 128-byte lines, engine.hip) after the batched 2-D r2c of
 // the y-z planes; gtab = [K0][K1][K2/2+1]; tw = (cos, sin)(2 pi k / K0), k < K0 / 2
 template <class T>
-void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot, int khp) {
+void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot, int khp,
+                      int ny) {
   const int N = K[0], Kh = K[2] / 2 + 1;
   if (khp < Kh) khp = Kh;
+  if (ny <= 0) ny = K[1];
   int logN = 0;
   while ((1 << logN) < N) ++logN;
   int NC = (int)(128 / (2 * sizeof(T)));                 // one 128-B line of columns
   while (NC > 1 && sizeof(Cx<T>) * ((size_t)N / 2 + (size_t)N * NC) > 60 * 1024) NC >>= 1;
   const size_t sh = sizeof(Cx<T>) * ((size_t)N / 2 + (size_t)N * NC);
   const int ntile = (Kh + NC - 1) / NC;
-  k_fftx_conv<T><<<xcd_grid((unsigned)(ntile * K[1])), kFftxBlock, sh, st>>>(N, logN, Kh, K[1], NC, (long)K[1] * khp, (long)khp,
-                                                                          (long)K[1] * Kh, (long)Kh, K[2],
+  k_fftx_conv<T><<<xcd_grid((unsigned)(ntile * ny)), kFftxBlock, sh, st>>>(N, logN, Kh, ny, NC, (long)ny * khp, (long)khp,
+                                                                        (long)ny * Kh, (long)Kh, K[2],
                                                                           reinterpret_cast<Cx<T>*>(spec), gtab,
                                                                           reinterpret_cast<const Cx<T>*>(tw), energies, slot);
 }
-template void launch_fftx_conv<float>(hipStream_t, const int*, const float*, float*, const float*, double*, int, int);
-template void launch_fftx_conv<double>(hipStream_t, const int*, const double*, double*, const double*, double*, int, int);
+template void launch_fftx_conv<float>(hipStream_t, const int*, const float*, float*, const float*, double*, int, int, int);
+template void launch_fftx_conv<double>(hipStream_t, const int*, const double*, double*, const double*, double*, int, int, int);
 
 }  // namespace admp

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <initializer_list>
+
 #include "frame_math.h"
 #include "pme_math.h"
 #include "spline_math.h"
@@ -35,6 +37,17 @@ struct NbrTable {
   int* order_plain = nullptr;   // na, only with cls: the row order WITHOUT the class grouping, for the kernels that have no
                                 // use for classes (dispersion, Tang-Toennies: grouping costs them locality -- 0.49 -> 0.74 ms
                                 // at 1M atoms on a borrowed, class-ordered table)
+  // build scratch kept with the table (no allocation / synchronisation per rebuild): the second column buffer that the
+  // out-of-place passes (row sort, class partition) write and swap with `col`, and the degree / cursor words
+  int* col_alt = nullptr;
+  int64_t cap_alt = 0;
+  int* deg = nullptr;
+  int deg_na = 0;
+  void free_all() {             // the owner's buffers (a borrowed table is a copy of the lender's struct: never freed)
+    for (int** p : {&rowptr, &col, &order, &cls, &order_plain, &col_alt, &deg})
+      if (*p) { (void)hipFree(*p); *p = nullptr; }
+    n_half = cap = cap_alt = 0; deg_na = 0;
+  }
 };
 constexpr int kRowWindow = 1024;
 constexpr int kColMask = 0x0fffffff;
@@ -68,7 +81,8 @@ enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_NACT = 4 /* int: number
        E_SLOTS = E_FMAX1 + E_CHAIN,
        E_PARTS = 64 /* partial sums of the atom-side reciprocal energy (k_gather<.., true>): 32k workgroups adding into ONE
                        word serialise at the memory side (0.2 ms at 1M atoms); 64 words take them in parallel */,
-       E_WORDS = E_SLOTS + E_PARTS /* one half of the double-buffered energy block */ };
+       E_RED = E_SLOTS + E_PARTS /* 4 words: (real, recip, self, penalty) packed for the SUM all-reduce of a slab evaluation */,
+       E_WORDS = E_RED + 4 /* one half of the double-buffered energy block */ };
 
 // optional epilogue of the gather (small systems) or of the closing kernel (large ones), speculative first SCF cycle on
 // one rank: total dE/dU and its maximum, exactly what launch_field_finish computes, without a separate dispatch
@@ -97,8 +111,6 @@ void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, con
                           int* cls_flags = nullptr /* ... this word (CLS_STALE / CLS_BETTER) */,
                           RQ4<T>* rq = nullptr /* optional: compact copy (position, charge) of every row */);
 template <class T>
-void launch_update_U(hipStream_t st, int na, const T* Ucart, Site<T>* sites);
-template <class T>
 void launch_local_frames(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, T* out /* (na,3,3) */);
 // field (Cartesian dE/dU) = pair (harmonic order) + recip (cartesian) + self + penalty; also max |field| over
 // sites with pol > 0.001 (admp/pme.py:130,136) into *fmax_bits (order-preserving bit pattern of a non-negative real)
@@ -115,10 +127,6 @@ template <class T>
 void launch_jacobi_delta(hipStream_t st, int n_act, const int* act, const T* pol, const T* field, T* Ucart, Site<T>* sites,
                          Site<T>* isites, const unsigned long long* gate = nullptr /* device word: bit pattern of the residual */,
                          double gate_min = 0.0 /* with gate: a zero step unless residual >= gate_min */);
-// Unew <- U - field * pol / DIELECTRIC (admp/pme.py:138), refreshing the packed harmonic copy (Unew may be U)
-template <class T>
-void launch_jacobi_update(hipStream_t st, int na, const T* pol, const T* field, const T* Ucart, T* Unew,
-                          Site<T>* sites, const int* list);
 // self term + polarization penalty energies, self potential, local-frame adjoint, dE/dQ_local
 template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
@@ -143,16 +151,6 @@ void launch_scalar_sites_batch(hipStream_t st, int na, const T* pos, const T* va
                                const double* self_coefs, Site<T>* sites, double* energies,
                                const RecipGeom<T>* g = nullptr /* with bases: the mesh the rows will be spread on */,
                                int4* bases = nullptr /* optional: stencil base indices per atom, as launch_prepare_sites */);
-// atoms whose lowest stencil plane lies in the local slab (local base index < width): appended to `list`
-template <class T>
-void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
-                      int* count);
-
-// slab decomposition: mark[j] <- 1 + owner rank for every atom the rank's kernels read without owning it (see
-// ADMP_ST_MARK_IMPORTS); bases = the per-atom stencil records of launch_prepare_sites (local x index in .x)
-void launch_mark_imports(hipStream_t st, int n_home, const int* home, const NbrTable& nb, const Topology& top,
-                         const int4* bases, int width, int K0, int X0, int nranks, int* mark);
-
 // ---- dft_kernels.hip: direct-DFT mesh convolution for mesh sizes rocFFT only does with Bluestein (dft_math.h)
 // tw = (cos, sin)(2 pi m / K[d]) tables of the three dimensions back to back (K[0] + K[1] + K[2] complex numbers)
 int dft_tile_cols(int N);
@@ -199,7 +197,8 @@ void launch_pfa_x_conv(hipStream_t st, const PfaPlan& p, const T* tw, T* spec, c
 bool fftx_usable(int N);
 template <class T>
 void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot,
-                      int khp = 0 /* row pitch of spec in complex numbers (0: K[2]/2+1) */);
+                      int khp = 0 /* row pitch of spec in complex numbers (0: K[2]/2+1) */,
+                      int ny = 0 /* y rows held: spec and gtab are [K0][ny][..] (0: K[1]; a slab rank holds its own rows) */);
 
 // ---- pair_kernels.hip
 template <class T>
@@ -347,10 +346,7 @@ template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
                    T* grad, const int* list, T* fld_recip /* optional: cartesian reciprocal dE/dU */,
                    const FieldFin<T>& ff = FieldFin<T>(),
-                   double* e_recip = nullptr /* optional: += 1/2 sum_i Q_tot,i . dE_recip/dQ_i = the reciprocal energy */,
-                   const BinScratch* bins = nullptr /* the brick lists launch_spread built from these sites at these positions
-                                                       (whole-mesh, list == nullptr): one workgroup per brick, phi from LDS */,
-                   const int4* bases = nullptr /* with bins: the stencil records launch_spread was given */);
+                   double* e_recip = nullptr /* optional: += 1/2 sum_i Q_tot,i . dE_recip/dQ_i = the reciprocal energy */);
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
                          T* fld_recip, const int* list, int nb = 1 /* batch: phi of b at phi + b * mesh size, fld + b * 3 * na */,
@@ -382,6 +378,48 @@ int cell_fill_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, dou
 template <class T>
 int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const double* heights,
                      double rc, CellScratch& cs, NbrTable& nb);
+
+// ---- slab_kernels.hip: x-slab decomposition (multi-GPU) ------------------------------------------------------------------
+// per-atom word of a rank's view of the decomposition (see slab_kernels.hip)
+constexpr int kSlabHome = 1 << 30, kSlabPolar = 1 << 29;
+constexpr int kSlabMaxRanks = 28, kSlabMaxCols = 3 + 2 * kSlabMaxRanks;
+// columns of the ordered compaction: column c keeps x = seq[c][p] (seq[c] == nullptr: x = p), p < len[c], where
+// (bits[x] & mask[c]) == want[c]
+struct SlabCols {
+  int ncols = 0;
+  int len[kSlabMaxCols];
+  const int* seq[kSlabMaxCols];
+  int mask[kSlabMaxCols];
+  int want[kSlabMaxCols];
+};
+// segments of a joined per-peer list: segment s = column col[s] of the compaction, entries off[s] .. off[s+1]-1 of the result
+struct SlabSegs {
+  int n = 0;
+  int off[kSlabMaxRanks + 1];
+  int col[kSlabMaxRanks];
+};
+// owner[na] / bits[na] of this evaluation and the compacted columns lists[c * na ..]; totals[ncols] stay on the device
+// (the caller reads them once).  counts: ncols * slab_compact_blocks(max len) ints of scratch.  hipError_t as int.
+int launch_slab_decompose(hipStream_t st, int na, const NbrTable& nb, const Topology& top, const int4* bases, const void* pol,
+                          int prec, int width, int K0, int X0, int nranks, int me, int* owner, int* bits,
+                          const SlabCols& cs, int* counts, int* totals, int* lists);
+int slab_compact_blocks(int maxlen);
+void launch_slab_concat(hipStream_t st, const SlabSegs& segs, const int* lists, long col_stride, int* out);
+template <class T>
+void launch_rows_gather(hipStream_t st, int n, int w, const int* idx, const T* src, T* out);
+// mode 0: dst[idx[k]] = in[k]; 1: dst[idx[k]] += in[k]; 2: dst[idx[k]] = 0 (in unused)
+template <class T>
+void launch_rows_scatter(hipStream_t st, int mode, int n, int w, const int* idx, const T* in, T* dst);
+// what 0: Cartesian induced dipoles of the listed atoms; what 1: the last Jacobi step's change (site pad words)
+template <class T>
+void launch_halo_u_pack(hipStream_t st, int n, int what, const int* idx, const T* Ucart, const Site<T>* sites, T* out);
+template <class T>
+void launch_halo_u_unpack(hipStream_t st, int n, int what, const int* idx, const T* in, T* Ucart, Site<T>* sites);
+// spec[nx][K1][nh] complex <-> all-to-all buffer (block of peer t: [nx][ny_t][nh]); dir 0 pack, 1 unpack
+template <class T>
+void launch_transpose_pack(hipStream_t st, int nx, int K1, int nh, int nranks, int dir, T* spec, T* buf);
+// out[4] = (real, recip, self, penalty) of the energy block e; recip_slot >= 0: that word, -1: the sum of the E_PARTS words
+void launch_energy_pack(hipStream_t st, const double* e, int recip_slot, double* out);
 
 // ---- nbr_kernels.hip
 // order[] <- the rows of every window of W <= kRowWindow consecutive rows sorted by neighbour count (ties by index).  The

@@ -615,132 +615,11 @@ __global__ __launch_bounds__(256) void k_kspace(int K0, int ny, int K2, const T*
   if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
 }
 
-// Gather: 8-lane groups, one atom per group, lanes 0..5 each take one z-index of the 6^3 stencil (36 mesh
-// loads in flight per lane; the six lanes' loads of one (x, y) are neighbours in memory -- one or two cache lines
-// per group and instruction, where a per-x-plane split touches six: the L1 line rate was the bound, 0.30 -> see
-// DESIGN.md 6), the 20 (or 3) partial sums are folded across the group with xor shuffles and
-// lane 0 converts them to dE/dQ, dE/dr.
-constexpr int kGatherBlock = 256;
-
-template <class T>
-__device__ __forceinline__ T group8_sum(T v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  return v;
-}
-
-// the lane's own spline weights along the z axis (register arrays are indexed by compare-select, not dynamically)
-template <class T>
-__device__ __forceinline__ void zcol_weights(const Stencil<T>& st, int c, T w[4]) {
-  w[0] = w[1] = w[2] = w[3] = T(0);
-#pragma unroll
-  for (int k = 0; k < 6; ++k)
-    if (k == c) { w[0] = st.M[2][k]; w[1] = st.D1[2][k]; w[2] = st.D2[2][k]; w[3] = st.D3[2][k]; }
-}
-
-template <class T, bool ERECIP>
-__global__ __launch_bounds__(kGatherBlock) void k_gather(int na, const Site<T>* __restrict__ sites, int lpol,
-                                                         RecipGeom<T> g, const T* __restrict__ phi,
-                                                         T* __restrict__ pot, T* __restrict__ grad,
-                                                         const int* __restrict__ list, T* __restrict__ fld,
-                                                         FieldFin<T> ff, double* e_recip) {
-  // XCD-aware block order: consecutive atoms (neighbours in space when the caller's order is) stay on one XCD, so a phi
-  // line is pulled into ONE L2 instead of all eight (measured L2-fabric traffic of this kernel: 629 MB for a 67 MB mesh)
-  const long blk = xcd_block(blockIdx.x, (unsigned)((8l * na + kGatherBlock - 1) / kGatherBlock));
-  const long t = (blk < 0 ? 8l * na : blk * kGatherBlock) + threadIdx.x;
-  const int slot = (int)(t >> 3), a = (int)(t & 7);
-  const int i = slot < na ? (list ? list[slot] : slot) : na;
-  T F[NF];
-#pragma unroll
-  for (int k = 0; k < NF; ++k) F[k] = T(0);
-  T r[3] = {0, 0, 0}, Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  T er = T(0);
-  if (slot < na) {
-    site_qtot(sites[i], lpol, r, Q);
-    if (a < 6) {
-      Stencil<T> st;
-      st.init(g, r);
-      T w[4];
-      zcol_weights(st, a, w);
-      gather_zcol(g, st, wrap_add(st.base[2], a, g.K[2]), w, [&](long idx) { return phi[idx]; }, F);
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NF; ++k) F[k] = group8_sum(F[k]);
-  if (slot < na && a == 0) {
-    T P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gr[3] = {0, 0, 0};
-    unfold_potential(g, Q, F, P, gr);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) pot[9 * i + k] += P[k];
-    if (fld) { fld[3 * i] = P[2]; fld[3 * i + 1] = P[3]; fld[3 * i + 2] = P[1]; }   // harmonic (z,x,y) -> cartesian
-    if (grad) {
-      grad[3 * i] += gr[0]; grad[3 * i + 1] += gr[1]; grad[3 * i + 2] += gr[2];
-    }
-    if (ERECIP) {       // the mesh energy is a quadratic form of the multipoles: E = 1/2 sum_h Q_h dE/dQ_h
-#pragma unroll
-      for (int k = 0; k < 9; ++k) er += Q[k] * P[k];
-    }
-  }
-  if (ERECIP) {
-    const double e = block_reduce_sum<kGatherBlock>((double)er);
-    if (threadIdx.x == 0) atomicAdd(&e_recip[(blockIdx.x >> 3) & (E_PARTS - 1)], 0.5 * e);
-  }
-  if (ff.fmax_bits) {   // kernel-uniform
-    double fm = 0.0;
-    if (slot < na && a == 0) {
-      const T al = ff.pol[i];
-      T fx, fy, fz;
-      total_field(sites[i], al, ff.Ucart + 3 * i, ff.fld_pair + 3 * i, fld + 3 * i, ff.kappa, fx, fy, fz);
-      ff.field[3 * i] = fx; ff.field[3 * i + 1] = fy; ff.field[3 * i + 2] = fz;
-      if (al > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
-    }
-    fm = block_reduce_max<kGatherBlock>(fm);
-    if (threadIdx.x == 0 && fm > 0.0) atomicMax(ff.fmax_bits, nonneg_bits(fm));
-  }
-}
-
-template <class T>
-__global__ __launch_bounds__(kGatherBlock) void k_gather_field(int na, const Site<T>* __restrict__ sites,
-                                                               RecipGeom<T> g, const T* __restrict__ phi,
-                                                               T* __restrict__ fld, const int* __restrict__ list,
-                                                               const int* __restrict__ n_dev,
-                                                               const int* __restrict__ add_to) {
-  phi += (size_t)blockIdx.y * ((size_t)g.nloc0 * g.K[1] * g.K[2]);            // batch: same atoms, another mesh
-  fld += (size_t)blockIdx.y * 3 * na;
-  if (n_dev) na = min(na, *n_dev);
-  const long blk = xcd_block(blockIdx.x, (unsigned)((8l * na + kGatherBlock - 1) / kGatherBlock));
-  const long t = (blk < 0 ? 8l * na : blk * kGatherBlock) + threadIdx.x;
-  const int slot = (int)(t >> 3), a = (int)(t & 7);
-  const int i = slot < na ? (list ? list[slot] : slot) : na;
-  T f[3] = {0, 0, 0};
-  if (slot < na && a < 6) {
-    T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
-    Stencil<T> st;
-    st.init(g, r);
-    T w[4];
-    zcol_weights(st, a, w);
-    gather_zcol_field(g, st, wrap_add(st.base[2], a, g.K[2]), w[0], w[1], [&](long idx) { return phi[idx]; }, f);
-  }
-  f[0] = group8_sum(f[0]); f[1] = group8_sum(f[1]); f[2] = group8_sum(f[2]);
-  if (slot < na && a == 0) {
-    const T* A = g.Aop;
-    if (add_to) {      // compact rows (incremental SCF): accumulate into the owning atom's entry
-      T* o = fld + 3 * (size_t)add_to[slot];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) o[k] += A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fld[3 * i + k] = A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
-    }
-  }
-}
-
 // ---- staged gather ---------------------------------------------------------------------------------------------------
-// Of the ~1100 instructions a wave of k_gather issues only a quarter are the 36 loads and their sums: every lane of an atom's
-// group evaluates the same three splines (~420 instructions with the index arithmetic), the 20 sums are folded with 60
-// shuffles, and the conversion to dE/dQ, dE/dr runs with one lane in eight.  Here a workgroup takes 32 atoms with SIX lanes
-// each (192 threads: no idle lanes in the load loop) and
+// The adjoint of the spread (the reference leaves it to jax.grad): dE/dQ, dE/dr of every atom from phi = c2r(G S).
+// Round 1's form (8 lanes per atom, every lane its own splines, 60 shuffles per atom, one lane in eight converting: in the
+// history) issued ~1100 instructions per wave of which a quarter were the 36 loads and their sums.  Here a workgroup takes
+// 32 atoms with SIX lanes each (192 threads: no idle lanes in the load loop) and
 //   0. wave d evaluates the dimension-d spline of the 32 atoms once and leaves the weights in LDS (W4 rows),
 //   1. every lane sums its z-index over the 36 (x, y) with weights read from LDS,
 //   2. the partial sums go to LDS (over the weight rows, after a barrier) and are folded by 192 threads, 6 words each,
@@ -860,207 +739,6 @@ __global__ __launch_bounds__(kGsBlock) void k_gather_staged(int na, const Site<T
   }
 }
 
-// ---- brick gather ----------------------------------------------------------------------------------------------------
-// The staged gather is bound by the cache-line rate of its mesh loads (a wave instruction touches ~14 lines: 16 cycles of
-// the vector cache per 10.7 atoms, about half the kernel time at 1M atoms, in series with the arithmetic).  When the spread
-// has binned the atoms by 16^3 mesh bricks, a workgroup takes one brick instead: it copies the brick's phi plus the five
-// planes the stencils reach beyond it into LDS once (21^3 words, coalesced), picks the entries of the brick's list whose
-// stencil STARTS in the brick (every atom has exactly one such brick; ordered compaction, 192 at a time), and runs the
-// staged steps on them with the mesh words read from LDS at constant offsets -- no wrap logic, no address arithmetic.
-// The conversion step runs once per 192 atoms with every thread busy.
-// Occupancy decides this kernel (a whole 21^3 tile is 37 KB: two workgroups = six waves per CU, and every step then waits on
-// its own latencies -- measured 0.43 ms at 1M atoms).  A workgroup therefore takes a QUARTER of a brick (the y and z ranges
-// split at 8): 21 x 13 x 13 words, ~60 owners, four workgroups per CU; the brick's entry list is read by its four
-// workgroups, the loads of the list walk (entry -> stencil record and position) are issued for four slices at a time.
-constexpr int kGbX = 21;               // x planes of the tile: 16 brick points + 5
-constexpr int kGbSlices = 4;           // 192-entry slices of the list in flight
-
-template <class T, int PY, int PZ, int CH>
-struct GatherBrickLds {
-  union {
-    W4<T> w[kGsAtoms][kGsRow];
-    T part[NF][kGsBlock];
-  };
-  T sum[CH][NF + 1];
-  T tile[kGbX * PY * PZ];
-  T pos[CH][3];
-  int off[CH][3];
-  int own[CH];
-  int wcnt[2][4];
-  int next;
-};
-extern __shared__ __align__(32) unsigned char gather_smem[];
-
-// SY, SZ: the brick is cut in SY x SZ parts along y and z (1 or 2; a part covers 8 points, the last one the rest)
-template <class T, bool ERECIP, int SY, int SZ>
-__global__ __launch_bounds__(kGsBlock) void k_gather_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
-                                                            BrickGrid bg, const int* __restrict__ brick_start,
-                                                            const int* __restrict__ entries,
-                                                            const int4* __restrict__ bases, const T* __restrict__ phi,
-                                                            T* __restrict__ pot, T* __restrict__ grad,
-                                                            T* __restrict__ fld, FieldFin<T> ff, double* e_recip) {
-  constexpr int PY = SY == 2 ? 13 : 21, PZ = SZ == 2 ? 13 : 21, PLANE = PY * PZ, CH = SY * SZ == 1 ? kGsBlock : kGsBlock / 2;
-  constexpr int NSUB = SY * SZ;
-  using Lds = GatherBrickLds<T, PY, PZ, CH>;
-  Lds& L = *reinterpret_cast<Lds*>(gather_smem);
-  const long blk = xcd_block(blockIdx.x, (unsigned)(bg.ncell * NSUB));      // neighbouring bricks (shared halo) on one XCD
-  if (blk < 0) return;
-  const int bid = (int)(blk / NSUB), sub = (int)(blk - (long)bid * NSUB), sy = SY == 2 ? sub & 1 : 0, sz = SZ == 2 ? sub / SY : 0;
-  const int beg = brick_start[bid], cnt = brick_start[bid + 1] - beg;
-  if (cnt == 0) return;
-  const int bz = bid % bg.nb[2], by = (bid / bg.nb[2]) % bg.nb[1], bx = bid / (bg.nb[2] * bg.nb[1]);
-  const int bb[3] = {bx, by, bz}, mycode = bx | (by << 9) | (bz << 18);
-  int lo[3], n[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    lo[d] = (bb[d] * g.K[d]) / bg.nb[d];
-    n[d] = ((bb[d] + 1) * g.K[d]) / bg.nb[d] - lo[d];
-  }
-  if (SY == 2) { if (sy) { lo[1] += 8; n[1] -= 8; } else n[1] = 8; }          // bricks have 15 or 16 points: parts of 8 and 7..8
-  if (SZ == 2) { if (sz) { lo[2] += 8; n[2] -= 8; } else n[2] = 8; }
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (threadIdx.x == 0) L.next = cnt;
-  // tile <- phi[lo .. lo + n + 5) (periodic): the (y, z) part of the offsets is the same for every x plane
-  {
-    constexpr int NK = (PLANE + kGsBlock - 1) / kGsBlock;
-    long goff[NK];
-    int loff[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int e = (int)threadIdx.x + k * kGsBlock, jb = e / PZ, jc = e - jb * PZ;
-      loff[k] = (jb < n[1] + 5 && jc < n[2] + 5) ? e : -1;
-      int y = lo[1] + jb, z = lo[2] + jc;
-      if (y >= g.K[1]) y -= g.K[1];
-      if (z >= g.K[2]) z -= g.K[2];
-      goff[k] = (long)y * g.K[2] + z;
-    }
-    const long k12 = (long)g.K[1] * g.K[2];
-    const int nx = n[0] + 5;
-#pragma unroll
-    for (int j0 = 0; j0 < kGbX; j0 += 7) {               // 7 planes of loads in flight
-      T v[7][NK];
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        int x = lo[0] + j0 + j;
-        if (x >= g.K[0]) x -= g.K[0];
-        const T* plane = phi + (long)x * k12;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) v[j][k] = (j0 + j < nx && loff[k] >= 0) ? plane[goff[k]] : T(0);
-      }
-#pragma unroll
-      for (int j = 0; j < 7; ++j)
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-          if (j0 + j < nx && loff[k] >= 0) L.tile[(j0 + j) * PLANE + loff[k]] = v[j][k];
-    }
-  }
-  const int s6 = threadIdx.x / 6, c6 = threadIdx.x - 6 * s6;
-  T er = T(0);
-  double fm = 0.0;
-  int pos = 0, round = 0;
-  while (pos < cnt) {                                    // rounds of <= CH owners (workgroup-uniform control flow)
-    int nown = 0;
-    bool full = false;
-    for (int p = pos; p < cnt && !full; p += kGbSlices * kGsBlock) {
-      int idx[kGbSlices];
-      int4 rec[kGbSlices];
-      T rr[kGbSlices][3];
-#pragma unroll
-      for (int k = 0; k < kGbSlices; ++k) {
-        const int e = p + k * kGsBlock + (int)threadIdx.x;
-        idx[k] = e < cnt ? entries[beg + e] : -1;
-      }
-#pragma unroll
-      for (int k = 0; k < kGbSlices; ++k) {
-        rec[k] = make_int4(0, 0, 0, -1);
-        rr[k][0] = rr[k][1] = rr[k][2] = T(0);
-        if (idx[k] >= 0) {
-          rec[k] = atom_bases(sites, bases, g, bg, idx[k]);
-          rr[k][0] = sites[idx[k]].r[0]; rr[k][1] = sites[idx[k]].r[1]; rr[k][2] = sites[idx[k]].r[2];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kGbSlices; ++k) {
-        if (p + k * kGsBlock >= cnt || full) break;      // uniform
-        const int e = p + k * kGsBlock + (int)threadIdx.x;
-        const int oy = rec[k].y - lo[1], oz = rec[k].z - lo[2];
-        const bool mine = idx[k] >= 0 && (rec[k].w & 0x7ffffff) == mycode && (unsigned)oy < (unsigned)n[1] &&
-                          (unsigned)oz < (unsigned)n[2];
-        const unsigned long long mask = __ballot(mine);
-        int* wc = L.wcnt[round & 1];
-        ++round;
-        if (lane == 0) wc[wave] = __popcll(mask);
-        __syncthreads();                                 // (first time: orders the tile and L.next as well)
-        int o = nown + __popcll(mask & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) o += wc[w];
-        if (mine) {
-          if (o < CH) {
-            L.own[o] = idx[k];
-            L.off[o][0] = rec[k].x - lo[0]; L.off[o][1] = oy; L.off[o][2] = oz;
-            L.pos[o][0] = rr[k][0]; L.pos[o][1] = rr[k][1]; L.pos[o][2] = rr[k][2];
-          } else {
-            atomicMin(&L.next, e);                       // does not fit: the next round starts here
-          }
-        }
-        nown += wc[0] + wc[1] + wc[2];
-        if (nown > CH) { nown = CH; full = true; }
-      }
-    }
-    __syncthreads();                                     // own / off / pos / next are complete
-    pos = full ? L.next : cnt;
-    for (int q = 0; q < nown; q += kGsAtoms) {
-      if (lane < kGsAtoms && q + lane < nown) {          // step 0: wave d, dimension d of 32 owners
-        const int d = wave;
-        const T r[3] = {L.pos[q + lane][0], L.pos[q + lane][1], L.pos[q + lane][2]};
-        int b;
-        const T f = grid_ref(g, r, d, b);
-        T M[6], D1[6], D2[6], D3[6];
-        bspline6(f, M, D1, D2, D3);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          W4<T> v;
-          v.m = M[k]; v.d1 = D1[k]; v.d2 = D2[k]; v.d3 = D3[k];
-          L.w[lane][6 * d + k] = v;
-        }
-      }
-      __syncthreads();
-      T F[NF];
-#pragma unroll
-      for (int k = 0; k < NF; ++k) F[k] = T(0);
-      if (q + s6 < nown) {                               // step 1
-        const int* o3 = L.off[q + s6];
-        const T* t0 = L.tile + (o3[0] * PY + o3[1]) * PZ + o3[2] + c6;
-        const W4<T> wz = L.w[s6][12 + c6];
-        gather_zcol_core(&L.w[s6][0], &L.w[s6][6], wz, [&](int a, int b) { return t0[a * PLANE + b * PZ]; }, F);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < NF; ++k) L.part[k][threadIdx.x] = F[k];
-      __syncthreads();
-      for (int t = threadIdx.x; t < NF * kGsAtoms; t += kGsBlock) {      // step 2
-        const int k = t >> 5, a = t & 31;
-        const T* v = &L.part[k][6 * a];
-        if (q + a < CH) L.sum[q + a][k] = ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
-      }
-      __syncthreads();
-    }
-    if ((int)threadIdx.x < nown)                         // step 3: one owner per thread
-      convert_sums<T, ERECIP>(L.own[threadIdx.x], L.sum[threadIdx.x], sites, lpol, g, pot, grad, fld, ff, er, fm);
-    if (pos < cnt) {
-      __syncthreads();
-      if (threadIdx.x == 0) L.next = cnt;
-    }
-  }
-  if (ERECIP) {
-    const double e = wave_reduce_sum((double)er);
-    if (lane == 0) atomicAdd(&e_recip[(blockIdx.x >> 3) & (E_PARTS - 1)], 0.5 * e);
-  }
-  if (ff.fmax_bits) {   // kernel-uniform
-    fm = wave_reduce_max(fm);
-    if (lane == 0 && fm > 0.0) atomicMax(ff.fmax_bits, nonneg_bits(fm));
-  }
-}
-
 template <class T>
 __global__ __launch_bounds__(kGsBlock) void k_gather_field_staged(int na, const Site<T>* __restrict__ sites,
                                                                   RecipGeom<T> g, const T* __restrict__ phi,
@@ -1142,6 +820,10 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
                   T* mesh, const int* list, const int4* bases, int nb, int reuse_bins) {
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
+  if (na <= 0) {      // nothing to spread (a slab rank without atoms of this kind): the mesh is zero
+    RC(hipMemsetAsync(mesh, 0, sizeof(T) * (size_t)g.nloc0 * g.K[1] * g.K[2] * (size_t)(nb > 0 ? nb : 1), st));
+    return 0;
+  }
   // the binned brick kernel expresses a stencil as ONE run of local indices per axis, which needs >= 2 bricks per axis
   // (a stencil that wraps around inside a single brick is two runs): meshes of <= 16 points per axis take the scan kernel
   const bool one_brick_axis = bg.nb[0] == 1 || bg.nb[1] == 1 || bg.nb[2] == 1;
@@ -1241,80 +923,22 @@ void launch_gather_virial(hipStream_t st, int na, const Site<T>* sites, int lpol
   k_gather_virial<T><<<(na + 127) / 128, 128, 0, st>>>(na, sites, lpol, g, phi, xw, yy);
 }
 
-// home list of a slab rank: atoms whose local base plane index is below the slab width
-template <class T>
-__global__ __launch_bounds__(256) void k_home_list(int na, const Site<T>* __restrict__ sites, RecipGeom<T> g, int width,
-                                                   int* __restrict__ list, int* __restrict__ count) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  bool mine = false;
-  if (i < na) {
-    T r[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
-    int base;
-    grid_ref(g, r, 0, base);
-    mine = base < width;
-  }
-  const int slot = wave_agg_add(count, 0, mine);
-  if (mine) list[slot] = i;
-}
-template <class T>
-void launch_home_list(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, int width, int* list,
-                      int* count) {
-  k_home_list<T><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, width, list, count);
-}
-// ADMP_GATHER=lanes8: the 8-lane form; =bricks: the brick form where the spread left its lists (slower as measured, kept for
-// A/B); default: the staged form
-static int gather_mode() {
-  static const int m = [] {
-    const char* e = getenv("ADMP_GATHER");
-    return e && !strcmp(e, "lanes8") ? 0 : (e && !strcmp(e, "bricks") ? 2 : 1);
-  }();
-  return m;
-}
-static bool gather_staged() { return gather_mode() != 0; }
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad, const int* list, T* fld, const FieldFin<T>& ff, double* e_recip, const BinScratch* bs,
-                   const int4* bases) {
-  const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
-  const BrickGrid bg = make_bricks(dims);
-  const bool whole = g.xoff == 0 && g.nloc0 == g.K[0] && g.wrap0 == g.K[0];
-  if (bs && bs->cell_start && !list && whole && gather_mode() == 2 && bg.nb[0] > 1 && bg.nb[1] > 1 && bg.nb[2] > 1 &&
-      bg.nb[0] < 512 && bg.nb[1] < 512 && bg.nb[2] < 512) {
-    const unsigned grid = xcd_grid((unsigned)bg.ncell * 4u);
-    const size_t sh = sizeof(GatherBrickLds<T, 13, 13, kGsBlock / 2>);
-    if (e_recip)
-      k_gather_bricks<T, true, 2, 2><<<grid, kGsBlock, sh, st>>>(sites, lpol, g, bg, bs->cell_start, bs->sorted, bases, phi, pot,
-                                                                 grad, fld, ff, e_recip);
-    else
-      k_gather_bricks<T, false, 2, 2><<<grid, kGsBlock, sh, st>>>(sites, lpol, g, bg, bs->cell_start, bs->sorted, bases, phi, pot,
-                                                                  grad, fld, ff, e_recip);
-    return;
-  }
-  if (gather_staged()) {
-    const unsigned gs = xcd_grid((unsigned)nblk(na, kGsAtoms));
-    if (e_recip)
-      k_gather_staged<T, true><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
-    else
-      k_gather_staged<T, false><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
-    return;
-  }
-  const unsigned grid = xcd_grid((unsigned)nblk(na * 8, kGatherBlock));
+                   T* grad, const int* list, T* fld, const FieldFin<T>& ff, double* e_recip) {
+  if (na <= 0) return;
+  const unsigned gs = xcd_grid((unsigned)nblk(na, kGsAtoms));
   if (e_recip)
-    k_gather<T, true><<<grid, kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
+    k_gather_staged<T, true><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
   else
-    k_gather<T, false><<<grid, kGatherBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
+    k_gather_staged<T, false><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
 }
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
                          const int* list, int nb, const int* n_dev, const int* add_to, const FieldFin<T>& ff) {
   if (na <= 0) return;
-  if (gather_staged() || ff.fmax_bits) {
-    k_gather_field_staged<T><<<dim3(xcd_grid((unsigned)nblk(na, kGsAtoms)), nb), kGsBlock, 0, st>>>(na, sites, g, phi, fld, list,
-                                                                                                  n_dev, add_to, ff);
-    return;
-  }
-  k_gather_field<T><<<dim3(xcd_grid((unsigned)nblk(na * 8, kGatherBlock)), nb), kGatherBlock, 0, st>>>(na, sites, g, phi, fld, list,
-                                                                                                      n_dev, add_to);
+  k_gather_field_staged<T><<<dim3(xcd_grid((unsigned)nblk(na, kGsAtoms)), nb), kGsBlock, 0, st>>>(na, sites, g, phi, fld, list,
+                                                                                                n_dev, add_to, ff);
 }
 #define INST(T)                                                                                                       \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
@@ -1322,9 +946,8 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
   template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*, int,             \
                                const int*, int);                                                                      \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
-  template void launch_home_list<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, int, int*, int*);          \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
-                                 const int*, T*, const FieldFin<T>&, double*, const BinScratch*, const int4*);          \
+                                 const int*, T*, const FieldFin<T>&, double*);                                         \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
                                        const int*, int, const int*, const int*, const FieldFin<T>&);                  \
   template void launch_kspace_virial<T>(hipStream_t, const int*, const double*, double, double, int, int, const T*,   \

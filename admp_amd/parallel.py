@@ -1,34 +1,36 @@
 """Multi-GPU evaluation of the PME path: 1-D slab decomposition along x, one process per GPU.
 
-The reference is single-device; this module is the multi-GPU layer of the MI355X build.  Every rank is
-handed the same full input arrays (the reference's calling convention), owns the mesh planes [X0, X1) and works on its
-"home" atoms (lowest B-spline stencil plane inside the slab).  The DATA PATH between the ranks is halo-only:
+The reference is single-device; this module is the multi-GPU layer of the MI355X build.  Every rank makes
+the SAME call with the same full input arrays (the reference's calling convention), owns the mesh planes [X0, X1) and
+works on its "home" atoms (lowest B-spline stencil plane inside the slab).  Since round 3 the whole evaluation -- the
+same kernels, the same SCF forms (speculative / chained / plain, incremental field updates, charge-only pair forms) as
+on one GPU -- runs inside the library (`admp_pme_energy_grad` on a handle configured with `admp_slab_configure` +
+`admp_set_comm`); the library calls back into the communicator below where ranks exchange data:
 
-  * real space   : pair kernels over the home rows only -- the i-grouped neighbour table evaluates each pair from the
-                   row atom's side, so nothing is written to a remote atom;
-  * imports      : once per evaluation the library marks the atoms a rank reads without owning them (partners of its
-                   home rows, axis atoms of its home sites' frames: ADMP_ST_MARK_IMPORTS); the owners learn who needs
-                   what through one small all-to-all of index lists;
-  * spread       : home atoms -> local mesh (slab + 5 ghost planes), ghost planes sent to the next rank (point to point);
-  * 3-D FFT      : batched 2-D r2c on the owned planes, all-to-all transpose (RCCL over xGMI: every GPU exchanges an equal
-                   block with each of the other N-1 peers, all 7 links busy), batched 1-D c2c along x, k-space multiply on
-                   the y-slab, and back; blocks go through pre-allocated send / receive buffers, one collective each way;
-  * gather       : phi ghost planes fetched from the next rank, home atoms gathered;
-  * SCF          : max|field| reduced ON THE DEVICE (one MAX all-reduce of a device word, one host read per cycle); after
-                   a Jacobi step only the dipoles of the imported atoms travel (all-to-all-v of n_import x 3 reals);
-  * gradient     : contributions a rank made to atoms it does not own (local-frame adjoint of molecules that straddle a
-                   slab boundary) go back to the owners over the same lists; the four energies by one SUM all-reduce.
+  * decomposition : every rank derives owner / home / import / export lists of the evaluation BY ITSELF from the replicated
+                    inputs and the (symmetric) neighbour table -- no communication, one host read of the list lengths;
+  * real space    : pair kernels over the home rows only -- the i-grouped table evaluates each pair from the row atom's
+                    side, so nothing is written to a remote atom;
+  * spread        : home atoms -> local mesh (slab + 5 ghost planes), ghost planes sent to the next rank (`shift`);
+  * 3-D FFT       : batched 2-D r2c on the owned planes, all-to-all transpose (`all_to_all_v`; RCCL over xGMI: every GPU
+                    exchanges a block with each of the other N-1 peers, all 7 links busy), x lines forward * G * inverse in
+                    one kernel on the y rows the rank owns, and back;
+  * gather        : phi ghost planes fetched from the next rank, home atoms gathered;
+  * SCF           : max|field| reduced on the device (`all_reduce` MAX of one word per check); after a Jacobi step only
+                    the dipole CHANGES of the imported atoms travel (`all_to_all_v` of n_import x 3 reals);
+  * gradient      : contributions a rank made to atoms it does not own (local-frame adjoint of molecules that straddle a
+                    slab face) go back to the owners over the same lists; the four energies by one SUM all-reduce.
 
-With outputs='replicated' (default: the reference's API hands every caller the full arrays) the home rows of gradient
-and dipoles are finally summed over the ranks once per evaluation; with outputs='home' nothing proportional to the
-number of atoms is ever sent -- each rank returns its home rows (`home_atoms`), the form an MD driver that keeps the
-atoms distributed would use.  Not decomposed yet: dispersion PME and the Tang-Toennies term; the incremental SCF of the
-single-GPU path (engine.hip) is not used here.
+The library returns the rank's home rows of gradient / dipoles / dE/dQ_local.  With outputs='replicated' (default: the
+reference's API hands every caller the full arrays) they are summed over the ranks once per evaluation here; with
+outputs='home' nothing proportional to the number of atoms is ever sent -- each rank keeps its home rows (`home_atoms`),
+the form an MD driver that keeps the atoms distributed would use.
 
-`SlabPme` drives the staged C ABI (admp_stage_*, include/admp_hip.h) and is written against a small communicator
-interface so that the same code runs over torch.distributed (`TorchComm`: nccl = RCCL, or gloo with host staging) and
-over an in-process thread communicator (`ThreadComm`) used by the tests.  Both count the bytes they send per label
-(`bytes_sent`) and, on request, time every collective with device events (`report`).
+The communicator interface (`all_reduce`, `all_to_all_v`, `shift` on flat device tensors) has two implementations:
+torch.distributed (`TorchComm`: nccl = RCCL, or gloo with host staging) and an in-process thread communicator
+(`ThreadComm`) used by the tests.  Both count the bytes they send per label (`bytes_sent`) and, on request, time every
+collective with device events (`report`).  `SlabDispPme` / `SlabPairInteraction` decompose dispersion PME and the pair
+potentials over the same slabs.
 """
 import collections
 import ctypes
@@ -38,6 +40,7 @@ import numpy as np
 import torch
 
 from . import _lib, settings
+from .disp_pme import ADMPDispPmeForce
 from .pme import ADMPPmeForce
 
 
@@ -212,242 +215,156 @@ def slab_bounds(K, size):
     return [((s * K) // size, ((s + 1) * K) // size) for s in range(size)]
 
 
-class SlabPme(ADMPPmeForce):
-    """ADMPPmeForce whose evaluation is spread over the ranks of `comm` (SPMD: every rank makes the same
-    get_energy / get_forces call with the same full input arrays).  outputs='replicated': every rank receives the full
-    gradient / dipoles; outputs='home': only the rows of `home_atoms` are valid on a rank (no O(Na) communication)."""
+_TORCH_OF = {_lib.T_I32: (torch.int32, '<i4'), _lib.T_F32: (torch.float32, '<f4'), _lib.T_F64: (torch.float64, '<f8')}
 
-    GHOST = 5
 
-    def __init__(self, comm, box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol=False, device=None,
-                 outputs='replicated'):
+class _DevArray:
+    """raw device memory of the library as an object torch can wrap (CUDA array interface; works on ROCm builds)"""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
+
+
+class CommBinding:
+    """The admp_comm callbacks (include/admp_hip.h) of one handle, bound to a communicator object.  The library hands over
+    raw device pointers of its own buffers; they are wrapped as flat torch tensors (cached per pointer / length / type: the
+    buffers are the same step after step) and passed to the communicator, which works on the caller's current stream --
+    the stream the library runs on."""
+
+    def __init__(self, comm, device):
+        self.comm, self.device = comm, device
+        self.error = None
+        self._views = {}
+        self._cbs = (_lib.ALL_REDUCE_FN(self._all_reduce), _lib.ALL_TO_ALL_V_FN(self._all_to_all_v), _lib.SHIFT_FN(self._shift))
+        self.struct = _lib.AdmpComm(None, *self._cbs)
+
+    def _view(self, ptr, count, dtype):
+        key = (ptr, count, dtype)
+        t = self._views.get(key)
+        if t is None:
+            td, ts = _TORCH_OF[dtype]
+            if count == 0 or not ptr:
+                t = torch.empty(0, dtype=td, device=self.device)
+            else:
+                t = torch.as_tensor(_DevArray(ptr, count, ts), device=self.device)
+            if len(self._views) > 256:
+                self._views.clear()
+            self._views[key] = t
+        return t
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except BaseException as e:      # never let an exception cross the C frame
+            self.error = e
+            return 1
+
+    def _all_reduce(self, ctx, buf, count, dtype, op, tag):
+        return self._guard(lambda: self.comm.all_reduce(self._view(buf, count, dtype), 'max' if op == _lib.OP_MAX else 'sum',
+                                                        label=_lib.TAGS.get(tag, 'all_reduce')))
+
+    def _all_to_all_v(self, ctx, send, scounts, recv, rcounts, dtype, tag):
+        def run():
+            n = self.comm.size
+            sc, rc = [int(scounts[t]) for t in range(n)], [int(rcounts[t]) for t in range(n)]
+            self.comm.all_to_all_v(self._view(recv, sum(rc), dtype), self._view(send, sum(sc), dtype), rc, sc,
+                                   label=_lib.TAGS.get(tag, 'all_to_all'))
+        return self._guard(run)
+
+    def _shift(self, ctx, send, recv, count, dtype, to_next, tag):
+        return self._guard(lambda: self.comm.shift(self._view(send, count, dtype), self._view(recv, count, dtype), bool(to_next),
+                                                   label=_lib.TAGS.get(tag, 'shift')))
+
+
+class _SlabMixin:
+    """What the decomposed calculators share: binding the communicator to the handle, the home list of an evaluation and
+    the assembly of per-atom outputs."""
+
+    def _bind_comm(self, comm, outputs):
         if outputs not in ('replicated', 'home'):
             raise ValueError("outputs must be 'replicated' or 'home'")
         self.comm = comm
         self.outputs = outputs
         self.home_atoms = None
+        self.n_home = 0
         self.n_import = 0
+        self._binding = CommBinding(comm, self._device)
+        _lib.check(self._h, self._L.admp_slab_configure(self._h, comm.rank, comm.size), 'admp_slab_configure')
+        _lib.check(self._h, self._L.admp_set_comm(self._h, ctypes.byref(self._binding.struct) if comm.size > 1 else None),
+                   'admp_set_comm')
+
+    def _checked(self, fn):
+        """run a library call; an exception raised inside a communicator callback is re-raised as itself"""
+        self._binding.error = None
+        try:
+            return fn()
+        except _lib.AdmpHipError:
+            if self._binding.error is not None:
+                raise self._binding.error
+            raise
+
+    def _fetch_home(self):
+        if self.comm.size == 1:
+            self.home_atoms = torch.arange(self.n_atoms, device=self._device)
+            self.n_home, self.n_import = self.n_atoms, 0
+            return
+        home = torch.empty(self.n_atoms, dtype=torch.int32, device=self._device)
+        nh, ni = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._h, self._L.admp_slab_home(self._h, self._ptr(home), ctypes.byref(nh), ctypes.byref(ni)), 'admp_slab_home')
+        self.n_home, self.n_import = int(nh.value), int(ni.value)
+        self.home_atoms = home[:self.n_home].to(torch.int64)
+
+    def _assemble(self, x):
+        """per-atom output of a decomposed call: the rank's home rows are valid.  'replicated': one sum over the ranks gives
+        every caller the full array (the reference's API); 'home': the other rows are zeroed, nothing is sent."""
+        if x is None or self.comm.size == 1:
+            return x
+        full = torch.zeros_like(x)
+        full.index_copy_(0, self.home_atoms, x.index_select(0, self.home_atoms))
+        if self.outputs == 'replicated':
+            self.comm.all_reduce(full.view(-1), op='sum', label='replicate_outputs')
+        return full
+
+
+class SlabPme(_SlabMixin, ADMPPmeForce):
+    """ADMPPmeForce whose evaluation is spread over the ranks of `comm` (SPMD: every rank makes the same
+    get_energy / get_forces call with the same full input arrays).  outputs='replicated': every rank receives the full
+    gradient / dipoles; outputs='home': only the rows of `home_atoms` are valid on a rank (no O(Na) communication)."""
+
+    def __init__(self, comm, box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol=False, device=None,
+                 outputs='replicated'):
+        self._pending = (comm, outputs)
         super().__init__(box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol, device)
 
     def refresh_calculators(self):
+        if getattr(self, '_binding', None) is None:
+            self._bind_comm(*self._pending)
         super().refresh_calculators()
-        _lib.check(self._h, self._L.admp_slab_configure(self._h, self.comm.rank, self.comm.size), 'admp_slab_configure')
-        self._bufs = None
 
-    # -- helpers -------------------------------------------------------------------------------------------
-    def _stage(self, what, a=None, b=None, iarg=0, dout=None):
-        _lib.check(self._h, self._L.admp_stage(self._h, what, self._ptr(a), self._ptr(b), iarg, dout), 'admp_stage(%d)' % what)
-
-    def _buffers(self):
-        info = (ctypes.c_int64 * 11)()
-        _lib.check(self._h, self._L.admp_slab_info(self._h, info), 'admp_slab_info')
-        X0, X1, Y0, Y1, nloc, ghost, K0, K1, K2h = (int(v) for v in info[:9])
-        key = (X0, X1, Y0, Y1, K0, K1, K2h, self._dtype)
-        if self._bufs is None or self._bufs['key'] != key:
-            K2 = int(self.K3)
-            dev, dt = self._device, self._dtype
-            nx, ny = X1 - X0, Y1 - Y0
-            xs, ys = slab_bounds(K0, self.comm.size), slab_bounds(K1, self.comm.size)
-            # transposes: block (x in slab s) x (y in slab t) x K2h complex numbers travels between ranks s and t
-            fwd_send = [nx * (y1 - y0) * K2h * 2 for (y0, y1) in ys]          # my x-slab, peer's y-slab
-            fwd_recv = [(x1 - x0) * ny * K2h * 2 for (x0, x1) in xs]          # peer's x-slab, my y-slab
-            self._bufs = dict(key=key, nx=nx, ny=ny, K0=K0, K1=K1, K2h=K2h,
-                              mesh=torch.empty((nloc, K1, K2), dtype=dt, device=dev),
-                              spec=torch.empty((nx, K1, K2h, 2), dtype=dt, device=dev),
-                              tbuf=torch.empty((K0, ny, K2h, 2), dtype=dt, device=dev),
-                              pack=torch.empty(sum(fwd_send), dtype=dt, device=dev),
-                              ghost=torch.empty((ghost, K1, K2), dtype=dt, device=dev),
-                              xs=xs, ys=ys, fwd_send=fwd_send, fwd_recv=fwd_recv,
-                              mark=torch.zeros(self.n_atoms, dtype=torch.int32, device=dev),
-                              fmax=torch.zeros(1, dtype=torch.float64, device=dev),
-                              e4=torch.zeros(4, dtype=torch.float64, device=dev))
-        return self._bufs
-
-    def _recip(self, scf):
-        """spread -> distributed r2c -> G multiply (+ energy) -> distributed c2r; mesh then holds phi incl. ghosts."""
-        B, c = self._buffers(), self.comm
-        mesh, spec, tbuf, pack, nx = B['mesh'], B['spec'], B['tbuf'], B['pack'], B['nx']
-        self._stage(_lib.ST_SPREAD, mesh)
-        if c.size > 1:
-            # stencil overhang: my ghost planes are the next rank's first planes
-            c.shift(mesh[nx:nx + self.GHOST], B['ghost'], to_next=True, label='ghost_planes')
-            mesh[:self.GHOST] += B['ghost']
-            self._stage(_lib.ST_FFT_YZ, mesh, spec, 0)
-            off = 0
-            for (y0, y1), n in zip(B['ys'], B['fwd_send']):          # pack: one strided copy per peer, no allocation
-                pack[off:off + n].view(nx, y1 - y0, B['K2h'], 2).copy_(spec[:, y0:y1])
-                off += n
-            # the rows of tbuf that belong to peer s are contiguous: receive straight into the transposed layout
-            c.all_to_all_v(tbuf.view(-1), pack, B['fwd_recv'], B['fwd_send'], label='transpose')
-            self._stage(_lib.ST_FFT_X, tbuf, None, 0)
-            self._stage(_lib.ST_KSPACE, tbuf, None, 1 if scf else 0)
-            self._stage(_lib.ST_FFT_X, tbuf, None, 1)
-            c.all_to_all_v(pack, tbuf.view(-1), B['fwd_send'], B['fwd_recv'], label='transpose')
-            off = 0
-            for (y0, y1), n in zip(B['ys'], B['fwd_send']):
-                spec[:, y0:y1].copy_(pack[off:off + n].view(nx, y1 - y0, B['K2h'], 2))
-                off += n
-            self._stage(_lib.ST_FFT_YZ, mesh, spec, 1)
-            # phi halo: my ghost planes hold the next rank's first planes
-            c.shift(mesh[:self.GHOST], B['ghost'], to_next=False, label='ghost_planes')
-            mesh[nx:nx + self.GHOST] = B['ghost']
-        else:
-            self._stage(_lib.ST_FFT_YZ, mesh, spec, 0)
-            self._stage(_lib.ST_KSPACE, spec, None, 1 if scf else 0)
-            self._stage(_lib.ST_FFT_YZ, mesh, spec, 1)
-
-    def _exchange_lists(self, B):
-        """Import set of this evaluation: the atoms this rank reads without owning them, grouped by owner; and, from the
-        peers' requests, the home atoms of this rank that others import.  Two small collectives, one host read."""
-        c = self.comm
-        mark = B['mark']
-        mark.zero_()
-        self._stage(_lib.ST_MARK_IMPORTS, mark)
-        imp = torch.nonzero(mark).squeeze(1)                        # ascending atom index
-        owner = (mark[imp] - 1).to(torch.int64)
-        order = torch.sort(owner, stable=True).indices
-        imp = imp[order].contiguous()                               # grouped by owner, ascending inside a group
-        counts = torch.bincount(owner, minlength=c.size).to(torch.int64)
-        req_counts = torch.empty_like(counts)
-        ones = [1] * c.size
-        c.all_to_all_v(req_counts, counts, ones, ones, label='halo_lists')
-        both = torch.stack([counts, req_counts]).cpu().tolist()     # the one host read
-        imp_counts, req_counts = [int(x) for x in both[0]], [int(x) for x in both[1]]
-        req = torch.empty(sum(req_counts), dtype=torch.int32, device=self._device)
-        c.all_to_all_v(req, imp.to(torch.int32), req_counts, imp_counts, label='halo_lists')
-        self.n_import = int(imp.numel())
-        return imp, imp_counts, req.to(torch.int64), req_counts
-
-    # -- the evaluation --------------------------------------------------------------------------------------
-    def _evaluate_on_stream(self, positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales, U_init,
-                            want_grad, want_dQ, maxiter, thresh):
-        if want_dQ:
-            raise NotImplementedError('dE/dQ_local is not assembled across ranks yet')
-        L, h, na, c = self._L, self._h, self.n_atoms, self.comm
-        self.set_pairs(pairs)
-        pos = self._real(positions, (na, 3))
-        Q = self._pad_Q(Q_local)
-        boxh = self._host64(box, 9)
-        mS = self._host64(mScales)
-        ns = len(mS)
-        pol_t = th_t = U = None
-        pS = None
-        if self.lpol:
-            pol_t = self._real(pol, (na,))
-            th_t = self._real(tholes, (na,))
-            pS = self._host64(pScales, ns)
-            U = (torch.zeros((na, 3), dtype=self._dtype, device=self._device) if U_init is None
-                 else self._real(U_init, (na, 3)).clone())
-        maxiter = settings.MAX_N_POL if maxiter is None else int(maxiter)
-        thresh = settings.POL_CONV if thresh is None else float(thresh)
-        nhome = ctypes.c_int(0)
-        _lib.check(h, L.admp_stage_begin(h, self._ptr(pos), _lib.darr(boxh), self._ptr(Q), self._ptr(pol_t), self._ptr(th_t),
-                                         ns, _lib.darr(mS), None if pS is None else _lib.darr(pS), self._ptr(U),
-                                         ctypes.byref(nhome)), 'admp_stage_begin')
-        self.n_home = int(nhome.value)
-        B = self._buffers()
-        mesh = B['mesh']
-        multi = c.size > 1
-        if multi:
-            imp, imp_counts, req, req_counts = self._exchange_lists(B)
-            home = torch.empty(self.n_home, dtype=torch.int32, device=self._device)
-            self._stage(_lib.ST_HOME_LIST, home)
-            self.home_atoms = home.to(torch.int64)
-            w3i, w3r = [3 * n for n in imp_counts], [3 * n for n in req_counts]
-
-            def pull_import_dipoles(U):
-                """U[imports] <- the owners' current values: n_import x 3 reals per rank, never (Na, 3)"""
-                send = U.index_select(0, req).reshape(-1)
-                recv = torch.empty(3 * self.n_import, dtype=U.dtype, device=U.device)
-                c.all_to_all_v(recv, send, w3i, w3r, label='halo_dipoles')
-                U.index_copy_(0, imp, recv.view(-1, 3))
-                self._stage(_lib.ST_SET_U, U)
-            if self.lpol and U_init is not None:
-                pull_import_dipoles(U)      # the result must not depend on rows of U_init this rank does not own
-        else:
-            self.home_atoms = torch.arange(na, device=self._device)
-        phi_valid, cyc, flag, done = False, 0, True, False
-        grad = torch.empty((na, 3), dtype=self._dtype, device=self._device)
-        fmax_d = B['fmax']
-
-        def field_max():
-            """max |dE/dU| over all ranks' polarizable home atoms: device word, one MAX all-reduce, one host read"""
-            fmax_d.zero_()
-            self._stage(_lib.ST_FIELD_MAX_DEV, fmax_d)
-            if multi:
-                c.all_reduce(fmax_d, op='max', label='scf_max')
-            return float(fmax_d.item())
-
-        def jacobi(U):
-            self._stage(_lib.ST_JACOBI, U)                          # home rows of U (and their packed copies) in place
-            if multi:
-                pull_import_dipoles(U)      # only the dipoles somebody imports travel, instead of all-reducing (Na, 3)
-            return U
-
-        if self.lpol:
-            start = 0
-            if getattr(self, '_warm_regime', False):
-                # steady-state regime (previous call passed its first check): first cycle with the full kernels, which
-                # also deliver dE/dU -- if the check passes again the step is finished (engine.hip, `warm_regime`)
-                self._stage(_lib.ST_PAIR_FULL, grad, None, 1)
-                self._recip(scf=True)
-                self._stage(_lib.ST_GATHER, mesh, grad, 1)
-                if field_max() < thresh:
-                    phi_valid = done = True
-                else:
-                    U = jacobi(U)
-                    start = 1
-            i = 0 if done else start
-            for i in ([] if done else range(start, maxiter)):       # admp/pme.py:132-138
-                self._stage(_lib.ST_PAIR_FIELD)
-                self._recip(scf=True)
-                self._stage(_lib.ST_GATHER_FIELD, mesh)
-                if field_max() < thresh:
-                    phi_valid = True
-                    break
-                U = jacobi(U)
-            cyc = min(i, maxiter - 1)
-            flag = (cyc != maxiter - 1)                    # admp/pme.py:139-143
-            self._warm_regime = (cyc == 0)
-        if not done:
-            self._stage(_lib.ST_PAIR_FULL, grad)
-            if not phi_valid:
-                self._recip(scf=False)
-            self._stage(_lib.ST_GATHER, mesh, grad)
-        e4 = B['e4']
-        self._stage(_lib.ST_FINISH_DEV, grad if want_grad else None, e4, 1 if phi_valid else 0)
-        if multi:
-            c.all_reduce(e4, op='sum', label='energies')
-            if want_grad:
-                # what this rank added to atoms it does not own (frame adjoint across a slab boundary) goes to the owners
-                send = grad.index_select(0, imp).reshape(-1)
-                recv = torch.empty(3 * int(req.numel()), dtype=grad.dtype, device=grad.device)
-                c.all_to_all_v(recv, send, w3r, w3i, label='halo_gradient')
-                grad.index_add_(0, req, recv.view(-1, 3))
-            if self.outputs == 'replicated':
-                # the reference's API returns full arrays to every caller: one sum over the ranks' home rows per evaluation
-                def assemble(x):
-                    full = torch.zeros_like(x)
-                    full.index_copy_(0, self.home_atoms, x.index_select(0, self.home_atoms))
-                    return c.all_reduce(full, op='sum', label='replicate_outputs')
-                if want_grad:
-                    grad = assemble(grad)
-                if self.lpol:
-                    U = assemble(U)
-            else:
-                keep = torch.zeros(na, dtype=torch.bool, device=self._device)
-                keep[self.home_atoms] = True
-                if want_grad:
-                    grad = grad * keep[:, None]
-                if self.lpol:
-                    U = U * keep[:, None]
-        Eh = e4.cpu().tolist()
-        self.energy_parts = tuple(Eh)
-        out = {'E': np.float64(sum(Eh))}
-        if self.lpol:
-            out['U'] = U
-            out['flag'] = bool(flag)
-            out['i'] = int(cyc)
-        if want_grad:
-            out['grad'] = grad
+    def _evaluate_on_stream(self, *args):
+        out = self._checked(lambda: ADMPPmeForce._evaluate_on_stream(self, *args))
+        self._fetch_home()
+        for k in ('grad', 'U', 'dQ'):
+            if k in out:
+                out[k] = self._assemble(out[k])
         return out
+
+
+class SlabDispPme(_SlabMixin, ADMPDispPmeForce):
+    """ADMPDispPmeForce decomposed over the same x-slabs (real-space pairs over the home rows, the C6 / C8 / C10 meshes
+    through the distributed transform, gathers at the home atoms)."""
+
+    def __init__(self, comm, box, covalent_map, rc, ethresh, pmax, device=None, outputs='replicated'):
+        self._pending = (comm, outputs)
+        super().__init__(box, covalent_map, rc, ethresh, pmax, device)
+
+    def refresh_calculators(self):
+        if getattr(self, '_binding', None) is None:
+            self._bind_comm(*self._pending)
+        super().refresh_calculators()
+
+    def _evaluate(self, positions, box, pairs, c_list, mScales, want_grad=True):
+        E, grad = self._checked(lambda: ADMPDispPmeForce._evaluate(self, positions, box, pairs, c_list, mScales, want_grad))
+        self._fetch_home()
+        return E, self._assemble(grad)

@@ -156,12 +156,12 @@ class ADMPPmeForce(HipForceBase):
     def _evaluate_on_stream(self, positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales, U_init,
                             want_grad, want_dQ, maxiter, thresh):
         L, h, na = self._L, self._h, self.n_atoms
-        if (self.K1 != self.K2 or self.K2 != self.K3) and not self._ref_korder and not getattr(self, '_warned_k', False):
+        if (self.K1 != self.K2 or self.K2 != self.K3) and self._ref_korder and not getattr(self, '_warned_k', False):
             self._warned_k = True
-            warnings.warn('unequal PME mesh dimensions: the reference assigns the k-points in the order of '
-                          'admp/recip.py:339-340, which is not self-consistent here; this implementation uses the '
-                          'physically consistent assignment (settings.REFERENCE_KPOINT_ORDER = True reproduces the '
-                          'reference\'s numbers)')
+            warnings.warn('unequal PME mesh dimensions: the k-points are assigned in the reference\'s literal order '
+                          '(admp/recip.py:339-340, meshgrid(kz, kx, ky)), which reproduces its numbers but is not a '
+                          'self-consistent Ewald sum on this mesh; settings.REFERENCE_KPOINT_ORDER = False selects the '
+                          'consistent assignment')
         self.set_pairs(pairs)
         pos = self._real(positions, (na, 3))
         Q = self._pad_Q(Q_local)

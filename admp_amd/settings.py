@@ -18,13 +18,13 @@ MAX_N_POL = 30            # maximum number of SCF cycles
 FFT_FRIENDLY_MESH = False
 
 
-# Not in the reference as a switch -- it IS the reference's behaviour: build the reciprocal-space k-point table in the literal
-# order of admp/recip.py:339-340 (`meshgrid(kz, kx, ky)`: the frequencies of mesh axes (1, 0, 2) end up in k-columns
-# (0, 1, 2), and for K2 != K3 the flattened table is also scrambled against the mesh).  On a cubic box with K1 = K2 = K3
-# (every shipped example) both orders give the same numbers; elsewhere the reference's order is not a valid Ewald sum
-# (it pairs a mesh axis with another axis' reciprocal vector), so the default is the consistent assignment.  Set to True
-# to reproduce the reference's numbers bit for bit on such boxes (read when a calculator is created / refreshed).
-REFERENCE_KPOINT_ORDER = False
+# The reciprocal-space k-point table.  True (default since round 3: a drop-in returns the reference's numbers): the literal
+# order of admp/recip.py:339-340 -- `meshgrid(kz, kx, ky)` puts the frequencies of mesh axes (1, 0, 2) into k-columns
+# (0, 1, 2) and, for K2 != K3, scrambles the flattened table against the mesh.  On a cubic box with K1 = K2 = K3 (every
+# shipped example and benchmark case) both orders give the same energies and forces; elsewhere the reference's order is not
+# a consistent Ewald sum (it pairs a mesh axis with another axis' reciprocal vector) and a warning says so.  False: the
+# axis-by-axis (physically consistent) assignment.  Read when a calculator is created / refreshed.
+REFERENCE_KPOINT_ORDER = True
 
 
 def jit_condition(*args, **kwargs):

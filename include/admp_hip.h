@@ -32,7 +32,8 @@ enum {
   ADMP_E_HIP = -2,      /* HIP runtime error */
   ADMP_E_FFT = -3,      /* rocFFT error */
   ADMP_E_NOGPU = -4,    /* no usable device */
-  ADMP_E_STATE = -5     /* topology / ewald / pairs not set */
+  ADMP_E_STATE = -5,    /* topology / ewald / pairs not set, or an internal precondition violated */
+  ADMP_E_COMM = -6      /* a communicator callback of a slab-decomposed handle failed */
 };
 
 /* library version, and the gfx target the kernels were built for ("gfx950") */
@@ -121,7 +122,7 @@ int admp_pme_energy_fixed_dipoles(admp_handle* h, const void* positions, const d
  * admp/disp_pme.py:76 with argnums).  dE_dbox is 9 doubles (host), row-major like `box` (lattice vectors in rows).
  * Positions / parameters are DEVICE pointers.  For a polarizable handle U holds the induced dipoles to evaluate at (the
  * converged ones: the reference differentiates energy_fn at stop_gradient(U_ind), admp/pme.py:81-85).
- * E_out as in the corresponding energy_grad call.  Not available on a slab-decomposed handle. */
+ * E_out as in the corresponding energy_grad call.  Not available on a slab-decomposed handle (ADMP_E_ARG). */
 int admp_pme_box_grad(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
                       const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
                       double* E_out, double* dE_dbox);
@@ -202,50 +203,48 @@ int admp_neighbor_fill(admp_handle* h, int32_t* pairs_out);
  * from DEVICE positions (n_atoms of admp_set_topology), without materialising the pair array. */
 int admp_set_pairs_from_positions(admp_handle* h, const void* positions, const double* box, double rc);
 
-/* ---- multi-GPU: x-slab decomposition, staged evaluation ---------------------------------------------
- * (no counterpart in the reference, which is single-device)  One process per GPU; every rank
- * holds all atoms' inputs, owns the mesh planes [X0,X1) along x and works on its "home" atoms (lowest stencil
- * plane inside the slab).  The caller (admp_amd/parallel.py) runs the stages of one evaluation and puts the
- * RCCL collectives in between: ghost-plane exchange after SPREAD / before GATHER, the all-to-all transposes
- * between FFT_YZ and FFT_X, sum all-reduce of dipoles / gradient / energies, max all-reduce of the SCF field.
- * All pointers are DEVICE pointers.  With nranks = 1 the same stages reproduce admp_pme_energy_grad. */
+/* ---- multi-GPU: x-slab decomposition ---------------------------------------------------------------------
+ * (no counterpart in the reference, which is single-device)  One process per GPU, SPMD: every rank makes
+ * the same admp_pme_energy_grad / admp_disp_energy_grad / admp_tt_energy_grad call with the same full input arrays.  Rank s
+ * owns the mesh planes [X0,X1) along x and works on its "home" atoms (lowest stencil plane inside the slab); the library
+ * runs the whole evaluation -- the same kernels and the same SCF forms as on one GPU -- and calls back into the caller's
+ * communicator where ranks exchange data: ghost planes after the spread / before the gather (shift), the two transposes
+ * of the distributed 3-D transform (all_to_all_v), the dipoles / gradient contributions of the halo atoms (all_to_all_v
+ * over index lists both ends derive by themselves), the SCF residual (all_reduce MAX of one word) and the energies
+ * (all_reduce SUM of four words).  The host side binds the callbacks to RCCL (torch.distributed backend "nccl" in
+ * admp_amd/parallel.py); nothing proportional to the number of atoms is ever exchanged by the library itself.
+ *
+ * Callback contract: buffers are DEVICE pointers owned by the library; counts are in elements of `dtype`; a callback is
+ * entered on the thread that made the library call, with the handle's stream being the caller's current stream, and must
+ * enqueue its communication ordered after the work already on that stream and before whatever is enqueued on it later
+ * (torch.distributed collectives on the current stream do exactly that).  Return 0, or non-zero to abort the call with
+ * ADMP_E_COMM.  `tag` says what travels (accounting only). */
+enum { ADMP_T_I32 = 0, ADMP_T_F32 = 1, ADMP_T_F64 = 2 };
+enum { ADMP_OP_SUM = 0, ADMP_OP_MAX = 1 };
+enum { ADMP_TAG_GHOST = 1, ADMP_TAG_TRANSPOSE = 2, ADMP_TAG_HALO_DIPOLES = 3, ADMP_TAG_HALO_GRADIENT = 4, ADMP_TAG_SCF_MAX = 5,
+       ADMP_TAG_ENERGIES = 6 };
+typedef struct admp_comm {
+  void* ctx;
+  /* in place over `count` elements of every rank */
+  int (*all_reduce)(void* ctx, void* buf, int64_t count, int dtype, int op, int tag);
+  /* segment t of `send` (send_counts[t] elements, segments back to back in rank order) goes to rank t; segment s of `recv`
+   * (recv_counts[s] elements) comes from rank s */
+  int (*all_to_all_v)(void* ctx, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
+                      int dtype, int tag);
+  /* ring shift: send `count` elements to rank+1 (to_next != 0) or rank-1, receive as many from the opposite neighbour */
+  int (*shift)(void* ctx, const void* send, void* recv, int64_t count, int dtype, int to_next, int tag);
+} admp_comm;
+/* rank / nranks of this handle (nranks = 1: not decomposed; at most 28 ranks).  Call before the first evaluation. */
 int admp_slab_configure(admp_handle* h, int rank, int nranks);
+/* the communicator of a decomposed handle (copied; ctx must outlive the handle).  NULL detaches. */
+int admp_set_comm(admp_handle* h, const admp_comm* comm);
 /* out11 = {X0, X1, Y0, Y1, local planes (X1-X0+ghost), ghost, K1, K2, K3/2+1, rank, nranks} */
 int admp_slab_info(admp_handle* h, int64_t* out11);
-/* starts an evaluation: packs the sites of ALL atoms, builds this rank's home list; arguments as in
- * admp_pme_energy_grad.  n_home receives the number of home atoms. */
-int admp_stage_begin(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
-                     const void* tholes, int n_scales, const double* mScales, const double* pScales, void* U,
-                     int* n_home);
-enum {
-  ADMP_ST_SET_U = 1,         /* a = U (Na,3), all atoms: refresh packed dipoles                                   */
-  ADMP_ST_PAIR_FIELD = 2,    /* real-space dE/dU of the home atoms                                                */
-  ADMP_ST_SPREAD = 3,        /* a = local real mesh [nloc][K2][K3] (fully overwritten)                             */
-  ADMP_ST_FFT_YZ = 4,        /* a = real mesh, b = spectrum [nx][K2][K3/2+1]; iarg 0: r2c, 1: c2r (b -> a); with one
-                                rank this is the complete 3-D transform                                           */
-  ADMP_ST_FFT_X = 5,         /* a = transposed spectrum [K1][ny][K3/2+1], in place; iarg 0 forward, 1 inverse     */
-  ADMP_ST_KSPACE = 6,        /* a = spectrum in k-space layout; multiplies by G, accumulates the reciprocal energy
-                                (iarg 1: into the SCF slot, 0: into the final slot)                               */
-  ADMP_ST_GATHER_FIELD = 7,  /* a = phi mesh (local, ghosts filled): reciprocal dE/dU of the home atoms            */
-  ADMP_ST_FIELD_FINISH = 8,  /* dout[0] = max |dE/dU| over this rank's polarizable home atoms                      */
-  ADMP_ST_JACOBI = 9,        /* a = U_new (Na,3): home entries <- U - field*pol/D (other entries untouched)         */
-  ADMP_ST_PAIR_FULL = 10,    /* a = gradient (Na,3): zeroed, home rows written; real-space energy accumulated;
-                                iarg 1: the real-space dE/dU is produced as well (speculative first SCF cycle)      */
-  ADMP_ST_GATHER = 11,       /* a = phi mesh, b = gradient: adds reciprocal dE/dr, dE/dQ of the home atoms;
-                                iarg 1: the reciprocal dE/dU is produced as well                                   */
-  ADMP_ST_FINISH = 12,       /* a = gradient (or NULL), b = dE/dQ_local (or NULL), iarg = which reciprocal slot,
-                                dout[4] = this rank's (real, recip, self, penalty) energies                        */
-  /* halo-only data path (no host read-back in any of these; the caller reduces / exchanges the device words): */
-  ADMP_ST_MARK_IMPORTS = 13, /* a = int32 mark[Na], zeroed by the caller: mark[j] <- 1 + owner rank of every atom j that
-                                is NOT a home atom of this rank but is read by its kernels: partner of a home row in the
-                                neighbour table, or axis atom of a home site's local frame (the rank's "import" set)  */
-  ADMP_ST_HOME_LIST = 14,    /* a = int32 out[n_home]: the home atoms of this evaluation                             */
-  ADMP_ST_FIELD_MAX_DEV = 15,/* a = device double, zeroed by the caller: max |dE/dU| over this rank's polarizable home
-                                atoms (what ADMP_ST_FIELD_FINISH returns through the host)                            */
-  ADMP_ST_FINISH_DEV = 16    /* a = gradient (or NULL), b = device double[4] <- this rank's (real, recip, self,
-                                penalty), iarg = which reciprocal slot; closes the evaluation like ADMP_ST_FINISH      */
-};
-int admp_stage(admp_handle* h, int what, void* a, void* b, int iarg, double* dout);
+/* Outputs of a decomposed evaluation: dE_dpos / U_inout / dE_dQlocal hold this rank's HOME rows (the other rows are
+ * unspecified); E_out, n_cycle and converged are the global values on every rank.  home_out (device, room for n_atoms
+ * int32) receives the home atoms of the last evaluation in ascending order, *n_home their number; n_import (optional) the
+ * number of atoms the rank read without owning them. */
+int admp_slab_home(admp_handle* h, int32_t* home_out, int* n_home, int* n_import);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream. */

@@ -36,20 +36,21 @@ def orthorhombic_water(n_mol=96, seed=3, scale=(1.0, 1.25, 1.6)):
 
 @pytest.mark.parametrize('lpol', [False, True])
 def test_reference_kpoint_order_vs_oracle_quirk(env, lpol):
-    """a18: with settings.REFERENCE_KPOINT_ORDER the HIP tables reproduce the reference's meshgrid(kz, kx, ky) order
-    (admp/recip.py:339-340) on a box where it matters (K1 != K2 != K3); the oracle runs UNMODIFIED (quirk=True default)."""
+    """a18: through the reference's import name and with the DEFAULT settings the HIP tables reproduce the reference's
+    meshgrid(kz, kx, ky) order (admp/recip.py:339-340) on a box where it matters (K1 != K2 != K3); the oracle runs
+    UNMODIFIED (quirk=True default).  The drop-in says once that this order is not a consistent Ewald sum here."""
     import warnings
-    from admp_amd.pme import ADMPPmeForce
+    import admp.settings
+    from admp.pme import ADMPPmeForce
     from oracle import admp_oracle as O
     pos, box, at, ai, cov = orthorhombic_water()
     par = S.water_parameters(len(pos) // 3, polarizable=lpol)
     pairs = S.build_pairs(pos, box, 4.0)
-    settings.REFERENCE_KPOINT_ORDER = True
+    assert admp.settings is settings and settings.REFERENCE_KPOINT_ORDER is True      # the default of a drop-in
     f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
     assert len({f.K1, f.K2, f.K3}) == 3
     sysm = O.PmeSystem(at, ai, cov, f.kappa, (f.K1, f.K2, f.K3), 2, lpol)
-    with warnings.catch_warnings():
-        warnings.simplefilter('error')            # the "not self-consistent" warning must stay silent in this mode
+    with pytest.warns(UserWarning, match='literal order'):
         if lpol:
             E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
                                 par['dScales'])
@@ -63,10 +64,10 @@ def test_reference_kpoint_order_vs_oracle_quirk(env, lpol):
     for got, want in zip(f.energy_parts, ref['parts']):
         assert abs(got - want) <= 1e-9 * scale
     assert rel(G, ref['grad']) < 1e-8
-    # and the default (consistent) assignment is a DIFFERENT number here -- the switch is not a no-op
+    # and the consistent assignment (opt-in) is a DIFFERENT number here -- the switch is not a no-op; it does not warn
     settings.REFERENCE_KPOINT_ORDER = False
     with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
+        warnings.simplefilter('error')
         f2 = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
         if lpol:
             f2.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],

@@ -146,7 +146,7 @@ def test_admp_alias_package_resolves_to_admp_amd():
     from admp.multipole import convert_cart2harm                    # noqa: F401
     import admp_amd.pme
     assert admp.settings is admp_amd.settings and admp.pme is admp_amd.pme
-    assert hasattr(admp.settings, 'REFERENCE_KPOINT_ORDER') and admp.settings.REFERENCE_KPOINT_ORDER is False
+    assert hasattr(admp.settings, 'REFERENCE_KPOINT_ORDER') and admp.settings.REFERENCE_KPOINT_ORDER is True
 
 
 def _tt_kernel(dr, m, ai, aj, bi, bj, qi, qj, ci, cj):
