@@ -585,7 +585,10 @@ struct Engine : EngineBase {
   static constexpr int real_dtype() { return sizeof(T) == 4 ? ADMP_T_F32 : ADMP_T_F64; }
   // Who owns what in this evaluation, derived by every rank from the replicated inputs (no communication): home atoms, home
   // rows in pair-kernel order, polarizable home atoms, imports per owner, exports per reader.  One host read (the counts).
-  void decompose() {
+  void decompose() { decompose(K[0], X0, X1, nbr.order); }
+  // K0v / X0v / X1v: the planes the ownership rule works on (the PME mesh's; a handle without a mesh takes a virtual one);
+  // order: the row order of the table to filter (nullptr: natural order)
+  void decompose(int K0v, int X0v, int X1v, const int* order) {
     const int na = top.na, N = snranks, me = srank;
     ARG_CHECK(N <= kSlabMaxRanks, "at most 28 slab ranks");
     sl.owner.need(sizeof(int) * (size_t)na);
@@ -596,7 +599,7 @@ struct Engine : EngineBase {
       return cs.ncols++;
     };
     const int c_home = col(nullptr, na, kSlabHome, kSlabHome);
-    const int c_rows = col(nbr.order, na, kSlabHome, kSlabHome);          // nbr.order == nullptr: natural order
+    const int c_rows = col(order, na, kSlabHome, kSlabHome);
     const int c_act = col(nullptr, na, kSlabHome | kSlabPolar, kSlabHome | kSlabPolar);
     int c_imp[kSlabMaxRanks], c_exp[kSlabMaxRanks];
     for (int t = 0; t < N; ++t) {
@@ -610,7 +613,7 @@ struct Engine : EngineBase {
     sl.lists.need(sizeof(int) * (size_t)cs.ncols * (size_t)na);
     {
       TIMED("slab_decompose");
-      int rc = launch_slab_decompose(stream, na, nbr, top, ev.bases, ev.pol, (int)sizeof(T), X1 - X0, K[0], X0, N, me,
+      int rc = launch_slab_decompose(stream, na, nbr, top, ev.bases, ev.pol, (int)sizeof(T), X1v - X0v, K0v, X0v, N, me,
                                      sl.owner.as<int>(), sl.bits.as<int>(), cs, sl.counts.as<int>(), sl.totals.as<int>(),
                                      sl.lists.as<int>());
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("slab decomposition: ") + hipGetErrorString((hipError_t)rc)};
@@ -1808,20 +1811,49 @@ struct Engine : EngineBase {
     o[0] = X0; o[1] = X1; o[2] = Y0; o[3] = Y1; o[4] = nloc0(); o[5] = kGhost; o[6] = K[0]; o[7] = K[1]; o[8] = K[2] / 2 + 1;
     o[9] = srank; o[10] = snranks;
   }
+  // energies of a dispersion / pair-potential call: (real, recip, self) of all ranks
+  void read_scalar_energies(double* Ed, double* E, int n) {
+    double Eh2[E_WORDS];
+    if (snranks > 1) {
+      TIMED("comm_energies");
+      launch_energy_pack(stream, Ed, E_RECIP, Ed + E_RED);
+      c_all_reduce(Ed + E_RED, 4, ADMP_T_F64, ADMP_OP_SUM, ADMP_TAG_ENERGIES);
+    }
+    HIP_TRY(hipMemcpyAsync(Eh2, Ed, sizeof(Eh2), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const double* src = snranks > 1 ? Eh2 + E_RED : Eh2;      // (E_REAL, E_RECIP, E_SELF are words 0, 1, 2 either way)
+    for (int k = 0; k < n; ++k) E[k] = src[k];
+  }
+  // rows of a scalar pair / dispersion call: all atoms in the table's length-sorted order, or -- on a slab rank -- the
+  // home rows of this evaluation (ownership by the stencil base plane of mesh geometry g)
+  struct ScalarRows { const int* rows; int n; const int* home; };
+  ScalarRows scalar_rows(const T* pos, const RecipGeom<T>& g, int K0v, int X0v, int X1v, bool need_bases) {
+    const int na = top.na;
+    const int* order = nbr.order_plain ? nbr.order_plain : nbr.order;
+    if (snranks > 1 || need_bases) {
+      bases_d.need(sizeof(int4) * (size_t)na);
+      launch_atom_bases<T>(stream, na, pos, g, bases_d.as<int4>());
+    }
+    if (snranks == 1) return {order, na, nullptr};
+    ev.bases = bases_d.as<int4>(); ev.pol = nullptr; ev.U = nullptr;
+    decompose(K0v, X0v, X1v, order);
+    return {sl.rows, sl.n_home, sl.home};
+  }
+
   // dispersion PME (admp/disp_pme.py:80-123): real-space pairs + one scalar reciprocal pass per power
   void disp(const void* pos_, const double* box, const void* clist_, int pmax, int ns, const double* mS, double* E,
             void* dpos_, int on_device) override {
     ARG_CHECK(have_top && have_ewald && have_pairs, "topology, ewald parameters and pairs must be set first");
-    ARG_CHECK(snranks == 1, "dispersion PME is not slab-decomposed");
+    ARG_CHECK(snranks == 1 || on_device, "a slab-decomposed handle takes device pointers");
     ARG_CHECK(pos_ && box && clist_ && E, "null argument");
     ARG_CHECK(pmax == 6 || pmax == 8 || pmax == 10, "pmax must be 6, 8 or 10");
     const int na = top.na;
     HIP_TRY(hipSetDevice(device));
     double inv[9], vol;
     Box<T> bx = make_box(box, inv, &vol);
+    ensure_mesh();
     RecipGeom<T> g = make_geom(inv);
     ScaleTab<T> tab = make_tab(ns, mS, nullptr);
-    ensure_mesh();
     const T* pos = stage_in(s_pos, pos_, 3 * (size_t)na, on_device);
     const T* cl = stage_in(s_par, clist_, 3 * (size_t)na, on_device);
     T* dpos = nullptr;
@@ -1831,18 +1863,46 @@ struct Engine : EngineBase {
     energies_d.need(2 * E_WORDS * sizeof(double));
     ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
-    HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
-    { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, dpos, Ed); }
-    // one scalar reciprocal pass per power through the same brick spread / lane-group gather as the electrostatics:
-    // the channel is packed into charge-only site rows (which also accumulates the self term, disp_pme.py:254-279)
+    HIP_TRY(hipMemsetAsync(Ed, 0, E_WORDS * sizeof(double), stream));
+    const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
+    const int nch = (pmax - 4) / 2;
     cls_sites_na = -1;   // other rows than an electrostatics evaluation's
+    // At scale (brick regime) and on every slab rank the channels go through ONE binning, ONE spread and ONE gather straight
+    // from the caller's position / coefficient arrays (disp_kernels.hip); small single-GPU systems keep the batched
+    // scan-spread / direct-DFT path below (dispatch-bound: nine launches for the three powers).
+    const bool fused = !(use_dft || use_pfa) && (snranks > 1 || spread_uses_bricks(na, g));
+    if (snranks > 1) ARG_CHECK(spread_uses_bricks(1 << 30, g), "slab-decomposed dispersion PME needs at least 17 local mesh planes and K2, K3 >= 17");
+    const ScalarRows sr = scalar_rows(pos, g, K[0], X0, X1, fused);
+    { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, dpos, Ed, sr.rows, sr.n); }
+    if (fused) {
+      const size_t nreal = nreal_local();
+      mesh.need(nch * nreal * sizeof(T));
+      ensure_bins(std::max(sr.n, 1));
+      { TIMED("spread");
+        int rc = launch_bin_bricks<T>(stream, sr.n, (const Site<T>*)nullptr, g, bins, sr.home, bases_d.as<int4>());
+        if (rc == 0) rc = launch_spread_scalar<T>(stream, nch, pos, cl, 3, g, bins, mesh.as<T>(), (long)nreal);
+        if (rc != 0) throw Err{ADMP_E_HIP, std::string("dispersion spread: ") + hipGetErrorString((hipError_t)rc)};
+        bins.counters_zero = true; }
+      for (int c = 0; c < nch; ++c) {
+        ensure_gtab(box, inv, vol, 6 + 2 * c);
+        convolve(mesh.as<T>() + c * nreal, spec.as<T>(), gtab_cur, E_RECIP);
+      }
+      { TIMED("gather_field");
+        launch_gather_scalar<T>(stream, nch, sr.n, pos, cl, 3, g, mesh.as<T>(), (long)nreal, dpos, sr.home, kp, Ed); }
+      read_scalar_energies(Ed, E, 3);
+      if (dpos_ && !on_device) {
+        HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+      }
+      return;
+    }
+    // one scalar reciprocal pass per power through the same spread / gather kernels as the electrostatics:
+    // the channel is packed into charge-only site rows (which also accumulates the self term, disp_pme.py:254-279)
     sites.need(sizeof(Site<T>) * (size_t)na);
     fld_recip.need(3 * (size_t)na * sizeof(T));
     ensure_bins(na);
     RecipGeom<T> gj = g;                       // scalar sites: dE/dr = c * Jac . F1 (gather_field applies g.Aop)
     for (int k = 0; k < 9; ++k) gj.Aop[k] = g.Jac[k];
-    const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
-    const int nch = (pmax - 4) / 2;
     if ((use_dft || use_pfa) && nch > 1) {
       // direct-DFT meshes are small and dispatch bound: the powers are spread into separate meshes and transformed
       // as ONE batch (5 launches instead of 5 per power); gather per power from its own mesh
@@ -1854,7 +1914,6 @@ struct Engine : EngineBase {
         ensure_gtab(box, inv, vol, 6 + 2 * c);
         tabs.p[c] = gtab_cur;
       }
-      cls_sites_na = -1;   // other rows than an electrostatics evaluation's
       sites.need(sizeof(Site<T>) * (size_t)na * nch);
       fld_recip.need(3 * (size_t)na * sizeof(T) * nch);
       const bool batch_spread = na < spread_brick_min_atoms();     // the scan-spread regime takes the channels as a batch
@@ -1884,12 +1943,12 @@ struct Engine : EngineBase {
         { TIMED("dft_y_inv"); launch_pfa_y<T>(stream, pfa, tw, spec.as<T>(), 1, nch, (long)nspec); }
         { TIMED("dft_z_c2r"); launch_pfa_z<T>(stream, pfa, tw, mesh.as<T>(), spec.as<T>(), 1, nch, (long)nreal, (long)nspec); }
       } else {
-      const T* tw = dft_tw.as<T>();
-      { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 0, nch, (long)nreal, (long)nspec); }
-      { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 0, nch, (long)nspec); }
-      { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec.as<T>(), tabs, Ed, E_RECIP, nch, (long)nspec); }
-      { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 1, nch, (long)nspec); }
-      { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 1, nch, (long)nreal, (long)nspec); }
+        const T* tw = dft_tw.as<T>();
+        { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 0, nch, (long)nreal, (long)nspec); }
+        { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 0, nch, (long)nspec); }
+        { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec.as<T>(), tabs, Ed, E_RECIP, nch, (long)nspec); }
+        { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 1, nch, (long)nspec); }
+        { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 1, nch, (long)nreal, (long)nspec); }
       }
       // the site rows hold the positions (only the charge slot differs per power): one gather over the batch of meshes
       { TIMED("gather_field"); launch_gather_field<T>(stream, na, sites.as<Site<T>>(), gj, mesh.as<T>(), fld_recip.as<T>(), nullptr, nch); }
@@ -1917,6 +1976,7 @@ struct Engine : EngineBase {
   void tt(const void* pos_, const double* box, const void* abqc_, int ns, const double* mS, double* E, void* dpos_,
           int on_device) override {
     ARG_CHECK(have_top && have_pairs, "topology and pairs must be set first");
+    ARG_CHECK(snranks == 1 || on_device, "a slab-decomposed handle takes device pointers");
     ARG_CHECK(pos_ && box && abqc_ && E, "null argument");
     const int na = top.na;
     HIP_TRY(hipSetDevice(device));
@@ -1930,13 +1990,23 @@ struct Engine : EngineBase {
     energies_d.need(2 * E_WORDS * sizeof(double));
     ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
-    HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
-    { TIMED("tt_pair"); launch_tt_pair<T>(stream, na, nbr, pos, par, bx, tab, dpos, Ed); }
-    double Eh[E_SLOTS];
-    HIP_TRY(hipMemcpyAsync(Eh, Ed, sizeof(Eh), hipMemcpyDeviceToHost, stream));
-    if (dpos_ && !on_device) HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    E[0] = Eh[E_REAL];
+    HIP_TRY(hipMemsetAsync(Ed, 0, E_WORDS * sizeof(double), stream));
+    ScalarRows sr{nullptr, na, nullptr};
+    if (snranks > 1) {     // no mesh on a pair potential: ownership by x-slabs of a virtual mesh of 64 planes per rank
+      ARG_CHECK(have_comm, "slab-decomposed handle without a communicator (admp_set_comm)");
+      RecipGeom<T> g;
+      const int Kv = 64 * snranks;
+      g.K[0] = Kv; g.K[1] = g.K[2] = 32;
+      for (int k = 0; k < 9; ++k) { g.hinv[k] = (T)inv[k]; g.Aop[k] = g.Jac[k] = T(0); }
+      g.xoff = 64 * srank; g.nloc0 = 64 + kGhost; g.wrap0 = 1 << 30;
+      sr = scalar_rows(pos, g, Kv, 64 * srank, 64 * (srank + 1), true);
+    }
+    { TIMED("tt_pair"); launch_tt_pair<T>(stream, na, nbr, pos, par, bx, tab, dpos, Ed, sr.rows, sr.n); }
+    read_scalar_energies(Ed, E, 1);
+    if (dpos_ && !on_device) {
+      HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+    }
   }
 
   // a traced pair kernel (pair_program_build) on the current neighbour table: admp/pairwise.py:67-91 with any kernel

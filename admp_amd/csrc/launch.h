@@ -249,10 +249,12 @@ void launch_pscale_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T
                         const ScaleTab<T>& tab, double* cls16);
 template <class T>
 void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
-                      const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies);
+                      const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies,
+                      const int* rows = nullptr /* the n_rows rows to evaluate (nullptr: all, in the table's order) */,
+                      int n_rows = 0);
 template <class T>
 void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* abqc, const Box<T>& box,
-                    const ScaleTab<T>& tab, T* grad, double* energies);
+                    const ScaleTab<T>& tab, T* grad, double* energies, const int* rows = nullptr, int n_rows = 0);
 
 // ---- box gradient (dE/dbox at fixed Cartesian positions; on request only).  All sums are double device words.
 // vir[9] += 1/2 sum_entries shift (x) dE_pair/dr_I over the pairs whose minimum image crosses the cell boundary
@@ -357,6 +359,22 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
 // a += b over n mesh points
 template <class T>
 void launch_mesh_add(hipStream_t st, long n, T* a, const T* b);
+// the binning passes of launch_spread on their own (count, scan, fill): leaves the brick lists of the n listed atoms in bs;
+// `bases` must hold the stencil records of those atoms (sites may then be nullptr).  hipError_t as int.
+template <class T>
+int launch_bin_bricks(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, BinScratch& bs, const int* list,
+                      const int4* bases);
+// ---- disp_kernels.hip: the scalar channels of dispersion PME through ONE spread and ONE gather
+template <class T>
+void launch_atom_bases(hipStream_t st, int na, const T* pos, const RecipGeom<T>& g, int4* bases);
+// mesh of channel c (vals[i * stride + c]) at mesh + c * mesh_stride, from the brick lists in bs.  hipError_t as int.
+template <class T>
+int launch_spread_scalar(hipStream_t st, int nch, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
+                         const BinScratch& bs, T* mesh, long mesh_stride);
+// grad[i] += sum_c vals[i][c] Jac . grad phi_c(r_i) for the n listed atoms; energies[E_SELF] += sum_c self_coefs[c] vals[i][c]^2
+template <class T>
+void launch_gather_scalar(hipStream_t st, int nch, int na, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
+                          const T* phi, long mesh_stride, T* grad, const int* list, const double* self_coefs, double* energies);
 // ---- cell_kernels.hip: positions -> half pair list (cell list), two phases so that the caller can size `pairs`
 struct CellScratch {
   int n[3] = {0, 0, 0};

@@ -101,12 +101,14 @@ __global__ __launch_bounds__(kSortRows * kSortLanes) void k_nbr_rank_sort(int na
   const int row = r0 + (int)threadIdx.x / kSortLanes, sub = (int)threadIdx.x % kSortLanes;
   if (row >= r1) return;
   const int b = rowptr[row], e = rowptr[row + 1];
-  const int* src = lds ? seg - sb : cin;                                  // src[k] = entry k of the table
+  // (no `seg - sb` base pointer: an LDS pointer below its array wraps in 32 bits, and the flat pointer made from it does not
+  // wrap back when the index is added -- the address leaves the LDS aperture)
+  auto entry = [&](int k) { return lds ? seg[k - sb] : cin[k]; };          // entry k of the table
   for (int k = b + sub; k < e; k += kSortLanes) {
-    const int v = src[k], key = v & kColMask;
+    const int v = entry(k), key = v & kColMask;
     int rank = 0;
     for (int m = b; m < e; ++m) {
-      const int u = src[m] & kColMask;
+      const int u = entry(m) & kColMask;
       rank += (u < key || (u == key && m < k)) ? 1 : 0;
     }
     cout[b + rank] = v;

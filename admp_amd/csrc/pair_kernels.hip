@@ -254,11 +254,12 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
   stage_tab(tab, s_tab);
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
   const int slot = (int)(t / LPR), sub = (int)(t % LPR);
-  const int row = slot < na ? (rows ? rows[slot] : slot) : na;      // length-sorted row order (launch_row_order)
+  // `na` counts the rows of this launch (all atoms in the table's length-sorted order, or a slab rank's home rows)
+  const int row = slot < na ? (rows ? rows[slot] : slot) : -1;
   constexpr int NP = TT ? 4 : 3;
   T g[3] = {0, 0, 0};
   double e = 0.0;
-  if (row < na) {
+  if (row >= 0) {
     T ri[3] = {pos[3 * row], pos[3 * row + 1], pos[3 * row + 2]}, pi[4] = {0, 0, 0, 0};
     for (int k = 0; k < NP; ++k) pi[k] = par[NP * row + k];
     const int end = rowptr[row + 1];
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) g[k] = row_reduce<T, LPR>(g[k]);
-  if (row < na && sub == 0) {
+  if (row >= 0 && sub == 0) {
     grad[3 * row] = g[0]; grad[3 * row + 1] = g[1]; grad[3 * row + 2] = g[2];
   }
   e = block_reduce_sum<kPairBlock>(e);
@@ -576,6 +577,7 @@ template <class T>
 void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int lpol, T* grad, T* pot, double* energies, const int* rows,
                       T* fld, int use_mono, const int* cls_flags, const RQ4<T>* rq, const T* tholes) {
+  if (na <= 0) return;
   const int lpr = pair_lanes_per_row(na);
   const int minw = pair_min_waves<T>();
   static const bool mono_off = [] { const char* e = getenv("ADMP_PAIR_MONO"); return e && atoi(e) == 0; }();
@@ -603,6 +605,7 @@ void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>
                        const RQ4<T>* rq, const T* tholes) {
   static const bool mono_off = [] { const char* e = getenv("ADMP_PAIR_MONO"); return e && atoi(e) == 0; }();
   if (mono_off || !rq) cls_flags = nullptr;
+  if (na <= 0) return;
   const int lpr = field_lanes_per_row(na, false);
 #define CALL(L)                                                                                              \
   k_pair_field<T, L><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, \
@@ -624,21 +627,25 @@ void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const
 }
 template <class T>
 void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
-                      const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies) {
-  const int lpr = pair_lanes_per_row(na);
+                      const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies, const int* rows, int n_rows) {
+  if (!rows) { rows = nb.order_plain ? nb.order_plain : nb.order; n_rows = na; }
+  if (n_rows <= 0) return;
+  const int lpr = pair_lanes_per_row(n_rows);
 #define CALL(L)                                                                                                        \
-  k_pair_scalar<T, L, false><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, clist, box, tab, kappa, \
-                                                                     pmax, grad, energies, nb.order_plain ? nb.order_plain : nb.order)
+  k_pair_scalar<T, L, false><<<grid_for(n_rows, L), kPairBlock, 0, st>>>(n_rows, nb.rowptr, nb.col, pos, clist, box, tab, \
+                                                                         kappa, pmax, grad, energies, rows)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
 template <class T>
 void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* abqc, const Box<T>& box,
-                    const ScaleTab<T>& tab, T* grad, double* energies) {
-  const int lpr = pair_lanes_per_row(na);
+                    const ScaleTab<T>& tab, T* grad, double* energies, const int* rows, int n_rows) {
+  if (!rows) { rows = nb.order_plain ? nb.order_plain : nb.order; n_rows = na; }
+  if (n_rows <= 0) return;
+  const int lpr = pair_lanes_per_row(n_rows);
 #define CALL(L)                                                                                                       \
-  k_pair_scalar<T, L, true><<<grid_for(na, L), kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, abqc, box, tab, T(0), 0, \
-                                                                    grad, energies, nb.order_plain ? nb.order_plain : nb.order)
+  k_pair_scalar<T, L, true><<<grid_for(n_rows, L), kPairBlock, 0, st>>>(n_rows, nb.rowptr, nb.col, pos, abqc, box, tab, \
+                                                                        T(0), 0, grad, energies, rows)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
@@ -653,9 +660,9 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
   template void launch_pair_field_ind<T>(hipStream_t, int, const IndTable&, const Site<T>*, const Box<T>&,          \
                                          const ScaleTab<T>&, T, T*, const int*);                                    \
   template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,           \
-                                    const ScaleTab<T>&, T, int, T*, double*);                                       \
+                                    const ScaleTab<T>&, T, int, T*, double*, const int*, int);                      \
   template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,             \
-                                  const ScaleTab<T>&, T*, double*);                                                 \
+                                  const ScaleTab<T>&, T*, double*, const int*, int);                                \
   template void launch_mscale_sums<T>(hipStream_t, int, int, const NbrTable&, const Site<T>*, const T*, const T*,   \
                                       const Box<T>&, int, double*);                                                 \
   template void launch_thole_sums<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \

@@ -845,21 +845,29 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
     k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr);
     return 0;
   }
+  { const int rc = launch_bin_bricks<T>(st, na, sites, g, bs, list, bases); if (rc != 0) return rc; }
+  k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
+  bs.counters_zero = true;      // element ncell of both arrays is never written: it stays zero
+  return 0;
+}
+template <class T>
+int launch_bin_bricks(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, BinScratch& bs, const int* list,
+                      const int4* bases) {
+  const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
+  const BrickGrid bg = make_bricks(dims);
   if (!bs.counters_zero) {
     RC(hipMemsetAsync(bs.cursor, 0, sizeof(int) * (bg.ncell + 1), st));
     RC(hipMemsetAsync(bs.fillcur, 0, sizeof(int) * (bg.ncell + 1), st));
   }
   bs.counters_zero = false;
-  k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list, bases, nullptr);
+  if (na > 0) k_bin<T, 0><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.cursor, nullptr, list, bases, nullptr);
   if (bg.ncell + 1 <= 8192) {
     k_scan_small<<<1, 1024, 0, st>>>(bg.ncell + 1, bs.cursor, bs.cell_start);
   } else {
     size_t need = bs.scan_bytes;
     RC(hipcub::DeviceScan::ExclusiveSum(bs.scan_tmp, need, bs.cursor, bs.cell_start, bg.ncell + 1, st));
   }
-  k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.fillcur, bs.sorted, list, bases, bs.cell_start);
-  k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
-  bs.counters_zero = true;      // element ncell of both arrays is never written: it stays zero
+  if (na > 0) k_bin<T, 1><<<nblk(na, 256), 256, 0, st>>>(na, sites, g, bg, bs.fillcur, bs.sorted, list, bases, bs.cell_start);
   return 0;
 }
 #undef RC
@@ -941,6 +949,8 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
                                                                                                 n_dev, add_to, ff);
 }
 #define INST(T)                                                                                                       \
+  template int launch_bin_bricks<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, BinScratch&, const int*,   \
+                                    const int4*);                                                                     \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
                                 const int*, const int4*, int, int);                                                   \
   template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*, int,             \

@@ -202,6 +202,7 @@ import os, sys, numpy as np
 sys.path.insert(0, %r)
 from tests.test_gpu_parity import water_system
 from admp_amd import settings
+settings.REFERENCE_KPOINT_ORDER = False      # unequal meshes: the transform legs are compared on a self-consistent Ewald sum
 out = {}
 pos, box, at, ai, cov, par, pairs = water_system(216, 5, True)
 for prec in ('double', 'single'):
@@ -993,7 +994,7 @@ def test_update_neighbors_equals_explicit_pair_list(precision):
 
 
 def test_slab_warm_regime_matches_fused_path(precision):
-    """Staged driver (1 and 2 ranks), repeated warm-started calls: the speculative first cycle must give the fused
+    """Decomposed handle (1 and 2 ranks), repeated warm-started calls: the speculative first cycle must give the
     single-GPU result both when the check passes and when it fails."""
     import threading
     from admp_amd.parallel import SlabPme, ThreadComm
@@ -1095,8 +1096,11 @@ def test_slab_halo_only_traffic_and_home_outputs(precision):
         assert sent['halo_gradient'] == 3 * w * n_imp                     # my contributions to my imports, back to the owners
         assert sent['halo_dipoles'] % (calls['halo_dipoles'] * 3 * w) == 0 and \
             sent['halo_dipoles'] // (calls['halo_dipoles'] * 3 * w) < 0.45 * na   # rows my peers import from me, per cycle
-        assert calls['halo_dipoles'] == ncyc and calls['halo_gradient'] == 1 and calls['scf_max'] == ncyc + 1
-        per_atom_traffic = sent['halo_dipoles'] + sent['halo_gradient'] + sent['halo_lists']
+        # dipoles: once at the start (the imports' starting values) and once per Jacobi step (their changes); no index lists
+        # travel any more -- both ends derive them from the replicated inputs
+        assert calls['halo_dipoles'] == ncyc + 1 and calls['halo_gradient'] == 1 and calls['scf_max'] == ncyc + 1
+        assert 'halo_lists' not in sent
+        per_atom_traffic = sent['halo_dipoles'] + sent['halo_gradient']
         assert per_atom_traffic < 0.5 * (ncyc + 1) * na * 3 * w            # what the full-array all-reduces used to move
         assert sent['scf_max'] <= 8 * (ncyc + 1) and sent['energies'] <= 32
 
@@ -1214,6 +1218,7 @@ sys.path.insert(0, %r)
 from tests.test_gpu_parity import water_system
 from admp_amd import settings
 settings.PRECISION = 'double'
+settings.REFERENCE_KPOINT_ORDER = False      # unequal mesh: the transform legs are compared on a self-consistent Ewald sum
 from admp_amd.pme import ADMPPmeForce
 from admp_amd.disp_pme import ADMPDispPmeForce
 pos, box, at, ai, cov, par, pairs = water_system(216, 5, True)
@@ -1285,6 +1290,7 @@ import os, sys, numpy as np
 sys.path.insert(0, %r)
 from tests.test_gpu_parity import water_system
 from admp_amd import settings
+settings.REFERENCE_KPOINT_ORDER = False      # unequal meshes: the transform legs are compared on a self-consistent Ewald sum
 out = {}
 pos, box, at, ai, cov, par, pairs = water_system(216, 5, True)
 for prec in ('double', 'single'):
