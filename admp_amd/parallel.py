@@ -41,6 +41,7 @@ import torch
 
 from . import _lib, settings
 from .disp_pme import ADMPDispPmeForce
+from .pairwise import _HipPairKernel, _PairInteraction
 from .pme import ADMPPmeForce
 
 
@@ -368,3 +369,19 @@ class SlabDispPme(_SlabMixin, ADMPDispPmeForce):
         E, grad = self._checked(lambda: ADMPDispPmeForce._evaluate(self, positions, box, pairs, c_list, mScales, want_grad))
         self._fetch_home()
         return E, self._assemble(grad)
+
+
+class SlabPairInteraction(_SlabMixin, _PairInteraction):
+    """generate_pairwise_interaction(kernel, covalent_map, static_args) for the kernels of libadmp_hip (Tang-Toennies),
+    decomposed over x-slabs: every rank evaluates the rows of its home atoms; one SUM all-reduce of the energy."""
+
+    def __init__(self, comm, kernel, covalent_map, static_args=None, outputs='replicated'):
+        if not isinstance(kernel, _HipPairKernel):
+            raise TypeError('the slab decomposition takes the named pair kernels of admp_amd.pairwise')
+        super().__init__(kernel, covalent_map, static_args)
+        self._bind_comm(comm, outputs)
+
+    def _evaluate(self, positions, box, pairs, mScales, atomic_params, want_grad):
+        E, grad = self._checked(lambda: _PairInteraction._evaluate(self, positions, box, pairs, mScales, atomic_params, True))
+        self._fetch_home()
+        return E, (self._assemble(grad) if want_grad else None)

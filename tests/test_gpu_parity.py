@@ -1034,6 +1034,68 @@ def test_slab_warm_regime_matches_fused_path(precision):
             assert n_d == 2 and abs(d[0] - E0) < 1e-10 * scale and rel(d[1], G0) < 1e-10 and rel(U, U0) < 1e-10
 
 
+def test_slab_all_terms_and_parameter_outputs(precision):
+    """What the reference's drivers evaluate per step (examples/water_1024/run_admp.py:115-137: PME, dispersion PME and
+    the Tang-Toennies pair term) on 2 and 3 slab ranks, plus dE/dQ_local of the decomposed PME: every rank returns the
+    single-GPU numbers.  Both precisions for the dispersion meshes (32-bit fixed-point tiles in f32)."""
+    import threading
+    import torch
+    from admp_amd.parallel import SlabPme, SlabDispPme, SlabPairInteraction, ThreadComm
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel
+    n_mol = 1728
+    pos, box = S.synthetic_water_box(n_mol, seed=17)
+    pos = np.mod(pos, box[0, 0])                      # wrapped: molecules straddle the cell and slab faces
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, True)
+    pairs = S.build_pairs(pos, box, 4.0)
+    tt_lists = (par['a_list'], par['b_list'], par['q_list'], par['c_list'][:, 0].copy())
+    pol_args = (par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    for prec, tol in (('double', 1e-10), ('single', 3e-4)):
+        settings.PRECISION = prec
+        f0 = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+        E0, G0, dQ0 = f0.get_forces_and_dQ(pos, box, pairs, *pol_args)
+        d0 = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+        Ed0, Gd0 = d0.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+        t0 = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+        Et0, Gt0 = t0.value_and_grad(pos, box, pairs, par['mScales'], *tt_lists)
+        for nranks in ((2, 3) if prec == 'double' else (2,)):
+            world = ThreadComm.World(nranks)
+            out, errors = [None] * nranks, []
+
+            def work(rank):
+                try:
+                    comm = ThreadComm(world, rank)
+                    f = SlabPme(comm, box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+                    r = f.get_forces_and_dQ(pos, box, pairs, *pol_args)
+                    d = SlabDispPme(comm, box, cov, 4.0, 1e-4, 10)
+                    rd = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+                    t = SlabPairInteraction(comm, TT_damping_qq_c6_kernel, cov)
+                    rt = t.value_and_grad(pos, box, pairs, par['mScales'], *tt_lists)
+                    out[rank] = (r, f.n_cycle, rd, d.energy_parts, rt, f.n_home, d.n_home, t.n_home)
+                except Exception as e:      # noqa: BLE001
+                    errors.append((rank, repr(e)))
+                    try:
+                        world.barrier.abort()
+                    except Exception:
+                        pass
+            ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+            [t.start() for t in ts]
+            [t.join(timeout=600) for t in ts]
+            assert not errors, errors
+            sc = max(abs(p) for p in f0.energy_parts)
+            scd = max(abs(p) for p in d0.energy_parts)
+            for k in (5, 6, 7):
+                assert sum(o[k] for o in out) == 3 * n_mol             # every calculator's home lists partition the atoms
+            for (r, ncyc, rd, dparts, rt, *_) in out:
+                assert abs(r[0] - E0) < tol * sc and rel(r[1], G0) < tol and rel(r[2], dQ0) < tol and ncyc == f0.n_cycle
+                assert abs(rd[0] - Ed0) < tol * scd and rel(rd[1], Gd0) < max(tol, 1e-9)
+                for a, b in zip(dparts, d0.energy_parts):
+                    assert abs(a - b) < tol * scd
+                assert abs(rt[0] - Et0) < tol * abs(Et0) and rel(rt[1], Gt0) < max(tol, 1e-9)
+
+
 def test_slab_halo_only_traffic_and_home_outputs(precision):
     """outputs='home': a rank returns its home rows and nothing proportional to the number of atoms is ever sent -- the
     SCF exchanges only the dipoles of imported atoms (all-to-all-v over index lists), the gradient only what a rank
