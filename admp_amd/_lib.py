@@ -42,6 +42,8 @@ PROTOTYPES = {
     'admp_tt_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _dp, _vp, _i32]),
     'admp_pair_program_build': (_i32, [_vp, _c.c_char_p, _i32, _ip]),
     'admp_pair_program_energy_grad': (_i32, [_vp, _i32, _vp, _dp, _vp, _i32, _dp, _dp, _vp, _i32]),
+    'admp_disp_param_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _i32, _dp, _vp]),
+    'admp_tt_param_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _vp]),
     'admp_thole_sums': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _vp, _vp]),
     'admp_pscale_grad': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _dp]),
     'admp_mscale_grad': (_i32, [_vp, _i32, _vp, _dp, _vp, _i32, _i32, _dp, _i32]),

@@ -77,6 +77,52 @@ ADMP_HD T tt_pair(const Box<T>& box, const T ri[3], const T rj[3], const T pi[4]
   return m * f.v;
 }
 
+// Parameter derivatives of the two scalar pair terms (what jax.grad(pot_disp, argnums=3) differentiates in the reference's
+// examples/openmm_api/run.py:41-43 through admp/api.py:183-199).
+// Dispersion: E_pair = sum_p (mm + g_p) c_p,i c_p,j / r^p is linear in c_p,i: out[p] += dE_pair/dc_p,i.
+template <class T>
+ADMP_HD void disp_pair_dc(const Box<T>& box, const T ri[3], const T rj[3], const T cj[3], T mm, T kappa, int pmax, T out[3]) {
+  T d[3] = {ri[0] - rj[0], ri[1] - rj[1], ri[2] - rj[2]};
+  min_image(box, d);
+  const T r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const T x2 = kappa * kappa * r2, x4 = x2 * x2, ex = m_exp(-x2);
+  const T ir2 = T(1) / r2, ir6 = ir2 * ir2 * ir2;
+  T g = (T(1) + x2 + T(0.5) * x4) * ex;
+  out[0] += (mm + g) * cj[0] * ir6;
+  if (pmax >= 8) {
+    g += x4 * x2 * ex * T(1.0 / 6.0);
+    out[1] += (mm + g) * cj[1] * ir6 * ir2;
+    if (pmax >= 10) {
+      g += x4 * x4 * ex * T(1.0 / 24.0);
+      out[2] += (mm + g) * cj[2] * ir6 * ir2 * ir2;
+    }
+  }
+}
+// Tang-Toennies: E_pair = m f(r; a, b, q, c) with a = sqrt(a_i a_j), b = sqrt(b_i b_j), q = q_i q_j, c = c_i c_j
+// (pairwise.py:94-113): out[0..3] += dE_pair/d(a_i, b_i, q_i, c_i).  d/db at fixed r through x = 1.889726878 r b by a dual
+// number.  A zero a_i or b_i has an infinite one-sided derivative (sqrt at 0; NaN in the reference's autodiff): 0 is returned.
+template <class T>
+ADMP_HD void tt_pair_dparams(const Box<T>& box, const T ri[3], const T rj[3], const T pi[4], const T pj[4], T m, T out[4]) {
+  T d[3] = {ri[0] - rj[0], ri[1] - rj[1], ri[2] - rj[2]};
+  min_image(box, d);
+  const T rr = m_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  typedef Dual<T> S;
+  const T a = m_sqrt(pi[0] * pj[0]), b = m_sqrt(pi[1] * pj[1]), q = pi[2] * pj[2], c = pi[3] * pj[3];
+  const S x(rr * b * T(1.889726878), T(1));
+  const S ex = m_exp(-x);
+  const S x2 = x * x, x3 = x2 * x;
+  const S poly = x + T(1) + x2 * T(0.5) + x3 * T(1.0 / 6.0) + x2 * x2 * T(1.0 / 24.0) + x2 * x3 * T(1.0 / 120.0) +
+                 x3 * x3 * T(1.0 / 720.0);
+  const T ir2 = T(1) / (rr * rr), ir6 = ir2 * ir2 * ir2;
+  const S fq = ex * (x + T(1)) * recip(x) * T(-2625.5);      // df/dq
+  const S fc = ex * poly * ir6;                             // df/dc
+  const S f = ex * (T(2625.5) * a) + fq * q + fc * c;
+  if (pi[0] != T(0)) out[0] += m * T(2625.5) * ex.v * a / (T(2) * pi[0]);
+  if (pi[1] != T(0)) out[1] += m * f.d * x.v / (T(2) * pi[1]);          // df/db = f'(x) x / b ; db/db_i = b / (2 b_i)
+  out[2] += m * fq.v * pj[2];
+  out[3] += m * fc.v * pj[3];
+}
+
 // k-space dispersion kernels Ck_6/8/10 (recip.py:437-462); which = 6, 8, 10.
 ADMP_HD double disp_ck(int which, double ksq, double kappa, double V) {
   const double sqrt_pi = 1.7724538509055159, pi = 3.141592653589793;

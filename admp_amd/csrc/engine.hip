@@ -274,6 +274,9 @@ struct EngineBase {
                     void* dpos, int on_device) = 0;
   virtual void tt(const void* pos, const double* box, const void* abqc, int ns, const double* mS, double* E, void* dpos,
                   int on_device) = 0;
+  virtual void disp_param_grad(const void* pos, const double* box, const void* clist, int pmax, int ns, const double* mS,
+                               void* out) = 0;
+  virtual void tt_param_grad(const void* pos, const double* box, const void* abqc, int ns, const double* mS, void* out) = 0;
   virtual void thole_sums(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                           const double* mS, const double* pS, const void* U, void* sumX, void* sumXw) = 0;
   virtual void pscale_grad(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
@@ -523,7 +526,7 @@ struct Engine : EngineBase {
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
                       &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp,
-                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw, &bin_cells_ind, &bin_sorted_ind})
+                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw, &bin_cells_ind, &bin_sorted_ind, &srow_d})
       b->release();
     free_topology();
     if (ind.rowptr) (void)hipFree(ind.rowptr);
@@ -1712,7 +1715,7 @@ struct Engine : EngineBase {
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     double* acc = vir_begin();
-    launch_disp_pair<T>(stream, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, grad.as<T>(), Ed);
+    launch_disp_pair<T>(stream, na, nbr, pack_srows(pos, cl, 3), bx, tab, (T)kappa, pmax, grad.as<T>(), Ed);
     launch_scalar_pair_virial<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, acc + V_XW);
     cls_sites_na = -1;   // other rows than an electrostatics evaluation's
     sites.need(sizeof(Site<T>) * (size_t)na);
@@ -1751,7 +1754,7 @@ struct Engine : EngineBase {
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     double* acc = vir_begin();
-    launch_tt_pair<T>(stream, na, nbr, pos, par, bx, tab, grad.as<T>(), Ed);
+    launch_tt_pair<T>(stream, na, nbr, pack_srows(pos, par, 4), bx, tab, grad.as<T>(), Ed);
     launch_scalar_pair_virial<T>(stream, 1, na, nbr, pos, par, bx, tab, T(0), 0, acc + V_XW);
     double Eh2[E_SLOTS];
     HIP_TRY(hipMemcpyAsync(Eh2, Ed, sizeof(Eh2), hipMemcpyDeviceToHost, stream));
@@ -1810,6 +1813,12 @@ struct Engine : EngineBase {
     update_slab();
     o[0] = X0; o[1] = X1; o[2] = Y0; o[3] = Y1; o[4] = nloc0(); o[5] = kGhost; o[6] = K[0]; o[7] = K[1]; o[8] = K[2] / 2 + 1;
     o[9] = srank; o[10] = snranks;
+  }
+  DevBuf srow_d;      // packed (position, parameters) rows of the scalar pair kernels, rebuilt per call
+  const SRow<T>* pack_srows(const T* pos, const T* par, int np) {
+    srow_d.need(sizeof(SRow<T>) * (size_t)top.na);
+    launch_pack_scalar_rows<T>(stream, top.na, np, pos, par, srow_d.as<SRow<T>>());
+    return srow_d.as<SRow<T>>();
   }
   // energies of a dispersion / pair-potential call: (real, recip, self) of all ranks
   void read_scalar_energies(double* Ed, double* E, int n) {
@@ -1873,7 +1882,7 @@ struct Engine : EngineBase {
     const bool fused = !(use_dft || use_pfa) && (snranks > 1 || spread_uses_bricks(na, g));
     if (snranks > 1) ARG_CHECK(spread_uses_bricks(1 << 30, g), "slab-decomposed dispersion PME needs at least 17 local mesh planes and K2, K3 >= 17");
     const ScalarRows sr = scalar_rows(pos, g, K[0], X0, X1, fused);
-    { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, dpos, Ed, sr.rows, sr.n); }
+    { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pack_srows(pos, cl, 3), bx, tab, (T)kappa, pmax, dpos, Ed, sr.rows, sr.n); }
     if (fused) {
       const size_t nreal = nreal_local();
       mesh.need(nch * nreal * sizeof(T));
@@ -2001,12 +2010,64 @@ struct Engine : EngineBase {
       g.xoff = 64 * srank; g.nloc0 = 64 + kGhost; g.wrap0 = 1 << 30;
       sr = scalar_rows(pos, g, Kv, 64 * srank, 64 * (srank + 1), true);
     }
-    { TIMED("tt_pair"); launch_tt_pair<T>(stream, na, nbr, pos, par, bx, tab, dpos, Ed, sr.rows, sr.n); }
+    { TIMED("tt_pair"); launch_tt_pair<T>(stream, na, nbr, pack_srows(pos, par, 4), bx, tab, dpos, Ed, sr.rows, sr.n); }
     read_scalar_energies(Ed, E, 1);
     if (dpos_ && !on_device) {
       HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
     }
+  }
+
+  // dE/dc_list (Na,3) of the dispersion PME energy (real + reciprocal + self; admp/disp_pme.py:80-123): the pair part is a
+  // per-atom sum of (m + g_p - 1) c_j / r^p, the reciprocal part the mesh potential of every channel at the atom (E_recip is
+  // a quadratic form of the channel's coefficients), the self part 2 kp c.  Device pointers; on request only.
+  void disp_param_grad(const void* pos_, const double* box, const void* clist_, int pmax, int ns, const double* mS,
+                       void* out_) override {
+    ARG_CHECK(have_top && have_ewald && have_pairs, "topology, ewald parameters and pairs must be set first");
+    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
+    ARG_CHECK(pos_ && box && clist_ && out_, "null argument");
+    ARG_CHECK(pmax == 6 || pmax == 8 || pmax == 10, "pmax must be 6, 8 or 10");
+    const int na = top.na;
+    double inv[9], vol;
+    Box<T> bx = make_box(box, inv, &vol);
+    ensure_mesh();
+    RecipGeom<T> g = make_geom(inv);
+    ScaleTab<T> tab = make_tab(ns, mS, nullptr);
+    const T* pos = reinterpret_cast<const T*>(pos_);
+    const T* cl = reinterpret_cast<const T*>(clist_);
+    T* out = reinterpret_cast<T*>(out_);
+    energies_d.need(2 * E_WORDS * sizeof(double));
+    ehalf = 0; other_clean = false;
+    double* Ed = energies_d.as<double>();
+    HIP_TRY(hipMemsetAsync(Ed, 0, E_WORDS * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(out, 0, 3 * (size_t)na * sizeof(T), stream));
+    launch_scalar_pair_pgrad<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, out);
+    cls_sites_na = -1;
+    sites.need(sizeof(Site<T>) * (size_t)na);
+    ensure_bins(na);
+    const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
+    const int nch = (pmax - 4) / 2;
+    for (int c = 0; c < nch; ++c) {
+      ensure_gtab(box, inv, vol, 6 + 2 * c);
+      launch_scalar_sites<T>(stream, na, pos, cl, 3, c, kp[c], sites.as<Site<T>>(), Ed);
+      int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr, nullptr, 1, c > 0);
+      if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)};
+      convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, E_RECIP);
+      launch_gather_value<T>(stream, na, pos, cl, 3, c, g, mesh.as<T>(), 2.0 * kp[c], out);
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  // dE/d(a, b, q, c6) (Na,4) of the Tang-Toennies pair term (admp/pairwise.py:94-113).  Device pointers; on request only.
+  void tt_param_grad(const void* pos_, const double* box, const void* abqc_, int ns, const double* mS, void* out_) override {
+    ARG_CHECK(have_top && have_pairs, "topology and pairs must be set first");
+    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
+    ARG_CHECK(pos_ && box && abqc_ && out_, "null argument");
+    double inv[9], vol;
+    Box<T> bx = make_box(box, inv, &vol);
+    ScaleTab<T> tab = make_tab(ns, mS, nullptr);
+    launch_scalar_pair_pgrad<T>(stream, 1, top.na, nbr, reinterpret_cast<const T*>(pos_), reinterpret_cast<const T*>(abqc_), bx,
+                                tab, T(0), 0, reinterpret_cast<T*>(out_));
+    HIP_TRY(hipStreamSynchronize(stream));
   }
 
   // a traced pair kernel (pair_program_build) on the current neighbour table: admp/pairwise.py:67-91 with any kernel
@@ -2313,6 +2374,15 @@ int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box
 int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const double* box, const void* params, int pmax,
                      int n_scales, double* dE_dmScales, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.mscale_grad(kind, positions, box, params, pmax, n_scales, dE_dmScales, on_device); });
+}
+
+int admp_disp_param_grad(admp_handle* h, const void* positions, const double* box, const void* c_list, int pmax, int n_scales,
+                         const double* mScales, void* dE_dc) {
+  return guarded(h, [&](EngineBase& e) { e.disp_param_grad(positions, box, c_list, pmax, n_scales, mScales, dE_dc); });
+}
+int admp_tt_param_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
+                       const double* mScales, void* dE_dabqc) {
+  return guarded(h, [&](EngineBase& e) { e.tt_param_grad(positions, box, abqc, n_scales, mScales, dE_dabqc); });
 }
 
 int admp_pscale_grad(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,

@@ -247,13 +247,21 @@ void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, co
 template <class T>
 void launch_pscale_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
                         const ScaleTab<T>& tab, double* cls16);
+// packed rows of the scalar pair kernels: position (3) + up to 4 per-atom parameters + pad, one aligned 8-real row per atom
 template <class T>
-void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
+struct alignas(8 * sizeof(T)) SRow {
+  T v[8];
+};
+template <class T>
+void launch_pack_scalar_rows(hipStream_t st, int na, int np /* parameters per atom: 3 (c6, c8, c10) or 4 (a, b, q, c6) */,
+                             const T* pos, const T* par, SRow<T>* rows);
+template <class T>
+void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* srows, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies,
                       const int* rows = nullptr /* the n_rows rows to evaluate (nullptr: all, in the table's order) */,
                       int n_rows = 0);
 template <class T>
-void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* abqc, const Box<T>& box,
+void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* srows, const Box<T>& box,
                     const ScaleTab<T>& tab, T* grad, double* energies, const int* rows = nullptr, int n_rows = 0);
 
 // ---- box gradient (dE/dbox at fixed Cartesian positions; on request only).  All sums are double device words.
@@ -375,6 +383,15 @@ int launch_spread_scalar(hipStream_t st, int nch, const T* pos, const T* vals, i
 template <class T>
 void launch_gather_scalar(hipStream_t st, int nch, int na, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
                           const T* phi, long mesh_stride, T* grad, const int* list, const double* self_coefs, double* energies);
+// out[i * stride + chan] += phi(r_i) + extra * vals[i * stride + chan]  (mesh potential at the atoms: dE_recip/dc_i)
+template <class T>
+void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, const RecipGeom<T>& g,
+                         const T* phi, double extra, T* out);
+// (pair_kernels.hip) per-atom parameter derivatives of the scalar pair terms: tt = 0 dispersion, out (na,3) = dE/dc6,c8,c10;
+// tt = 1 Tang-Toennies, out (na,4) = dE/d(a, b, q, c6)
+template <class T>
+void launch_scalar_pair_pgrad(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par, const Box<T>& box,
+                              const ScaleTab<T>& tab, T kappa, int pmax, T* out);
 // ---- cell_kernels.hip: positions -> half pair list (cell list), two phases so that the caller can size `pairs`
 struct CellScratch {
   int n[3] = {0, 0, 0};

@@ -243,11 +243,29 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field_ind(int na, const int
   if (row >= 0 && sub == 0) { fld[3 * row] += F[0]; fld[3 * row + 1] += F[1]; fld[3 * row + 2] += F[2]; }
 }
 
-// dispersion / Tang-Toennies: scalar pair terms, same row layout
+// dispersion / Tang-Toennies: scalar pair terms, same row layout.  Position and parameters of an atom are packed into ONE
+// 8-real row (k_pack_scalar_rows, per call): a partner costs one 32-byte (f32) fetch instead of two unrelated 12 / 16-byte ones
+// from the caller's (Na,3) / (Na,NP) arrays -- the kernels are bound by those dependent fetches, not by their arithmetic.
+template <class T>
+__global__ __launch_bounds__(256) void k_pack_scalar_rows(int na, int np, const T* __restrict__ pos, const T* __restrict__ par,
+                                                          SRow<T>* __restrict__ rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= na) return;
+  SRow<T> r;
+  r.v[0] = pos[3 * i]; r.v[1] = pos[3 * i + 1]; r.v[2] = pos[3 * i + 2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.v[3 + k] = k < np ? par[np * i + k] : T(0);
+  r.v[7] = T(0);
+  rows[i] = r;
+}
+template <class T>
+void launch_pack_scalar_rows(hipStream_t st, int na, int np, const T* pos, const T* par, SRow<T>* rows) {
+  if (na > 0) k_pack_scalar_rows<T><<<(na + 255) / 256, 256, 0, st>>>(na, np, pos, par, rows);
+}
 template <class T, int LPR, bool TT>
 __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* __restrict__ rowptr,
-                                                            const int* __restrict__ col, const T* __restrict__ pos,
-                                                            const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
+                                                            const int* __restrict__ col, const SRow<T>* __restrict__ srows,
+                                                            Box<T> box, ScaleTab<T> tab,
                                                             T kappa, int pmax, T* __restrict__ grad, double* energies,
                                                             const int* __restrict__ rows) {
   __shared__ T s_tab[48];
@@ -256,21 +274,21 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
   const int slot = (int)(t / LPR), sub = (int)(t % LPR);
   // `na` counts the rows of this launch (all atoms in the table's length-sorted order, or a slab rank's home rows)
   const int row = slot < na ? (rows ? rows[slot] : slot) : -1;
-  constexpr int NP = TT ? 4 : 3;
   T g[3] = {0, 0, 0};
   double e = 0.0;
   if (row >= 0) {
-    T ri[3] = {pos[3 * row], pos[3 * row + 1], pos[3 * row + 2]}, pi[4] = {0, 0, 0, 0};
-    for (int k = 0; k < NP; ++k) pi[k] = par[NP * row + k];
+    const SRow<T> I = srows[row];
     const int end = rowptr[row + 1];
+    int k = rowptr[row] + sub;
+    int c = k < end ? col[k] : 0;
 #pragma unroll 1
-    for (int k = rowptr[row] + sub; k < end; k += LPR) {
-      const int c = col[k];
-      const int nb = col_nb(c), j = c & kColMask;
-      T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]}, pj[4] = {0, 0, 0, 0};
-      for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
-      if (TT) e += (double)tt_pair(box, ri, rj, pi, pj, s_tab[nb] + T(1), g);
-      else e += (double)disp_pair(box, ri, rj, pi, pj, s_tab[nb], kappa, pmax, g);
+    for (; k < end; k += LPR) {
+      const int cn = k + LPR < end ? col[k + LPR] : 0;           // next entry fetched ahead of the dependent row fetch
+      const SRow<T> J = srows[c & kColMask];
+      const int nb = col_nb(c);
+      if (TT) e += (double)tt_pair(box, I.v, J.v, I.v + 3, J.v + 3, s_tab[nb] + T(1), g);
+      else e += (double)disp_pair(box, I.v, J.v, I.v + 3, J.v + 3, s_tab[nb], kappa, pmax, g);
+      c = cn;
     }
   }
 #pragma unroll
@@ -280,6 +298,48 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
   }
   e = block_reduce_sum<kPairBlock>(e);
   if (threadIdx.x == 0) atomicAdd(&energies[E_REAL], 0.5 * e);
+}
+
+// per-atom parameter derivatives of the scalar pair terms (disp_math.h): out[row][0..NP) = sum over the row's partners
+template <class T, bool TT>
+__global__ __launch_bounds__(kPairBlock) void k_pair_scalar_pgrad(int na, const int* __restrict__ rowptr,
+                                                                  const int* __restrict__ col, const T* __restrict__ pos,
+                                                                  const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
+                                                                  T kappa, int pmax, T* __restrict__ out) {
+  __shared__ T s_tab[48];
+  stage_tab(tab, s_tab);
+  constexpr int LPR = 8, NP = TT ? 4 : 3;
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  T acc[4] = {0, 0, 0, 0};
+  if (row < na) {
+    const T ri[3] = {pos[3 * row], pos[3 * row + 1], pos[3 * row + 2]};
+    T pi[4] = {0, 0, 0, 0};
+    for (int k = 0; k < NP; ++k) pi[k] = par[NP * row + k];
+    const int end = rowptr[row + 1];
+#pragma unroll 1
+    for (int k = rowptr[row] + sub; k < end; k += LPR) {
+      const int c = col[k];
+      const int nb = col_nb(c), j = c & kColMask;
+      const T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]};
+      T pj[4] = {0, 0, 0, 0};
+      for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
+      if (TT) tt_pair_dparams(box, ri, rj, pi, pj, s_tab[nb] + T(1), acc);
+      else disp_pair_dc(box, ri, rj, pj, s_tab[nb], kappa, pmax, acc);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) acc[k] = row_reduce<T, LPR>(acc[k]);
+  if (row < na && sub == 0)
+    for (int k = 0; k < NP; ++k) out[NP * row + k] = acc[k];
+}
+template <class T>
+void launch_scalar_pair_pgrad(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par, const Box<T>& box,
+                              const ScaleTab<T>& tab, T kappa, int pmax, T* out) {
+  if (na <= 0) return;
+  const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
+  if (tt) k_pair_scalar_pgrad<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out);
+  else k_pair_scalar_pgrad<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out);
 }
 
 // dE/dmScales (the parameter gradient the reference's examples/openmm_api/run.py:41-46 prints): per covalent class
@@ -626,25 +686,25 @@ void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const
 #undef CALL
 }
 template <class T>
-void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* clist, const Box<T>& box,
+void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* srows, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies, const int* rows, int n_rows) {
   if (!rows) { rows = nb.order_plain ? nb.order_plain : nb.order; n_rows = na; }
   if (n_rows <= 0) return;
   const int lpr = pair_lanes_per_row(n_rows);
 #define CALL(L)                                                                                                        \
-  k_pair_scalar<T, L, false><<<grid_for(n_rows, L), kPairBlock, 0, st>>>(n_rows, nb.rowptr, nb.col, pos, clist, box, tab, \
+  k_pair_scalar<T, L, false><<<grid_for(n_rows, L), kPairBlock, 0, st>>>(n_rows, nb.rowptr, nb.col, srows, box, tab,    \
                                                                          kappa, pmax, grad, energies, rows)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
 template <class T>
-void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, const T* abqc, const Box<T>& box,
+void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* srows, const Box<T>& box,
                     const ScaleTab<T>& tab, T* grad, double* energies, const int* rows, int n_rows) {
   if (!rows) { rows = nb.order_plain ? nb.order_plain : nb.order; n_rows = na; }
   if (n_rows <= 0) return;
   const int lpr = pair_lanes_per_row(n_rows);
 #define CALL(L)                                                                                                       \
-  k_pair_scalar<T, L, true><<<grid_for(n_rows, L), kPairBlock, 0, st>>>(n_rows, nb.rowptr, nb.col, pos, abqc, box, tab, \
+  k_pair_scalar<T, L, true><<<grid_for(n_rows, L), kPairBlock, 0, st>>>(n_rows, nb.rowptr, nb.col, srows, box, tab,    \
                                                                         T(0), 0, grad, energies, rows)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
@@ -659,9 +719,10 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
                                      const RQ4<T>*, const T*);                                                      \
   template void launch_pair_field_ind<T>(hipStream_t, int, const IndTable&, const Site<T>*, const Box<T>&,          \
                                          const ScaleTab<T>&, T, T*, const int*);                                    \
-  template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,           \
+  template void launch_pack_scalar_rows<T>(hipStream_t, int, int, const T*, const T*, SRow<T>*);                    \
+  template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const SRow<T>*, const Box<T>&,               \
                                     const ScaleTab<T>&, T, int, T*, double*, const int*, int);                      \
-  template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const T*, const T*, const Box<T>&,             \
+  template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const SRow<T>*, const Box<T>&,                 \
                                   const ScaleTab<T>&, T*, double*, const int*, int);                                \
   template void launch_mscale_sums<T>(hipStream_t, int, int, const NbrTable&, const Site<T>*, const T*, const T*,   \
                                       const Box<T>&, int, double*);                                                 \
@@ -670,7 +731,9 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const T* pos, co
   template void launch_pair_virial<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,             \
                                       const ScaleTab<T>&, T, int, double*);                                         \
   template void launch_scalar_pair_virial<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,            \
-                                             const Box<T>&, const ScaleTab<T>&, T, int, double*);
+                                             const Box<T>&, const ScaleTab<T>&, T, int, double*);                   \
+  template void launch_scalar_pair_pgrad<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,             \
+                                            const Box<T>&, const ScaleTab<T>&, T, int, T*);
 INST(float)
 INST(double)
 #undef INST

@@ -117,6 +117,22 @@ class ADMPDispPmeForce(HipForceBase):
             c[:, :nc] = np.asarray(c_list, dtype=np.float64)[:, :nc]
         return self._mscale_gradient(1, positions, box, pairs, c, 3, len(self._host64(mScales)), self.pmax)
 
+    def get_param_gradient(self, positions, box, pairs, c_list, mScales):
+        """dE/dc_list (Na, (pmax-4)/2): the per-atom form of the 'C6' / 'C8' / 'C10' entries of `grad(pot_disp, argnums=3)` in
+        the reference (examples/openmm_api/run.py:41-43, admp/api.py:183-199) -- real-space pair sums, the mesh potential of
+        every channel at the atoms, and the self term (admp_disp_param_grad)."""
+        with self._on_stream():
+            na = self.n_atoms
+            self.set_pairs(pairs)
+            pos = self._real(positions, (na, 3))
+            c3 = self._packed_c(c_list)
+            mS = self._host64(mScales)
+            out = torch.empty((na, 3), dtype=self._dtype, device=self._device)
+            rc = self._L.admp_disp_param_grad(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(c3), self.pmax,
+                                              len(mS), _lib.darr(mS), self._ptr(out))
+            _lib.check(self._h, rc, 'admp_disp_param_grad')
+        return self._like(out[:, :(self.pmax - 4) // 2], positions)
+
     def generate_get_energy(self):
         def get_energy(positions, box, pairs, c_list, mScales):
             return self._evaluate(positions, box, pairs, c_list, mScales, False)[0]

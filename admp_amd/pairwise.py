@@ -80,6 +80,24 @@ class _PairInteraction(HipForceBase):
         par = torch.stack([self._real(p, (self.n_atoms,)) for p in atomic_params], dim=1).contiguous()
         return self._mscale_gradient(2, positions, box, pairs, par, self.kernel.n_params, len(self._host64(mScales)))
 
+    def get_param_gradient(self, positions, box, pairs, mScales, *atomic_params):
+        """(dE/dp1, dE/dp2, ...), each (Na,): the derivative of the pair energy with respect to the per-atom parameter lists
+        -- what `grad(pot_disp, argnums=3)` chains to the 'A' / 'B' / 'Q' / 'C6' tables in the reference
+        (admp/api.py:183-199).  Tang-Toennies: a zero a_i or b_i gets 0 (no finite derivative of sqrt(a_i a_j) there)."""
+        if len(atomic_params) != self.kernel.n_params:
+            raise TypeError('%s takes %d atomic parameter lists' % (self.kernel.name, self.kernel.n_params))
+        with self._on_stream():
+            na = self.n_atoms
+            self.set_pairs(pairs)
+            pos = self._real(positions, (na, 3))
+            par = self._packed_params(atomic_params)
+            mS = self._host64(mScales)
+            out = torch.empty((na, self.kernel.n_params), dtype=self._dtype, device=self._device)
+            rc = self._L.admp_tt_param_grad(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(par), len(mS),
+                                            _lib.darr(mS), self._ptr(out))
+            _lib.check(self._h, rc, 'admp_tt_param_grad')
+        return tuple(self._like(out[:, k].contiguous(), positions) for k in range(self.kernel.n_params))
+
     def get_energy_and_box_gradient(self, positions, box, pairs, mScales, *atomic_params):
         """(E, dE/dbox (3,3)) at fixed Cartesian positions: value_and_grad(pair_int, argnums=1) of the reference."""
         with self._on_stream():
@@ -146,6 +164,9 @@ class _TracedPairInteraction(_PairInteraction):
 
     def get_mscale_gradient(self, *a, **k):
         raise NotImplementedError('dE/dmScales is available for the named kernels only')
+
+    def get_param_gradient(self, *a, **k):
+        raise NotImplementedError('parameter gradients are available for the named kernels only')
 
     def get_energy_and_box_gradient(self, *a, **k):
         raise NotImplementedError('the box gradient is available for the named kernels only')

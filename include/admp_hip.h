@@ -170,6 +170,18 @@ int admp_pair_program_energy_grad(admp_handle* h, int program_id, const void* po
 int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const double* box, const void* params, int pmax,
                      int n_scales, double* dE_dmScales, int on_device);
 
+/* replaces: the 'C6' / 'C8' / 'C10' and 'A' / 'B' / 'Q' entries of jax.grad(pot_disp, argnums=3) of the reference's
+ * dispersion front-end (examples/openmm_api/run.py:41-43 through admp/api.py:183-199), at the level of the per-ATOM lists the
+ * calculators take (the caller chains them to its per-type tables and unit conversions, admp_amd/api.py):
+ *   admp_disp_param_grad   dE_dc (Na,3) real = d(E_real + E_recip + E_self)/dc_list of admp_disp_energy_grad
+ *   admp_tt_param_grad     dE_dabqc (Na,4) real = dE/d(a, b, q, c6) of admp_tt_energy_grad; an atom whose a or b is zero gets 0
+ *                          for that entry (the geometric mean sqrt(a_i a_j) has no finite derivative there: NaN in autodiff)
+ * All array arguments are DEVICE pointers.  Not available on a slab-decomposed handle. */
+int admp_disp_param_grad(admp_handle* h, const void* positions, const double* box, const void* c_list, int pmax, int n_scales,
+                         const double* mScales, void* dE_dc);
+int admp_tt_param_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
+                       const double* mScales, void* dE_dabqc);
+
 /* replaces: the 'pol' / 'tholes' entries of jax.grad(pot_pme, argnums=3) (parameter gradients of the polarizable model).
  * The polarizabilities and Thole parameters enter the pair energy only through the Thole argument
  * au = a_w r / (alpha_i alpha_j)^(1/6) (admp/pme.py:408-414).  This call returns, for the induced dipoles U given

@@ -4,6 +4,7 @@ parameters, pair-list builder, scale-table wrap, synthetic box generator)."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -231,3 +232,46 @@ def test_parser_reproduces_example_inputs(tmp_path):
     assert (assemble_covalent(residues, n) == cov.toarray()).all()
     pol = np.vstack([(a.polarizabilityXX, a.polarizabilityYY, a.polarizabilityZZ) for a in atoms.values()]).astype(np.float32)
     assert np.abs(1000 * np.mean(pol, axis=1) - par['pol']).max() < 1e-12
+
+
+def test_force_field_front_end_without_gpu(tmp_path):
+    """admp.api (reference admp/api.py:120-488): the XML force field is read into generators holding the parameter tables, the
+    PDB into a topology; atom types, bonds, covalent map and local-frame rules of water come out as the reference's
+    front-end derives them (tests/test_sptial.py:74-84 axis atoms).  Host side only -- no calculator is built."""
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    import make_inputs
+    from admp_amd import systems as S
+    from admp_amd import api, parser
+    import admp.api
+    assert admp.api is api
+    n_mol = 8
+    pos, box = S.synthetic_water_box(n_mol, seed=3)
+    make_inputs.write_pdb(str(tmp_path / 'w.pdb'), pos, box)
+    make_inputs.write_forcefield_xml(str(tmp_path / 'ff.xml'))
+    H = api.Hamiltonian(str(tmp_path / 'ff.xml'))
+    disp_g, pme_g = H.getGenerators()
+    assert isinstance(disp_g, api.ADMPDispGenerator) and isinstance(pme_g, api.ADMPPmeGenerator)
+    assert set(disp_g.params) == {'A', 'B', 'Q', 'C6', 'C8', 'C10', 'mScales'} and disp_g.pmax == 10
+    np.testing.assert_allclose(np.sqrt(disp_g.params['C6'] * 1e6), S.C6, rtol=1e-12)        # admp/api.py:190
+    np.testing.assert_allclose(disp_g.params['A'] / 2625.5, S.TT_A, rtol=1e-12)
+    assert pme_g.lpol and pme_g.lmax == 2 and list(pme_g.params['mScales']) == [0, 0, 0, 1, 1]
+    top = api.Topology.from_pdb(str(tmp_path / 'w.pdb'))
+    assert top.n_atoms == 3 * n_mol and len(top.residues) == n_mol
+    np.testing.assert_allclose(top.box, box, atol=1e-3)
+    typed = api._Typed(H._templates, top)
+    assert typed.types[:3] == ['380', '381', '381'] and sorted(typed.bonds[:2]) == [(1, 0), (2, 0)]
+    cov = api.build_covalent_map(top.n_atoms, typed.bonds, 6).toarray()
+    _, _, cov_ref = S.water_topology(n_mol)
+    assert (cov == cov_ref.toarray()).all()
+    # local-frame rule and anchors of the first molecule (O: bisector of the hydrogens; H: z = O, x = the other H)
+    rules = []
+    for t, kz, kx in (('380', '-381', '-381'), ('381', '380', '381')):
+        d = {'type': t, 'kz': kz, 'kx': kx, 'ky': ''}
+        parser._axis_rule(d)
+        rules.append(d['axisType'])
+    assert rules == [parser.Bisector, parser.ZThenX]
+    assert api._cutoff_angstrom(4.0) == 4.0
+
+    class Q:                                   # an OpenMM-style quantity
+        _value, unit = 0.4, 'nanometer'
+    assert abs(api._cutoff_angstrom(Q()) - 4.0) < 1e-12
