@@ -15,25 +15,12 @@ namespace admp {
 constexpr int kDftBlock = ADMP_DFT_BLOCK;
 constexpr size_t kDftLdsBudget = 60 * 1024;
 
-// outputs per thread (KQ output pairs share one read of the pair sums); ADMP_DFT_KQ = 1 | 2 | 4 for tuning
-static int dft_kq() {
-  static int v = 0;
-  if (!v) {
-    const char* e = getenv("ADMP_DFT_KQ");
-    v = e ? atoi(e) : 2;
-    if (v != 1 && v != 2 && v != 4) v = 2;
-  }
-  return v;
-}
-// threads per output set: ADMP_DFT_JS = 1 (default) | 2.  With 2, a pair of neighbouring lanes shares one task -- each sums half
-// of the pair positions, the halves are combined with one lane exchange: twice the waves, half the dependent chain.  Measured
-// on the 97^3 f64 mesh (< 2 waves per SIMD with one thread per task): SLOWER, x pass 36.8 -> 44.4 us with 256-thread blocks
-// (half the columns per tile: 80-byte instead of 160-byte runs in memory), 38.2 us with 512-thread blocks (same tiles) -- like
-// KQ = 1, more and thinner threads do not help these passes.  Kept for A/B.
-static int dft_js() {
-  static const int v = [] { const char* e = getenv("ADMP_DFT_JS"); return e && atoi(e) == 2 ? 2 : 1; }();
-  return v;
-}
+// Two output pairs per thread (they share one read of the pair sums), one thread per output set.  Round 2 measured the
+// alternatives on the 97^3 f64 mesh and dropped them (variants in the history): 1 or 4 output pairs per thread, and two
+// lanes per output set (each summing half of the pair positions: x pass 36.8 -> 44.4 us) -- more, thinner threads do not
+// help these latency-bound passes.  The kernels keep the two template parameters; one instantiation is compiled.
+static int dft_kq() { return 2; }
+static int dft_js() { return 1; }
 // thread-tasks per line and lines (columns) per block
 static int dft_tasks(int N, int KQ) { return (N / 2 + 1 + KQ - 1) / KQ; }
 static int dft_cols(int N, int KQ, size_t bytes_per_col, size_t fixed_bytes) {
@@ -368,32 +355,11 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
 }
 
 // ---- launchers.  K = mesh dimensions, tw = (cos, sin) tables of K[0], K[1], K[2] back to back.
-#define KQ_SWITCH_JS(CALL)         \
-  switch (dft_kq()) {              \
-    case 1: { constexpr int KQ = 1; CALL; } break; \
-    case 4: { constexpr int KQ = 4; CALL; } break; \
-    default: { constexpr int KQ = 2; CALL; } break; \
-  }
-#define KQ_SWITCH(CALL)                                          \
-  if (dft_js() == 2) { constexpr int JS = 2; KQ_SWITCH_JS(CALL) } \
-  else { constexpr int JS = 1; KQ_SWITCH_JS(CALL) }
-
-// matrix-core forms (dft_mfma.hip), opt-in with ADMP_DFT_MFMA=1: measured no faster than the vector forms below
-bool dftm_enabled(int N);
-template <class T>
-void launch_dftm_z(hipStream_t, const int*, const T*, T*, T*, int, int, long, long);
-template <class T>
-void launch_dftm_y(hipStream_t, const int*, const T*, T*, int, int, long);
-template <class T>
-void launch_dftm_x_conv(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long);
+#define KQ_SWITCH(CALL) { constexpr int KQ = 2; constexpr int JS = 1; CALL; }
 
 template <class T>
 bool launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb, long mesh_stride,
                   long spec_stride, T* accum) {
-  if (dftm_enabled(K[2])) {
-    launch_dftm_z<T>(st, K, tw, mesh, spec, inverse, nb, mesh_stride, spec_stride);
-    return false;
-  }
   const int N = K[2], nlines = K[0] * K[1], H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NL = dft_cols(N, dft_kq(), sizeof(Cx<T>) * (size_t)H + 2 * sizeof(T), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(Cx<T>) * (size_t)(N + H * NL) + sizeof(T) * 2 * (size_t)NL;
@@ -410,7 +376,6 @@ bool launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec,
 }
 template <class T>
 void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inverse, int nb, long spec_stride) {
-  if (dftm_enabled(K[1])) return launch_dftm_y<T>(st, K, tw, spec, inverse, nb, spec_stride);
   const int N = K[1], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + 2 * sizeof(Cx<T>), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC);
@@ -427,7 +392,6 @@ void launch_dft_y(hipStream_t st, const int K[3], const T* tw, T* spec, int inve
 template <class T>
 void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
                        int slot, int nb, long spec_stride) {
-  if (dftm_enabled(K[0])) return launch_dftm_x_conv<T>(st, K, tw, spec, tabs, energies, slot, nb, spec_stride);
   const int N = K[0], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
   const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + sizeof(Cx<T>) * (size_t)(2 + N), sizeof(Cx<T>) * (size_t)N);
   const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC + N * NC);
@@ -438,7 +402,6 @@ void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, con
                                                              spec_stride / 2)))
 }
 #undef KQ_SWITCH
-#undef KQ_SWITCH_JS
 #define INST(T)                                                                                   \
   template bool launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*); \
   template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int, int, long);           \

@@ -697,12 +697,11 @@ struct Engine : EngineBase {
     if (nspec_t > nspec) nspec = nspec_t;
     // fused-x path: the kz rows of the spectrum are padded to whole 128-byte lines.  With K2/2+1 = 129 complex numbers per row
     // every row of a tile straddles two lines; padded to 144, rocFFT's batched 2-D r2c / c2r of the 256^3 f32 mesh take
-    // 61 / 64 us instead of 88 / 91 (tools/ubench/rocfft_yz_layouts.cpp).  ADMP_FX_PAD=0: unpadded.
+    // 61 / 64 us instead of 88 / 91 (tools/ubench/rocfft_yz_layouts.cpp).
     static const bool fx_off = [] { const char* e = getenv("ADMP_FUSED_X"); return e && atoi(e) == 0; }();
-    static const bool fx_pad = [] { const char* e = getenv("ADMP_FX_PAD"); return !(e && atoi(e) == 0); }();
     const bool want_fx = snranks == 1 && !fx_off && fftx_usable(K[0]);
     const size_t per_line = 128 / (2 * sizeof(T));
-    const int khp = want_fx && fx_pad ? (int)((K2h + per_line - 1) / per_line * per_line) : (int)K2h;
+    const int khp = want_fx ? (int)((K2h + per_line - 1) / per_line * per_line) : (int)K2h;
     if (want_fx && (size_t)K[0] * K[1] * khp > nspec) nspec = (size_t)K[0] * K[1] * khp;
     mesh.need(nreal * sizeof(T));
     spec.need(nspec * 2 * sizeof(T));
@@ -1892,12 +1891,14 @@ struct Engine : EngineBase {
         if (rc == 0) rc = launch_spread_scalar<T>(stream, nch, pos, cl, 3, g, bins, mesh.as<T>(), (long)nreal);
         if (rc != 0) throw Err{ADMP_E_HIP, std::string("dispersion spread: ") + hipGetErrorString((hipError_t)rc)};
         bins.counters_zero = true; }
+      // every channel is gathered right after its transform, while its phi is still in L2 / MALL (the three meshes at once --
+      // 201 MB at 256^3 -- in one gather pass measured 0.52-0.61 ms against 0.39 for three single-mesh passes)
       for (int c = 0; c < nch; ++c) {
         ensure_gtab(box, inv, vol, 6 + 2 * c);
         convolve(mesh.as<T>() + c * nreal, spec.as<T>(), gtab_cur, E_RECIP);
+        TIMED("gather_field");
+        launch_gather_scalar<T>(stream, 1, sr.n, pos, cl + c, 3, g, mesh.as<T>() + c * nreal, (long)nreal, dpos, sr.home, kp + c, Ed);
       }
-      { TIMED("gather_field");
-        launch_gather_scalar<T>(stream, nch, sr.n, pos, cl, 3, g, mesh.as<T>(), (long)nreal, dpos, sr.home, kp, Ed); }
       read_scalar_energies(Ed, E, 3);
       if (dpos_ && !on_device) {
         HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
@@ -1925,7 +1926,7 @@ struct Engine : EngineBase {
       }
       sites.need(sizeof(Site<T>) * (size_t)na * nch);
       fld_recip.need(3 * (size_t)na * sizeof(T) * nch);
-      const bool batch_spread = na < spread_brick_min_atoms();     // the scan-spread regime takes the channels as a batch
+      const bool batch_spread = !spread_uses_bricks(na, g);        // the scan-spread regime takes the channels as a batch
       if (batch_spread) {
         // the stencil records ride along: every (brick, channel) workgroup of the scan spread reads them instead of
         // redoing three grid_ref per atom (3072 atoms x 1029 workgroups at 97^3)

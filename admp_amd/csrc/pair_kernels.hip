@@ -280,15 +280,18 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
     const SRow<T> I = srows[row];
     const int end = rowptr[row + 1];
     int k = rowptr[row] + sub;
-    int c = k < end ? col[k] : 0;
+    // two entries and one partner row are fetched ahead of the arithmetic (the chain col -> row -> pair term is what the
+    // kernel waits on); out-of-range prefetches read entry 0 / row 0: valid addresses, results unused
+    int c0 = k < end ? col[k] : 0, c1 = k + LPR < end ? col[k + LPR] : 0;
+    SRow<T> J = srows[c0 & kColMask];
 #pragma unroll 1
     for (; k < end; k += LPR) {
-      const int cn = k + LPR < end ? col[k + LPR] : 0;           // next entry fetched ahead of the dependent row fetch
-      const SRow<T> J = srows[c & kColMask];
-      const int nb = col_nb(c);
+      const int c2 = k + 2 * LPR < end ? col[k + 2 * LPR] : 0;
+      const SRow<T> Jn = srows[c1 & kColMask];
+      const int nb = col_nb(c0);
       if (TT) e += (double)tt_pair(box, I.v, J.v, I.v + 3, J.v + 3, s_tab[nb] + T(1), g);
       else e += (double)disp_pair(box, I.v, J.v, I.v + 3, J.v + 3, s_tab[nb], kappa, pmax, g);
-      c = cn;
+      c0 = c1; c1 = c2; J = Jn;
     }
   }
 #pragma unroll
@@ -690,7 +693,7 @@ void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>*
                       const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies, const int* rows, int n_rows) {
   if (!rows) { rows = nb.order_plain ? nb.order_plain : nb.order; n_rows = na; }
   if (n_rows <= 0) return;
-  const int lpr = pair_lanes_per_row(n_rows);
+  const int lpr = field_lanes_per_row(n_rows, false);      // light arithmetic per partner: more lanes = more fetches in flight
 #define CALL(L)                                                                                                        \
   k_pair_scalar<T, L, false><<<grid_for(n_rows, L), kPairBlock, 0, st>>>(n_rows, nb.rowptr, nb.col, srows, box, tab,    \
                                                                          kappa, pmax, grad, energies, rows)
@@ -702,7 +705,7 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* s
                     const ScaleTab<T>& tab, T* grad, double* energies, const int* rows, int n_rows) {
   if (!rows) { rows = nb.order_plain ? nb.order_plain : nb.order; n_rows = na; }
   if (n_rows <= 0) return;
-  const int lpr = pair_lanes_per_row(n_rows);
+  const int lpr = field_lanes_per_row(n_rows, false);
 #define CALL(L)                                                                                                       \
   k_pair_scalar<T, L, true><<<grid_for(n_rows, L), kPairBlock, 0, st>>>(n_rows, nb.rowptr, nb.col, srows, box, tab,    \
                                                                         T(0), 0, grad, energies, rows)

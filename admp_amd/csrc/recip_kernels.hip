@@ -13,6 +13,7 @@
 namespace admp {
 
 constexpr int kRecipBlock = 128;
+bool spread_wants_bricks(int na, int ncell);
 
 template <class T>
 __device__ __forceinline__ void site_qtot(const Site<T>& s, int lpol, T r[3], T Q[9]) {
@@ -827,7 +828,7 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
   // the binned brick kernel expresses a stencil as ONE run of local indices per axis, which needs >= 2 bricks per axis
   // (a stencil that wraps around inside a single brick is two runs): meshes of <= 16 points per axis take the scan kernel
   const bool one_brick_axis = bg.nb[0] == 1 || bg.nb[1] == 1 || bg.nb[2] == 1;
-  if (na < spread_brick_min_atoms() || one_brick_axis) {
+  if (!spread_wants_bricks(na, bg.ncell) || one_brick_axis) {
     // measured (f32, reference K rule): 12 288 atoms scan 0.052 / bricks 0.066 / global atomics 0.130 ms; 18 000 atoms
     // 0.070 / 0.083 / 0.189; 30 000 atoms 0.144 / 0.109 -- the scan kernel serves everything below the brick threshold
     static const int scan_max = [] { const char* e = getenv("ADMP_SPREAD_SCAN_MAX"); return e ? atoi(e) : 20000; }();
@@ -876,11 +877,19 @@ template <class T>
 bool spread_uses_bricks(int na, const RecipGeom<T>& g) {
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
-  return na >= spread_brick_min_atoms() && bg.nb[0] > 1 && bg.nb[1] > 1 && bg.nb[2] > 1;
+  return spread_wants_bricks(na, bg.ncell) && bg.nb[0] > 1 && bg.nb[1] > 1 && bg.nb[2] > 1;
 }
 template bool spread_uses_bricks<float>(int, const RecipGeom<float>&);
 template bool spread_uses_bricks<double>(int, const RecipGeom<double>&);
 
+// The scan kernel costs (bricks x atoms) record tests, the binned kernel two binning passes: bricks win above ~20 000 atoms on
+// a whole mesh (measured, see launch_spread) -- and on a slab rank's local mesh, or for the polarizable subset of an SCF
+// increment, whenever a brick still gets a few dozen atoms (16 384 polarizable home atoms on 320 local bricks took the scan
+// kernel in round 2's rule: 0.076 ms against 0.060 ms for the full spread of 49 152 atoms).
+bool spread_wants_bricks(int na, int ncell) {
+  const int m = spread_brick_min_atoms();
+  return na >= m || (m > 0 && na >= 4096 && (long)na >= 24l * ncell);
+}
 int spread_brick_min_atoms() {
   static int v = -1;
   if (v < 0) {

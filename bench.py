@@ -154,7 +154,7 @@ class ThermalFrames:
                                                                EXCURSION))
 
 
-def make_force(w, comm=None):
+def make_force(w, comm=None, outputs='replicated'):
     import torch
     from admp_amd import settings
     from admp_amd.pme import ADMPPmeForce
@@ -163,7 +163,7 @@ def make_force(w, comm=None):
         f = ADMPPmeForce(w['box'], w['at'], w['ai'], w['cov'], RC, 1e-4, 2, lpol=True)
     else:
         from admp_amd.parallel import SlabPme
-        f = SlabPme(comm, w['box'], w['at'], w['ai'], w['cov'], RC, 1e-4, 2, lpol=True)
+        f = SlabPme(comm, w['box'], w['at'], w['ai'], w['cov'], RC, 1e-4, 2, lpol=True, outputs=outputs)
     if w['K'] is not None:
         for k in ('K1', 'K2', 'K3'):
             f.update_env(k, w['K'])
@@ -483,7 +483,10 @@ def slab_child(outpath):
     rdev = 'cuda' if backend == 'nccl' else 'cpu'
     w3 = make_workload(os.environ.get('ADMP_BENCH_SCALE', 'S3'))
     comm = TorchComm()
-    f3, a3 = make_force(w3, comm)
+    # outputs='home': every rank keeps the gradient / dipole rows of its home atoms, as an MD driver that keeps the atoms
+    # distributed would; the reference's calling convention (full arrays to every caller: outputs='replicated') costs one
+    # all-reduce of (Na, 3) per output on top (ADMP_BENCH_OUTPUTS=replicated measures it)
+    f3, a3 = make_force(w3, comm, os.environ.get('ADMP_BENCH_OUTPUTS', 'home'))
     fr3 = ThermalFrames(w3, torch.device('cuda', local))
     run_timed(f3, a3, 2, 0, fr3, dist.barrier, only=False)          # warm-up (plans, buffers, RCCL channels)
     comm.reset_stats()
@@ -492,7 +495,7 @@ def slab_child(outpath):
     dt3 = reduce_max_seconds(dt3, dist, rdev)
     if rank == 0:
         res = {'workload': w3['desc'], 'decomposition': 'x-slab over %d GPUs (RCCL all-to-all transposes, ghost-plane '
-               'shifts, halo exchange of dipoles/gradient)' % world, 'scaling': 'strong',
+               'shifts, halo exchange of dipoles/gradient); outputs: %s rows' % (world, f3.outputs), 'scaling': 'strong',
                'n_atoms': 3 * w3['n_mol'], 'n_pairs': int(f3.n_pairs), 'home_atoms_rank0': int(f3.n_home),
                'ms_per_step': round(dt3 / 5 * 1e3, 3), 'ns_per_day': round(0.0864 / (dt3 / 5), 3),
                'geometry': 'moving (thermal frames)', 'dtype': 'f32',

@@ -1,6 +1,8 @@
 """Boundary rows of SURVEY.md section 8 that round 2 closed, checked on the GPU through the C ABI:
 the reference's literal k-point order (a18), the bare calculators energy_fn / grad_U_fn / grad_pos_fn and the
 construct_local_frames / pme_recip attributes (a1), the `admp` import name (b), the numpy pair-list cache."""
+import os
+
 import numpy as np
 import pytest
 

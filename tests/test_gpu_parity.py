@@ -183,16 +183,13 @@ for prec, tol in (('double', 1e-9), ('single', 5e-4)):
         assert abs(E - dref['E']) < tol * max(abs(p) for p in dref['parts']) and rel(G, dref['grad']) < max(tol, 1e-8), (prec, K)
 print('BRICK-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # the three forms of the gather (recip_kernels.hip launch_gather): staged (default), one workgroup per quarter brick reading
-    # phi from LDS (takes the lists of the brick spread), and the 8-lane form of round 1
-    for gather in ('staged', 'bricks', 'lanes8'):
-        env = dict(os.environ, ADMP_SPREAD_BRICK_MIN='0', ADMP_GATHER=gather)
-        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
-        assert r.returncode == 0 and 'BRICK-OK' in r.stdout, gather + r.stdout[-2000:] + r.stderr[-3000:]
+    env = dict(os.environ, ADMP_SPREAD_BRICK_MIN='0')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'BRICK-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_direct_dft_convolution_vs_rocfft(tmp_path):
-    """Meshes with a Bluestein dimension go through dft_mfma.hip / dft_kernels.hip instead of rocFFT (engine.hip setup_dft).
+    """Meshes with a Bluestein dimension go through dft_kernels.hip / pfa_kernels.hip instead of rocFFT (engine.hip setup_dft).
     The k-space legs must agree to round-off: polarizable PME and dispersion PME, even / odd / prime dimensions, both
     precisions; ADMP_DFT is read per handle, the child processes only keep the runs independent."""
     import subprocess
@@ -225,13 +222,10 @@ np.savez(sys.argv[1], **out)
 print('DFT-RUN-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    # 'dft', 'dft_kq4', 'dft_js2': the vector forms of dft_kernels.hip (the default; 4 outputs per thread; two lanes per task);
-    # 'dft_mfma': the matrix-core kernels of dft_mfma.hip
+    # 'dft': the direct line transforms of dft_kernels.hip
     # 'pfa': the two-level (Good-Thomas) kernels of pfa_kernels.hip forced onto these small meshes, every dimension split
     # that has a coprime split (34 = 2 * 17, 38 = 2 * 19, 96 = 32 * 3, 100 = 4 * 25, 45 = 9 * 5, 51 = 3 * 17; 31, 97, 64 plain)
-    modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'dft_mfma': dict(ADMP_DFT='1', ADMP_DFT_MFMA='1'),
-             'dft_kq4': dict(ADMP_DFT='1', ADMP_DFT_KQ='4'), 'dft_js2': dict(ADMP_DFT='1', ADMP_DFT_JS='2'),
-             'pfa': dict(ADMP_DFT='2', ADMP_PFA_MIN='0')}
+    modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'pfa': dict(ADMP_DFT='2', ADMP_PFA_MIN='0')}
     for mode, extra in modes.items():
         path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
@@ -1374,8 +1368,8 @@ np.savez(sys.argv[1], **out)
 print('FX-RUN-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    # fused_x: spectrum rows padded to whole 128-byte lines (the default); fused_x_unpadded: K3/2+1 complex numbers per row
-    for mode, extra in {'rocfft3d': dict(ADMP_FUSED_X='0'), 'fused_x': {}, 'fused_x_unpadded': dict(ADMP_FX_PAD='0')}.items():
+    # fused_x: spectrum rows padded to whole 128-byte lines
+    for mode, extra in {'rocfft3d': dict(ADMP_FUSED_X='0'), 'fused_x': {}}.items():
         path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True, env=dict(os.environ, **extra),
                            timeout=900)
@@ -1383,7 +1377,7 @@ print('FX-RUN-OK')
         res[mode] = dict(np.load(path))
     assert len(res['rocfft3d']) == 2 * 3 * 5
     for key, a in res['rocfft3d'].items():
-        for mode in ('fused_x', 'fused_x_unpadded'):
+        for mode in ('fused_x',):
             b = res[mode][key]
             tol = 1e-10 if key.startswith('double') else 2e-4
             assert np.abs(a - b).max() <= tol * np.abs(a).max(), (mode, key, np.abs(a - b).max(), np.abs(a).max())

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Slab-decomposed step rehearsed on ONE GPU with N in-process ranks (threads + ThreadComm): what every rank's kernels cost.
+The ranks take turns on the one device, so every kernel is timed alone (HIP events on the shared stream) -- unlike the
+2-process gloo rehearsal of bench.py, where the processes time-slice the GPU and event brackets include the other rank's
+work.  Collectives go through a host mailbox: their times mean nothing here.
+
+    python tools/slab_rehearsal.py [S2|S3] [nranks] [steps]
+prints one JSON line: single-GPU step, per-rank sums of kernel ms per step, home / import atom counts."""
+import json
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch                                                                                    # noqa: E402
+import bench                                                                                    # noqa: E402
+from admp_amd.parallel import SlabPme, ThreadComm                                               # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'S2'
+nranks = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+w = bench.make_workload(name)
+dev = torch.device('cuda', 0)
+frames = bench.ThermalFrames(w, dev)
+f0, a0 = bench.make_force(w)
+dt0, _, cyc0 = bench.run_timed(f0, a0, steps, 3, frames, only=False)
+kb0 = bench.kernel_breakdown(f0, a0, frames, 3 + steps, steps)
+single_ms = dt0 / steps * 1e3
+world = ThreadComm.World(nranks)
+out, errors = [None] * nranks, []
+
+
+def work(rank):
+    try:
+        torch.cuda.set_device(0)
+        comm = ThreadComm(world, rank)
+        f = SlabPme(comm, w['box'], w['at'], w['ai'], w['cov'], bench.RC, 1e-4, 2, lpol=True, outputs='home')
+        if w['K'] is not None:
+            for k in ('K1', 'K2', 'K3'):
+                f.update_env(k, w['K'])
+        U = None
+        for k in range(3):                                   # warm-up
+            bench.step(f, a0, U, frames.step_frame(k))
+            U = f.U_ind
+        f.profile(True)
+        f.profile_reset()
+        t0 = time.perf_counter()
+        upd = 0
+        for k in range(3, 3 + steps):
+            bench.step(f, a0, U, frames.step_frame(k))
+            U = f.U_ind
+            upd += f.n_cycle
+        wall = time.perf_counter() - t0
+        rep = f.profile_report()
+        f.profile(False)
+        ker = {k: round(v[0] / steps, 4) for k, v in sorted(rep.items())}
+        out[rank] = dict(home_atoms=int(f.n_home), import_atoms=int(f.n_import),
+                         kernel_ms_per_step={k: v for k, v in ker.items() if not k.startswith('comm_')},
+                         kernel_ms_sum=round(sum(v for k, v in ker.items() if not k.startswith('comm_')), 4),
+                         jacobi_updates_per_step=upd / float(steps), wall_ms_per_step_all_ranks_interleaved=round(wall / steps * 1e3, 3))
+    except Exception as e:      # noqa: BLE001
+        errors.append((rank, repr(e)))
+        try:
+            world.barrier.abort()
+        except Exception:
+            pass
+
+
+ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+print(json.dumps({'workload': w['desc'], 'nranks': nranks, 'single_gpu_ms_per_step': round(single_ms, 4),
+                  'single_gpu_kernel_ms_sum': round(sum(kb0.values()), 4), 'single_gpu': cyc0, 'ranks': out, 'errors': errors,
+                  'ratio_rank0_kernels_to_single_step': round(out[0]['kernel_ms_sum'] / single_ms, 3) if out[0] else None}))
