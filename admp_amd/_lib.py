@@ -52,6 +52,7 @@ PROTOTYPES = {
     'admp_set_pairs_from_positions': (_i32, [_vp, _vp, _dp, _dbl]),
     'admp_slab_configure': (_i32, [_vp, _i32, _i32]),
     'admp_slab_info': (_i32, [_vp, _c.POINTER(_i64)]),
+    'admp_scf_stats': (_i32, [_vp, _c.POINTER(_i64), _i32]),
     'admp_set_comm': (_i32, [_vp, _vp]),
     'admp_slab_home': (_i32, [_vp, _vp, _ip, _ip]),
     'admp_profile_enable': (_i32, [_vp, _i32]),

@@ -328,7 +328,8 @@ class ADMPPmeGenerator:
         self.params['Q_local'] = convert_cart2harm(Q, 2)
         if self.lpol:
             pol = np.stack([p['polarizabilityXX'][mt], p['polarizabilityYY'][mt], p['polarizabilityZZ'][mt]], axis=1)
-            self.params['pol'] = 1000.0 * pol.astype(np.float32).mean(axis=1).astype(np.float64)    # nm^3 -> A^3 (:330-332)
+            self.params['pol'] = (np.float32(1000) * pol.astype(np.float32).mean(axis=1)).astype(np.float64)   # nm^3 -> A^3, in
+                                                                     # float32 like the reference (admp/api.py:330-332)
             self.params['tholes'] = p['thole'][mt].astype(np.float32).astype(np.float64)
             U = np.zeros((n, 3))
             if self.ref_dip:

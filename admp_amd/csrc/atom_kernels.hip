@@ -374,10 +374,18 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_groups(Topology top, cons
                                                               const T* __restrict__ pol, const T* __restrict__ Ucart,
                                                               int lpol, T kappa, const T* __restrict__ pot,
                                                               T* __restrict__ grad, T* __restrict__ dQlocal,
-                                                              double* energies, FieldFin<T> ff) {
+                                                              double* energies, FieldFin<T> ff,
+                                                              const int* __restrict__ slab_bits) {
   const int gidx = blockIdx.x * kAtomBlock + threadIdx.x;
   double eself = 0.0, epen = 0.0, fm = 0.0;
-  if (gidx < top.ngroups) {
+  // slab rank (slab_bits): a group is served by every rank that owns one of its atoms, each for the sites it owns; what a
+  // site's frame adds to atoms of other ranks lands in their (zeroed) rows and travels to the owners afterwards
+  bool any = gidx < top.ngroups;
+  if (any && slab_bits) {
+    any = false;
+    for (int i = top.grp_ptr[gidx]; i < top.grp_ptr[gidx + 1]; ++i) any = any || (slab_bits[i] & kSlabHome);
+  }
+  if (any) {
     const int a0 = top.grp_ptr[gidx], n = top.grp_ptr[gidx + 1] - a0;
     T f[3];
     self_factors(kappa, f);
@@ -388,6 +396,7 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_groups(Topology top, cons
     for (int m = 0; m < kMaxGroup; ++m) {
       if (m >= n) break;
       const int i = a0 + m;
+      if (slab_bits && !(slab_bits[i] & kSlabHome)) continue;
       T P[9];
       double es;
       total_potential(sites[i], pot + 9 * (size_t)i, lpol, f, P, &es);
@@ -443,7 +452,9 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_groups(Topology top, cons
     if (grad) {
 #pragma unroll
       for (int m = 0; m < kMaxGroup; ++m)
-        if (m < n) { grad[3 * (a0 + m)] += acc[m][0]; grad[3 * (a0 + m) + 1] += acc[m][1]; grad[3 * (a0 + m) + 2] += acc[m][2]; }
+        if (m < n && (!slab_bits || slab_bits[a0 + m] != 0)) {      // (slab: home atoms and the atoms the rank reads; others untouched)
+          grad[3 * (a0 + m)] += acc[m][0]; grad[3 * (a0 + m) + 1] += acc[m][1]; grad[3 * (a0 + m) + 2] += acc[m][2];
+        }
     }
   }
   eself = block_reduce_sum<kAtomBlock>(eself);
@@ -579,14 +590,14 @@ void launch_jacobi_delta(hipStream_t st, int n_act, const int* act, const T* pol
 template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
                    const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
-                   const int* list, int nlist, const FieldFin<T>& ff) {
+                   const int* list, int nlist, const FieldFin<T>& ff, const int* slab_bits) {
   // molecular liquid at scale: one thread per frame group (below ~8k atoms the 4-lane pull form is faster: latency bound).
   // ADMP_FINISH_GROUPS_MIN overrides the threshold; read per call so that the parity tests can force either form.
   const char* gmin_env = getenv("ADMP_FINISH_GROUPS_MIN");
   const int gmin = gmin_env ? atoi(gmin_env) : 8192;
-  if (!list && top.ngroups > 0 && top.na > gmin) {
+  if ((!list || slab_bits) && top.ngroups > 0 && top.na > gmin) {
     k_finish_groups<T><<<nblk(top.ngroups), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
-                                                                 energies, ff);
+                                                                 energies, ff, list ? slab_bits : nullptr);
     return;
   }
   if (!list && top.inv_ptr)   // single GPU: pull formulation, no atomics
@@ -648,7 +659,7 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
   template void launch_jacobi_delta<T>(hipStream_t, int, const int*, const T*, const T*, T*, Site<T>*, Site<T>*,        \
                                        const unsigned long long*, double);                                            \
   template void launch_finish<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const Site<T>*, const T*,        \
-                                 const T*, int, T, T*, T*, T*, double*, const int*, int, const FieldFin<T>&);
+                                 const T*, int, T, T*, T*, T*, double*, const int*, int, const FieldFin<T>&, const int*);
 INST(float)
 INST(double)
 #undef INST

@@ -210,8 +210,7 @@ template <class T, int NCH>
 __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __restrict__ pos, const T* __restrict__ vals,
                                                             int stride, RecipGeom<T> g, const T* __restrict__ phi,
                                                             long mesh_stride, T* __restrict__ grad,
-                                                            const int* __restrict__ list, SelfCoefs self_coefs,
-                                                            double* energies) {
+                                                            const int* __restrict__ list) {
   __shared__ T wm[kSgAtoms][kSgRow], wd[kSgAtoms][kSgRow];        // M and M' of the 18 stencil indices of every atom
   __shared__ int sbase[kSgAtoms][4];
   __shared__ T part[3][kSgBlock];
@@ -297,7 +296,6 @@ __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __r
   __syncthreads();
   if (threadIdx.x >= 64) return;                         // one wave converts the 32 atoms
   const int slot = slot0 + (int)threadIdx.x;
-  double es = 0.0;
   if (threadIdx.x < kSgAtoms && slot < na) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -308,23 +306,41 @@ __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __r
     const T* A = g.Jac;                                  // scalar sites: dE/dr = c Jac . F1
 #pragma unroll
     for (int k = 0; k < 3; ++k) grad[3 * i + k] += A[3 * k + 0] * f[0] + A[3 * k + 1] * f[1] + A[3 * k + 2] * f[2];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) { const double q = (double)vals[(long)stride * i + ch]; es += self_coefs.c[ch] * q * q; }
   }
-  es = wave_reduce_sum(es);
+}
+// energies[E_SELF] += sum over the listed atoms and the channels of self_coefs[c] vals[i][c]^2 (admp/disp_pme.py:254-279).
+// Few, fat workgroups: thousands of workgroups adding doubles into ONE word serialise at the memory side (0.27 ms per launch
+// when this sum rode in the 32 768 workgroups of the gather at 1M atoms).
+template <class T>
+__global__ __launch_bounds__(256) void k_scalar_self(int na, int nch, const T* __restrict__ vals, int stride,
+                                                     const int* __restrict__ list, SelfCoefs self_coefs, double* energies) {
+  double es = 0.0;
+  for (int s = blockIdx.x * 256 + threadIdx.x; s < na; s += gridDim.x * 256) {
+    const int i = list ? list[s] : s;
+    for (int ch = 0; ch < nch; ++ch) { const double q = (double)vals[(long)stride * i + ch]; es += self_coefs.c[ch] * q * q; }
+  }
+  es = block_reduce_sum<256>(es);
   if (threadIdx.x == 0 && es != 0.0) atomicAdd(&energies[E_SELF], es);
 }
 
 template <class T>
 void launch_gather_scalar(hipStream_t st, int nch, int na, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
-                          const T* phi, long mesh_stride, T* grad, const int* list, const double* self_coefs, double* energies) {
+                          const T* phi, long mesh_stride, T* grad, const int* list) {
+  if (na <= 0) return;
+  const unsigned grid = xcd_grid((unsigned)((na + kSgAtoms - 1) / kSgAtoms));
+  if (nch == 3) k_gather_scalar<T, 3><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+  else if (nch == 2) k_gather_scalar<T, 2><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+  else k_gather_scalar<T, 1><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+}
+template <class T>
+void launch_scalar_self(hipStream_t st, int nch, int na, const T* vals, int stride, const int* list, const double* self_coefs,
+                        double* energies) {
   if (na <= 0) return;
   SelfCoefs sc;
   for (int b = 0; b < nch && b < 3; ++b) sc.c[b] = self_coefs[b];
-  const unsigned grid = xcd_grid((unsigned)((na + kSgAtoms - 1) / kSgAtoms));
-  if (nch == 3) k_gather_scalar<T, 3><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, sc, energies);
-  else if (nch == 2) k_gather_scalar<T, 2><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, sc, energies);
-  else k_gather_scalar<T, 1><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, sc, energies);
+  int blocks = (na + 4095) / 4096;
+  if (blocks > 256) blocks = 256;
+  k_scalar_self<T><<<blocks, 256, 0, st>>>(na, nch, vals, stride, list, sc, energies);
 }
 
 // out[i * stride + chan] += phi(r_i) + extra * vals[i * stride + chan]: the mesh potential at every atom (the stencil weights
@@ -369,7 +385,8 @@ void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, in
   template int launch_spread_scalar<T>(hipStream_t, int, const T*, const T*, int, const RecipGeom<T>&, const BinScratch&, \
                                        T*, long);                                                                        \
   template void launch_gather_scalar<T>(hipStream_t, int, int, const T*, const T*, int, const RecipGeom<T>&, const T*,    \
-                                        long, T*, const int*, const double*, double*);                                   \
+                                        long, T*, const int*);                                                           \
+  template void launch_scalar_self<T>(hipStream_t, int, int, const T*, int, const int*, const double*, double*);         \
   template void launch_gather_value<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, const T*,     \
                                        double, T*);
 INST(float)

@@ -174,6 +174,11 @@ struct EngineBase {
     const int rc = comm.shift(comm.ctx, send, recv, n, dtype, to_next, tag);
     if (rc != 0) comm_fail("shift", rc);
   }
+  // how the polarizable calls of this handle were enqueued and how the guesses behind it turned out (admp_scf_stats):
+  // [0] plain calls, [1] speculative calls, [2] ... whose first check failed (closing pass wasted), [3] chained calls,
+  // [4] ... that needed more steps than enqueued (closing pass wasted), [5] ... that enqueued more steps than needed,
+  // [6] increments that ran for nothing in those, [7] Jacobi steps in total
+  int64_t scf_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
   int keep_pol_sites = 0;       // ADMP_OPT_KEEP_POL_SITES: the caller vouches that the set {i : pol_i > 0} has not changed
   long nbr_gen = 0;             // bumped whenever the neighbour table is rebuilt
@@ -451,14 +456,20 @@ struct EngineBase {
 
 // decomposition state of one evaluation on a slab rank (snranks > 1; slab_kernels.hip)
 struct SlabState {
-  DevBuf owner, bits, counts, totals, lists, imp, exp, sendb, recvb, ghost, pack, tbuf;
+  DevBuf owner, owner_prev, mig, bits, counts, totals, lists, imp, exp, mig_in, mig_out, sendb, recvb, ghost, pack, tbuf;
+  int prev_na = -1;             // owner_prev holds the owners of this handle's previous decomposed evaluation of prev_na atoms
+  int64_t min_cnt[kSlabMaxRanks], mout_cnt[kSlabMaxRanks];   // atoms taken over from / given away to every rank since then
+  int n_min = 0, n_mout = 0;
   int64_t tr_send[kSlabMaxRanks], tr_recv[kSlabMaxRanks];
   int64_t imp_cnt[kSlabMaxRanks], exp_cnt[kSlabMaxRanks];     // atoms imported from / exported to every rank
   int n_home = 0, n_act = 0, n_imp = 0, n_exp = 0;
   const int* home = nullptr;    // home atoms, ascending
   const int* rows = nullptr;    // home rows in the pair kernels' order (the table's class-grouped order, filtered)
   const int* act = nullptr;     // polarizable home atoms, ascending
-  void release() { for (DevBuf* b : {&owner, &bits, &counts, &totals, &lists, &imp, &exp, &sendb, &recvb, &ghost, &pack, &tbuf}) b->release(); }
+  void release() {
+    for (DevBuf* b : {&owner, &owner_prev, &mig, &bits, &counts, &totals, &lists, &imp, &exp, &mig_in, &mig_out, &sendb, &recvb,
+                      &ghost, &pack, &tbuf}) b->release();
+  }
 };
 
 template <class T>
@@ -588,28 +599,38 @@ struct Engine : EngineBase {
   static constexpr int real_dtype() { return sizeof(T) == 4 ? ADMP_T_F32 : ADMP_T_F64; }
   // Who owns what in this evaluation, derived by every rank from the replicated inputs (no communication): home atoms, home
   // rows in pair-kernel order, polarizable home atoms, imports per owner, exports per reader.  One host read (the counts).
-  void decompose() { decompose(K[0], X0, X1, nbr.order); }
+  void decompose() { decompose(K[0], X0, X1, nbr.order, lpol != 0); }
   // K0v / X0v / X1v: the planes the ownership rule works on (the PME mesh's; a handle without a mesh takes a virtual one);
-  // order: the row order of the table to filter (nullptr: natural order)
-  void decompose(int K0v, int X0v, int X1v, const int* order) {
+  // order: the row order of the table to filter (nullptr: natural order); with_dipoles: the evaluation carries induced
+  // dipoles from call to call (atoms that change hands take theirs along)
+  void decompose(int K0v, int X0v, int X1v, const int* order, bool with_dipoles = false) {
     const int na = top.na, N = snranks, me = srank;
     ARG_CHECK(N <= kSlabMaxRanks, "at most 28 slab ranks");
     sl.owner.need(sizeof(int) * (size_t)na);
     sl.bits.need(sizeof(int) * (size_t)na);
+    // Atoms that changed hands since the previous evaluation (the home rule follows the positions): their dipoles are valid on
+    // the PREVIOUS owner only when the caller keeps home rows (outputs of a decomposed call), so they travel with the atom.
+    const bool track = with_dipoles && sl.prev_na == na && sl.owner_prev.p;
+    sl.owner_prev.need(sizeof(int) * (size_t)na);
+    if (track) sl.mig.need(sizeof(int) * (size_t)na);
     SlabCols cs;
-    auto col = [&](const int* seq, int len, int mask, int want) {
-      cs.seq[cs.ncols] = seq; cs.len[cs.ncols] = len; cs.mask[cs.ncols] = mask; cs.want[cs.ncols] = want;
+    auto col = [&](const int* seq, int len, int mask, int want, const int* src = nullptr) {
+      cs.seq[cs.ncols] = seq; cs.len[cs.ncols] = len; cs.mask[cs.ncols] = mask; cs.want[cs.ncols] = want; cs.src[cs.ncols] = src;
       return cs.ncols++;
     };
     const int c_home = col(nullptr, na, kSlabHome, kSlabHome);
     const int c_rows = col(order, na, kSlabHome, kSlabHome);
     const int c_act = col(nullptr, na, kSlabHome | kSlabPolar, kSlabHome | kSlabPolar);
-    int c_imp[kSlabMaxRanks], c_exp[kSlabMaxRanks];
+    int c_imp[kSlabMaxRanks], c_exp[kSlabMaxRanks], c_min[kSlabMaxRanks], c_mout[kSlabMaxRanks];
     for (int t = 0; t < N; ++t) {
-      c_imp[t] = c_exp[t] = -1;
+      c_imp[t] = c_exp[t] = c_min[t] = c_mout[t] = -1;
       if (t == me) continue;
       c_imp[t] = col(nullptr, na, kSlabHome | (1 << t), 1 << t);
       c_exp[t] = col(nullptr, na, kSlabHome | (1 << t), kSlabHome | (1 << t));
+      if (track) {
+        c_min[t] = col(nullptr, na, kSlabHome | (1 << t), 1 << t, sl.mig.as<int>());
+        c_mout[t] = col(nullptr, na, kSlabHome | (1 << t), kSlabHome | (1 << t), sl.mig.as<int>());
+      }
     }
     sl.counts.need(sizeof(int) * (size_t)cs.ncols * (size_t)std::max(1, slab_compact_blocks(na)));
     sl.totals.need(sizeof(int) * kSlabMaxCols);
@@ -618,7 +639,7 @@ struct Engine : EngineBase {
       TIMED("slab_decompose");
       int rc = launch_slab_decompose(stream, na, nbr, top, ev.bases, ev.pol, (int)sizeof(T), X1v - X0v, K0v, X0v, N, me,
                                      sl.owner.as<int>(), sl.bits.as<int>(), cs, sl.counts.as<int>(), sl.totals.as<int>(),
-                                     sl.lists.as<int>());
+                                     sl.lists.as<int>(), track ? sl.owner_prev.as<int>() : nullptr, track ? sl.mig.as<int>() : nullptr);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("slab decomposition: ") + hipGetErrorString((hipError_t)rc)};
     }
     int tot[kSlabMaxCols];
@@ -643,10 +664,39 @@ struct Engine : EngineBase {
     sl.exp.need(sizeof(int) * (size_t)std::max(1, sl.n_exp));
     launch_slab_concat(stream, si, L, (long)na, sl.imp.as<int>());
     launch_slab_concat(stream, se, L, (long)na, sl.exp.as<int>());
-    const size_t w = 9 * sizeof(T) * (size_t)std::max(1, std::max(sl.n_imp, sl.n_exp));
+    sl.n_min = sl.n_mout = 0;
+    if (track) {
+      SlabSegs mi, mo;
+      mi.off[0] = mo.off[0] = 0;
+      for (int t = 0; t < N; ++t) {
+        sl.min_cnt[t] = t == me ? 0 : tot[c_min[t]];
+        sl.mout_cnt[t] = t == me ? 0 : tot[c_mout[t]];
+        if (t == me) continue;
+        mi.col[mi.n] = c_min[t]; mi.off[mi.n + 1] = mi.off[mi.n] + tot[c_min[t]]; ++mi.n;
+        mo.col[mo.n] = c_mout[t]; mo.off[mo.n + 1] = mo.off[mo.n] + tot[c_mout[t]]; ++mo.n;
+      }
+      sl.n_min = mi.off[mi.n]; sl.n_mout = mo.off[mo.n];
+      sl.mig_in.need(sizeof(int) * (size_t)std::max(1, sl.n_min));
+      sl.mig_out.need(sizeof(int) * (size_t)std::max(1, sl.n_mout));
+      launch_slab_concat(stream, mi, L, (long)na, sl.mig_in.as<int>());
+      launch_slab_concat(stream, mo, L, (long)na, sl.mig_out.as<int>());
+    }
+    // the owners of this evaluation are the "previous owners" of the next one
+    HIP_TRY(hipMemcpyAsync(sl.owner_prev.p, sl.owner.p, sizeof(int) * (size_t)na, hipMemcpyDeviceToDevice, stream));
+    sl.prev_na = with_dipoles ? na : -1;
+    const size_t w = 9 * sizeof(T) * (size_t)std::max(1, std::max(std::max(sl.n_imp, sl.n_exp), std::max(sl.n_min, sl.n_mout)));
     sl.sendb.need(w); sl.recvb.need(w);
     ev.n_home = sl.n_home;
     ev.home = sl.home;
+  }
+  // the dipoles of the atoms that changed hands: previous owner -> new owner
+  void exchange_migrants() {
+    TIMED("comm_halo_dipoles");                            // (every rank takes part: the caller's condition is rank-uniform)
+    int64_t sc[kSlabMaxRanks], rc[kSlabMaxRanks];
+    for (int t = 0; t < snranks; ++t) { sc[t] = 3 * sl.mout_cnt[t]; rc[t] = 3 * sl.min_cnt[t]; }
+    launch_halo_u_pack<T>(stream, sl.n_mout, 0, sl.mig_out.as<int>(), ev.U, sites.as<Site<T>>(), sl.sendb.as<T>());
+    c_all_to_all_v(sl.sendb.p, sc, sl.recvb.p, rc, real_dtype(), ADMP_TAG_HALO_DIPOLES);
+    launch_halo_u_unpack<T>(stream, sl.n_min, 0, sl.mig_in.as<int>(), sl.recvb.as<T>(), ev.U, sites.as<Site<T>>());
   }
   // rows of width w of the halo atoms: owners -> readers (to_readers: exports out, imports in) or back (gradient contributions)
   void halo_counts(int w, bool to_readers, int64_t* sc, int64_t* rc) const {
@@ -701,8 +751,9 @@ struct Engine : EngineBase {
     static const bool fx_off = [] { const char* e = getenv("ADMP_FUSED_X"); return e && atoi(e) == 0; }();
     const bool want_fx = snranks == 1 && !fx_off && fftx_usable(K[0]);
     const size_t per_line = 128 / (2 * sizeof(T));
-    const int khp = want_fx ? (int)((K2h + per_line - 1) / per_line * per_line) : (int)K2h;
-    if (want_fx && (size_t)K[0] * K[1] * khp > nspec) nspec = (size_t)K[0] * K[1] * khp;
+    // (a slab rank pads the rows of its batched 2-D transforms the same way; the transposes carry the unpadded rows)
+    const int khp = (want_fx || snranks > 1) ? (int)((K2h + per_line - 1) / per_line * per_line) : (int)K2h;
+    if ((size_t)nxown() * K[1] * khp > nspec) nspec = (size_t)nxown() * K[1] * khp;
     mesh.need(nreal * sizeof(T));
     spec.need(nspec * 2 * sizeof(T));
     binv_d.need(9 * sizeof(double));
@@ -747,8 +798,21 @@ struct Engine : EngineBase {
       // distributed transform = batched 2-D r2c over the owned planes, all-to-all transpose (done by the caller over
       // RCCL), batched strided 1-D c2c along x
       const size_t len2[2] = {(size_t)K[2], (size_t)K[1]};
-      FFT_TRY(rocfft_plan_create(&plan_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 2, len2, (size_t)nxown(), nullptr));
-      FFT_TRY(rocfft_plan_create(&plan_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 2, len2, (size_t)nxown(), nullptr));
+      {
+        const size_t rs[2] = {1, (size_t)K[2]}, cs[2] = {1, (size_t)khp};
+        const size_t rdist = (size_t)K[1] * K[2], cdist = (size_t)K[1] * khp;
+        rocfft_plan_description df = nullptr, db = nullptr;
+        FFT_TRY(rocfft_plan_description_create(&df));
+        FFT_TRY(rocfft_plan_description_set_data_layout(df, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr,
+                                                        nullptr, 2, rs, rdist, 2, cs, cdist));
+        FFT_TRY(rocfft_plan_description_create(&db));
+        FFT_TRY(rocfft_plan_description_set_data_layout(db, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr,
+                                                        nullptr, 2, cs, cdist, 2, rs, rdist));
+        FFT_TRY(rocfft_plan_create(&plan_f, rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 2, len2, (size_t)nxown(), df));
+        FFT_TRY(rocfft_plan_create(&plan_b, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 2, len2, (size_t)nxown(), db));
+        rocfft_plan_description_destroy(df);
+        rocfft_plan_description_destroy(db);
+      }
       const size_t len1[1] = {(size_t)K[0]};
       const size_t stride[1] = {(size_t)nyown() * K2h};
       const size_t batch = (size_t)nyown() * K2h;
@@ -871,7 +935,7 @@ struct Engine : EngineBase {
       { TIMED("comm_ghost"); c_shift(mesh_p + (size_t)nx * plane, sl.ghost.p, (int64_t)(kGhost * plane), real_dtype(), 1, ADMP_TAG_GHOST); }
       { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)(kGhost * plane), mesh_p, sl.ghost.as<T>()); }
       fft_forward(mesh_p, spec_p);
-      { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, snranks, 0, spec_p, sl.pack.as<T>()); }
+      { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, fx_khp, snranks, 0, spec_p, sl.pack.as<T>()); }
       { TIMED("comm_transpose"); c_all_to_all_v(sl.pack.p, sl.tr_send, sl.tbuf.p, sl.tr_recv, real_dtype(), ADMP_TAG_TRANSPOSE); }
       if (use_fx) {
         TIMED("fftx_kspace");
@@ -882,7 +946,7 @@ struct Engine : EngineBase {
         fft_x(sl.tbuf.as<T>(), 1);
       }
       { TIMED("comm_transpose"); c_all_to_all_v(sl.tbuf.p, sl.tr_recv, sl.pack.p, sl.tr_send, real_dtype(), ADMP_TAG_TRANSPOSE); }
-      { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, snranks, 1, spec_p, sl.pack.as<T>()); }
+      { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, fx_khp, snranks, 1, spec_p, sl.pack.as<T>()); }
       fft_inverse(spec_p, mesh_p);
       { TIMED("comm_ghost"); c_shift(mesh_p, mesh_p + (size_t)nx * plane, (int64_t)(kGhost * plane), real_dtype(), 0, ADMP_TAG_GHOST); }
       (void)accum;
@@ -1111,7 +1175,9 @@ struct Engine : EngineBase {
     }
     other_clean = true;
     if (snranks > 1) {
+      const bool tracked = lpol && sl.prev_na == na;       // (decompose() then lists the atoms that changed hands)
       decompose();
+      if (tracked) exchange_migrants();
       if (lpol) exchange_U(0);
     } else {
       ev.n_home = na;
@@ -1186,7 +1252,7 @@ struct Engine : EngineBase {
     }
     { TIMED("finish");
       launch_finish<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), ev.pol, ev.U, lpol, (T)kappa, pot.as<T>(), grad_p,
-                       dQl, Ed_cur(), ev.home, ev.n_home, ff); }
+                       dQl, Ed_cur(), ev.home, ev.n_home, ff, snranks > 1 ? sl.bits.as<int>() : nullptr); }
     if (snranks > 1 && grad_p) exchange_grad(grad_p);
   }
   // ---- incremental SCF ------------------------------------------------------------------------------------------
@@ -1440,6 +1506,7 @@ struct Engine : EngineBase {
       static const bool scf_trace = getenv("ADMP_SCF_TRACE") != nullptr;     // one line per call: which form ran
       if (scf_trace) fprintf(stderr, "[admp scf] %s (predicted residual %.4g, threshold %.4g, %d steps)\n",
                              chain ? "chained" : (speculate ? "speculative" : "plain"), pred, thresh, chain ? nhat : 0);
+      ++scf_stats[chain ? 3 : (speculate ? 1 : 0)];
       if (chain) {
         n_act = nact_known();
         first_pair_field();
@@ -1471,7 +1538,9 @@ struct Engine : EngineBase {
           f_final = hit == 0 ? Eh[E_FMAX] : Eh[E_FMAX1 + hit - 1];
           phi_valid = done = finished = true;
           ev.active = false;
-        } else {   // more cycles are needed: undo the energy sums of the closing pass, go on like the plain loop
+          if (hit < nhat) { ++scf_stats[5]; scf_stats[6] += nhat - hit; }
+        } else {
+          ++scf_stats[4];   // more cycles are needed: undo the energy sums of the closing pass, go on like the plain loop
           HIP_TRY(hipMemsetAsync(Ed_cur() + E_SELF, 0, 2 * sizeof(double), stream));
           HIP_TRY(hipMemsetAsync(Ed_cur() + E_SLOTS, 0, E_PARTS * sizeof(double), stream));
           f_final = Eh[E_FMAX1 + nhat - 1];
@@ -1504,6 +1573,7 @@ struct Engine : EngineBase {
           phi_valid = done = finished = true;
           ev.active = false;
         } else {   // undo the speculative energy sums; gradient / dQ are rewritten by the regular closing pass
+          ++scf_stats[2];
           HIP_TRY(hipMemsetAsync(Ed_cur() + E_SELF, 0, 2 * sizeof(double), stream));
           scf_jacobi(n_act);
           i = 1;
@@ -1529,6 +1599,7 @@ struct Engine : EngineBase {
       }
       if (i == max_cycle) i = max_cycle - 1;   // python's loop variable after exhaustion
       cyc = i;
+      scf_stats[7] += cyc;
       flag = (i != max_cycle - 1);             // admp/pme.py:139-143
       warm_regime = (cyc == 0);
       if (f_first >= 0.0) {
@@ -1897,8 +1968,9 @@ struct Engine : EngineBase {
         ensure_gtab(box, inv, vol, 6 + 2 * c);
         convolve(mesh.as<T>() + c * nreal, spec.as<T>(), gtab_cur, E_RECIP);
         TIMED("gather_field");
-        launch_gather_scalar<T>(stream, 1, sr.n, pos, cl + c, 3, g, mesh.as<T>() + c * nreal, (long)nreal, dpos, sr.home, kp + c, Ed);
+        launch_gather_scalar<T>(stream, 1, sr.n, pos, cl + c, 3, g, mesh.as<T>() + c * nreal, (long)nreal, dpos, sr.home);
       }
+      launch_scalar_self<T>(stream, nch, sr.n, cl, 3, sr.home, kp, Ed);
       read_scalar_energies(Ed, E, 3);
       if (dpos_ && !on_device) {
         HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
@@ -2426,6 +2498,12 @@ int admp_set_comm(admp_handle* h, const admp_comm* comm) {
     ARG_CHECK(comm->all_reduce && comm->all_to_all_v && comm->shift, "communicator with a missing callback");
     e.comm = *comm;
     e.have_comm = true;
+  });
+}
+int admp_scf_stats(admp_handle* h, int64_t* out8, int reset) {
+  return guarded(h, [&](EngineBase& e) {
+    ARG_CHECK(out8, "null");
+    for (int k = 0; k < 8; ++k) { out8[k] = e.scf_stats[k]; if (reset) e.scf_stats[k] = 0; }
   });
 }
 int admp_slab_home(admp_handle* h, int32_t* home_out, int* n_home, int* n_import) {

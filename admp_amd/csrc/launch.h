@@ -132,7 +132,9 @@ template <class T>
 void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
                    const T* pol, const T* Ucart, int lpol, T kappa, T* pot, T* grad, T* dQlocal, double* energies,
                    const int* list, int nlist,
-                   const FieldFin<T>& ff = FieldFin<T>());
+                   const FieldFin<T>& ff = FieldFin<T>(),
+                   const int* slab_bits = nullptr /* slab rank: per-atom words, kSlabHome marks the rank's own atoms (with a
+                                                     home list); the frame-group kernel then serves the groups of home atoms */);
 // dispersion: site rows carrying one scalar channel (Q[0] = vals[i*stride+chan], no dipoles/quadrupoles); also
 // accumulates coef * sum_i vals^2 into energies[E_SELF] (the self term of admp/disp_pme.py:254-279)
 template <class T>
@@ -379,10 +381,14 @@ void launch_atom_bases(hipStream_t st, int na, const T* pos, const RecipGeom<T>&
 template <class T>
 int launch_spread_scalar(hipStream_t st, int nch, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
                          const BinScratch& bs, T* mesh, long mesh_stride);
-// grad[i] += sum_c vals[i][c] Jac . grad phi_c(r_i) for the n listed atoms; energies[E_SELF] += sum_c self_coefs[c] vals[i][c]^2
+// grad[i] += sum_c vals[i][c] Jac . grad phi_c(r_i) for the n listed atoms
 template <class T>
 void launch_gather_scalar(hipStream_t st, int nch, int na, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
-                          const T* phi, long mesh_stride, T* grad, const int* list, const double* self_coefs, double* energies);
+                          const T* phi, long mesh_stride, T* grad, const int* list);
+// energies[E_SELF] += sum over the n listed atoms and the nch channels of self_coefs[c] vals[i][c]^2
+template <class T>
+void launch_scalar_self(hipStream_t st, int nch, int na, const T* vals, int stride, const int* list, const double* self_coefs,
+                        double* energies);
 // out[i * stride + chan] += phi(r_i) + extra * vals[i * stride + chan]  (mesh potential at the atoms: dE_recip/dc_i)
 template <class T>
 void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, const RecipGeom<T>& g,
@@ -417,13 +423,14 @@ int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Bo
 // ---- slab_kernels.hip: x-slab decomposition (multi-GPU) ------------------------------------------------------------------
 // per-atom word of a rank's view of the decomposition (see slab_kernels.hip)
 constexpr int kSlabHome = 1 << 30, kSlabPolar = 1 << 29;
-constexpr int kSlabMaxRanks = 28, kSlabMaxCols = 3 + 2 * kSlabMaxRanks;
+constexpr int kSlabMaxRanks = 28, kSlabMaxCols = 3 + 4 * kSlabMaxRanks;
 // columns of the ordered compaction: column c keeps x = seq[c][p] (seq[c] == nullptr: x = p), p < len[c], where
 // (bits[x] & mask[c]) == want[c]
 struct SlabCols {
   int ncols = 0;
   int len[kSlabMaxCols];
   const int* seq[kSlabMaxCols];
+  const int* src[kSlabMaxCols];    // the flag words this column tests (nullptr: the `bits` array of the decomposition)
   int mask[kSlabMaxCols];
   int want[kSlabMaxCols];
 };
@@ -435,9 +442,12 @@ struct SlabSegs {
 };
 // owner[na] / bits[na] of this evaluation and the compacted columns lists[c * na ..]; totals[ncols] stay on the device
 // (the caller reads them once).  counts: ncols * slab_compact_blocks(max len) ints of scratch.  hipError_t as int.
+// owner_prev (optional): the owners of the previous evaluation; mig[na] then receives, for the atoms that changed hands,
+// 1 << previous owner (atoms this rank took over) or kSlabHome | 1 << new owner (atoms it gave away), else 0
 int launch_slab_decompose(hipStream_t st, int na, const NbrTable& nb, const Topology& top, const int4* bases, const void* pol,
                           int prec, int width, int K0, int X0, int nranks, int me, int* owner, int* bits,
-                          const SlabCols& cs, int* counts, int* totals, int* lists);
+                          const SlabCols& cs, int* counts, int* totals, int* lists, const int* owner_prev = nullptr,
+                          int* mig = nullptr);
 int slab_compact_blocks(int maxlen);
 void launch_slab_concat(hipStream_t st, const SlabSegs& segs, const int* lists, long col_stride, int* out);
 template <class T>
@@ -450,9 +460,9 @@ template <class T>
 void launch_halo_u_pack(hipStream_t st, int n, int what, const int* idx, const T* Ucart, const Site<T>* sites, T* out);
 template <class T>
 void launch_halo_u_unpack(hipStream_t st, int n, int what, const int* idx, const T* in, T* Ucart, Site<T>* sites);
-// spec[nx][K1][nh] complex <-> all-to-all buffer (block of peer t: [nx][ny_t][nh]); dir 0 pack, 1 unpack
+// spec[nx][K1][pitch] complex (nh used per row) <-> all-to-all buffer (block of peer t: [nx][ny_t][nh]); dir 0 pack, 1 unpack
 template <class T>
-void launch_transpose_pack(hipStream_t st, int nx, int K1, int nh, int nranks, int dir, T* spec, T* buf);
+void launch_transpose_pack(hipStream_t st, int nx, int K1, int nh, int pitch, int nranks, int dir, T* spec, T* buf);
 // out[4] = (real, recip, self, penalty) of the energy block e; recip_slot >= 0: that word, -1: the sum of the E_PARTS words
 void launch_energy_pack(hipStream_t st, const double* e, int recip_slot, double* out);
 

@@ -44,6 +44,15 @@ __global__ __launch_bounds__(256) void k_slab_owner(int na, const int4* __restri
   bits[i] = w;
 }
 
+// atoms that changed hands since the previous evaluation (see launch_slab_decompose)
+__global__ __launch_bounds__(256) void k_slab_migrants(int na, const int* __restrict__ owner, const int* __restrict__ prev, int me,
+                                                       int* __restrict__ mig) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= na) return;
+  const int o = owner[i], q = prev[i];
+  mig[i] = (o == me && q != me) ? (1 << q) : ((q == me && o != me) ? (kSlabHome | (1 << o)) : 0);
+}
+
 // import marks on the atoms other ranks own, export masks on the rank's own atoms; 8 lanes per row, every atom's row is
 // visited (rows of other ranks leave at once)
 __global__ __launch_bounds__(256) void k_slab_marks(int na, const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -88,7 +97,8 @@ constexpr int kCompactPer = 4, kCompactBlock = 256, kCompactSpan = kCompactPer *
 __device__ __forceinline__ bool compact_pred(const SlabCols& cs, int c, const int* __restrict__ bits, int p, int& x) {
   if (p >= cs.len[c]) return false;
   x = cs.seq[c] ? cs.seq[c][p] : p;
-  return (bits[x] & cs.mask[c]) == cs.want[c];
+  const int* __restrict__ w = cs.src[c] ? cs.src[c] : bits;
+  return (w[x] & cs.mask[c]) == cs.want[c];
 }
 
 __global__ __launch_bounds__(kCompactBlock) void k_compact_count(SlabCols cs, const int* __restrict__ bits, int nblocks,
@@ -172,11 +182,12 @@ __global__ __launch_bounds__(kCompactBlock) void k_compact_write(SlabCols cs, co
 
 int launch_slab_decompose(hipStream_t st, int na, const NbrTable& nb, const Topology& top, const int4* bases, const void* pol,
                           int prec, int width, int K0, int X0, int nranks, int me, int* owner, int* bits,
-                          const SlabCols& cs, int* counts, int* totals, int* lists) {
+                          const SlabCols& cs, int* counts, int* totals, int* lists, const int* owner_prev, int* mig) {
   if (na <= 0) return 0;
   const unsigned g1 = (unsigned)((na + 255) / 256);
   if (prec == 4) k_slab_owner<float><<<g1, 256, 0, st>>>(na, bases, (const float*)pol, width, K0, X0, nranks, me, owner, bits);
   else k_slab_owner<double><<<g1, 256, 0, st>>>(na, bases, (const double*)pol, width, K0, X0, nranks, me, owner, bits);
+  if (owner_prev && mig) k_slab_migrants<<<g1, 256, 0, st>>>(na, owner, owner_prev, me, mig);
   k_slab_marks<<<(unsigned)(((long)na * 8 + 255) / 256), 256, 0, st>>>(na, nb.rowptr, nb.col, top, owner, me, bits);
   int maxlen = 0;
   for (int c = 0; c < cs.ncols; ++c) maxlen = cs.len[c] > maxlen ? cs.len[c] : maxlen;
@@ -282,11 +293,11 @@ void launch_halo_u_unpack(hipStream_t st, int n, int what, const int* idx, const
 }
 
 // ---- transposes of the distributed transform ---------------------------------------------------------------------------------
-// x-slab layout spec[nx][K1][nh] (row pitch nh complex numbers) <-> send / receive buffer: the block for peer t holds
-// [nx][ny_t][nh] with ny_t = the y rows of rank t; one complex number per thread, z fastest (coalesced both sides).
+// x-slab layout spec[nx][K1][pitch >= nh] (rows padded to whole cache lines) <-> send / receive buffer: the block for peer t
+// holds [nx][ny_t][nh] with ny_t = the y rows of rank t; one complex number per thread, z fastest (coalesced both sides).
 // dir 0: spec -> buf (pack), dir 1: buf -> spec (unpack)
 template <class T>
-__global__ __launch_bounds__(256) void k_transpose_pack(int nx, int K1, int nh, int N, int dir, Cx<T>* __restrict__ spec,
+__global__ __launch_bounds__(256) void k_transpose_pack(int nx, int K1, int nh, int pitch, int N, int dir, Cx<T>* __restrict__ spec,
                                                         Cx<T>* __restrict__ buf) {
   const long n = (long)nx * K1 * nh;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
@@ -298,17 +309,18 @@ __global__ __launch_bounds__(256) void k_transpose_pack(int nx, int K1, int nh, 
     while ((int)(((long)(p + 1) * K1) / N) <= y) ++p;
     const int y0 = (int)(((long)p * K1) / N), ny = (int)(((long)(p + 1) * K1) / N) - y0;
     const long o = (long)nx * y0 * nh + ((long)x * ny + (y - y0)) * nh + z;   // blocks of lower peers hold nx * y0 rows
-    if (dir == 0) buf[o] = spec[t];
-    else spec[t] = buf[o];
+    const long si = r * pitch + z;
+    if (dir == 0) buf[o] = spec[si];
+    else spec[si] = buf[o];
   }
 }
 template <class T>
-void launch_transpose_pack(hipStream_t st, int nx, int K1, int nh, int nranks, int dir, T* spec, T* buf) {
+void launch_transpose_pack(hipStream_t st, int nx, int K1, int nh, int pitch, int nranks, int dir, T* spec, T* buf) {
   const long n = (long)nx * K1 * nh;
   if (n <= 0) return;
   long blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  k_transpose_pack<T><<<(unsigned)blocks, 256, 0, st>>>(nx, K1, nh, nranks, dir, reinterpret_cast<Cx<T>*>(spec),
+  k_transpose_pack<T><<<(unsigned)blocks, 256, 0, st>>>(nx, K1, nh, pitch, nranks, dir, reinterpret_cast<Cx<T>*>(spec),
                                                         reinterpret_cast<Cx<T>*>(buf));
 }
 
@@ -329,7 +341,7 @@ void launch_energy_pack(hipStream_t st, const double* e, int recip_slot, double*
   template void launch_rows_scatter<T>(hipStream_t, int, int, int, const int*, const T*, T*);                           \
   template void launch_halo_u_pack<T>(hipStream_t, int, int, const int*, const T*, const Site<T>*, T*);                 \
   template void launch_halo_u_unpack<T>(hipStream_t, int, int, const int*, const T*, T*, Site<T>*);                     \
-  template void launch_transpose_pack<T>(hipStream_t, int, int, int, int, int, T*, T*);
+  template void launch_transpose_pack<T>(hipStream_t, int, int, int, int, int, int, T*, T*);
 INST(float)
 INST(double)
 #undef INST

@@ -407,6 +407,14 @@ class ADMPPmeForce(HipForceBase):
         the values of mScales nor the induced dipoles enter."""
         return self._mscale_gradient(0, positions, box, pairs, self._pad_Q(Q_local), 9, len(self._host64(mScales)))
 
+    def scf_stats(self, reset=False):
+        """How the polarizable calls were enqueued and what wrong guesses cost (admp_scf_stats): dict of counters."""
+        out = (ctypes.c_int64 * 8)()
+        _lib.check(self._h, self._L.admp_scf_stats(self._h, out, 1 if reset else 0), 'admp_scf_stats')
+        keys = ('plain', 'speculative', 'speculative_failed', 'chained', 'chained_too_short', 'chained_too_long',
+                'wasted_increments', 'jacobi_steps')
+        return dict(zip(keys, (int(v) for v in out)))
+
     def optimize_Uind(self, positions, box, pairs, Q_local, pol, tholes, mScales, pScales, dScales, U_init=None,
                       maxiter=None, thresh=None):
         """Jacobi SCF of the induced dipoles; returns (U, converged, i) like admp/pme.py:111-143."""

@@ -258,6 +258,13 @@ int admp_slab_info(admp_handle* h, int64_t* out11);
  * number of atoms the rank read without owning them. */
 int admp_slab_home(admp_handle* h, int32_t* home_out, int* n_home, int* n_import);
 
+/* How the polarizable evaluations of this handle were enqueued (the residual history of the previous calls decides between
+ * the plain loop, a speculative first cycle and a chain of device-gated Jacobi steps: engine.hip pme()) and what the guesses
+ * cost.  out8 = {plain calls, speculative calls, speculative calls whose first check failed, chained calls, chained calls
+ * that needed more steps than enqueued, chained calls that enqueued more than needed, field increments that ran for nothing
+ * in those, Jacobi steps in total}; reset != 0 clears the counters.  The results never depend on the form. */
+int admp_scf_stats(admp_handle* h, int64_t* out8, int reset);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream. */
 int admp_profile_enable(admp_handle* h, int on);
