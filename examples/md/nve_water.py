@@ -136,6 +136,8 @@ def main():
     ns_day = opt.steps * h * 1e-6 / wall * 86400.0
     if opt.pol:
         print('# mean SCF cycles per evaluation (thresh %g): %.1f' % (settings.POL_CONV, state['cyc'] / state['n']))
+        # which form the library chose for every polarizable call (residual history, engine.hip pme()) and what wrong guesses cost
+        print('# SCF forms over the run (real dynamics): %s' % pme.scf_stats())
     print('# %d waters, %s, %s, dt %.2f fs: %.3f ms/step, %.2f ns/day (all terms, list rebuilt every %d steps); '
           'relative energy drift %.2e, T_final %.1f K' % (n_mol, 'polarizable' if opt.pol else 'fixed multipoles',
                                                          settings.PRECISION, h, wall / opt.steps * 1e3, ns_day, opt.rebuild,
