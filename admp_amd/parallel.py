@@ -167,21 +167,39 @@ class ThreadComm(_CommBase):
     through a shared mailbox guarded by a barrier.  Test infrastructure for the decomposition logic."""
 
     class World:
-        def __init__(self, size):
+        def __init__(self, size, serialize=False):
+            """serialize: only one rank at a time runs its compute segments (a token handed over at the collectives), so
+            that kernels of different ranks never interleave on the one GPU -- per-kernel event timings then mean what
+            they would on a GPU of the rank's own (tools/slab_rehearsal.py).  Every rank thread brackets its work with
+            comm.begin() / comm.end()."""
             self.size = size
             self.barrier = threading.Barrier(size)
             self.box = [None] * size
+            self.token = threading.Lock() if serialize else None
 
     def __init__(self, world, rank):
         self.w, self.rank, self.size = world, rank, world.size
         self._init_stats()
 
+    def begin(self):
+        if self.w.token is not None:
+            self.w.token.acquire()
+
+    def end(self):
+        if self.w.token is not None:
+            torch.cuda.current_stream().synchronize()
+            self.w.token.release()
+
     def _exchange(self, item):
         torch.cuda.current_stream().synchronize()
         self.w.box[self.rank] = item
+        if self.w.token is not None:
+            self.w.token.release()
         self.w.barrier.wait()
         got = list(self.w.box)
         self.w.barrier.wait()
+        if self.w.token is not None:
+            self.w.token.acquire()
         return got
 
     def all_reduce(self, t, op='sum', label='all_reduce'):

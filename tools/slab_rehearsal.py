@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Slab-decomposed step rehearsed on ONE GPU with N in-process ranks (threads + ThreadComm): what every rank's kernels cost.
-The ranks take turns on the one device, so every kernel is timed alone (HIP events on the shared stream) -- unlike the
-2-process gloo rehearsal of bench.py, where the processes time-slice the GPU and event brackets include the other rank's
-work.  Collectives go through a host mailbox: their times mean nothing here.
+The ranks take turns on the one device (ThreadComm.World(serialize=True): a token handed over at the collectives), so every
+kernel is timed alone -- unlike the 2-process gloo rehearsal of bench.py, where the processes time-slice the GPU and event
+brackets include the other rank's work.  Collectives go through a host mailbox: their times mean nothing here.
 
     python tools/slab_rehearsal.py [S2|S3] [nranks] [steps]
 prints one JSON line: single-GPU step, per-rank sums of kernel ms per step, home / import atom counts."""
@@ -27,7 +27,7 @@ f0, a0 = bench.make_force(w)
 dt0, _, cyc0 = bench.run_timed(f0, a0, steps, 3, frames, only=False)
 kb0 = bench.kernel_breakdown(f0, a0, frames, 3 + steps, steps)
 single_ms = dt0 / steps * 1e3
-world = ThreadComm.World(nranks)
+world = ThreadComm.World(nranks, serialize=True)
 out, errors = [None] * nranks, []
 
 
@@ -35,6 +35,7 @@ def work(rank):
     try:
         torch.cuda.set_device(0)
         comm = ThreadComm(world, rank)
+        comm.begin()
         f = SlabPme(comm, w['box'], w['at'], w['ai'], w['cov'], bench.RC, 1e-4, 2, lpol=True, outputs='home')
         if w['K'] is not None:
             for k in ('K1', 'K2', 'K3'):
@@ -59,10 +60,12 @@ def work(rank):
                          kernel_ms_per_step={k: v for k, v in ker.items() if not k.startswith('comm_')},
                          kernel_ms_sum=round(sum(v for k, v in ker.items() if not k.startswith('comm_')), 4),
                          jacobi_updates_per_step=upd / float(steps), wall_ms_per_step_all_ranks_interleaved=round(wall / steps * 1e3, 3))
+        comm.end()
     except Exception as e:      # noqa: BLE001
         errors.append((rank, repr(e)))
         try:
             world.barrier.abort()
+            comm.end()
         except Exception:
             pass
 
@@ -71,5 +74,5 @@ ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
 [t.start() for t in ts]
 [t.join() for t in ts]
 print(json.dumps({'workload': w['desc'], 'nranks': nranks, 'single_gpu_ms_per_step': round(single_ms, 4),
-                  'single_gpu_kernel_ms_sum': round(sum(kb0.values()), 4), 'single_gpu': cyc0, 'ranks': out, 'errors': errors,
+                  'single_gpu_kernel_ms_sum': round(sum(kb0.values()), 4), 'single_gpu_kernel_ms_per_step': kb0, 'single_gpu': cyc0, 'ranks': out, 'errors': errors,
                   'ratio_rank0_kernels_to_single_step': round(out[0]['kernel_ms_sum'] / single_ms, 3) if out[0] else None}))
