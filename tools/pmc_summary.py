@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one directory per counter and workload, written
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (one directory per counter and workload, written
 by the gpurun command in profiles/README.md) into profiles/pmc_traffic.json and a per-kernel CSV.
 
 HBM bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024
@@ -19,7 +19,7 @@ out = {}
 rows_out = []
 for wl in ('S1', 'S2', 'S3'):
     per = collections.defaultdict(dict)
-    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for c in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU'):
         f = glob.glob(os.path.join(src, 'pmc_%s_%s' % (wl, c), '**', '*counter_collection.csv'), recursive=True)
         if not f:
             continue
@@ -36,18 +36,22 @@ for wl in ('S1', 'S2', 'S3'):
         fk = d.get('FETCH_SIZE', (0.0, 0))
         wk = d.get('WRITE_SIZE', (0.0, 0))
         hbm = 2 * fk[0] * 1024 + wk[0] * 1024
-        rows_out.append([wl, k[:100], fk[1], round(fk[0], 1), round(wk[0], 1), int(hbm)])
+        vi = d.get('SQ_INSTS_VALU', (0.0, 0))
+        rows_out.append([wl, k[:100], fk[1], round(fk[0], 1), round(wk[0], 1), int(hbm), int(vi[0])])
         short = k.split('(')[0].replace('void admp::', '').strip()
         if short.startswith('k_pair_full'):
             out[wl]['pair_full_bytes_per_launch'] = int(hbm)
             out[wl]['pair_full_fetch_kb_raw'] = round(fk[0], 1)
             out[wl]['pair_full_write_kb'] = round(wk[0], 1)
+            if vi[1]:
+                out[wl]['pair_full_valu_insts_per_launch'] = int(vi[0])      # wave-level VALU instructions (SQ_INSTS_VALU)
 for wl in out:
     out[wl]['measured_at'] = tag
 with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w') as fh:
     json.dump(out, fh, indent=1)
 with open(os.path.join(ROOT, 'profiles', '%s_pmc_per_kernel.csv' % tag), 'w') as fh:
     w = csv.writer(fh)
-    w.writerow(['workload', 'kernel', 'launches', 'FETCH_SIZE_KB_avg', 'WRITE_SIZE_KB_avg', 'hbm_bytes_per_launch(2F+W)'])
+    w.writerow(['workload', 'kernel', 'launches', 'FETCH_SIZE_KB_avg', 'WRITE_SIZE_KB_avg', 'hbm_bytes_per_launch(2F+W)',
+                'SQ_INSTS_VALU_avg'])
     w.writerows(rows_out)
 print(json.dumps(out, indent=1))
