@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __r
                                                             int stride, RecipGeom<T> g, const T* __restrict__ phi,
                                                             long mesh_stride, T* __restrict__ grad,
                                                             const int* __restrict__ list) {
-  __shared__ T wm[kSgAtoms][kSgRow], wd[kSgAtoms][kSgRow];        // M and M' of the 18 stencil indices of every atom
+  __shared__ W4<T> w[kSgAtoms][kSgRow];                   // the four orders of the 18 stencil indices of every atom
   __shared__ int sbase[kSgAtoms][4];
   __shared__ T part[3][kSgBlock];
   const long blk = xcd_block(blockIdx.x, (unsigned)((na + kSgAtoms - 1) / kSgAtoms));
@@ -228,7 +228,11 @@ __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __r
       bspline6(f, M, D1, D2, D3);
       sbase[s][d] = b;
 #pragma unroll
-      for (int p = 0; p < 6; ++p) { wm[s][6 * d + p] = M[p]; wd[s][6 * d + p] = D1[p]; }
+      for (int p = 0; p < 6; ++p) {
+        W4<T> o;
+        o.m = M[p]; o.d1 = D1[p]; o.d2 = T(0); o.d3 = T(0);
+        w[s][6 * d + p] = o;
+      }
     }
   }
   __syncthreads();
@@ -236,61 +240,18 @@ __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __r
   T f[3] = {0, 0, 0};
   if (slot0 + s < na) {
     const int i = list ? list[slot0 + s] : slot0 + s;
-    T q[NCH];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) q[ch] = vals[(long)stride * i + ch];
     const int base[3] = {sbase[s][0], sbase[s][1], sbase[s][2]};
+    const W4<T> wz = w[s][12 + c];
     const int ic = wrap_add(base[2], c, g.K[2]);
-    T ym[6], yd[6];
-    long rb[6];
-    {
-      int ib = base[1];
-      long r = (long)ib * g.K[2] + ic;
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        ym[b] = wm[s][6 + b]; yd[b] = wd[s][6 + b];
-        rb[b] = r;
-        r += g.K[2];
-        if (++ib == g.K[1]) { ib = 0; r = ic; }
-      }
-    }
-    const long k12 = (long)g.K[1] * g.K[2];
-    long rax[6];                                           // plane offsets of the six x indices
-    {
-      int ia = base[0];
-      long ra = (long)ia * k12;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        rax[a] = ra;
-        ra += k12;
-        if (++ia == g.wrap0) { ia = 0; ra = 0; }
-      }
-    }
-    // one channel at a time (its 36 loads in flight together; three meshes at once made the kernel slower than three
-    // single-mesh launches: 0.52 against 0.39 ms at 1M atoms), the channel sums combined with the atom's coefficients
-    T u00 = 0, u10 = 0, u01 = 0;
+    // one channel at a time (its 36 loads in flight together), the channels' sums combined with the atom's coefficients
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const T* __restrict__ ph = phi + (long)ch * mesh_stride;
-      T v00 = 0, v10 = 0, v01 = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        T t0 = 0, t1 = 0;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          const T v = ph[rax[a] + rb[b]];
-          t0 += v * ym[b];
-          t1 += v * yd[b];
-        }
-        const T xm = wm[s][a], xd = wd[s][a];
-        v00 += xm * t0;
-        v10 += xd * t0;
-        v01 += xm * t1;
-      }
-      u00 += q[ch] * v00; u10 += q[ch] * v10; u01 += q[ch] * v01;
+      T fc[3];
+      gather_zcol_field_w(g, base, &w[s][0], &w[s][6], wz, ic, [&](long idx) { return ph[idx]; }, fc);
+      const T q = vals[(long)stride * i + ch];
+      f[0] += q * fc[0]; f[1] += q * fc[1]; f[2] += q * fc[2];
     }
-    const T zm = wm[s][12 + c], zd = wd[s][12 + c];
-    f[0] = zm * u10; f[1] = zm * u01; f[2] = zd * u00;
   }
   part[0][threadIdx.x] = f[0]; part[1][threadIdx.x] = f[1]; part[2][threadIdx.x] = f[2];
   __syncthreads();

@@ -1293,6 +1293,7 @@ struct Engine : EngineBase {
     if (rc != 0) throw Err{ADMP_E_HIP, std::string("sort_ints: ") + hipGetErrorString((hipError_t)rc)};
   }
   void first_pair_field() {          // real-space dE/dU of the polarizable rows, all partners
+    check_mono_inputs(true);         // (the flag word handed over below switches the charge-only form on)
     TIMED("pair_field");
     launch_pair_field<T>(stream, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
                          act_list(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole);

@@ -104,6 +104,26 @@ __global__ __launch_bounds__(kSortRows * kSortLanes) void k_nbr_rank_sort(int na
   // (no `seg - sb` base pointer: an LDS pointer below its array wraps in 32 bits, and the flat pointer made from it does not
   // wrap back when the index is added -- the address leaves the LDS aperture)
   auto entry = [&](int k) { return lds ? seg[k - sb] : cin[k]; };          // entry k of the table
+  constexpr int kMine = 8;                                                // rows of up to 8 * kMine = 64 entries: the lane
+  if (e - b <= kSortLanes * kMine) {                                      // keeps its entries in registers and walks the row
+    int v[kMine], key[kMine], rank[kMine];                                // ONCE (one LDS read per row entry serves all of them)
+#pragma unroll
+    for (int q = 0; q < kMine; ++q) {
+      const int k = b + sub + q * kSortLanes;
+      v[q] = k < e ? entry(k) : 0;
+      key[q] = k < e ? (v[q] & kColMask) : 0x7fffffff;
+      rank[q] = 0;
+    }
+    for (int m = b; m < e; ++m) {
+      const int u = entry(m) & kColMask;
+#pragma unroll
+      for (int q = 0; q < kMine; ++q) rank[q] += (u < key[q] || (u == key[q] && m < b + sub + q * kSortLanes)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < kMine; ++q)
+      if (b + sub + q * kSortLanes < e) cout[b + rank[q]] = v[q];
+    return;
+  }
   for (int k = b + sub; k < e; k += kSortLanes) {
     const int v = entry(k), key = v & kColMask;
     int rank = 0;
