@@ -920,8 +920,10 @@ struct Engine : EngineBase {
   // mesh <- IFFT( G * FFT(mesh) ), energies[slot] += sum w G |S|^2 : the whole k-space leg of one reciprocal pass
   // accum (optional): a second mesh the result is to be ADDED to; returns true when the last pass did that itself (the direct
   // DFT writes every word once anyway), false when the caller still has to add
-  bool convolve(T* mesh_p, T* spec_p, const T* gtab, int slot, T* accum = nullptr) {
+  // out (optional, rocFFT paths): phi is written there instead of over mesh_p
+  bool convolve(T* mesh_p, T* spec_p, const T* gtab, int slot, T* accum = nullptr, T* out = nullptr) {
     double* Ed = Ed_cur();
+    T* mesh_o = out ? out : mesh_p;
     if (snranks > 1) {
       // x-slab ranks: the stencils of the home atoms overhang into kGhost planes of the next rank (added there before the
       // transform), the 3-D transform is batched 2-D r2c on the owned planes -> transpose (all-to-all over the ranks: every
@@ -947,8 +949,8 @@ struct Engine : EngineBase {
       }
       { TIMED("comm_transpose"); c_all_to_all_v(sl.tbuf.p, sl.tr_recv, sl.pack.p, sl.tr_send, real_dtype(), ADMP_TAG_TRANSPOSE); }
       { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, fx_khp, snranks, 1, spec_p, sl.pack.as<T>()); }
-      fft_inverse(spec_p, mesh_p);
-      { TIMED("comm_ghost"); c_shift(mesh_p, mesh_p + (size_t)nx * plane, (int64_t)(kGhost * plane), real_dtype(), 0, ADMP_TAG_GHOST); }
+      fft_inverse(spec_p, mesh_o);
+      { TIMED("comm_ghost"); c_shift(mesh_o, mesh_o + (size_t)nx * plane, (int64_t)(kGhost * plane), real_dtype(), 0, ADMP_TAG_GHOST); }
       (void)accum;
       return false;
     }
@@ -978,12 +980,12 @@ struct Engine : EngineBase {
     if (use_fx) {      // rocFFT for the y-z planes, one fused kernel for x forward * G * x inverse
       run_plan("rocfft_r2c_yz", plan2_f, mesh_p, spec_p);
       { TIMED("fftx_kspace"); launch_fftx_conv<T>(stream, K, fx_tw.as<T>(), spec_p, gtab, Ed, slot, fx_khp); }
-      run_plan("rocfft_c2r_yz", plan2_b, spec_p, mesh_p);
+      run_plan("rocfft_c2r_yz", plan2_b, spec_p, mesh_o);
       return false;
     }
     fft_forward(mesh_p, spec_p);
     { TIMED("kspace"); launch_kspace<T>(stream, K, nyown(), gtab, spec_p, Ed, slot); }
-    fft_inverse(spec_p, mesh_p);
+    fft_inverse(spec_p, mesh_o);
     return false;
   }
 
@@ -1912,6 +1914,7 @@ struct Engine : EngineBase {
     const int* order = nbr.order_plain ? nbr.order_plain : nbr.order;
     if (snranks > 1 || need_bases) {
       bases_d.need(sizeof(int4) * (size_t)na);
+      TIMED("atom_bases");
       launch_atom_bases<T>(stream, na, pos, g, bases_d.as<int4>());
     }
     if (snranks == 1) return {order, na, nullptr};
@@ -1963,15 +1966,17 @@ struct Engine : EngineBase {
         if (rc == 0) rc = launch_spread_scalar<T>(stream, nch, pos, cl, 3, g, bins, mesh.as<T>(), (long)nreal);
         if (rc != 0) throw Err{ADMP_E_HIP, std::string("dispersion spread: ") + hipGetErrorString((hipError_t)rc)};
         bins.counters_zero = true; }
-      // every channel is gathered right after its transform, while its phi is still in L2 / MALL (the three meshes at once --
-      // 201 MB at 256^3 -- in one gather pass measured 0.52-0.61 ms against 0.39 for three single-mesh passes)
+      // every channel is gathered right after its transform.  The gather is bound by the cache-line rate of its 36 mesh loads
+      // per lane, whatever it sums: 0.175 ms per channel at 1M atoms in every form tried (one pass over the three meshes
+      // 0.52-0.61 ms; one pass per channel from its own or from a shared, cache-resident phi buffer 0.525; round 2's
+      // k_gather_field_staged on site rows 0.525) -- what the fused path saves is the site rows and the scale-add pass.
       for (int c = 0; c < nch; ++c) {
         ensure_gtab(box, inv, vol, 6 + 2 * c);
         convolve(mesh.as<T>() + c * nreal, spec.as<T>(), gtab_cur, E_RECIP);
         TIMED("gather_field");
         launch_gather_scalar<T>(stream, 1, sr.n, pos, cl + c, 3, g, mesh.as<T>() + c * nreal, (long)nreal, dpos, sr.home);
       }
-      launch_scalar_self<T>(stream, nch, sr.n, cl, 3, sr.home, kp, Ed);
+      { TIMED("scalar_self"); launch_scalar_self<T>(stream, nch, sr.n, cl, 3, sr.home, kp, Ed); }
       read_scalar_energies(Ed, E, 3);
       if (dpos_ && !on_device) {
         HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
