@@ -1090,6 +1090,71 @@ def test_slab_all_terms_and_parameter_outputs(precision):
                 assert abs(rt[0] - Et0) < tol * abs(Et0) and rel(rt[1], Gt0) < max(tol, 1e-9)
 
 
+def test_slab_moving_sequence_with_migrating_atoms_and_fused_x_pass(precision):
+    """A warm-started sequence of displaced frames on 2 slab ranks that keep only their HOME rows (outputs='home'), on a
+    power-of-two mesh (K = 64: the x lines of the distributed transform run in the fused kernel on the transposed layout).
+    The whole box drifts along x from frame to frame, so atoms change hands between the evaluations: their induced dipoles
+    must travel with them -- every step then takes the SCF cycles of the single-GPU sequence and returns its numbers."""
+    import threading
+    import torch
+    from admp_amd.parallel import SlabPme, ThreadComm
+    from admp_amd.pme import ADMPPmeForce
+    settings.PRECISION = 'double'
+    n_mol, nranks, nframes = 1000, 2, 4
+    pos0, box = S.synthetic_water_box(n_mol, seed=23)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, True)
+    rng = np.random.default_rng(5)
+    frames = [pos0 + np.array([0.9 * k, 0.0, 0.0]) + 0.01 * k * rng.normal(size=pos0.shape) for k in range(nframes)]
+    rest = (par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+
+    def run(f, keep_home=None):
+        out, U = [], None
+        for p in frames:
+            pairs = S.build_pairs(p, box, 4.0)
+            E, G = f.get_forces(p, box, pairs, *rest, U_init=U)
+            U = f.U_ind
+            out.append((E, np.asarray(G), np.asarray(U).copy(), f.n_cycle,
+                        None if keep_home is None else f.home_atoms.cpu().numpy()))
+        return out
+    ref = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    for k in ('K1', 'K2', 'K3'):
+        ref.update_env(k, 64)
+    want = run(ref)
+    world = ThreadComm.World(nranks)
+    got, errors = [None] * nranks, []
+
+    def work(rank):
+        try:
+            f = SlabPme(ThreadComm(world, rank), box, at, ai, cov, 4.0, 1e-4, 2, lpol=True, outputs='home')
+            for k in ('K1', 'K2', 'K3'):
+                f.update_env(k, 64)
+            got[rank] = run(f, keep_home=True)
+        except Exception as e:      # noqa: BLE001
+            errors.append((rank, repr(e)))
+            try:
+                world.barrier.abort()
+            except Exception:
+                pass
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in ts]
+    [t.join(timeout=600) for t in ts]
+    assert not errors, errors
+    scale = max(abs(p) for p in ref.energy_parts)
+    moved = 0
+    for k in range(nframes):
+        E0, G0, U0, n0, _ = want[k]
+        homes = np.concatenate([got[r][k][4] for r in range(nranks)])
+        assert len(homes) == 3 * n_mol and len(np.unique(homes)) == 3 * n_mol
+        if k:
+            moved += len(np.setdiff1d(got[0][k][4], got[0][k - 1][4]))
+        for r in range(nranks):
+            E, G, U, n, home = got[r][k]
+            assert n == n0, (k, r, n, n0)                      # a migrant that lost its dipole would cost extra cycles
+            assert abs(E - E0) < 1e-10 * scale and rel(G[home], G0[home]) < 1e-9 and rel(U[home], U0[home]) < 1e-9, (k, r)
+    assert moved > 0                                           # atoms did change hands
+
+
 def test_slab_halo_only_traffic_and_home_outputs(precision):
     """outputs='home': a rank returns its home rows and nothing proportional to the number of atoms is ever sent -- the
     SCF exchanges only the dipoles of imported atoms (all-to-all-v over index lists), the gradient only what a rank
