@@ -9,7 +9,7 @@ import numpy as np
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libadmp_hip.so')
+LIB_PATH = os.environ.get('ADMP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libadmp_hip.so')      # (override: A/B builds of tools/ab_build.sh)
 
 _c = ctypes
 _vp, _i32, _i64, _dbl = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double

@@ -1219,7 +1219,10 @@ struct Engine : EngineBase {
     need_eval();
     if (snranks > 1)   // the closing kernel ADDS frame-adjoint contributions to atoms of other ranks: those rows start at zero
       launch_rows_scatter<T>(stream, 2, sl.n_imp, 3, sl.imp.as<int>(), nullptr, grad_p);
-    if (!slot_clean[E_REAL]) HIP_TRY(hipMemsetAsync(Ed_cur() + E_REAL, 0, sizeof(double), stream));
+    if (!slot_clean[E_REAL]) {
+      HIP_TRY(hipMemsetAsync(Ed_cur() + E_REAL, 0, sizeof(double), stream));
+      HIP_TRY(hipMemsetAsync(Ed_cur() + E_RPARTS, 0, E_PARTS * sizeof(double), stream));
+    }
     slot_clean[E_REAL] = false;
     check_mono_inputs(mono_ok);
     TIMED("pair_full");
@@ -1410,6 +1413,7 @@ struct Engine : EngineBase {
       return Eh[E_FMAX];
     }
     E[0] = Eh[E_REAL]; E[1] = recip_slot >= 0 ? Eh[recip_slot] : 0.0; E[2] = Eh[E_SELF]; E[3] = Eh[E_PEN];
+    for (int k = 0; k < E_PARTS; ++k) E[0] += Eh[E_RPARTS + k];      // k_pair_full's partial words
     if (recip_slot == E_PARTS_SUM) {         // atom-side reciprocal energy: the partial words of k_gather<.., true>
       double e = 0.0;
       for (int k = 0; k < E_PARTS; ++k) e += Eh[E_SLOTS + k];

@@ -82,7 +82,9 @@ enum { E_REAL = 0, E_RECIP = 1, E_SELF = 2, E_PEN = 3, E_NACT = 4 /* int: number
        E_PARTS = 64 /* partial sums of the atom-side reciprocal energy (k_gather<.., true>): 32k workgroups adding into ONE
                        word serialise at the memory side (0.2 ms at 1M atoms); 64 words take them in parallel */,
        E_RED = E_SLOTS + E_PARTS /* 4 words: (real, recip, self, penalty) packed for the SUM all-reduce of a slab evaluation */,
-       E_WORDS = E_RED + 4 /* one half of the double-buffered energy block */ };
+       E_RPARTS = E_RED + 4 /* E_PARTS partial sums of the real-space energy (k_pair_full: one word per workgroup modulo
+                               E_PARTS instead of every workgroup's atomic on E_REAL); the real-space energy is E_REAL + their sum */,
+       E_WORDS = E_RPARTS + E_PARTS /* one half of the double-buffered energy block */ };
 
 // optional epilogue of the gather (small systems) or of the closing kernel (large ones), speculative first SCF cycle on
 // one rank: total dE/dU and its maximum, exactly what launch_field_finish computes, without a separate dispatch

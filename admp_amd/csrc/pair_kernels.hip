@@ -16,6 +16,10 @@
 namespace admp {
 
 constexpr int kPairBlock = 256;
+#ifndef ADMP_FULL_BLOCK
+#define ADMP_FULL_BLOCK 256
+#endif
+constexpr int kFullBlock = ADMP_FULL_BLOCK;      // workgroup of k_pair_full (its waves end at one barrier: the energy sum)
 
 template <class T, int LPR>
 __device__ __forceinline__ T row_reduce(T v) {
@@ -35,7 +39,7 @@ __device__ __forceinline__ void stage_tab(const ScaleTab<T>& tab, T* s) {
 }
 
 template <class T, bool LPOL, int LPR, int MINW>
-__global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const int* __restrict__ rowptr,
+__global__ __launch_bounds__(kFullBlock, MINW) void k_pair_full(int na, const int* __restrict__ rowptr,
                                                           const int* __restrict__ col,
                                                           const Site<T>* __restrict__ sites, Box<T> box,
                                                           ScaleTab<T> tab, T kappa, T* __restrict__ grad,
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   const long blk = xcd_block(blockIdx.x, nblocks);
-  const long t = (blk < 0 ? (long)na * LPR : blk * kPairBlock) + threadIdx.x;
+  const long t = (blk < 0 ? (long)na * LPR : blk * kFullBlock) + threadIdx.x;
   const int slot = (int)(t / LPR), sub = (int)(t % LPR);
   // `na` counts the rows this launch owns; with a row list (multi-GPU: the rank's home atoms) slot -> atom
   const int row = slot < na ? (rows ? rows[slot] : slot) : na;
@@ -141,8 +145,8 @@ __global__ __launch_bounds__(kPairBlock, MINW) void k_pair_full(int na, const in
     for (int k = 0; k < 9; ++k) pot[9 * row + k] = P[k];
     if (LPOL && fld) { fld[3 * row] = F[0]; fld[3 * row + 1] = F[1]; fld[3 * row + 2] = F[2]; }
   }
-  e = block_reduce_sum<kPairBlock>(e);
-  if (threadIdx.x == 0) atomicAdd(&energies[E_REAL], 0.5 * e);
+  e = block_reduce_sum<kFullBlock>(e);
+  if (threadIdx.x == 0) atomicAdd(&energies[E_RPARTS + (blockIdx.x & (E_PARTS - 1))], 0.5 * e);
 }
 
 template <class T, int LPR>
@@ -625,6 +629,7 @@ static int pair_min_waves() {
 }
 
 static inline unsigned grid_for(int na, int lpr) { return (unsigned)(((long)na * lpr + kPairBlock - 1) / kPairBlock); }
+static inline unsigned grid_full(int na, int lpr) { return (unsigned)(((long)na * lpr + kFullBlock - 1) / kFullBlock); }
 
 #define ADMP_LPR_SWITCH(lpr, CALL) \
   switch (lpr) {                   \
@@ -647,16 +652,16 @@ void launch_pair_full(hipStream_t st, int na, const NbrTable& nb, const Site<T>*
   if (mono_off || !cls_flags || !rq) use_mono = 0;
 #define CALL(L)                                                                                                        \
   if (lpol && minw >= 2)                                                                                               \
-    k_pair_full<T, true, L, 2><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                      \
-        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L), use_mono,     \
+    k_pair_full<T, true, L, 2><<<xcd_grid(grid_full(na, L)), kFullBlock, 0, st>>>(                                      \
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_full(na, L), use_mono,     \
         cls_flags, rq, tholes);                                                                                        \
   else if (lpol)                                                                                                       \
-    k_pair_full<T, true, L, 1><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                      \
-        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L), use_mono,     \
+    k_pair_full<T, true, L, 1><<<xcd_grid(grid_full(na, L)), kFullBlock, 0, st>>>(                                      \
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_full(na, L), use_mono,     \
         cls_flags, rq, tholes);                                                                                        \
   else                                                                                                                 \
-    k_pair_full<T, false, L, 2><<<xcd_grid(grid_for(na, L)), kPairBlock, 0, st>>>(                                     \
-        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_for(na, L), use_mono, cls_flags, rq,    \
+    k_pair_full<T, false, L, 2><<<xcd_grid(grid_full(na, L)), kFullBlock, 0, st>>>(                                     \
+        na, nb.rowptr, nb.col, sites, box, tab, kappa, grad, pot, energies, rows, fld, grid_full(na, L), use_mono, cls_flags, rq,    \
         tholes)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL

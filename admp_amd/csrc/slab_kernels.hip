@@ -330,7 +330,9 @@ __global__ void k_energy_pack(const double* __restrict__ e, int recip_slot, doub
   double r = 0.0;
   if (recip_slot >= 0) r = e[recip_slot];
   else if (recip_slot == -1) for (int k = 0; k < E_PARTS; ++k) r += e[E_SLOTS + k];
-  out[0] = e[E_REAL]; out[1] = r; out[2] = e[E_SELF]; out[3] = e[E_PEN];
+  double er = e[E_REAL];
+  for (int k = 0; k < E_PARTS; ++k) er += e[E_RPARTS + k];
+  out[0] = er; out[1] = r; out[2] = e[E_SELF]; out[3] = e[E_PEN];
 }
 void launch_energy_pack(hipStream_t st, const double* e, int recip_slot, double* out) {
   k_energy_pack<<<1, 64, 0, st>>>(e, recip_slot, out);
