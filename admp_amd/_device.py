@@ -255,6 +255,11 @@ class HipForceBase:
         self._pairs_key = ('shared', id(lender)) if lender is not None else None
         self._pairs_keep = None
 
+    def set_cutoff(self, rc):
+        """Skip the pairs of the list beyond `rc` (minimum image) in the pair kernels: for Verlet lists built with a skin.
+        0 = evaluate every listed pair (default; what the reference does).  Dispersion and pair-potential calculators."""
+        _lib.check(self._h, self._L.admp_set_cutoff(self._h, float(rc)), 'admp_set_cutoff')
+
     @property
     def n_pairs(self):
         return int(self._L.admp_num_pairs(self._h))

@@ -179,6 +179,7 @@ struct EngineBase {
   // [4] ... that needed more steps than enqueued (closing pass wasted), [5] ... that enqueued more steps than needed,
   // [6] increments that ran for nothing in those, [7] Jacobi steps in total
   int64_t scf_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double cutoff = 0.0;          // admp_set_cutoff: listed pairs beyond it are skipped (0: every listed pair, as the reference)
   int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
   int keep_pol_sites = 0;       // ADMP_OPT_KEEP_POL_SITES: the caller vouches that the set {i : pol_i > 0} has not changed
   long nbr_gen = 0;             // bumped whenever the neighbour table is rebuilt
@@ -1960,7 +1961,7 @@ struct Engine : EngineBase {
     const bool fused = !(use_dft || use_pfa) && (snranks > 1 || spread_uses_bricks(na, g));
     if (snranks > 1) ARG_CHECK(spread_uses_bricks(1 << 30, g), "slab-decomposed dispersion PME needs at least 17 local mesh planes and K2, K3 >= 17");
     const ScalarRows sr = scalar_rows(pos, g, K[0], X0, X1, fused);
-    { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pack_srows(pos, cl, 3), bx, tab, (T)kappa, pmax, dpos, Ed, sr.rows, sr.n); }
+    { TIMED("disp_pair"); launch_disp_pair<T>(stream, na, nbr, pack_srows(pos, cl, 3), bx, tab, (T)kappa, pmax, dpos, Ed, sr.rows, sr.n, cutoff); }
     if (fused) {
       const size_t nreal = nreal_local();
       mesh.need(nch * nreal * sizeof(T));
@@ -2093,7 +2094,7 @@ struct Engine : EngineBase {
       g.xoff = 64 * srank; g.nloc0 = 64 + kGhost; g.wrap0 = 1 << 30;
       sr = scalar_rows(pos, g, Kv, 64 * srank, 64 * (srank + 1), true);
     }
-    { TIMED("tt_pair"); launch_tt_pair<T>(stream, na, nbr, pack_srows(pos, par, 4), bx, tab, dpos, Ed, sr.rows, sr.n); }
+    { TIMED("tt_pair"); launch_tt_pair<T>(stream, na, nbr, pack_srows(pos, par, 4), bx, tab, dpos, Ed, sr.rows, sr.n, cutoff); }
     read_scalar_energies(Ed, E, 1);
     if (dpos_ && !on_device) {
       HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
@@ -2508,6 +2509,12 @@ int admp_set_comm(admp_handle* h, const admp_comm* comm) {
     ARG_CHECK(comm->all_reduce && comm->all_to_all_v && comm->shift, "communicator with a missing callback");
     e.comm = *comm;
     e.have_comm = true;
+  });
+}
+int admp_set_cutoff(admp_handle* h, double rc) {
+  return guarded(h, [&](EngineBase& e) {
+    ARG_CHECK(rc >= 0.0, "negative cutoff");
+    e.cutoff = rc;
   });
 }
 int admp_scf_stats(admp_handle* h, int64_t* out8, int reset) {

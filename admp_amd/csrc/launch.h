@@ -263,10 +263,11 @@ template <class T>
 void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* srows, const Box<T>& box,
                       const ScaleTab<T>& tab, T kappa, int pmax, T* grad, double* energies,
                       const int* rows = nullptr /* the n_rows rows to evaluate (nullptr: all, in the table's order) */,
-                      int n_rows = 0);
+                      int n_rows = 0, double cutoff = 0.0 /* > 0: listed pairs beyond it are skipped (admp_set_cutoff) */);
 template <class T>
 void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* srows, const Box<T>& box,
-                    const ScaleTab<T>& tab, T* grad, double* energies, const int* rows = nullptr, int n_rows = 0);
+                    const ScaleTab<T>& tab, T* grad, double* energies, const int* rows = nullptr, int n_rows = 0,
+                    double cutoff = 0.0);
 
 // ---- box gradient (dE/dbox at fixed Cartesian positions; on request only).  All sums are double device words.
 // vir[9] += 1/2 sum_entries shift (x) dE_pair/dr_I over the pairs whose minimum image crosses the cell boundary

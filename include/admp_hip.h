@@ -89,6 +89,13 @@ int admp_set_pairs(admp_handle* h, int64_t n_rows, const int32_t* pairs, int on_
  * was destroyed is ADMP_E_ARG. */
 int admp_share_neighbors(admp_handle* h, admp_handle* lender);
 int64_t admp_num_pairs(const admp_handle* h);   /* pairs kept (i < j) */
+/* Verlet lists with a skin (MD drivers rebuild the list every few steps with rc + skin): pairs of the list whose
+ * minimum-image distance is >= rc are skipped by the pair kernels, so that the result is the one of the exact-rc list
+ * whatever the skin.  rc = 0 (default): every listed pair is evaluated -- what the reference does with whatever list it is
+ * handed (admp/pme.py:671-729 has no distance test).  Not a speed option (the kernels wait on the partner fetches, not on
+ * the pair arithmetic).  Honoured by the dispersion and Tang-Toennies pair kernels
+ * (admp_disp_energy_grad, admp_tt_energy_grad); the multipolar PME kernels evaluate every listed pair. */
+int admp_set_cutoff(admp_handle* h, double rc);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 /* replaces: ADMPPmeForce.get_energy / get_forces (admp/pme.py:58-86, 108) including the induced

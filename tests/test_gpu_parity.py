@@ -398,6 +398,66 @@ def test_slab_decomposition_two_processes_gloo(tmp_path):
     assert r.returncode == 0 and 'SLAB-PROC-OK 2' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+RCCL_WORKER = r'''
+import ctypes, datetime, os, sys
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', '29547')
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=90))
+from admp_amd import _lib
+from admp_amd.parallel import CommBinding, TorchComm
+comm = TorchComm()
+assert comm.native and comm.size == 1
+bind = CommBinding(comm, dev)
+hip = ctypes.CDLL('libamdhip64.so')
+n = 1 << 16
+bufs = []
+for _ in range(2):                      # device memory that torch's allocator does not own, like the library's buffers
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(8 * n)) == 0
+    bufs.append(p.value)
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):           # the calculators run on the caller's current stream, whichever it is
+    for dt, tdt in ((_lib.T_F32, torch.float32), (_lib.T_F64, torch.float64), (_lib.T_I32, torch.int32)):
+        a, b = bind._view(bufs[0], n, dt), bind._view(bufs[1], n, dt)
+        ref = (torch.arange(n, device=dev) %% 977).to(tdt)
+        a.copy_(ref); b.zero_()
+        for op in (_lib.OP_SUM, _lib.OP_MAX):
+            assert bind._all_reduce(None, bufs[0], n, dt, op, 0) == 0, bind.error
+        cnt = (ctypes.c_int64 * 1)(n)
+        assert bind._all_to_all_v(None, bufs[0], cnt, bufs[1], cnt, dt, 0) == 0, bind.error
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+        # the ring shift of TorchComm.shift between two ranks, here with this rank as both neighbours
+        b.zero_()
+        ops = [dist.P2POp(dist.isend, a, 0), dist.P2POp(dist.irecv, b, 0)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        assert torch.equal(b, ref)
+side.synchronize()
+assert comm.bytes_sent is not None
+dist.destroy_process_group()
+print('RCCL-OK')
+'''
+
+
+def test_rccl_collectives_on_library_buffers(tmp_path):
+    """RCCL itself (torch.distributed backend nccl) under the communicator callbacks, as far as ONE GPU allows: a
+    one-rank group, the admp_comm callbacks (CommBinding -> TorchComm) on raw hipMalloc'ed buffers wrapped as tensors, on a
+    non-default stream: all-reduce SUM / MAX in the three element types, the all-to-all, and the send/recv pair of the ring
+    shift.  What stays unexercised here is only traffic between different devices."""
+    import subprocess
+    import sys
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(RCCL_WORKER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547'))
+    assert r.returncode == 0 and 'RCCL-OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize('prec', ['double', 'single'])
 def test_gpu_neighbour_list_matches_kdtree(precision, prec):
     """Cell-list search (admp_amd.neighbor) against the host cKDTree builder, cubic and triclinic cells,
@@ -888,6 +948,44 @@ def test_dispersion_lower_orders_and_single_precision(precision, pmax):
         E, G = d.get_forces(pos, box, pairs, par['c_list'][:, :(pmax - 4) // 2], par['mScales'])
         ref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d.kappa, (d.K1, d.K2, d.K3), pmax)
         assert abs(E - ref['E']) < tol * max(abs(p) for p in ref['parts']) and rel(G, ref['grad']) < max(tol, 1e-8)
+
+
+def test_cutoff_on_skin_list_equals_exact_list(precision):
+    """set_cutoff(rc) on a Verlet list built with a skin (dispersion PME, Tang-Toennies): the partners beyond rc are
+    skipped inside the pair kernel, so energy and gradient are those of the exact-rc list -- and of the oracle on that list."""
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
+    from oracle import admp_oracle as O
+    pos, box, at, ai, cov, par, pairs = water_system(216, 21, False)
+    wide = S.build_pairs(pos, box, 5.2)
+    assert len(wide) > 1.5 * len(pairs)
+    c6 = np.ascontiguousarray(par['c_list'][:, 0])
+    for prec, tol in (('double', 1e-11), ('single', 2e-5)):
+        settings.PRECISION = prec
+        d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+        E0, G0 = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+        Ew, Gw = d.get_forces(pos, box, wide, par['c_list'], par['mScales'])
+        d.set_cutoff(4.0)
+        E1, G1 = d.get_forces(pos, box, wide, par['c_list'], par['mScales'])
+        scale = max(abs(x) for x in d.energy_parts)
+        assert abs(E1 - E0) < tol * scale and rel(G1, G0) < tol * 10
+        assert abs(Ew - E0) > 1.0                                # the skin pairs do contribute when nobody cuts them
+        d.set_cutoff(0.0)
+        E2, _ = d.get_forces(pos, box, wide, par['c_list'], par['mScales'])
+        assert abs(E2 - Ew) < tol * scale
+        t = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+        tt = value_and_grad(t)
+        targs = (par['mScales'], par['a_list'], par['b_list'], par['q_list'], c6)
+        E0, G0 = tt(pos, box, pairs, *targs)
+        t.set_cutoff(4.0)
+        E1, G1 = tt(pos, box, wide, *targs)
+        assert abs(E1 - E0) < tol * 10 * abs(E0) and rel(G1, G0) < tol * 10
+        if prec == 'double':
+            ref = O.tt_energy_and_grad(pos, box, pairs, par['mScales'], cov, par['a_list'], par['b_list'], par['q_list'], c6)
+            assert abs(E1 - ref['E']) < 1e-9 * abs(ref['E']) and rel(G1, ref['grad']) < 1e-9
+    from admp_amd._lib import AdmpHipError
+    with pytest.raises(AdmpHipError):
+        d.set_cutoff(-1.0)
 
 
 def test_full_size_directional_derivative(precision):
