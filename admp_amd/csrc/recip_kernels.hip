@@ -116,35 +116,161 @@ __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__
 // One workgroup per brick: each listed atom adds the part of its stencil that falls inside the brick into a
 // 16^3 LDS tile; the tile is then stored once -- no memset, no global atomics.  The spline weights are
 // recomputed per (atom, brick) entry: ~0.5 kflop against up to 216 LDS atomics.
-// The tile is 64-bit FIXED POINT in both precisions (round 2).  Measured on MI355X, wave-level LDS atomics with 64 scattered
-// addresses -- the access shape of this kernel, 64 unrelated atoms per instruction (tools/ubench/lds_atomics_lanes.hip):
-// ds_add_f32 193 CU-cycles per instruction (why round 1 moved from an f32 to an f64 tile), ds_add_f64 27.3, ds_add_u64 13.6.
-// The LDS array was the bound of the f64 form (SQ_LDS_IDX_ACTIVE = 63 % of the kernel time), so the integer form halves
-// it; and integer sums do not depend on the order of the adds: the mesh is bitwise reproducible.
-// Scale, per brick: a first pass over the brick's entries finds bmax = max |q| + |c1|_1 + |c2|_1 of the folded multipoles
-// (every spline weight and derivative is <= 1 in magnitude), so no word can exceed bmax * entries; the scale is the power
-// of two that keeps 8x that below 2^62 (>= 2^45 for any brick a 16^3 tile can hold: finer than f64 on values of O(1)).
-// v * scale is turned into an integer by the 2^52 + 2^51 trick (one f64 fma + a 64-bit subtract; |v * scale| < 2^51 holds
-// by construction).
+//
+// The tile is FIXED POINT: integer LDS atomics run at twice (64-bit) to four times (32-bit) the rate of ds_add_f64 on the
+// scattered addresses of this kernel (tools/ubench/lds_atomics_lanes.hip: ds_add_f32 193 CU-cycles per wave instruction,
+// ds_add_f64 27.3, ds_add_u64 13.7, ds_add_u32 6.3), and integer sums do not depend on the order of the adds: the mesh is
+// bitwise reproducible.  A first pass over the brick's entries finds bmax = max |q| + |c1|_1 + |c2|_1 of the folded
+// multipoles; every spline weight and derivative is <= 1 in magnitude and a mesh word receives at most one term per entry,
+// so no term exceeds bmax and no word bmax * cnt.
+//   f64 meshes: 64-bit words, scale = the power of two that keeps 8 bmax cnt below 2^62 and bmax below 2^50 (the terms are
+//               turned into integers by the 2^52 + 2^51 trick: one f64 add and a 64-bit subtract); finer than f64 on O(1).
+//   f32 meshes: 32-bit words (round 3), scale keeps bmax cnt below 2^30: a resolution of 2^-30 bmax cnt, 5e-7 bmax for the
+//               ~600 entries of a brick of liquid water, rounded to nearest by v_cvt_rpi_i32_f32 -- a few 1e-7 of the mesh
+//               values, where the f32 path as a whole differs from f64 by 2e-5 (bench.py precision_check).
+//
+// The kernel is VALU bound (round 3: without its atomics it takes the same time; SQ_ACTIVE_INST_VALU 85 % of the SIMD
+// cycles), so the work per entry is cut by what the entry carries: most sites of a force field are bare charges (the
+// hydrogens of the water model: 2/3 of the entries), and the entries of an SCF increment are bare dipoles.  The entries of
+// a chunk are counting-sorted by class (charge only | dipole only | general) in LDS and handed to the waves 64 in sorted
+// order at a time, so that a wave runs one form:
+//                      per entry                     per (x, y) row          per point
+//   general            3 x (M, M', M''), fold        6 FMA (regrouped:       3 FMA + convert + add
+//   dipole only        3 x (M, M'), fold of d        3       row factors     2 FMA + ...
+//   charge only        3 x M                         1       per x)          1 MUL + ...
 #ifndef ADMP_BRICK_ROW
 #define ADMP_BRICK_ROW 17
 #endif
+#ifndef ADMP_SPREAD_CLASSES
+#define ADMP_SPREAD_CLASSES 1     // 0: every entry takes the general form (A/B)
+#endif
 constexpr int kBrickRow = ADMP_BRICK_ROW;   // z-row pitch of the LDS tile in words (17: bank skew)
+constexpr int kBrickChunk = 2048;           // entries sorted at a time
+template <class T> struct BrickWord { using type = unsigned long long; };
+template <> struct BrickWord<float> { using type = unsigned; };
 __device__ __forceinline__ unsigned long long fixed_bits(double v) {     // v already scaled, |v| < 2^51
   const double t = v + 6755399441055744.0;                                // 2^52 + 2^51: the integer sits in the mantissa
   return (unsigned long long)__double_as_longlong(t) - 0x4338000000000000ull;
 }
-__device__ __forceinline__ unsigned long long fixed_bits(float v) {      // v already scaled, |v| < 2^30: one conversion
-  const int i = (int)v;                                                   // (truncation: half an LSB of 2^-30 bmax) and a
-  return (unsigned long long)(long long)i;                                // sign extension instead of f64 arithmetic
+__device__ __forceinline__ unsigned fixed_bits(float v) {                // v already scaled, |v| < 2^30: floor(v + 0.5)
+  int i;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(v));
+  return (unsigned)i;
 }
+__device__ __forceinline__ double brick_value(unsigned long long w, double inv) { return (double)(long long)w * inv; }
+__device__ __forceinline__ float brick_value(unsigned w, double inv) { return (float)(int)w * (float)inv; }
+
+enum { SK_GENERAL = 0, SK_DIPOLE = 1, SK_CHARGE = 2 };
+// what an entry carries: SK_CHARGE if it has no dipole (permanent + induced) and no quadrupole, SK_DIPOLE if it has
+// neither charge nor quadrupole
+template <class T>
+__device__ __forceinline__ int site_kind(const Site<T>& s, int lpol) {
+  T d = m_abs(s.Q[1]) + m_abs(s.Q[2]) + m_abs(s.Q[3]);
+  if (lpol) d += m_abs(s.U[0]) + m_abs(s.U[1]) + m_abs(s.U[2]);
+  const T q2 = m_abs(s.Q[4]) + m_abs(s.Q[5]) + m_abs(s.Q[6]) + m_abs(s.Q[7]) + m_abs(s.Q[8]);
+  if (q2 == T(0) && d == T(0)) return SK_CHARGE;
+  if (q2 == T(0) && s.Q[0] == T(0)) return SK_DIPOLE;
+  return SK_GENERAL;
+}
+
+// one entry (a site and this brick) into the tile
+template <class T, int KIND, class W>
+__device__ __forceinline__ void brick_add_entry(W* __restrict__ tile, const Site<T>& site, int lpol, const RecipGeom<T>& g,
+                                                const int lo[3], const int n[3], T scale) {
+  const T r[3] = {site.r[0], site.r[1], site.r[2]};
+  // The stencil's position is expressed once per entry RELATIVE to the brick (off = base - lo, folded by the period when
+  // the stencil reaches the brick across the periodic seam), so that point p of an axis sits at local index off + p with no
+  // wrap, the LDS address is "row + constant", and validity is one bit of a 6-bit mask per axis.
+  int off[3], ok[3];
+  T M[3][6], D1[3][6], D2[3][6];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int base;
+    T D3[6];
+    const T f = grid_ref(g, r, d, base);
+    bspline6(f, M[d], D1[d], D2[d], D3);              // (what a form does not use is never computed: all of it is inlined)
+    const int period = d == 0 ? g.wrap0 : g.K[d];
+    int o = base - lo[d];
+    if (o + 5 < 0) o += period;                      // stencil starts before the seam, ends inside this brick
+    else if (o >= n[d]) o -= period;                 // brick at the low end, stencil wraps around from the high end
+    off[d] = o;
+    int m = 0;
+#pragma unroll
+    for (int p6 = 0; p6 < 6; ++p6) m |= ((unsigned)(o + p6) < (unsigned)n[d]) << p6;
+    ok[d] = m;
+  }
+  if (!(ok[0] && ok[1] && ok[2])) return;
+  T q = T(0), c1[3] = {T(0), T(0), T(0)}, c2[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  if (KIND == SK_CHARGE) {
+    q = scale * site.Q[0];
+  } else {
+    T Q[9];
+    Q[0] = KIND == SK_DIPOLE ? T(0) : site.Q[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) Q[k] = site.Q[k] + (lpol ? site.U[k - 1] : T(0));      // Q_global_tot, admp/pme.py:236
+#pragma unroll
+    for (int k = 4; k < 9; ++k) Q[k] = KIND == SK_DIPOLE ? T(0) : site.Q[k];
+    fold_multipole(g, Q, c1, c2);
+    q = scale * Q[0];                                 // the power-of-two scale goes into the coefficients: exact
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c1[k] *= scale;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c2[k] *= scale;
+  }
+  // z axis: no branch per point -- an out-of-brick point gets zero weights and a clamped (in-tile) index, so it adds an
+  // exact integer 0 to a word of the row; x and y keep their `continue` (they skip 36 / 6 points at a time)
+  T wz[6], w1z[6], w2z[6];
+  int jz[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const bool in = (ok[2] >> c) & 1;
+    wz[c] = in ? M[2][c] : T(0); w1z[c] = in ? D1[2][c] : T(0); w2z[c] = in ? D2[2][c] : T(0);
+    const int j = off[2] + c;
+    jz[c] = j < 0 ? 0 : (j >= n[2] ? n[2] - 1 : j);
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    if (!((ok[0] >> a) & 1)) continue;
+    const int ja = off[0] + a;
+    const T m0 = M[0][a], d0 = D1[0][a], e0 = D2[0][a];
+    // value(a, b, c) = P0 M(z) + P1 M'(z) + P2 M''(z) with
+    //   P0 = m1 A0 + d1 A1 + e1 A2,  P1 = m1 B0 + d1 B1,  P2 = m1 C0          (m1, d1, e1: M, M', M'' of the y axis)
+    // -- spread_atom's (spline_math.h) sums regrouped by the y factor, the x factors taken out of the y loop
+    const T A0 = q * m0 + c1[0] * d0 + c2[0] * e0, A1 = c1[1] * m0 + c2[3] * d0, A2 = c2[1] * m0;
+    const T B0 = c1[2] * m0 + c2[4] * d0, B1 = c2[5] * m0, C0 = c2[2] * m0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      if (!((ok[1] >> b) & 1)) continue;
+      const int jb = off[1] + b;
+      const T m1 = M[1][b], d1 = D1[1][b], e1 = D2[1][b];
+      W* row = tile + (ja * 16 + jb) * kBrickRow;
+      if (KIND == SK_CHARGE) {
+        const T P0 = m1 * A0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomicAdd(&row[jz[c]], fixed_bits(P0 * wz[c]));
+      } else if (KIND == SK_DIPOLE) {
+        const T P0 = m1 * A0 + d1 * A1, P1 = m1 * B0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomicAdd(&row[jz[c]], fixed_bits(P0 * wz[c] + P1 * w1z[c]));
+      } else {
+        const T P0 = m1 * A0 + d1 * A1 + e1 * A2, P1 = m1 * B0 + d1 * B1, P2 = m1 * C0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomicAdd(&row[jz[c]], fixed_bits(P0 * wz[c] + P1 * w1z[c] + P2 * w2z[c]));
+      }
+    }
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                        BrickGrid bg, const int* __restrict__ brick_start,
                                                        const int* __restrict__ entries, T* __restrict__ mesh,
                                                        int* __restrict__ clear_a, int* __restrict__ clear_b) {
-  __shared__ unsigned long long tile[16 * 16 * kBrickRow];
+  using W = typename BrickWord<T>::type;
+  __shared__ W tile[16 * 16 * kBrickRow];
   __shared__ unsigned s_bmax;
+  __shared__ unsigned short s_order[kBrickChunk];
+  __shared__ int s_hist[4];
   const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
   const int bb[3] = {bx, by, bz};
   int lo[3], n[3];
@@ -152,7 +278,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     lo[d] = (bb[d] * g.dim(d)) / bg.nb[d];
     n[d] = ((bb[d] + 1) * g.dim(d)) / bg.nb[d] - lo[d];
   }
-  for (int t = threadIdx.x; t < 16 * 16 * kBrickRow; t += 256) tile[t] = 0ull;
+  for (int t = threadIdx.x; t < 16 * 16 * kBrickRow; t += 256) tile[t] = W(0);
   if (threadIdx.x == 0) s_bmax = 0u;
   __syncthreads();
   const int beg = brick_start[blockIdx.x], cnt = brick_start[blockIdx.x + 1] - beg;
@@ -177,14 +303,13 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     if (bm > 0.f) atomicMax(&s_bmax, __float_as_uint(bm * 1.0001f));    // non-negative floats order like their bits
   }
   __syncthreads();
-  const double bmax = (double)__uint_as_float(s_bmax), bound = 8.0 * bmax * (double)(cnt > 0 ? cnt : 1);
+  const double bmax = (double)__uint_as_float(s_bmax), bound = bmax * (double)(cnt > 0 ? cnt : 1);
   int ex = 20;
   if (bmax > 0.0) {
     if (sizeof(T) == 4) {
-      ex = 29 - ilogb(bmax);                             // f32: every term fits an int32 (|term| 2^ex < 2^30); the 64-bit
-                                                         // words then hold 2^32 of them; resolution bmax 2^-30 << f32 eps
+      ex = 29 - ilogb(bound);                            // f32: 2^ex * bound < 2^30, no 32-bit word (and no term) overflows
     } else {
-      ex = 61 - ilogb(bound);                            // f64: 2^ex * bound < 2^62, no word can overflow ...
+      ex = 58 - ilogb(bound);                            // f64: 2^ex * 8 bound < 2^62, no word can overflow ...
       const int e1 = 49 - ilogb(bmax);                   // ... and 2^ex * bmax < 2^50: every term fits the mantissa trick
       ex = ex < e1 ? ex : e1;
       ex = ex > 60 ? 60 : ex;
@@ -192,68 +317,42 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   }
   const T scale = (T)ldexp(1.0, ex);
   const double inv_scale = ldexp(1.0, -ex);
-  // Entries arrive in atom order; the list is read transposed -- lane l of the wavefront's pass p takes entry
-  // l * rows + p -- so the 64 entries of one instruction are `rows` list positions apart (different molecules).
-  const int rows = (cnt + 63) >> 6, lane = threadIdx.x & 63;
-  for (int pass = threadIdx.x >> 6; pass < rows; pass += 4) {
-    const int e = lane * rows + pass;
-    if (e >= cnt) continue;
-    T r[3], Q[9];
-    site_qtot(sites[entries[beg + e]], lpol, r, Q);
-    Stencil<T> st;
-    st.init(g, r);
-    T c1[3], c2[6];
-    fold_multipole(g, Q, c1, c2);
-    const T q = Q[0];
-    // The kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU = 86 % of its time at 18 instructions per stencil point), so
-    // the per-point work is stripped to 3 FMAs, the integer conversion and one mask test: the stencil's position is
-    // expressed once per entry RELATIVE to the brick (off = base - lo, folded by the period when the stencil reaches the
-    // brick across the periodic seam), so that point p of an axis sits at local index off + p with no wrap, the LDS
-    // address is "row + constant", and validity is one bit of a 6-bit mask per axis.
-    int off[3], ok[3];
+  const int lane = threadIdx.x & 63;
+  for (int c0 = 0; c0 < cnt; c0 += kBrickChunk) {
+    const int nch = min(kBrickChunk, cnt - c0);
+    // counting sort of the chunk by class: LDS atomics on three counters hand out the places within a class
+    __syncthreads();                                   // the previous chunk's order is no longer read
+    if (threadIdx.x < 4) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    int kind[kBrickChunk / 256], slot[kBrickChunk / 256];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const int period = d == 0 ? g.wrap0 : g.K[d];
-      int o = st.base[d] - lo[d];
-      if (o + 5 < 0) o += period;                      // stencil starts before the seam, ends inside this brick
-      else if (o >= n[d]) o -= period;                 // brick at the low end, stencil wraps around from the high end
-      off[d] = o;
-      int m = 0;
-#pragma unroll
-      for (int p6 = 0; p6 < 6; ++p6) m |= ((unsigned)(o + p6) < (unsigned)n[d]) << p6;
-      ok[d] = m;
-    }
-    if (!(ok[0] && ok[1] && ok[2])) continue;
-    // z axis: no branch per point -- an out-of-brick point gets zero weights and a clamped (in-tile) index, so it adds an
-    // exact integer 0 to a word of the row; x and y keep their `continue` (they skip 36 / 6 points at a time)
-    T wz[6], w1z[6], w2z[6];
-    int jz[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const bool in = (ok[2] >> c) & 1;
-      wz[c] = in ? st.M[2][c] : T(0); w1z[c] = in ? st.D1[2][c] : T(0); w2z[c] = in ? st.D2[2][c] : T(0);
-      const int j = off[2] + c;
-      jz[c] = j < 0 ? 0 : (j >= n[2] ? n[2] - 1 : j);
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      if (!((ok[0] >> a) & 1)) continue;
-      const int ja = off[0] + a;
-      const T m0 = st.M[0][a], d0 = st.D1[0][a], e0 = st.D2[0][a];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        if (!((ok[1] >> b) & 1)) continue;
-        const int jb = off[1] + b;
-        const T m1 = st.M[1][b], d1 = st.D1[1][b], e1 = st.D2[1][b];
-        const T mm = m0 * m1;
-        // the power-of-two scale goes into the three (a, b) factors: exact, and no multiply per point
-        const T P0 = scale * (q * mm + c1[0] * d0 * m1 + c1[1] * m0 * d1 + c2[0] * e0 * m1 + c2[1] * m0 * e1 + c2[3] * d0 * d1);
-        const T P1 = scale * (c1[2] * mm + c2[4] * d0 * m1 + c2[5] * m0 * d1);
-        const T P2 = scale * (c2[2] * mm);
-        unsigned long long* row = tile + (ja * 16 + jb) * kBrickRow;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) atomicAdd(&row[jz[c]], fixed_bits(P0 * wz[c] + P1 * w1z[c] + P2 * w2z[c]));
+    for (int k = 0; k < kBrickChunk / 256; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      kind[k] = 0; slot[k] = 0;
+      if (e < nch) {
+        kind[k] = ADMP_SPREAD_CLASSES ? site_kind(sites[entries[beg + c0 + e]], lpol) : SK_GENERAL;
+        slot[k] = atomicAdd(&s_hist[kind[k]], 1);
       }
+    }
+    __syncthreads();
+    const int n_gen = s_hist[SK_GENERAL], n_dip = s_hist[SK_DIPOLE];
+#pragma unroll
+    for (int k = 0; k < kBrickChunk / 256; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      if (e < nch) s_order[(kind[k] == SK_GENERAL ? 0 : (kind[k] == SK_DIPOLE ? n_gen : n_gen + n_dip)) + slot[k]] = (unsigned short)e;
+    }
+    __syncthreads();
+    // 64 consecutive places of the sorted chunk per wave instruction: one class, except where two classes meet (that
+    // group takes the general form, which is right for every entry)
+    const int groups = (nch + 63) >> 6;
+    for (int grp = threadIdx.x >> 6; grp < groups; grp += 4) {
+      const int first = grp << 6, last = min(first + 64, nch);
+      const int place = first + lane;
+      if (place >= nch) continue;
+      const Site<T>& site = sites[entries[beg + c0 + s_order[place]]];
+      if (first >= n_gen + n_dip) brick_add_entry<T, SK_CHARGE>(tile, site, lpol, g, lo, n, scale);
+      else if (first >= n_gen && last <= n_gen + n_dip) brick_add_entry<T, SK_DIPOLE>(tile, site, lpol, g, lo, n, scale);
+      else brick_add_entry<T, SK_GENERAL>(tile, site, lpol, g, lo, n, scale);
     }
   }
   __syncthreads();
@@ -262,14 +361,14 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     for (int t = threadIdx.x; t < ntot; t += 256) {
       const int ja = t >> 8, jb = (t >> 4) & 15, jc = t & 15;
       mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] =
-          (T)((double)(long long)tile[(ja * 16 + jb) * kBrickRow + jc] * inv_scale);
+          (T)brick_value(tile[(ja * 16 + jb) * kBrickRow + jc], inv_scale);
     }
   } else {
     const float inv_yz = 1.0f / (float)nyz, inv_z = 1.0f / (float)n[2];
     for (int t = threadIdx.x; t < ntot; t += 256) {
       const int ja = fast_div(t, nyz, inv_yz), rem = t - ja * nyz, jb = fast_div(rem, n[2], inv_z), jc = rem - jb * n[2];
       mesh[((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc] =
-          (T)((double)(long long)tile[(ja * 16 + jb) * kBrickRow + jc] * inv_scale);
+          (T)brick_value(tile[(ja * 16 + jb) * kBrickRow + jc], inv_scale);
     }
   }
   // this brick's binning counters are consumed: clear them for the next binning (no memset dispatches per step)

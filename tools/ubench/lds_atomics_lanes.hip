@@ -6,6 +6,8 @@
 
 // pattern 0: lane l -> word l (+ moving offset): conflict free; 1: scattered (hash); 2: stride 17 words;
 // 3: 36 active lanes laid out as 6 rows of 6 consecutive words, row pitch `pitch`
+// 4 / 5 / 6: scattered, but the words of each contiguous group of 16 / 32 / 64 lanes are distinct modulo 16 / 32 / 64
+// (which grouping and modulus makes a scattered 64-bit atomic conflict free?)
 template <int PATTERN, class V = double>
 __global__ __launch_bounds__(256) void k(double* out, int iters, int active, int pitch) {
   __shared__ V tile[8192];
@@ -16,12 +18,15 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, int active, int
   if (PATTERN == 0) base = lane;
   else if (PATTERN == 1) base = (int)(((threadIdx.x + 1) * 2654435761u) >> 9) & 4095;
   else if (PATTERN == 2) base = lane * 17;
+  else if (PATTERN == 4) base = (((int)(((threadIdx.x + 1) * 2654435761u) >> 9) & 4095) & ~15) | (lane & 15);
+  else if (PATTERN == 5) base = (((int)(((threadIdx.x + 1) * 2654435761u) >> 9) & 4095) & ~31) | (lane & 31);
+  else if (PATTERN == 6) base = (((int)(((threadIdx.x + 1) * 2654435761u) >> 9) & 4095) & ~63) | (lane & 63);
   else base = (lane / 6) * pitch + (lane % 6);
   base += (threadIdx.x >> 6) * 64;
   if (lane < active) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) atomicAdd(&tile[(base + u * 97 + it * 13) & 8191], V(1));
+      for (int u = 0; u < 16; ++u) atomicAdd(&tile[(base + (PATTERN >= 4 ? u * 128 + it * 64 : u * 97 + it * 13)) & 8191], V(1));
     }
   }
   __syncthreads();
@@ -56,6 +61,9 @@ int main() {
   // integer atomics (fixed-point accumulation): 64-bit and 32-bit
   run<0, unsigned long long>("u64 consecutive", 64, 0);
   run<1, unsigned long long>("u64 scattered", 64, 0);
+  run<4, unsigned long long>("u64 scattered, distinct mod 16 per 16 lanes", 64, 0);
+  run<5, unsigned long long>("u64 scattered, distinct mod 32 per 32 lanes", 64, 0);
+  run<6, unsigned long long>("u64 scattered, distinct mod 64 per 64 lanes", 64, 0);
   run<0, unsigned>("u32 consecutive", 64, 0);
   run<1, unsigned>("u32 scattered", 64, 0);
   run<0, float>("f32 consecutive", 64, 0);
