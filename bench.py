@@ -287,13 +287,15 @@ def roofline_of(rep, w, n_pairs):
     ms, cnt = rep.get('pair_full', (0.0, 0))
     avg_s = (ms / cnt) * 1e-3 if cnt else float('nan')
     alg = total / avg_s / 1e9 if cnt else float('nan')
-    traffic = tag = valu = None
+    traffic = tag = valu = n_trans = n_f64 = None
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tfile):
         try:
             rec = json.load(open(tfile)).get(w['name'], {})
             traffic = rec.get('pair_full_bytes_per_launch')
             valu = rec.get('pair_full_valu_insts_per_launch')
+            n_trans = rec.get('pair_full_valu_trans_insts_per_launch')
+            n_f64 = rec.get('pair_full_valu_f64_insts_per_launch')
             tag = rec.get('measured_at')
         except Exception:
             traffic = None
@@ -305,6 +307,13 @@ def roofline_of(rep, w, n_pairs):
         rate = valu / avg_s / 1e9
         out.update({'bound': 'valu', 'achieved': round(rate, 2), 'peak': VALU_PEAK_GINST, 'unit': 'G wave-instructions/s',
                     'frac': round(rate / VALU_PEAK_GINST, 5), 'valu_insts_per_launch': int(valu)})
+        if n_trans is not None and n_f64 is not None:
+            # not every instruction issues in 2 cycles: transcendentals (exp / rcp / rsq / sqrt) take 8, f64 arithmetic 4
+            # (MI355X_MICROARCH.md constants table; f64 vector peak = half of f32).  The issue cycles the kernel's instruction
+            # mix needs per SIMD against the SIMD cycles of the launch (2.4 GHz):
+            cyc = 2.0 * (valu - n_trans - n_f64) + 8.0 * n_trans + 4.0 * n_f64
+            out['valu_issue_cycles_frac'] = round(cyc / 1024.0 / (avg_s * 2.4e9), 5)
+            out['valu_mix'] = {'transcendental': int(n_trans), 'f64': int(n_f64)}
     else:      # no counter record for this workload: fall back to the contract's byte figure, labelled as such
         out.update({'bound': 'hbm', 'achieved': round(alg, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(alg / HBM_PEAK_GBS, 5)})

@@ -5,7 +5,7 @@
 out=$1; sub=$2; shift 2
 root=$(pwd); export TMPDIR=/tmp
 rm -rf gpurun_out/$out
-rocprofv3 --pmc "$@" --kernel-trace -d $root/gpurun_out/$out --output-format csv -- python3 $root/bench.py --workload ${WORKLOAD:-S3} --steps 3 --warmup 2 --no-cpu --no-scale --no-extras > gpurun_out/$out.log 2>&1
+timeout -k 5 120 rocprofv3 --pmc "$@" --kernel-trace -d $root/gpurun_out/$out --output-format csv -- python3 $root/bench.py --workload ${WORKLOAD:-S3} --steps 3 --warmup 2 --no-cpu --no-scale --no-extras > gpurun_out/$out.log 2>&1
 python3 - "$out" "$sub" <<'PY'
 import csv, glob, collections, sys
 out, sub = sys.argv[1], sys.argv[2]

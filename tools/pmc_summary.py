@@ -29,9 +29,20 @@ for wl in ('S1', 'S2', 'S3'):
                 agg[r['Kernel_Name']].append(float(r['Counter_Value']))
         for k, v in agg.items():
             per[k][c] = (sum(v) / len(v), len(v))
+    mix = collections.defaultdict(lambda: collections.defaultdict(list))      # instruction classes of the pair kernel
+    for f in glob.glob(os.path.join(src, 'pmc_%s_MIX' % wl, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'k_pair_full' in r['Kernel_Name']:
+                mix[r['Counter_Name']]['v'].append(float(r['Counter_Value']))
     if not per:
         continue
     out[wl] = {}
+    if mix:
+        avg = {c: sum(d['v']) / len(d['v']) for c, d in mix.items()}
+        out[wl]['pair_full_valu_trans_insts_per_launch'] = int(avg.get('SQ_INSTS_VALU_TRANS_F32', 0) + avg.get('SQ_INSTS_VALU_TRANS_F64', 0))
+        out[wl]['pair_full_valu_f64_insts_per_launch'] = int(avg.get('SQ_INSTS_VALU_FMA_F64', 0) + avg.get('SQ_INSTS_VALU_ADD_F64', 0) +
+                                                             avg.get('SQ_INSTS_VALU_MUL_F64', 0))
+        out[wl]['pair_full_valu_cvt_insts_per_launch'] = int(avg.get('SQ_INSTS_VALU_CVT', 0))
     for k, d in sorted(per.items()):
         fk = d.get('FETCH_SIZE', (0.0, 0))
         wk = d.get('WRITE_SIZE', (0.0, 0))
