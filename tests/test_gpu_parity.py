@@ -359,8 +359,14 @@ SLAB_PROC_WORKER = '''
 import os, sys
 sys.path.insert(0, %r)
 import numpy as np, torch, torch.distributed as dist
-dist.init_process_group('gloo')
-torch.cuda.set_device(0)
+backend = os.environ.get('ADMP_TEST_BACKEND', 'gloo')
+local = int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0       # gloo: the ranks share GPU 0
+torch.cuda.set_device(local)
+if backend == 'nccl':
+    import datetime
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(seconds=120))
+else:
+    dist.init_process_group('gloo')
 from admp_amd import systems as S
 from admp_amd.parallel import SlabPme, TorchComm
 from admp_amd.pme import ADMPPmeForce
@@ -394,6 +400,23 @@ def test_slab_decomposition_two_processes_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
                         '--master-addr', '127.0.0.1', '--master-port', '29541', str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'SLAB-PROC-OK 2' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_slab_decomposition_two_processes_rccl(tmp_path):
+    """The same worker on TWO GPUs over RCCL (backend nccl: device-to-device all-to-all, send / recv ring shifts, MAX and
+    SUM all-reduces on the library's buffers).  Needs two devices: skipped on the one-GPU box this suite usually runs on."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    script = tmp_path / 'slab_worker.py'
+    script.write_text(SLAB_PROC_WORKER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', ADMP_TEST_BACKEND='nccl', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29543', str(script)],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and 'SLAB-PROC-OK 2' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
@@ -986,6 +1009,40 @@ def test_cutoff_on_skin_list_equals_exact_list(precision):
     from admp_amd._lib import AdmpHipError
     with pytest.raises(AdmpHipError):
         d.set_cutoff(-1.0)
+
+
+def test_spread_fixed_point_tile_dense_brick_and_large_charges(precision):
+    """The f32 brick spread sums 32-bit fixed-point words whose scale comes from the brick's entry count and largest folded
+    multipole: 2100 atoms crowded into one 6 A cube (ten times the entries of a liquid brick) and a few charges a thousand
+    times the others must neither overflow a word nor drown the rest.  Reciprocal space only (empty pair list), f32
+    against f64."""
+    from admp_amd.pme import ADMPPmeForce
+    nm = 8192
+    pos, box = S.synthetic_water_box(nm, seed=77)
+    at, ai, cov = S.water_topology(nm)
+    par = S.water_parameters(nm, False)
+    rng = np.random.default_rng(5)
+    pos = pos.copy().reshape(nm, 3, 3)
+    centre = pos[:700, 0].copy()
+    pos[:700] += (20.0 + 6.0 * rng.random((700, 1, 3))) - centre[:, None, :]        # 700 molecules into one 6 A cube
+    pos = pos.reshape(-1, 3)
+    Q = par['Q_local'].copy()
+    Q[3 * 4000:3 * 4000 + 30] *= 1000.0                                            # ten molecules with huge multipoles
+    pairs = np.zeros((0, 2), dtype=np.int32)
+    out = {}
+    for prec in ('double', 'single'):
+        settings.PRECISION = prec
+        f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=False)
+        E, G = f.get_forces(pos, box, pairs, Q, par['mScales'])
+        out[prec] = (float(E), np.array(G, dtype=np.float64), max(abs(x) for x in f.energy_parts))
+    E64, G64, scale = out['double']
+    E32, G32, _ = out['single']
+    assert np.isfinite(G32).all() and abs(E32 - E64) < 2e-5 * scale
+    assert rel(G32, G64) < 2e-4
+    quiet = np.ones(len(G64), bool)
+    quiet[3 * 4000:3 * 4000 + 30] = False
+    quiet[:2100] = False
+    assert rel(G32[quiet], G64[quiet]) < 2e-3       # the ordinary atoms are not drowned by the bricks that hold the outliers
 
 
 def test_full_size_directional_derivative(precision):
