@@ -354,6 +354,195 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
 }
 
+// ---- z and y lines of one x plane in ONE workgroup (round 3) ------------------------------------------------------------
+// A pass of the chain above is 11-14 us of kernel for 1-2 us of f64 arithmetic at 97^3: ~4 us between the kernel's start and
+// its first block / its last block and its end, ~3 us of loads, ~1 us of stores, a 48-step dependent loop over < 2 waves per
+// SIMD (tools/ubench/dftm_phases.hip).  The z and the y lines of one x plane touch only that plane: 97 x 97 reals and its
+// 97 x 49 half spectrum fit the 160 KB of LDS together, so one workgroup of 1024 threads per plane does both transforms --
+// one launch, one load of the plane, one store of the spectrum, and 16 waves per CU to hide the loop's LDS latency.  Measured
+// at 97^3 f64 (rocprof / HIP events): z 11.2 + y 13.5 us as two passes; one workgroup per plane 32 us (97 of 256 CUs, bound by
+// their f64 FMAs); two workgroups per plane (below) 24.5 us forward, 23.2 us inverse: the step 0.234 -> 0.219 ms.  The z results are paired in place along y (row j <- x_j + x_{N-j}, row N-j <-
+// x_j - x_{N-j}: dft_pair_outputs_rows) between the two stages.
+constexpr int kZyBlock = 1024;
+
+template <class T>
+struct ZyLayout {          // LDS carve-up of the plane kernels (bytes); the same for both directions
+  size_t tw3, tw2, a, x0, b, total;
+  __host__ __device__ ZyLayout(int N2, int N3) {
+    const size_t H3 = (size_t)(N3 - 1) / 2, Kh = (size_t)N3 / 2 + 1;
+    tw3 = 0;
+    tw2 = tw3 + sizeof(Cx<T>) * N3;
+    a = tw2 + sizeof(Cx<T>) * N2;                          // forward: z pair sums [H3][N2]; inverse: y results [N2][Kh]
+    const size_t fa = sizeof(Cx<T>) * H3 * N2, ia = sizeof(Cx<T>) * N2 * Kh;
+    x0 = a + (fa > ia ? fa : ia);                          // forward: x_0 and x_{N/2} of the z lines [2][N2]
+    b = x0 + sizeof(Cx<T>) * N2;                           // the plane's half spectrum [N2][Kh]
+    total = b + sizeof(Cx<T>) * N2 * Kh;
+  }
+};
+
+// gridDim.z = 2 splits a plane between two workgroups (K1 planes alone leave most of the 256 CUs idle and the kernel is then
+// bound by the f64 FMAs of its CUs): forward by kz halves -- a z line's outputs are independent, so each workgroup computes
+// its half of the outputs of every z line and transforms its own columns along y; inverse by halves of the y output pairs
+// (y, N-y) -- each workgroup transforms every column along y for its pairs only and then the z lines of those y.  Both
+// load the whole plane.
+template <class T, int KQ>
+__global__ __launch_bounds__(kZyBlock) void k_dft_zy_fwd(int N2, int N3, const T* __restrict__ mesh, Cx<T>* __restrict__ spec,
+                                                         const Cx<T>* __restrict__ tw2g, const Cx<T>* __restrict__ tw3g,
+                                                         long mesh_stride, long spec_stride) {
+  const ZyLayout<T> L(N2, N3);
+  const int H3 = (N3 - 1) / 2, Kh = N3 / 2 + 1, H2 = (N2 - 1) / 2;
+  const int kz0 = (int)(((long)Kh * blockIdx.z) / gridDim.z), kz1 = (int)(((long)Kh * (blockIdx.z + 1)) / gridDim.z);
+  const int Kl = kz1 - kz0;                                     // this workgroup's columns
+  Cx<T>* tw3 = reinterpret_cast<Cx<T>*>(dft_smem + L.tw3);
+  Cx<T>* tw2 = reinterpret_cast<Cx<T>*>(dft_smem + L.tw2);
+  Cx<T>* p = reinterpret_cast<Cx<T>*>(dft_smem + L.a);          // [H3][N2]
+  T* x0 = reinterpret_cast<T*>(dft_smem + L.x0);                // [N2], then xn [N2]
+  T* xn = x0 + N2;
+  Cx<T>* Z = reinterpret_cast<Cx<T>*>(dft_smem + L.b);          // [N2][Kl]
+  const T* plane = mesh + blockIdx.y * mesh_stride + (long)blockIdx.x * N2 * N3;
+  Cx<T>* out = spec + blockIdx.y * spec_stride + (long)blockIdx.x * N2 * Kh;
+  for (int t = threadIdx.x; t < N3; t += kZyBlock) tw3[t] = tw3g[t];
+  for (int t = threadIdx.x; t < N2; t += kZyBlock) tw2[t] = tw2g[t];
+  for (int t = threadIdx.x; t < H3 * N2; t += kZyBlock) {
+    const int l = t / H3, jj = t - l * H3;
+    const T* x = plane + (long)l * N3;
+    const T a = x[1 + jj], b = x[N3 - 1 - jj];
+    p[jj * N2 + l] = Cx<T>{a + b, a - b};
+  }
+  for (int l = threadIdx.x; l < N2; l += kZyBlock) {
+    x0[l] = plane[(long)l * N3];
+    xn[l] = (N3 & 1) ? T(0) : plane[(long)l * N3 + N3 / 2];
+  }
+  __syncthreads();
+  // z lines: task = (line l, group g of KQ of this workgroup's outputs)
+  const int TK3 = (Kl + KQ - 1) / KQ;
+  for (int task = threadIdx.x; task < N2 * TK3; task += kZyBlock) {
+    const int l = task / TK3, g = task - l * TK3;
+    int k[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK3 < Kl) ? kz0 + g + q * TK3 : 0;
+    Cx<T> X[KQ];
+    rdft_outputs<T, KQ>(N3, k, N2, p + l, x0[l], xn[l], tw3, X);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+      if (g + q * TK3 < Kl) Z[l * Kl + g + q * TK3] = X[q];
+  }
+  __syncthreads();
+  // pair the rows along y in place
+  for (int t = threadIdx.x; t < H2 * Kl; t += kZyBlock) {
+    const int jj = t / Kl, c = t - jj * Kl;
+    const Cx<T> a = Z[(1 + jj) * Kl + c], b = Z[(N2 - 1 - jj) * Kl + c];
+    Z[(1 + jj) * Kl + c] = Cx<T>{a.re + b.re, a.im + b.im};
+    Z[(N2 - 1 - jj) * Kl + c] = Cx<T>{a.re - b.re, a.im - b.im};
+  }
+  __syncthreads();
+  // y lines: task = (group g, column c): neighbouring threads store neighbouring kz
+  const int Kh2 = N2 / 2 + 1, TK2 = (Kh2 + KQ - 1) / KQ;
+  for (int task = threadIdx.x; task < TK2 * Kl; task += kZyBlock) {
+    const int g = task / Kl, c = task - g * Kl;
+    int k[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK2 < Kh2) ? g + q * TK2 : 0;
+    Cx<T> Xk[KQ], Xnk[KQ];
+    dft_pair_outputs_rows<T, -1, KQ>(N2, k, Kl, Z + c, tw2, Xk, Xnk);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK2;
+      if (kq < Kh2) {
+        out[(long)kq * Kh + kz0 + c] = Xk[q];
+        if (kq != 0 && 2 * kq != N2) out[(long)(N2 - kq) * Kh + kz0 + c] = Xnk[q];
+      }
+    }
+  }
+}
+
+template <class T, int KQ>
+__global__ __launch_bounds__(kZyBlock) void k_dft_yz_inv(int N2, int N3, const Cx<T>* __restrict__ spec, T* __restrict__ mesh,
+                                                         const Cx<T>* __restrict__ tw2g, const Cx<T>* __restrict__ tw3g,
+                                                         long mesh_stride, long spec_stride, T* __restrict__ accum) {
+  __shared__ int s_lines[2 * 160 + 2];
+  __shared__ int s_nlines;
+  const ZyLayout<T> L(N2, N3);
+  const int Kh = N3 / 2 + 1, H2 = (N2 - 1) / 2;
+  Cx<T>* tw3 = reinterpret_cast<Cx<T>*>(dft_smem + L.tw3);
+  Cx<T>* tw2 = reinterpret_cast<Cx<T>*>(dft_smem + L.tw2);
+  Cx<T>* V = reinterpret_cast<Cx<T>*>(dft_smem + L.a);          // y results [N2][Kh] (this workgroup's rows filled)
+  Cx<T>* Z = reinterpret_cast<Cx<T>*>(dft_smem + L.b);          // the plane's spectrum [N2][Kh]
+  const Cx<T>* in = spec + blockIdx.y * spec_stride + (long)blockIdx.x * N2 * Kh;
+  T* plane = mesh + blockIdx.y * mesh_stride + (long)blockIdx.x * N2 * N3;
+  T* acc = accum ? accum + (long)blockIdx.x * N2 * N3 : nullptr;      // SCF increment: phi += this mesh in the same pass
+  const int Kh2 = N2 / 2 + 1, TK2 = (Kh2 + KQ - 1) / KQ;
+  const int g0 = (int)(((long)TK2 * blockIdx.z) / gridDim.z), g1 = (int)(((long)TK2 * (blockIdx.z + 1)) / gridDim.z);
+  for (int t = threadIdx.x; t < N3; t += kZyBlock) tw3[t] = tw3g[t];
+  for (int t = threadIdx.x; t < N2; t += kZyBlock) tw2[t] = tw2g[t];
+  if (threadIdx.x == 0) {            // the y lines this workgroup produces: both members of its output pairs
+    int n = 0;
+    for (int g = g0; g < g1; ++g)
+      for (int q = 0; q < KQ; ++q) {
+        const int kq = g + q * TK2;
+        if (kq >= Kh2) continue;
+        s_lines[n++] = kq;
+        if (kq != 0 && 2 * kq != N2) s_lines[n++] = N2 - kq;
+      }
+    s_nlines = n;
+  }
+  // rows 0 and N/2 as they are, the others paired on the way in (row j and row N-j by the same thread)
+  for (int t = threadIdx.x; t < (H2 + 1) * Kh; t += kZyBlock) {
+    const int jj = t / Kh, c = t - jj * Kh;
+    if (jj == H2) {                                   // rows 0 and (N2 even) N2/2
+      Z[c] = in[c];
+      if ((N2 & 1) == 0) Z[(N2 / 2) * Kh + c] = in[(long)(N2 / 2) * Kh + c];
+      continue;
+    }
+    const Cx<T> a = in[(long)(1 + jj) * Kh + c], b = in[(long)(N2 - 1 - jj) * Kh + c];
+    Z[(1 + jj) * Kh + c] = Cx<T>{a.re + b.re, a.im + b.im};
+    Z[(N2 - 1 - jj) * Kh + c] = Cx<T>{a.re - b.re, a.im - b.im};
+  }
+  __syncthreads();
+  for (int task = threadIdx.x; task < (g1 - g0) * Kh; task += kZyBlock) {
+    const int g = g0 + task / Kh, c = task % Kh;
+    int k[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK2 < Kh2) ? g + q * TK2 : 0;
+    Cx<T> Xk[KQ], Xnk[KQ];
+    dft_pair_outputs_rows<T, +1, KQ>(N2, k, Kh, Z + c, tw2, Xk, Xnk);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK2;
+      if (kq < Kh2) {
+        V[kq * Kh + c] = Xk[q];
+        if (kq != 0 && 2 * kq != N2) V[(N2 - kq) * Kh + c] = Xnk[q];
+      }
+    }
+  }
+  __syncthreads();
+  // z lines back: line l reads its half spectrum V[l][0 .. Kh)
+  const int TK3 = (Kh + KQ - 1) / KQ, nl = s_nlines;
+  for (int task = threadIdx.x; task < nl * TK3; task += kZyBlock) {
+    const int l = s_lines[task / TK3], g = task % TK3;
+    int j[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) j[q] = (g + q * TK3 < Kh) ? g + q * TK3 : 0;
+    const Cx<T>* v = V + l * Kh;
+    T xj[KQ], xnj[KQ];
+    irdft_pair_outputs<T, KQ>(N3, j, 1, v + 1, v[0].re, (N3 & 1) ? T(0) : v[N3 / 2].re, tw3, xj, xnj);
+    T* x = plane + (long)l * N3;
+    T* ac = acc ? acc + (long)l * N3 : nullptr;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int jq = g + q * TK3;
+      if (jq < Kh) {
+        x[jq] = xj[q];
+        if (ac) ac[jq] += xj[q];
+        if (jq != 0 && 2 * jq != N3) {
+          x[N3 - jq] = xnj[q];
+          if (ac) ac[N3 - jq] += xnj[q];
+        }
+      }
+    }
+  }
+}
+
 // ---- launchers.  K = mesh dimensions, tw = (cos, sin) tables of K[0], K[1], K[2] back to back.
 #define KQ_SWITCH(CALL) { constexpr int KQ = 2; constexpr int JS = 1; CALL; }
 
@@ -401,8 +590,37 @@ void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, con
                                                              reinterpret_cast<const Cx<T>*>(tw), energies, slot,
                                                              spec_stride / 2)))
 }
+// the two plane kernels in place of launch_dft_z + launch_dft_y (forward) / launch_dft_y + launch_dft_z (inverse)
+template <class T>
+bool dft_zy_fits(const int K[3]) {
+  static const bool off = [] { const char* e = getenv("ADMP_DFT_PLANES"); return e && atoi(e) == 0; }();
+  // two workgroups per plane must fit the chip in one round (one workgroup per CU): with more planes the separate passes win
+  return !off && 2 * K[0] <= 256 && ZyLayout<T>(K[1], K[2]).total + 2048 <= 160 * 1024;      // (+ the kernels' static LDS)
+}
+template <class T>
+bool launch_dft_zy(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb, long mesh_stride,
+                   long spec_stride, T* accum) {
+  const size_t sh = ZyLayout<T>(K[1], K[2]).total;
+  const Cx<T>* t1 = reinterpret_cast<const Cx<T>*>(tw) + K[0];
+  const Cx<T>* t2 = t1 + K[1];
+  const dim3 grid(K[0], nb, 2);                  // two workgroups per plane
+  static size_t attr_set[2] = {0, 0};            // more than 64 KB of dynamic LDS has to be asked for (per kernel and size)
+  if (inverse) {
+    auto kern = k_dft_yz_inv<T, 2>;
+    if (attr_set[1] < sh) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set[1] = sh; }
+    kern<<<grid, kZyBlock, sh, st>>>(K[1], K[2], reinterpret_cast<const Cx<T>*>(spec), mesh, t1, t2, mesh_stride, spec_stride / 2,
+                                     nb == 1 ? accum : nullptr);
+    return accum != nullptr && nb == 1;
+  }
+  auto kern = k_dft_zy_fwd<T, 2>;
+  if (attr_set[0] < sh) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set[0] = sh; }
+  kern<<<grid, kZyBlock, sh, st>>>(K[1], K[2], mesh, reinterpret_cast<Cx<T>*>(spec), t1, t2, mesh_stride, spec_stride / 2);
+  return false;
+}
 #undef KQ_SWITCH
 #define INST(T)                                                                                   \
+  template bool dft_zy_fits<T>(const int*);                                                       \
+  template bool launch_dft_zy<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*); \
   template bool launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*); \
   template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int, int, long);           \
   template void launch_dft_x_conv<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long);

@@ -968,14 +968,21 @@ struct Engine : EngineBase {
     }
     if (use_dft) {
       const T* tw = dft_tw.as<T>();
-      { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 0); }
-      { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec_p, 0); }
+      const bool planes = dft_zy_fits<T>(K);         // z and y lines of a plane in one workgroup (dft_kernels.hip)
+      if (planes) { TIMED("dft_zy_fwd"); launch_dft_zy<T>(stream, K, tw, mesh_p, spec_p, 0); }
+      else {
+        { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 0); }
+        { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec_p, 0); }
+      }
       DftTabs<T> tabs;
       tabs.p[0] = gtab;
       { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec_p, tabs, Ed, slot); }
-      { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec_p, 1); }
       bool added;
-      { TIMED("dft_z_c2r"); added = launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 1, 1, 0, 0, accum); }
+      if (planes) { TIMED("dft_yz_inv"); added = launch_dft_zy<T>(stream, K, tw, mesh_p, spec_p, 1, 1, 0, 0, accum); }
+      else {
+        { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec_p, 1); }
+        { TIMED("dft_z_c2r"); added = launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 1, 1, 0, 0, accum); }
+      }
       return added;
     }
     if (use_fx) {      // rocFFT for the y-z planes, one fused kernel for x forward * G * x inverse

@@ -164,6 +164,12 @@ template <class T>
 struct DftTabs {
   const T* p[3] = {nullptr, nullptr, nullptr};
 };
+// z and y lines of every x plane in one kernel (dft_kernels.hip, round 3); dft_zy_fits: the plane and its spectrum fit the LDS
+template <class T>
+bool dft_zy_fits(const int K[3]);
+template <class T>
+bool launch_dft_zy(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb = 1, long mesh_stride = 0,
+                   long spec_stride = 0, T* accum = nullptr);
 template <class T>
 bool launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb = 1,
                   long mesh_stride = 0, long spec_stride = 0,                                     // r2c / c2r along z

@@ -225,7 +225,9 @@ print('DFT-RUN-OK')
     # 'dft': the direct line transforms of dft_kernels.hip
     # 'pfa': the two-level (Good-Thomas) kernels of pfa_kernels.hip forced onto these small meshes, every dimension split
     # that has a coprime split (34 = 2 * 17, 38 = 2 * 19, 96 = 32 * 3, 100 = 4 * 25, 45 = 9 * 5, 51 = 3 * 17; 31, 97, 64 plain)
-    modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'pfa': dict(ADMP_DFT='2', ADMP_PFA_MIN='0')}
+    # 'dft' runs the z and y lines of a plane in one kernel where the plane fits the LDS; 'dft_passes' keeps them apart
+    modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'dft_passes': dict(ADMP_DFT='1', ADMP_DFT_PLANES='0'),
+             'pfa': dict(ADMP_DFT='2', ADMP_PFA_MIN='0')}
     for mode, extra in modes.items():
         path = str(tmp_path / ('%s.npz' % mode))
         r = subprocess.run([sys.executable, '-c', code, path], capture_output=True, text=True,
@@ -234,7 +236,7 @@ print('DFT-RUN-OK')
         res[mode] = dict(np.load(path))
     assert len(res['rocfft']) == 2 * 4 * 5
     for key, a in res['rocfft'].items():
-        for mode in ('dft', 'pfa'):
+        for mode in ('dft', 'dft_passes', 'pfa'):
             b = res[mode][key]
             tol = 1e-10 if key.startswith('double') else 2e-4
             scale = np.abs(a).max()
