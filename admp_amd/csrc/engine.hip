@@ -548,6 +548,9 @@ struct Engine : EngineBase {
     free_programs();
     if (Eh) (void)hipHostFree(Eh);
     prof.destroy();
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 
@@ -1223,6 +1226,42 @@ struct Engine : EngineBase {
   void check_mono_inputs(bool use_mono) {
     if (use_mono && !rq_d.p) throw Err{ADMP_E_STATE, "charge-only pair forms requested without the compact site rows"};
   }
+  // ---- a second stream for the real-space kernels of small systems (round 3) ---------------------------------------------
+  // At a few thousand atoms a kernel fills a fraction of the chip and a step is a chain of ~20 short dispatches; the pair
+  // kernels (sites -> gradient / potential / field rows) do not depend on the mesh chain (spread -> convolution) that runs
+  // next to them, so they go to a side stream between a fork (side waits for what main has enqueued so far) and a join (main
+  // waits for the side stream before the first kernel that reads or adds to the pair kernel's rows: the gathers).
+  // ADMP_OVERLAP_MAX: atom count up to which this is done (0 = never); larger systems fill the chip with every kernel.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_busy = false;
+  bool overlap_ok() const {
+    static const int mx = [] { const char* e = getenv("ADMP_OVERLAP_MAX"); return e ? atoi(e) : 20000; }();
+    return snranks == 1 && top.na <= mx;
+  }
+  template <class F>
+  void on_side(F&& f) {
+    if (!overlap_ok()) { f(); return; }
+    if (!side) {
+      HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(ev_fork, stream));
+    HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+    hipStream_t main_stream = stream;
+    stream = side;
+    try { f(); } catch (...) { stream = main_stream; throw; }
+    stream = main_stream;
+    HIP_TRY(hipEventRecord(ev_join, side));
+    side_busy = true;
+  }
+  void join_side() {
+    if (!side_busy) return;
+    HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+    side_busy = false;
+  }
+
   void stage_pair_full(T* grad_p, T* fld_out = nullptr) {
     need_eval();
     if (snranks > 1)   // the closing kernel ADDS frame-adjoint contributions to atoms of other ranks: those rows start at zero
@@ -1248,6 +1287,7 @@ struct Engine : EngineBase {
       ff.pol = ev.pol; ff.Ucart = ev.U; ff.fld_pair = fld_pair.as<T>(); ff.kappa = (T)kappa;
       ff.field = field.as<T>(); ff.fmax_bits = fmax_word();
     }
+    join_side();                       // the gather adds to the rows the pair kernel has set
     TIMED("gather");
     launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff,
                      e_recip);
@@ -1312,6 +1352,7 @@ struct Engine : EngineBase {
                          act_list(), nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole);
   }
   void first_gather_field(const FieldFin<T>& ff) {   // reciprocal dE/dU of the polarizable rows from phi
+    join_side();                     // (its epilogue reads the pair field)
     TIMED("gather_field");
     launch_gather_field<T>(stream, nact_rows(), sites.as<Site<T>>(), ev.g, mesh.as<T>(), fld_recip.as<T>(), act_list(), 1,
                            nact_arg(), nullptr, ff);
@@ -1377,9 +1418,11 @@ struct Engine : EngineBase {
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("build_ind_table: ") + hipGetErrorString((hipError_t)rc)};
       ind_nbr_gen = nbr_gen; ind_act_gen = act_gen;
     }
-    { TIMED("pair_field_ind");
+    on_side([&] {
+      TIMED("pair_field_ind");
       launch_pair_field_ind<T>(stream, n_act, ind, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                               act_list()); }
+                               act_list());
+    });
     const size_t nreal = nreal_local();
     mesh2.need(nreal * sizeof(T));
     { TIMED("spread_ind");
@@ -1393,6 +1436,7 @@ struct Engine : EngineBase {
       ind_bins_eval = eval_seq; ind_bins_n = n_act; ind_bins_gen = act_gen; ind_bins_at = bins_ind.cell_start;
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)}; }
     const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>());
+    join_side();
     { TIMED("gather_field_ind");
       launch_gather_field<T>(stream, n_act, isites.as<Site<T>>(), ev.g, mesh2.as<T>(), fld_recip.as<T>(), nullptr, 1, nullptr,
                              act_list(), check_word ? field_epilogue(check_word) : FieldFin<T>()); }
@@ -1524,7 +1568,7 @@ struct Engine : EngineBase {
       ++scf_stats[chain ? 3 : (speculate ? 1 : 0)];
       if (chain) {
         n_act = nact_known();
-        first_pair_field();
+        on_side([&] { first_pair_field(); });
         recip_pass(E_SCF_RECIP);
         auto word = [&](int k) {      // residual of check k: E_FMAX, then the (still zero) chain words of this evaluation
           return k == 0 ? fmax_word() : reinterpret_cast<unsigned long long*>(Ed_cur() + E_FMAX1 + (k - 1));
@@ -1532,12 +1576,14 @@ struct Engine : EngineBase {
         next_check_word();
         first_gather_field(field_epilogue(word(0)));
         launch_field_check(word(0));
+        const bool early_full = overlap_ok();       // the closing pair kernel next to the last increment's mesh chain
         for (int c = 0; c < nhat; ++c) {
           scf_jacobi(n_act, word(c), thresh);        // a zero step once a check has passed: later residuals repeat it
+          if (early_full && c == nhat - 1) on_side([&] { stage_pair_full(gbuf); });      // (the dipoles are final now)
           scf_increment(n_act, word(c + 1));
           launch_field_check(word(c + 1));
         }
-        stage_pair_full(gbuf);
+        if (!early_full) stage_pair_full(gbuf);
         stage_gather(mesh.as<T>(), gbuf, nullptr, false, Ed_cur() + E_SLOTS);
         launch_finish_only(dpos ? gbuf : nullptr, dQl);
         read_energies(E_PARTS_SUM, E);
@@ -1569,7 +1615,7 @@ struct Engine : EngineBase {
         // again, the step is already finished (no separate field kernels, no second pass).  Same arithmetic and
         // same (U, flag, i) as the plain loop; a failed check only costs the difference between the kernels.
         // The closing kernel is enqueued speculatively as well, so the step has ONE host synchronisation.
-        stage_pair_full(gbuf, fld_pair.as<T>());
+        on_side([&] { stage_pair_full(gbuf, fld_pair.as<T>()); });
         recip_pass(E_SCF_RECIP);
         // small systems are dispatch-bound: the field finish rides in the gather's epilogue; larger ones keep the two
         // kernels (98k atoms: gather 26 -> 47 us fused against 9 us saved; 1M atoms: 0.40 vs 0.31 + 0.056 ms)
@@ -1597,7 +1643,7 @@ struct Engine : EngineBase {
       }
       for (; !done && i < max_cycle; ++i) {     // admp/pme.py:132-138
         if (!have_base) {        // first field evaluation of the call: everything, at the polarizable sites
-          first_pair_field();
+          on_side([&] { first_pair_field(); });
           recip_pass(E_SCF_RECIP);
           unsigned long long* w = fuse_ok() ? next_check_word() : nullptr;
           first_gather_field(field_epilogue(w));
@@ -1631,14 +1677,15 @@ struct Engine : EngineBase {
 
     const bool atoms_energy = phi_valid && phi_accum;
     if (!done) {
-      stage_pair_full(gbuf);
-      if (!phi_valid) recip_pass(E_RECIP);
+      if (!phi_valid) { on_side([&] { stage_pair_full(gbuf); }); recip_pass(E_RECIP); }
+      else stage_pair_full(gbuf);
       // (the partial words are zero: nothing else of this evaluation writes them)
       stage_gather(mesh.as<T>(), gbuf, nullptr, false, atoms_energy ? Ed_cur() + E_SLOTS : nullptr);
     }
     if (!finished)
       stage_finish(dpos ? gbuf : nullptr, dQl, atoms_energy ? (int)E_PARTS_SUM : (phi_valid ? (int)E_SCF_RECIP : (int)E_RECIP), E);
 
+    join_side();
     if (!on_device) {
       if (dpos_) HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
       if (dQl_) HIP_TRY(hipMemcpyAsync(dQl_, dQl, 9 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
