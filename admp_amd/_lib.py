@@ -31,6 +31,7 @@ PROTOTYPES = {
     'admp_share_neighbors': (_i32, [_vp, _vp]),
     'admp_num_pairs': (_i64, [_vp]),
     'admp_set_cutoff': (_i32, [_vp, _dbl]),
+    'admp_set_dipole_source': (_i32, [_vp, _vp]),
     'admp_pme_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _dp, _vp, _i32, _dbl, _dp, _vp, _vp,
                                     _ip, _ip, _i32]),
     'admp_pme_energy_fixed_dipoles': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _dp, _vp, _vp, _vp]),

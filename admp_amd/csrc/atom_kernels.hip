@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
                                                               RecipGeom<T> g, int4* __restrict__ bases,
                                                               int* __restrict__ act_list, int* __restrict__ act_count,
                                                               const int* __restrict__ cls, int* __restrict__ cls_flags,
-                                                              RQ4<T>* __restrict__ rq) {
+                                                              RQ4<T>* __restrict__ rq, T* __restrict__ Ucopy) {
   int i = blockIdx.x * kAtomBlock + threadIdx.x;
   if (zero_next && i < E_WORDS) zero_next[i] = 0.0;   // the NEXT evaluation's energy words (engine.hip: Ed_cur)
   if (act_list) {   // kernel-uniform: list of the polarizable sites (pol > 0); ONE counter update per workgroup (every
@@ -77,6 +77,8 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
   load3(pos, i, s.r);
   if (Ucart) {                     // C1_c2h: harmonic order (z, x, y) (admp/pme.py:235)
     s.U[0] = Ucart[3 * i + 2]; s.U[1] = Ucart[3 * i]; s.U[2] = Ucart[3 * i + 1];
+    // admp_set_dipole_source: the initial dipoles came from a read-only array; the evaluation's own array starts as a copy
+    if (Ucopy) { Ucopy[3 * i] = s.U[1]; Ucopy[3 * i + 1] = s.U[2]; Ucopy[3 * i + 2] = s.U[0]; }
   } else {
     s.U[0] = s.U[1] = s.U[2] = T(0);
   }
@@ -564,9 +566,9 @@ template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
                           const T* pol, const T* thole, const Box<T>& box, Site<T>* sites, double* zero_next,
                           const RecipGeom<T>& g, int4* bases, int* act_list, int* act_count, const int* cls,
-                          int* cls_flags, RQ4<T>* rq) {
+                          int* cls_flags, RQ4<T>* rq, T* Ucopy) {
   k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites, zero_next, g,
-                                                          bases, act_list, act_count, cls, cls_flags, rq);
+                                                          bases, act_list, act_count, cls, cls_flags, rq, Ucopy);
 }
 template <class T>
 void launch_site_classes(hipStream_t st, int na, const Site<T>* sites, int* cls) {
@@ -652,7 +654,7 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
                                              double*, const RecipGeom<T>*, int4*);                                      \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
                                         const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*, int*, int*,       \
-                                        const int*, int*, RQ4<T>*);                                                     \
+                                        const int*, int*, RQ4<T>*, T*);                                                 \
   template void launch_site_classes<T>(hipStream_t, int, const Site<T>*, int*);                                         \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
                                        unsigned long long*, const int*, const int*);                                    \

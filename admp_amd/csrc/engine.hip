@@ -179,6 +179,7 @@ struct EngineBase {
   // [4] ... that needed more steps than enqueued (closing pass wasted), [5] ... that enqueued more steps than needed,
   // [6] increments that ran for nothing in those, [7] Jacobi steps in total
   int64_t scf_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const void* U_src = nullptr;  // admp_set_dipole_source: read-only initial dipoles of the NEXT polarizable evaluation
   double cutoff = 0.0;          // admp_set_cutoff: listed pairs beyond it are skipped (0: every listed pair, as the reference)
   int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
   int keep_pol_sites = 0;       // ADMP_OPT_KEEP_POL_SITES: the caller vouches that the set {i : pol_i > 0} has not changed
@@ -1127,6 +1128,9 @@ struct Engine : EngineBase {
     ev.pol = lpol ? reinterpret_cast<const T*>(pol_) : nullptr;
     ev.thole = lpol ? reinterpret_cast<const T*>(thole_) : nullptr;
     ev.U = lpol ? reinterpret_cast<T*>(U_) : nullptr;
+    // admp_set_dipole_source (one shot): the initial dipoles are read from there, ev.U starts as their copy (k_prepare_sites)
+    const T* U_first = lpol && U_src ? reinterpret_cast<const T*>(U_src) : ev.U;
+    U_src = nullptr;
     sites.need(sizeof(Site<T>) * (size_t)na);
     pot.need(9 * (size_t)na * sizeof(T));
     energies_d.need(2 * E_WORDS * sizeof(double));
@@ -1165,10 +1169,10 @@ struct Engine : EngineBase {
       cls_pending = false;
       cls_sites_na = na;
       ++cls_quiet;
-      launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, ev.U, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>(),
+      launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, U_first, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>(),
                               energies_d.as<double>() + (size_t)(ehalf ^ 1) * E_WORDS, ev.g, bases_d.as<int4>(),
                               want_act ? act_d.as<int>() : nullptr, want_act ? nact_dev() : nullptr, nbr.cls,
-                              cls_flags_dev(), rq_p());
+                              cls_flags_dev(), rq_p(), U_first != ev.U ? ev.U : nullptr);
       ev.bases = bases_d.as<int4>();
       // First evaluation on a table compiled without classes: look at the flags right away (one extra host read, once) so
       // that this call already walks the parted rows -- a caller who evaluates once gets the reduced forms too.
@@ -2565,6 +2569,9 @@ int admp_set_comm(admp_handle* h, const admp_comm* comm) {
     e.comm = *comm;
     e.have_comm = true;
   });
+}
+int admp_set_dipole_source(admp_handle* h, const void* U_init) {
+  return guarded(h, [&](EngineBase& e) { e.U_src = U_init; });
 }
 int admp_set_cutoff(admp_handle* h, double rc) {
   return guarded(h, [&](EngineBase& e) {

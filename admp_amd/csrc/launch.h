@@ -111,7 +111,8 @@ void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, con
                           int* act_count = nullptr /* ... and their number: an int the caller has zeroed */,
                           const int* cls = nullptr /* NbrTable::cls, checked against the sites: flags OR-ed into ... */,
                           int* cls_flags = nullptr /* ... this word (CLS_STALE / CLS_BETTER) */,
-                          RQ4<T>* rq = nullptr /* optional: compact copy (position, charge) of every row */);
+                          RQ4<T>* rq = nullptr /* optional: compact copy (position, charge) of every row */,
+                          T* Ucopy = nullptr /* optional: Ucart is read-only; this array receives a copy of it */);
 template <class T>
 void launch_local_frames(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, T* out /* (na,3,3) */);
 // field (Cartesian dE/dU) = pair (harmonic order) + recip (cartesian) + self + penalty; also max |field| over

@@ -179,8 +179,12 @@ class ADMPPmeForce(HipForceBase):
             self._hint_pol_sites(pol, pol_t)
             pS, _ = self._harr('pS', pScales, ns)
             dS = self._harr('dS', dScales, ns)[0] if dScales is not None else pS
-            U = (torch.zeros((na, 3), dtype=self._dtype, device=self._device) if U_init is None
-                 else self._real(U_init, (na, 3)).clone())
+            if U_init is None:
+                U = torch.zeros((na, 3), dtype=self._dtype, device=self._device)
+            else:    # the caller's array is not touched: the library reads it and writes the new dipoles into a fresh one
+                U_first = self._real(U_init, (na, 3))
+                U = torch.empty((na, 3), dtype=self._dtype, device=self._device)
+                _lib.check(h, L.admp_set_dipole_source(h, self._ptr(U_first)), 'admp_set_dipole_source')
         maxiter = settings.MAX_N_POL if maxiter is None else int(maxiter)
         thresh = settings.POL_CONV if thresh is None else float(thresh)
         P = self._ptr

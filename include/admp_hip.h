@@ -96,6 +96,11 @@ int64_t admp_num_pairs(const admp_handle* h);   /* pairs kept (i < j) */
  * the pair arithmetic).  Honoured by the dispersion and Tang-Toennies pair kernels
  * (admp_disp_energy_grad, admp_tt_energy_grad); the multipolar PME kernels evaluate every listed pair. */
 int admp_set_cutoff(admp_handle* h, double rc);
+/* One shot, device pointers only: the NEXT admp_pme_energy_grad reads its initial dipoles from U_init ((Na,3), read-only) and
+ * uses U_inout purely as output (it starts as a copy made by the first kernel of the evaluation).  The reference's callers
+ * pass `U_init=pme.U_ind` and get a new array back (admp/pme.py:104-109: jnp arrays are immutable): with this entry the
+ * wrapper hands over a fresh output array without a device copy of its own.  NULL clears it. */
+int admp_set_dipole_source(admp_handle* h, const void* U_init);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 /* replaces: ADMPPmeForce.get_energy / get_forces (admp/pme.py:58-86, 108) including the induced

@@ -176,6 +176,36 @@ def test_admp_import_name_and_value_and_grad(env):
     assert abs(Ed - d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])[0]) < 1e-9 * abs(Ed)
 
 
+def test_initial_dipoles_are_read_only_and_results_are_new_arrays(env):
+    """admp/pme.py:104-109: `U_init` is an input (jnp arrays are immutable) and `pme.U_ind` a new array every call.  The
+    wrapper hands the library the caller's array as a read-only source (admp_set_dipole_source) and a fresh output array --
+    no device copy of its own; the caller's tensor must come back untouched, also when it is the previous call's U_ind."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    n_mol = 125
+    pos, box = S.synthetic_water_box(n_mol, seed=6)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, True)
+    pairs = S.build_pairs(pos, box, 4.0)
+    rest = (par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    dev = lambda x: torch.as_tensor(x, device='cuda')
+    p0 = dev(pos)
+    E0, _ = f.get_forces(p0, box, pairs, *rest)
+    U0 = f.U_ind
+    assert isinstance(U0, torch.Tensor)
+    keep = U0.clone()
+    p1 = p0 + 0.05 * torch.randn(p0.shape, generator=torch.Generator(device='cuda').manual_seed(3), device='cuda', dtype=p0.dtype)
+    E1, _ = f.get_forces(p1, box, pairs, *rest, U_init=U0)        # warm start from the previous result, geometry moved
+    U1 = f.U_ind
+    assert U1.data_ptr() != U0.data_ptr() and torch.equal(U0, keep)
+    assert float((U1 - U0).abs().max()) > 1e-6                     # the dipoles did move
+    cold = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    Ec, _ = cold.get_forces(p1, box, pairs, *rest, U_init=keep)    # the same call on another calculator
+    assert abs(Ec - E1) < 1e-9 * max(abs(x) for x in cold.energy_parts)
+    assert float((cold.U_ind - U1).abs().max()) < 1e-9 * float(U1.abs().max())
+
+
 def test_numpy_pair_list_refilled_in_place(env):
     """a caller who rewrites the same ndarray must get a fresh neighbour table (the whole array is hashed)."""
     from admp_amd.pme import ADMPPmeForce
