@@ -361,7 +361,10 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
 // 97 x 49 half spectrum fit the 160 KB of LDS together, so one workgroup of 1024 threads per plane does both transforms --
 // one launch, one load of the plane, one store of the spectrum, and 16 waves per CU to hide the loop's LDS latency.  Measured
 // at 97^3 f64 (rocprof / HIP events): z 11.2 + y 13.5 us as two passes; one workgroup per plane 32 us (97 of 256 CUs, bound by
-// their f64 FMAs); two workgroups per plane (below) 24.5 us forward, 23.2 us inverse: the step 0.234 -> 0.219 ms.  The z results are paired in place along y (row j <- x_j + x_{N-j}, row N-j <-
+// their f64 FMAs); two workgroups per plane (below) 24.5 us forward, 23.2 us inverse: the step 0.234 -> 0.219 ms.
+// Phases of the forward kernel (clock64 stamps, one workgroup): load + pair sums 3.0 us, z lines 6.6 us (1261 tasks: a second
+// round for 237 of them), pairing along y 0.5 us, y lines + stores 6.8 us.  Three outputs per z task (873 tasks, one round)
+// measured 2 % slower than two.  The z results are paired in place along y (row j <- x_j + x_{N-j}, row N-j <-
 // x_j - x_{N-j}: dft_pair_outputs_rows) between the two stages.
 constexpr int kZyBlock = 1024;
 
