@@ -180,6 +180,7 @@ struct EngineBase {
   // [6] increments that ran for nothing in those, [7] Jacobi steps in total
   int64_t scf_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const void* U_src = nullptr;  // admp_set_dipole_source: read-only initial dipoles of the NEXT polarizable evaluation
+  const void* U_src_now = nullptr;   // ... taken over by that evaluation (Engine::pme), consumed by its site pass
   double cutoff = 0.0;          // admp_set_cutoff: listed pairs beyond it are skipped (0: every listed pair, as the reference)
   int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
   int keep_pol_sites = 0;       // ADMP_OPT_KEEP_POL_SITES: the caller vouches that the set {i : pol_i > 0} has not changed
@@ -1129,8 +1130,8 @@ struct Engine : EngineBase {
     ev.thole = lpol ? reinterpret_cast<const T*>(thole_) : nullptr;
     ev.U = lpol ? reinterpret_cast<T*>(U_) : nullptr;
     // admp_set_dipole_source (one shot): the initial dipoles are read from there, ev.U starts as their copy (k_prepare_sites)
-    const T* U_first = lpol && U_src ? reinterpret_cast<const T*>(U_src) : ev.U;
-    U_src = nullptr;
+    const T* U_first = lpol && U_src_now ? reinterpret_cast<const T*>(U_src_now) : ev.U;
+    U_src_now = nullptr;
     sites.need(sizeof(Site<T>) * (size_t)na);
     pot.need(9 * (size_t)na * sizeof(T));
     energies_d.need(2 * E_WORDS * sizeof(double));
@@ -1496,6 +1497,10 @@ struct Engine : EngineBase {
   void pme(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
            const double* mS, const double* pS, void* U_, int max_cycle, double thresh, double* E, void* dpos_,
            void* dQl_, int* ncyc, int* conv, int on_device) override {
+    // (the one-shot dipole source is taken off the handle before anything can fail: a call that throws must not leave a
+    // pointer behind for the next one)
+    U_src_now = on_device ? U_src : nullptr;
+    U_src = nullptr;
     ARG_CHECK(snranks == 1 || on_device, "a slab-decomposed handle takes device pointers");
     ARG_CHECK(pos_ && box && Ql_ && E, "null argument");
     const int na = top.na;
@@ -2348,9 +2353,11 @@ static int guarded(admp_handle* h, F&& f) {
     return ADMP_OK;
   } catch (const Err& e) {
     h->err = e.msg;
+    h->eng->U_src = h->eng->U_src_now = nullptr;      // a failed call leaves no one-shot state behind
     return e.code;
   } catch (const std::exception& e) {
     h->err = e.what();
+    h->eng->U_src = h->eng->U_src_now = nullptr;
     return ADMP_E_ARG;
   }
 }
