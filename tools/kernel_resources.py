@@ -35,7 +35,7 @@ for line in out.splitlines():
         cur[k.strip()] = v.strip()
 print(f"{'kernel':58s} {'SGPR':>5s} {'VGPR':>5s} {'AGPR':>5s} {'scratch':>8s} {'occ':>4s} {'LDS':>7s}")
 for r in rows:
-    if flt in r['name']:
+    if flt in r['name'] and 'rocprim' not in r['name']:
         print(f"{r['name'][:58]:58s} {r.get('TotalSGPRs', '?'):>5s} {r.get('VGPRs', '?'):>5s} {r.get('AGPRs', '?'):>5s} "
               f"{r.get('ScratchSize [bytes/lane]', '?'):>8s} {r.get('Occupancy [waves/SIMD]', '?'):>4s} "
               f"{r.get('LDS Size [bytes/block]', '?'):>7s}")
