@@ -317,6 +317,10 @@ def roofline_of(rep, w, n_pairs):
     else:      # no counter record for this workload: fall back to the contract's byte figure, labelled as such
         out.update({'bound': 'hbm', 'achieved': round(alg, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(alg / HBM_PEAK_GBS, 5)})
+    if n_atoms <= int(os.environ.get('ADMP_OVERLAP_MAX', '200000')):
+        out['concurrent'] = ('this kernel runs on a side stream next to the spread / convolution kernels of the same step '
+                             '(engine.hip on_side): the HIP-event time brackets it on that stream and includes the time the '
+                             'two streams share the chip; its duration alone is the rocprofv3 average in profiles/')
     if traffic:
         out['traffic_source'] = 'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command%s), not collected in this run' % (
             ', ' + tag if tag else '')
