@@ -364,7 +364,8 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
 // their f64 FMAs); two workgroups per plane (below) 24.5 us forward, 23.2 us inverse: the step 0.234 -> 0.219 ms.
 // Phases of the forward kernel (clock64 stamps, one workgroup): load + pair sums 3.0 us, z lines 6.6 us (1261 tasks: a second
 // round for 237 of them), pairing along y 0.5 us, y lines + stores 6.8 us.  Three outputs per z task (873 tasks, one round)
-// measured 2 % slower than two.  The z results are paired in place along y (row j <- x_j + x_{N-j}, row N-j <-
+// measured 2 % slower than two; two lanes per z task, each summing half of the pair positions (three rounds of 24 steps
+// instead of two of 48, idle lanes running along for the shuffles): 17 % slower.  The z results are paired in place along y (row j <- x_j + x_{N-j}, row N-j <-
 // x_j - x_{N-j}: dft_pair_outputs_rows) between the two stages.
 constexpr int kZyBlock = 1024;
 
