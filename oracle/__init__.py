@@ -19,4 +19,13 @@ Pinning status
   independent Cartesian-tensor direct sum on isolated clusters, central finite
   differences of every gradient, and agreement with the values the survey
   derived independently.
+* one more reference-held number, percent level: the 1-2 component of
+  ``jax.grad(pot_disp, argnums=3)['mScales']`` printed in the reference's
+  ``examples/openmm_api/ref_out`` (-8.7891670e6) depends only on the rigid water geometry; the
+  oracle gives -8.896e6 on the shipped ``water1024.pdb`` (1.2 %;
+  ``tests/test_oracle_physics.py::test_oracle_vs_reference_held_mscale_gradient``, data in
+  ``tests/golden/ref_openmm_api_mscale_grad.json``).  Components [1], [4] and the three energies of the
+  reference's ``ref_out`` files belong to a different geometry (overlapping H-H contacts); they are
+  mutually consistent (221523.0 - 54660.043 = 166 863 vs 166834.94: ethresh 1e-5 vs 1e-4), i.e. one
+  coherent run on an input that was not shipped.  It does not lift "parity unpinned".
 """

@@ -506,6 +506,45 @@ def test_force_field_front_end_and_dispersion_parameter_gradients(env, tmp_path)
     assert set(gp) >= {'mScales', 'pScales', 'dScales', 'Q_local', 'pol', 'tholes'}
 
 
+def test_front_end_mscale_gradient_vs_reference_held_value(env, tmp_path):
+    """GPU twin of tests/test_oracle_physics.py::test_oracle_vs_reference_held_mscale_gradient: the reference's example
+    examples/openmm_api/run.py:40-43 (Hamiltonian -> createPotential -> pot_disp -> grad(..., argnums=3)['mScales']) run
+    through this package's front-end on the shipped water1024 geometry; the 1-2 component against the value the reference
+    holds in examples/openmm_api/ref_out (committed as data, tests/golden/ref_openmm_api_mscale_grad.json) at 2 %, and
+    against the oracle's autograd at 1e-8.  The other components of ref_out belong to a different geometry."""
+    import json
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples'))
+    import make_inputs
+    from admp.api import Hamiltonian, Topology, param_gradient
+    from oracle import admp_oracle as O
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref = json.load(open(os.path.join(here, 'golden', 'ref_openmm_api_mscale_grad.json')))
+    d = np.load(os.path.join(here, 'golden', 'p1_water1024.npz'))
+    make_inputs.write_pdb(str(tmp_path / 'water1024.pdb'), d['positions'], d['box'])
+    make_inputs.write_forcefield_xml(str(tmp_path / 'forcefield.xml'))
+    H = Hamiltonian(str(tmp_path / 'forcefield.xml'))
+    top = Topology.from_pdb(str(tmp_path / 'water1024.pdb'))
+    disp_g = H.getGenerators()[0]
+    pot_disp = H.createPotential(top, nonbondedCutoff=4.0)[0]
+    pos, box = top.positions, top.box
+    pairs = S.build_pairs(pos, box, 4.0)
+    g = np.asarray(param_gradient(pot_disp, pos, box, pairs, disp_g.params)['mScales'], dtype=np.float64)
+    want = ref['dE_dmScales'][0]
+    assert abs(g[0] - want) <= 0.02 * abs(want), (g, want)
+    assert g[2] == 0.0 and g[3] == 0.0
+    par = S.water_parameters(len(pos) // 3, True)
+    T = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64))          # noqa: E731
+    mS = torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0], dtype=torch.float64, requires_grad=True)
+    c = T(par['c_list'])
+    e = O.tt_damping_energy(T(pos), T(box), pairs, mS, disp_g.covalent_map, T(par['a_list']), T(par['b_list']), T(par['q_list']),
+                            c[:, 0]) - sum(O.disp_pme_parts(T(pos), T(box), pairs, c, mS, disp_g.covalent_map,
+                                                            disp_g.disp_force.kappa, (24, 24, 24), 10))
+    go, = torch.autograd.grad(e, [mS])
+    assert np.abs(g - go.numpy()).max() <= 1e-8 * np.abs(go.numpy()).max(), (g, go)
+
+
 def test_per_atom_parameter_gradients_of_dispersion_and_tang_toennies(env):
     """admp_disp_param_grad / admp_tt_param_grad (per-atom lists) against oracle autograd, both precisions, pmax 6 / 10."""
     import torch
