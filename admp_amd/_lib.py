@@ -57,6 +57,17 @@ PROTOTYPES = {
     'admp_scf_stats': (_i32, [_vp, _c.POINTER(_i64), _i32]),
     'admp_set_comm': (_i32, [_vp, _vp]),
     'admp_slab_home': (_i32, [_vp, _vp, _ip, _ip]),
+    'admp_rccl_unique_id': (_i32, [_vp]),
+    'admp_rccl_create': (_i32, [_c.POINTER(_vp), _i32, _vp, _i32, _i32]),
+    'admp_rccl_destroy': (_i32, [_vp]),
+    'admp_rccl_abort': (_i32, [_vp]),
+    'admp_rccl_stats': (_i32, [_vp, _c.POINTER(_i64), _c.POINTER(_i64), _i32]),
+    'admp_rccl_all_reduce': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    'admp_rccl_all_to_all_v': (_i32, [_vp, _vp, _c.POINTER(_i64), _vp, _c.POINTER(_i64), _i32, _vp]),
+    'admp_rccl_shift': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    'admp_rccl_version': (_i32, [_ip]),
+    'admp_rccl_last_error': (_c.c_char_p, []),
+    'admp_set_comm_rccl': (_i32, [_vp, _vp]),
     'admp_profile_enable': (_i32, [_vp, _i32]),
     'admp_profile_filter': (_i32, [_vp, _c.c_char_p]),
     'admp_profile_reset': (_i32, [_vp]),
@@ -67,7 +78,8 @@ PROTOTYPES = {
 # communicator of a slab-decomposed handle (include/admp_hip.h: admp_comm)
 T_I32, T_F32, T_F64 = 0, 1, 2
 OP_SUM, OP_MAX = 0, 1
-TAGS = {1: 'ghost_planes', 2: 'transpose', 3: 'halo_dipoles', 4: 'halo_gradient', 5: 'scf_max', 6: 'energies'}
+TAGS = {1: 'ghost_planes', 2: 'transpose', 3: 'halo_dipoles', 4: 'halo_gradient', 5: 'scf_max', 6: 'energies',
+        7: 'replicate_outputs'}
 _i64p = _c.POINTER(_i64)
 ALL_REDUCE_FN = _c.CFUNCTYPE(_i32, _vp, _vp, _i64, _i32, _i32, _i32)
 ALL_TO_ALL_V_FN = _c.CFUNCTYPE(_i32, _vp, _vp, _i64p, _vp, _i64p, _i32, _i32)
@@ -80,6 +92,8 @@ class AdmpComm(_c.Structure):
 
 OPT_REFERENCE_KPOINTS = 1
 OPT_KEEP_POL_SITES = 2
+OPT_SIDE_STREAM = 3
+RCCL_ID_BYTES, RCCL_NTAGS = 128, 8
 
 _lib = None
 

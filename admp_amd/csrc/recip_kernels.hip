@@ -125,9 +125,20 @@ __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__
 // so no term exceeds bmax and no word bmax * cnt.
 //   f64 meshes: 64-bit words, scale = the power of two that keeps 8 bmax cnt below 2^62 and bmax below 2^50 (the terms are
 //               turned into integers by the 2^52 + 2^51 trick: one f64 add and a 64-bit subtract); finer than f64 on O(1).
-//   f32 meshes: 32-bit words (round 3), scale keeps bmax cnt below 2^30: a resolution of 2^-30 bmax cnt, 5e-7 bmax for the
-//               ~600 entries of a brick of liquid water, rounded to nearest by v_cvt_rpi_i32_f32 -- a few 1e-7 of the mesh
-//               values, where the f32 path as a whole differs from f64 by 2e-5 (bench.py precision_check).
+//   f32 meshes: 32-bit words (round 3).  Round 3's scale kept bmax * cnt below 2^30 -- the worst case of EVERY entry of the
+//               brick landing on one word with weight 1.  That quantum (2^-30 of 1.56 x 580 for liquid water at 1M atoms,
+//               i.e. 2e-6 absolute per TERM, 14 terms per word) was 4e-5 of the mesh values: the f32 forces at 1M atoms went
+//               from 2.0e-5 to 8.3e-5 of the f64 ones (round-3 verdict).  Round 4 bounds what a word can actually receive:
+//                 (a) a term is q M M M + c1 (M' M M) + c2 (M'' M M | M' M' M) with max M = 0.55, max |M'| = 0.46004,
+//                     max |M''| = 1 for order 6 (attained at u = 3; checked numerically): bm_e = 0.1664 |q| + 0.1392 |c1|_1
+//                     + 0.3025 |c2|_1 instead of |q| + |c1|_1 + |c2|_1;
+//                 (b) only entries whose stencil covers a word add to it: the stencil bases of the entries, relative to the
+//                     brick (-5 .. 15 per axis), are histogrammed into 7^3 cells of 3 positions, weighted by bm_e in units
+//                     of 2^-20 bmax (integers, rounded up: the bound does not depend on the order of the adds, so the mesh
+//                     stays bitwise reproducible); the bases that reach a word span 6 positions = at most 3 cells per
+//                     axis, so the largest 3 x 3 x 3 block sum bounds sum_e |term_e| of every word.
+//               Liquid water at 1M atoms: 5.5 x from (a), ~10 x from (b): the quantum drops 50-fold, below f32 round-off
+//               of the values.  Bricks with more than 2048 entries fall back to (a) x cnt.
 //
 // The kernel is VALU bound (round 3: without its atomics it takes the same time; SQ_ACTIVE_INST_VALU 85 % of the SIMD
 // cycles), so the work per entry is cut by what the entry carries: most sites of a force field are bare charges (the
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   __shared__ unsigned s_bmax;
   __shared__ unsigned short s_order[kBrickChunk];
   __shared__ int s_hist[4];
+  __shared__ unsigned s_hist3[344];
   const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
   const int bb[3] = {bx, by, bz};
   int lo[3], n[3];
@@ -283,15 +295,81 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   __syncthreads();
   const int beg = brick_start[blockIdx.x], cnt = brick_start[blockIdx.x + 1] - beg;
   // pass 1: magnitude bound of this brick's folded multipoles -> fixed-point scale
-  {
-    // |c1|_1 <= amax |d|_1 and |c2|_1 <= 2 amax^2 |Theta/3|_1 with amax = the largest row (or column) sum of |Aop|
-    // (fold_multipole): a bound from norms costs a dozen instructions per entry instead of the fold itself
-    T amax = T(0);
+  // |c1|_1 <= amax |d|_1 and |c2|_1 <= 2 amax^2 |Theta/3|_1 with amax = the largest row (or column) sum of |Aop|
+  // (fold_multipole): a bound from norms costs a dozen instructions per entry instead of the fold itself
+  T amax = T(0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      amax = fmax(amax, m_abs(g.Aop[j]) + m_abs(g.Aop[3 + j]) + m_abs(g.Aop[6 + j]));
-      amax = fmax(amax, m_abs(g.Aop[3 * j]) + m_abs(g.Aop[3 * j + 1]) + m_abs(g.Aop[3 * j + 2]));
+  for (int j = 0; j < 3; ++j) {
+    amax = fmax(amax, m_abs(g.Aop[j]) + m_abs(g.Aop[3 + j]) + m_abs(g.Aop[6 + j]));
+    amax = fmax(amax, m_abs(g.Aop[3 * j]) + m_abs(g.Aop[3 * j + 1]) + m_abs(g.Aop[3 * j + 2]));
+  }
+  double bmax, bound;
+  if (sizeof(T) == 4) {
+    // (a) + (b) of the header comment.  A thread keeps the bounds and cells of its first kBrickChunk / 256 entries in
+    // registers between the two sub-passes (the unit of the histogram is known only after the maximum)
+    constexpr int kKeep = kBrickChunk / 256;
+    constexpr float kW0 = 0.55f * 0.55f * 0.55f, kW1 = 0.46004f * 0.55f * 0.55f, kW2 = 0.55f * 0.55f;   // see (a)
+    for (int t = threadIdx.x; t < 344; t += 256) s_hist3[t] = 0u;       // (word 343: the largest block sum)
+    float bme[kKeep];
+    int cell[kKeep];
+    float bm = 0.f;
+    auto bound_of = [&](int e, T r[3]) {
+      T Q[9];
+      site_qtot(sites[entries[beg + e]], lpol, r, Q);
+      const T d1 = m_abs(Q[1]) + m_abs(Q[2]) + m_abs(Q[3]);
+      const T q2 = m_abs(Q[4]) + m_abs(Q[5]) + m_abs(Q[6]) + m_abs(Q[7]) + m_abs(Q[8]);
+      return (float)(T(kW0) * m_abs(Q[0]) + T(kW1) * amax * d1 + T(kW2) * T(2) * amax * amax * q2);
+    };
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {                      // (compile-time k: the two arrays stay in registers)
+      const int e = threadIdx.x + 256 * k;
+      bme[k] = 0.f;
+      cell[k] = -1;
+      if (e < cnt) {
+        T r[3];
+        bme[k] = bound_of(e, r);
+        bm = fmaxf(bm, bme[k]);
+        int cl = 0;
+        bool in = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {                      // the stencil's base relative to the brick, as brick_add_entry sees it
+          int base;
+          (void)grid_ref(g, r, d, base);
+          const int period = d == 0 ? g.wrap0 : g.K[d];
+          int o = base - lo[d];
+          if (o + 5 < 0) o += period;
+          else if (o >= n[d]) o -= period;
+          in = in && o + 5 >= 0 && o < n[d];
+          cl = cl * 7 + (o + 5) / 3;
+        }
+        if (in) cell[k] = cl;                              // (an entry that misses the brick adds no term)
+      }
     }
+    for (int e = threadIdx.x + 256 * kKeep; e < cnt; e += 256) { T r[3]; bm = fmaxf(bm, bound_of(e, r)); }
+    if (bm > 0.f) atomicMax(&s_bmax, __float_as_uint(bm * 1.0001f));    // non-negative floats order like their bits
+    __syncthreads();
+    bmax = (double)__uint_as_float(s_bmax);
+    if (cnt <= kBrickChunk && bmax > 0.0) {
+      const float unit = (float)(1048576.0 / bmax);
+#pragma unroll
+      for (int k = 0; k < kKeep; ++k)
+        if (cell[k] >= 0) atomicAdd(&s_hist3[cell[k]], (unsigned)(bme[k] * unit) + 2u);      // rounded up: <= 2^20 + 2 each
+      __syncthreads();
+      if (threadIdx.x < 125) {
+        const int wx = threadIdx.x / 25, wy = (threadIdx.x / 5) % 5, wz = threadIdx.x % 5;
+        unsigned sum = 0u;
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b)
+            for (int c = 0; c < 3; ++c) sum += s_hist3[((wx + a) * 7 + wy + b) * 7 + wz + c];
+        atomicMax(&s_hist3[343], sum);
+      }
+      __syncthreads();
+      bound = bmax * (double)s_hist3[343] * (1.0 / 1048576.0);
+      if (bound < bmax) bound = bmax;
+    } else {
+      bound = bmax * (double)(cnt > 0 ? cnt : 1);
+    }
+  } else {
     float bm = 0.f;
     for (int e = threadIdx.x; e < cnt; e += 256) {
       T r[3], Q[9];
@@ -301,9 +379,10 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
       bm = fmaxf(bm, (float)(m_abs(Q[0]) + amax * d1 + T(2) * amax * amax * q2));
     }
     if (bm > 0.f) atomicMax(&s_bmax, __float_as_uint(bm * 1.0001f));    // non-negative floats order like their bits
+    __syncthreads();
+    bmax = (double)__uint_as_float(s_bmax);
+    bound = bmax * (double)(cnt > 0 ? cnt : 1);
   }
-  __syncthreads();
-  const double bmax = (double)__uint_as_float(s_bmax), bound = bmax * (double)(cnt > 0 ? cnt : 1);
   int ex = 20;
   if (bmax > 0.0) {
     if (sizeof(T) == 4) {

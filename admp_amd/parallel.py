@@ -21,15 +21,19 @@ on one GPU -- runs inside the library (`admp_pme_energy_grad` on a handle config
   * gradient      : contributions a rank made to atoms it does not own (local-frame adjoint of molecules that straddle a
                     slab face) go back to the owners over the same lists; the four energies by one SUM all-reduce.
 
-The library returns the rank's home rows of gradient / dipoles / dE/dQ_local.  With outputs='replicated' (default: the
-reference's API hands every caller the full arrays) they are summed over the ranks once per evaluation here; with
-outputs='home' nothing proportional to the number of atoms is ever sent -- each rank keeps its home rows (`home_atoms`),
-the form an MD driver that keeps the atoms distributed would use.
+The library returns the rank's home rows of gradient / dipoles / dE/dQ_local.  With outputs='home' (the default since round
+4) nothing proportional to the number of atoms is ever sent -- each rank keeps its home rows (`home_atoms`, the other rows
+are zero), the form an MD driver that keeps the atoms distributed uses.  outputs='replicated' gives every caller the full
+arrays, as the reference's single-device API does, at the price of one SUM all-reduce of (Na, 3) per output array.
 
-The communicator interface (`all_reduce`, `all_to_all_v`, `shift` on flat device tensors) has two implementations:
-torch.distributed (`TorchComm`: nccl = RCCL, or gloo with host staging) and an in-process thread communicator
-(`ThreadComm`) used by the tests.  Both count the bytes they send per label (`bytes_sent`) and, on request, time every
-collective with device events (`report`).  `SlabDispPme` / `SlabPairInteraction` decompose dispersion PME and the pair
+Communicators.  `RcclComm` (round 4, the production path): the library issues the collectives ITSELF -- ncclAllReduce and
+grouped ncclSend / ncclRecv on the handle's stream (admp_amd/csrc/rccl_comm.hip) -- Python only distributes the 128-byte
+unique id once, at construction.  `TorchComm` / `ThreadComm` implement the callback interface of include/admp_hip.h
+(`all_reduce`, `all_to_all_v`, `shift` on flat device tensors) on torch.distributed (gloo with host staging: functional
+rehearsal of several ranks on one GPU; nccl: the round-3 path, kept as the test double of the native one) and on in-process
+threads (tests).  `make_comm()` picks RcclComm for an nccl process group and TorchComm otherwise.  All count the bytes they
+send per label (`bytes_sent`) and time the collectives with device events (`report`; the native path through the library's
+own profiler labels `comm_*`).  `SlabDispPme` / `SlabPairInteraction` decompose dispersion PME and the pair
 potentials over the same slabs.
 """
 import collections
@@ -160,6 +164,101 @@ class TorchComm(_CommBase):
                 w.wait()
             if not self.native:
                 recv.copy_(r)
+
+
+class RcclComm(_CommBase):
+    """Native communicator: the collectives of a decomposed handle are RCCL calls made by libadmp_hip itself
+    (include/admp_hip.h admp_rccl_*), nothing re-enters Python during a step.  The 128-byte unique id is created on rank 0
+    and distributed over an existing torch.distributed group (any backend), or handed in by the caller (`unique_id` with
+    explicit `rank` / `size`: MPI, a file, ...)."""
+    native_rccl = True
+
+    def __init__(self, group=None, device=None, unique_id=None, rank=None, size=None):
+        self._L = _lib.load()
+        self._c = ctypes.c_void_p()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if unique_id is None:
+            import torch.distributed as dist
+            self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+            buf = ctypes.create_string_buffer(_lib.RCCL_ID_BYTES)
+            if self.rank == 0:
+                self._check(self._L.admp_rccl_unique_id(buf), 'admp_rccl_unique_id')
+            box = [bytes(buf.raw) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            unique_id = box[0]
+        else:
+            self.rank, self.size = int(rank), int(size)
+        if len(unique_id) != _lib.RCCL_ID_BYTES:
+            raise ValueError('unique_id must be %d bytes' % _lib.RCCL_ID_BYTES)
+        self._check(self._L.admp_rccl_create(ctypes.byref(self._c), self.device.index, unique_id, self.rank, self.size),
+                    'admp_rccl_create')
+        self._init_stats()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise _lib.AdmpHipError('%s failed (code %d): %s' % (what, rc, self._L.admp_rccl_last_error().decode()))
+
+    def version(self):
+        v = ctypes.c_int(0)
+        self._check(self._L.admp_rccl_version(ctypes.byref(v)), 'admp_rccl_version')
+        return int(v.value)
+
+    def all_reduce(self, t, op='sum', label='all_reduce'):
+        """in place on a contiguous device tensor, on the caller's current stream (the wrapper's `outputs='replicated'`)"""
+        dt = {torch.float32: _lib.T_F32, torch.float64: _lib.T_F64, torch.int32: _lib.T_I32}[t.dtype]
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._L.admp_rccl_all_reduce(self._c, ctypes.c_void_p(t.data_ptr()), t.numel(), dt,
+                                                 _lib.OP_MAX if op == 'max' else _lib.OP_SUM, ctypes.c_void_p(st)),
+                    'admp_rccl_all_reduce')
+        return t
+
+    def _pull_stats(self, reset=False):
+        b = (ctypes.c_int64 * _lib.RCCL_NTAGS)()
+        c = (ctypes.c_int64 * _lib.RCCL_NTAGS)()
+        self._check(self._L.admp_rccl_stats(self._c, b, c, 1 if reset else 0), 'admp_rccl_stats')
+        self.bytes_sent = collections.defaultdict(int, {_lib.TAGS[t]: int(b[t]) for t in _lib.TAGS if c[t]})
+        self.calls = collections.defaultdict(int, {_lib.TAGS[t]: int(c[t]) for t in _lib.TAGS if c[t]})
+
+    def refresh_stats(self):
+        """bytes_sent / calls per label since the last reset, read from the library"""
+        self._pull_stats()
+        return self.bytes_sent
+
+    def reset_stats(self):
+        if getattr(self, '_c', None) is not None and self._c.value:
+            self._pull_stats(reset=True)
+        self.bytes_sent = collections.defaultdict(int)
+        self.calls = collections.defaultdict(int)
+
+    def report(self, steps=1):
+        """collective times of the native path are the library profiler's `comm_*` labels (profile_report of the force)"""
+        return {}
+
+    def abort(self):
+        if self._c.value:
+            self._L.admp_rccl_abort(self._c)
+
+    def close(self):
+        if getattr(self, '_c', None) is not None and self._c.value:
+            self._L.admp_rccl_destroy(self._c)
+            self._c = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_comm(group=None, device=None):
+    """The communicator of this process for the slab calculators: RCCL issued by the library itself when the process group's
+    backend is nccl (one process per GPU), the host-staged TorchComm otherwise (gloo: rehearsals of several ranks on one GPU,
+    CPU tests).  ADMP_COMM=torch forces the callback path on nccl as well (A/B against the native one)."""
+    import os
+    import torch.distributed as dist
+    if dist.get_backend(group) == 'nccl' and os.environ.get('ADMP_COMM', 'rccl') != 'torch':
+        return RcclComm(group, device)
+    return TorchComm(group)
 
 
 class ThreadComm(_CommBase):
@@ -296,6 +395,10 @@ class CommBinding:
                                                    label=_lib.TAGS.get(tag, 'shift')))
 
 
+class _NoBinding:
+    error = None
+
+
 class _SlabMixin:
     """What the decomposed calculators share: binding the communicator to the handle, the home list of an evaluation and
     the assembly of per-atom outputs."""
@@ -308,6 +411,10 @@ class _SlabMixin:
         self.home_atoms = None
         self.n_home = 0
         self.n_import = 0
+        if getattr(comm, 'native_rccl', False):      # the library talks to RCCL itself: no callbacks
+            self._binding = _NoBinding()
+            _lib.check(self._h, self._L.admp_set_comm_rccl(self._h, comm._c), 'admp_set_comm_rccl')
+            return
         self._binding = CommBinding(comm, self._device)
         _lib.check(self._h, self._L.admp_slab_configure(self._h, comm.rank, comm.size), 'admp_slab_configure')
         _lib.check(self._h, self._L.admp_set_comm(self._h, ctypes.byref(self._binding.struct) if comm.size > 1 else None),
@@ -348,11 +455,11 @@ class _SlabMixin:
 
 class SlabPme(_SlabMixin, ADMPPmeForce):
     """ADMPPmeForce whose evaluation is spread over the ranks of `comm` (SPMD: every rank makes the same
-    get_energy / get_forces call with the same full input arrays).  outputs='replicated': every rank receives the full
-    gradient / dipoles; outputs='home': only the rows of `home_atoms` are valid on a rank (no O(Na) communication)."""
+    get_energy / get_forces call with the same full input arrays).  outputs='home' (default): only the rows of `home_atoms`
+    are valid on a rank (no O(Na) communication); outputs='replicated': every rank receives the full gradient / dipoles."""
 
     def __init__(self, comm, box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol=False, device=None,
-                 outputs='replicated'):
+                 outputs='home'):
         self._pending = (comm, outputs)
         super().__init__(box, axis_type, axis_indices, covalent_map, rc, ethresh, lmax, lpol, device)
 
@@ -374,7 +481,7 @@ class SlabDispPme(_SlabMixin, ADMPDispPmeForce):
     """ADMPDispPmeForce decomposed over the same x-slabs (real-space pairs over the home rows, the C6 / C8 / C10 meshes
     through the distributed transform, gathers at the home atoms)."""
 
-    def __init__(self, comm, box, covalent_map, rc, ethresh, pmax, device=None, outputs='replicated'):
+    def __init__(self, comm, box, covalent_map, rc, ethresh, pmax, device=None, outputs='home'):
         self._pending = (comm, outputs)
         super().__init__(box, covalent_map, rc, ethresh, pmax, device)
 
@@ -393,7 +500,7 @@ class SlabPairInteraction(_SlabMixin, _PairInteraction):
     """generate_pairwise_interaction(kernel, covalent_map, static_args) for the kernels of libadmp_hip (Tang-Toennies),
     decomposed over x-slabs: every rank evaluates the rows of its home atoms; one SUM all-reduce of the energy."""
 
-    def __init__(self, comm, kernel, covalent_map, static_args=None, outputs='replicated'):
+    def __init__(self, comm, kernel, covalent_map, static_args=None, outputs='home'):
         if not isinstance(kernel, _HipPairKernel):
             raise TypeError('the slab decomposition takes the named pair kernels of admp_amd.pairwise')
         super().__init__(kernel, covalent_map, static_args)

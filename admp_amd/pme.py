@@ -179,15 +179,18 @@ class ADMPPmeForce(HipForceBase):
             self._hint_pol_sites(pol, pol_t)
             pS, _ = self._harr('pS', pScales, ns)
             dS = self._harr('dS', dScales, ns)[0] if dScales is not None else pS
+        maxiter = settings.MAX_N_POL if maxiter is None else int(maxiter)
+        thresh = settings.POL_CONV if thresh is None else float(thresh)
+        P = self._ptr
+        if self.lpol:
             if U_init is None:
                 U = torch.zeros((na, 3), dtype=self._dtype, device=self._device)
             else:    # the caller's array is not touched: the library reads it and writes the new dipoles into a fresh one
                 U_first = self._real(U_init, (na, 3))
                 U = torch.empty((na, 3), dtype=self._dtype, device=self._device)
-                _lib.check(h, L.admp_set_dipole_source(h, self._ptr(U_first)), 'admp_set_dipole_source')
-        maxiter = settings.MAX_N_POL if maxiter is None else int(maxiter)
-        thresh = settings.POL_CONV if thresh is None else float(thresh)
-        P = self._ptr
+                # armed LAST, right before the call that consumes it: nothing that can raise stands between the two (a
+                # pointer left on the handle would be read by the next evaluation, possibly after U_first was freed)
+                _lib.check(h, L.admp_set_dipole_source(h, P(U_first)), 'admp_set_dipole_source')
         rc = L.admp_pme_energy_grad(h, P(pos), boxa, P(Q), P(pol_t), P(th_t), ns, mSa, pS, dS, P(U), maxiter, thresh, E,
                                     P(grad), P(dQ), self._out_ncyc_ref, self._out_conv_ref, 1)
         _lib.check(h, rc, 'admp_pme_energy_grad')

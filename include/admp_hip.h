@@ -68,10 +68,14 @@ enum {
   ADMP_OPT_REFERENCE_KPOINTS = 1,  /* value 1: build the reciprocal-space tables with the reference's literal k-point order
                                       (meshgrid(kz, kx, ky), admp/recip.py:339-340) instead of the axis-by-axis one; the
                                       two agree iff K1 = K2 = K3 on a cubic box.  Default 0. */
-  ADMP_OPT_KEEP_POL_SITES = 2      /* value 1: the caller vouches that the SET of polarizable sites {i : pol_i > 0} of the
+  ADMP_OPT_KEEP_POL_SITES = 2,     /* value 1: the caller vouches that the SET of polarizable sites {i : pol_i > 0} of the
                                       following admp_pme_energy_grad calls is the one of the previous call (the values may
                                       change); the library then keeps its list of those sites instead of rebuilding it in
                                       every call.  Default 0 (rebuild every call).  Speed only, never results. */
+  ADMP_OPT_SIDE_STREAM = 3         /* value 0: every kernel of a call runs on the handle's stream.  Default 1: on systems up to
+                                      200 000 atoms the real-space pair kernels run on a second stream next to the mesh chain
+                                      of the same call.  Speed only; switched off by measurements that bracket single kernels
+                                      with events (the event time of a kernel that shares the chip is not its duration). */
 };
 int admp_set_option(admp_handle* h, int option, int value);
 
@@ -264,6 +268,38 @@ int admp_slab_configure(admp_handle* h, int rank, int nranks);
 int admp_set_comm(admp_handle* h, const admp_comm* comm);
 /* out11 = {X0, X1, Y0, Y1, local planes (X1-X0+ghost), ghost, K1, K2, K3/2+1, rank, nranks} */
 int admp_slab_info(admp_handle* h, int64_t* out11);
+/* ---- native RCCL communicator (round 4) ---------------------------------------------------------------------
+ * The collectives of a decomposed handle issued by the library itself, on the handle's stream: ncclAllReduce, and
+ * ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd for the all-to-all-v and the ring shifts -- no callback, no host
+ * language in the step.  RCCL is bound at run time (dlopen of librccl.so.1; inside a PyTorch process that is the copy
+ * PyTorch already holds), so single-GPU users never load it.
+ *   admp_rccl_unique_id   rank 0 creates the 128-byte id (ncclGetUniqueId); the caller distributes it to the other ranks by
+ *                         whatever means it has (torch.distributed broadcast in admp_amd/parallel.py, MPI, a file ...)
+ *   admp_rccl_create      every rank: ncclCommInitRank on `device` (blocks until all ranks have joined)
+ *   admp_set_comm_rccl    binds the communicator to a handle: sets rank / nranks (as admp_slab_configure) and replaces the
+ *                         callbacks of admp_set_comm.  One communicator serves any number of handles of the process (PME,
+ *                         dispersion PME, pair potentials); it must outlive them.  NULL detaches.
+ *   admp_rccl_stats       bytes sent to other ranks / calls per ADMP_TAG_* (arrays of ADMP_RCCL_NTAGS), optionally cleared
+ *   admp_rccl_abort       ncclCommAbort: releases peers blocked in a collective of this communicator (error paths)
+ *   admp_rccl_all_reduce  in-place SUM / MAX over `count` elements of a caller-owned DEVICE buffer on `hip_stream` (what a
+ *                         driver that wants the reference's replicated outputs does once per output array; tag 7)
+ *   admp_rccl_all_to_all_v, admp_rccl_shift   the other two collectives of the decomposed evaluation on caller-owned DEVICE
+ *                         buffers, with the semantics of the admp_comm callbacks above (for drivers that move their own
+ *                         per-atom data between slab ranks, and for tests) */
+typedef struct admp_rccl admp_rccl;
+enum { ADMP_RCCL_ID_BYTES = 128, ADMP_RCCL_NTAGS = 8 };
+int admp_rccl_unique_id(void* out128);
+int admp_rccl_create(admp_rccl** out, int device, const void* id128, int rank, int nranks);
+int admp_rccl_destroy(admp_rccl* c);
+int admp_rccl_abort(admp_rccl* c);
+int admp_rccl_stats(admp_rccl* c, int64_t* bytes_out, int64_t* calls_out, int reset);
+int admp_rccl_all_reduce(admp_rccl* c, void* buf, int64_t count, int dtype /* ADMP_T_* */, int op /* ADMP_OP_* */, void* hip_stream);
+int admp_rccl_all_to_all_v(admp_rccl* c, const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
+                           int dtype, void* hip_stream);
+int admp_rccl_shift(admp_rccl* c, const void* send, void* recv, int64_t count, int dtype, int to_next, void* hip_stream);
+int admp_rccl_version(int* version);
+const char* admp_rccl_last_error(void);
+int admp_set_comm_rccl(admp_handle* h, admp_rccl* c);
 /* Outputs of a decomposed evaluation: dE_dpos / U_inout / dE_dQlocal hold this rank's HOME rows (the other rows are
  * unspecified); E_out, n_cycle and converged are the global values on every rank.  home_out (device, room for n_atoms
  * int32) receives the home atoms of the last evaluation in ascending order, *n_home their number; n_import (optional) the

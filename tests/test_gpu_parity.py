@@ -299,7 +299,7 @@ def _run_slab_ranks(nranks, prec, lpol, n_mol=125, seed=5):
 
     def work(rank):
         try:
-            f = SlabPme(ThreadComm(world, rank), box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+            f = SlabPme(ThreadComm(world, rank), box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol, outputs='replicated')
             if lpol:
                 E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
                                     par['pScales'], par['dScales'])
@@ -370,14 +370,14 @@ if backend == 'nccl':
 else:
     dist.init_process_group('gloo')
 from admp_amd import systems as S
-from admp_amd.parallel import SlabPme, TorchComm
+from admp_amd.parallel import SlabPme, make_comm
 from admp_amd.pme import ADMPPmeForce
 pos, box = S.synthetic_water_box(125, seed=5)
 at, ai, cov = S.water_topology(125)
 par = S.water_parameters(125, True)
 pairs = S.build_pairs(pos, box, 4.0)
 args = (pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
-f = SlabPme(TorchComm(), box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+f = SlabPme(make_comm(), box, at, ai, cov, 4.0, 1e-4, 2, lpol=True, outputs='replicated')
 E, G = f.get_forces(*args)
 E2, G2 = f.get_forces(*args, U_init=f.U_ind)          # second call: cached pair table, warm start
 ref = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
@@ -481,6 +481,91 @@ def test_rccl_collectives_on_library_buffers(tmp_path):
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547'))
     assert r.returncode == 0 and 'RCCL-OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+NATIVE_RCCL_WORKER = r'''
+import ctypes, os, sys
+sys.path.insert(0, %r)
+os.environ['ADMP_RCCL_SELF_SENDRECV'] = '1'      # one GPU: the rank's own segments go through ncclSend / ncclRecv too
+import torch
+from admp_amd import _lib
+from admp_amd.parallel import RcclComm
+L = _lib.load()
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+uid = ctypes.create_string_buffer(_lib.RCCL_ID_BYTES)
+assert L.admp_rccl_unique_id(uid) == 0, L.admp_rccl_last_error()
+comm = RcclComm(device=dev, unique_id=bytes(uid.raw), rank=0, size=1)
+assert comm.version() > 0
+hip = ctypes.CDLL('libamdhip64.so')
+n = 1 << 16
+bufs = []
+for _ in range(2):                      # device memory torch's allocator does not own, like the library's buffers
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(8 * n)) == 0
+    bufs.append(p.value)
+from admp_amd.parallel import _DevArray, _TORCH_OF
+def view(ptr, dt):
+    td, ts = _TORCH_OF[dt]
+    return torch.as_tensor(_DevArray(ptr, n, ts), device=dev)
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):           # the library runs on the caller's current stream, whichever it is
+    st = ctypes.c_void_p(side.cuda_stream)
+    for dt, tdt in ((_lib.T_F32, torch.float32), (_lib.T_F64, torch.float64), (_lib.T_I32, torch.int32)):
+        a, b = view(bufs[0], dt), view(bufs[1], dt)
+        ref = (torch.arange(n, device=dev) %% 977).to(tdt)
+        a.copy_(ref); b.zero_()
+        for op in (_lib.OP_SUM, _lib.OP_MAX):
+            assert L.admp_rccl_all_reduce(comm._c, bufs[0], n, dt, op, st) == 0, L.admp_rccl_last_error()
+        cnt = (ctypes.c_int64 * 1)(n)
+        assert L.admp_rccl_all_to_all_v(comm._c, bufs[0], cnt, bufs[1], cnt, dt, st) == 0, L.admp_rccl_last_error()
+        side.synchronize()
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+        b.zero_()
+        for to_next in (1, 0):
+            assert L.admp_rccl_shift(comm._c, bufs[0], bufs[1], n, dt, to_next, st) == 0, L.admp_rccl_last_error()
+            side.synchronize()
+            assert torch.equal(b, ref)
+            b.zero_()
+    # the SCF residual word: MAX over the bit patterns of non-negative doubles
+    w = view(bufs[0], _lib.T_F64)
+    w[0] = 12.5
+    assert L.admp_rccl_all_reduce(comm._c, bufs[0], 1, _lib.T_F64, _lib.OP_MAX, st) == 0
+    side.synchronize()
+    assert float(w[0]) == 12.5
+    # through a handle: admp_set_comm_rccl configures rank / nranks from the communicator
+    from admp_amd import systems as S
+    from admp_amd.parallel import SlabPme
+    from admp_amd.pme import ADMPPmeForce
+    pos, box = S.synthetic_water_box(64, seed=5)
+    at, ai, cov = S.water_topology(64)
+    par = S.water_parameters(64, True)
+    pairs = S.build_pairs(pos, box, 4.0)
+    args = (pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+    f = SlabPme(comm, box, at, ai, cov, 4.0, 1e-4, 2, lpol=True, outputs='replicated')
+    E, G = f.get_forces(*args)
+    Er, Gr = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True).get_forces(*args)
+    assert abs(E - Er) < 1e-9 * abs(Er) and abs(G - Gr).max() < 1e-9 * abs(Gr).max()
+comm.refresh_stats()
+assert comm.calls['replicate_outputs'] >= 6, dict(comm.calls)
+comm.close()
+print('NATIVE-RCCL-OK')
+'''
+
+
+def test_native_rccl_collectives_on_library_buffers(tmp_path):
+    """The round-4 communicator (admp_amd/csrc/rccl_comm.hip: RCCL called by the library itself, bound with dlsym) as far as
+    ONE GPU allows: a one-rank ncclComm created from a unique id, all-reduce SUM / MAX in the three element types, the
+    grouped ncclSend / ncclRecv of the all-to-all-v and of both ring-shift directions (the rank as its own peer:
+    ADMP_RCCL_SELF_SENDRECV), the residual word's MAX on bit patterns, on raw hipMalloc'ed buffers and a non-default stream;
+    then a handle bound to it with admp_set_comm_rccl.  Unexercised: traffic between different devices
+    (test_slab_decomposition_two_processes_rccl, skipped on a one-GPU box)."""
+    import subprocess
+    import sys
+    script = tmp_path / 'native_rccl_worker.py'
+    script.write_text(NATIVE_RCCL_WORKER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=dict(os.environ))
+    assert r.returncode == 0 and 'NATIVE-RCCL-OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 @pytest.mark.parametrize('prec', ['double', 'single'])
@@ -1163,7 +1248,7 @@ def test_slab_warm_regime_matches_fused_path(precision):
 
         def work(rank):
             try:
-                f = SlabPme(ThreadComm(world, rank), box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+                f = SlabPme(ThreadComm(world, rank), box, at, ai, cov, 4.0, 1e-4, 2, lpol=True, outputs='replicated')
                 a = f.get_forces(*args)                       # cold
                 b = f.get_forces(*args, U_init=U0)            # plain loop, passes at once -> arms the warm regime
                 c = f.get_forces(*args, U_init=U0)            # speculative cycle, passes
@@ -1218,11 +1303,11 @@ def test_slab_all_terms_and_parameter_outputs(precision):
             def work(rank):
                 try:
                     comm = ThreadComm(world, rank)
-                    f = SlabPme(comm, box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+                    f = SlabPme(comm, box, at, ai, cov, 4.0, 1e-4, 2, lpol=True, outputs='replicated')
                     r = f.get_forces_and_dQ(pos, box, pairs, *pol_args)
-                    d = SlabDispPme(comm, box, cov, 4.0, 1e-4, 10)
+                    d = SlabDispPme(comm, box, cov, 4.0, 1e-4, 10, outputs='replicated')
                     rd = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
-                    t = SlabPairInteraction(comm, TT_damping_qq_c6_kernel, cov)
+                    t = SlabPairInteraction(comm, TT_damping_qq_c6_kernel, cov, outputs='replicated')
                     rt = t.value_and_grad(pos, box, pairs, par['mScales'], *tt_lists)
                     out[rank] = (r, f.n_cycle, rd, d.energy_parts, rt, f.n_home, d.n_home, t.n_home)
                 except Exception as e:      # noqa: BLE001
@@ -1383,12 +1468,14 @@ def test_slab_halo_only_traffic_and_home_outputs(precision):
         assert sent['scf_max'] <= 8 * (ncyc + 1) and sent['energies'] <= 32
 
 
-@pytest.mark.parametrize('prec,tol', [('single', 1e-2), ('double', 2e-6)])
+@pytest.mark.parametrize('prec,tol', [('single', 3e-5), ('double', 2e-6)])
 def test_s2_config_size_vs_oracle_golden(precision, prec, tol):
     """BASELINE configs[2] AT SIZE (98 304 atoms, K = 128, rc 4 A) against the float64 oracle's numbers committed in
     tests/golden/s2_98304.npz (tests/golden/make_s2_golden.py, chunked evaluation): energy parts, gradient, dipoles and
-    SCF cycle count, non-polarizable and polarizable.  Bar (north_star): 1e-2 relative in single precision; the achieved
-    errors are printed.  The stored gradient / dipoles are float32 (6e-8), hence 2e-6 for the double-precision check."""
+    SCF cycle count, non-polarizable and polarizable.  Bar (north_star): 1e-2 relative in single precision; the test pins the
+    ACHIEVED level instead (gradient and dipoles <= 3e-5; 1.3e-5 / 1.2e-5 measured) so that a kernel change that spends the
+    margin shows up here -- round 3's 32-bit spread tile quadrupled the f32 force error at 1M atoms and no test saw it.
+    The stored gradient / dipoles are float32 (6e-8), hence 2e-6 for the double-precision check."""
     import torch
     from admp_amd.pme import ADMPPmeForce
     g = np.load(os.path.join(GOLD, 's2_98304.npz'))
