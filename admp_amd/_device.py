@@ -260,6 +260,11 @@ class HipForceBase:
         0 = evaluate every listed pair (default; what the reference does).  Dispersion and pair-potential calculators."""
         _lib.check(self._h, self._L.admp_set_cutoff(self._h, float(rc)), 'admp_set_cutoff')
 
+    def set_side_stream(self, on=True):
+        """ADMP_OPT_SIDE_STREAM: False keeps every kernel of a call on the handle's stream (clean per-kernel event times in
+        measurements); True (default) lets small systems run their pair kernels next to the mesh chain."""
+        _lib.check(self._h, self._L.admp_set_option(self._h, _lib.OPT_SIDE_STREAM, 1 if on else 0), 'admp_set_option')
+
     @property
     def n_pairs(self):
         return int(self._L.admp_num_pairs(self._h))

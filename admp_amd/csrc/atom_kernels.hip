@@ -471,6 +471,118 @@ __global__ __launch_bounds__(kAtomBlock) void k_finish_groups(Topology top, cons
   }
 }
 
+// Row form of the closing kernel (round 4).  k_finish_groups gives a lane one MOLECULE: its loads walk three 80-byte site
+// rows, 27 potential words, positions and gradient rows at a stride of 240 bytes between lanes -- every wave-level load
+// touches 64 cache lines, the address unit is busy 59 % of the kernel and the memory side moves 2.1 x the bytes the
+// kernel needs (round-3 verdict).  Here a lane takes one ATOM: neighbouring lanes read neighbouring rows (site row, pot,
+// gradient, axis record: all contiguous across the wave), every frame is still evaluated exactly once -- by its own site --
+// and what a frame needs of its group mates (positions in, gradient contributions out) goes through LDS: a workgroup owns a
+// run of WHOLE frame groups (Topology::rows_blk), so no group straddles two workgroups; each atom then pulls the
+// contributions addressed to it from the <= kMaxGroup - 1 mates of its group (no atomics).
+template <class T>
+__global__ __launch_bounds__(kFinishBlock) void k_finish_rows(Topology top, Box<T> box, const Site<T>* __restrict__ sites,
+                                                              const T* __restrict__ pol, int lpol, T kappa,
+                                                              const T* __restrict__ pot, T* __restrict__ grad,
+                                                              T* __restrict__ dQlocal, double* energies, FieldFin<T> ff,
+                                                              const int* __restrict__ slab_bits) {
+  __shared__ T spos[kFinishBlock][3];
+  __shared__ T sg[kFinishBlock][9];          // what the frame of site t adds to its z, x, y atoms
+  __shared__ int sidx[kFinishBlock][3];      // ... their indices relative to the workgroup's first atom (-1: none)
+  const int a0 = top.rows_blk[blockIdx.x], na_blk = top.rows_blk[blockIdx.x + 1] - a0;
+  const int t = threadIdx.x, i = a0 + t;
+  const bool live = t < na_blk;
+  // slab rank: a site is served by its owner; the contributions of its frame to atoms of other ranks land in their rows
+  // (zeroed by the caller) and travel to the owners afterwards.  bits == 0: an atom this rank neither owns nor reads.
+  const int bits = live ? (slab_bits ? slab_bits[i] : kSlabHome) : 0;
+  const bool mine = (bits & kSlabHome) != 0;
+  if (slab_bits && !__syncthreads_or(mine)) return;            // (workgroup-uniform) nothing of this rank's here
+  double eself = 0.0, epen = 0.0, fm = 0.0;
+  T gp[3] = {T(0), T(0), T(0)};
+  Site<T> s;
+  if (live) {
+    s = sites[i];
+    spos[t][0] = s.r[0]; spos[t][1] = s.r[1]; spos[t][2] = s.r[2];
+  }
+  sidx[t][0] = sidx[t][1] = sidx[t][2] = -1;
+  __syncthreads();
+  if (mine) {
+    T f[3], P[9];
+    self_factors(kappa, f);
+    total_potential(s, pot + 9 * (size_t)i, lpol, f, P, &eself);
+    if (lpol) {
+      T al = pol[i];
+      al = al < T(1e-8) ? T(1e-8) : al;
+      const double u2 = (double)s.U[0] * s.U[0] + (double)s.U[1] * s.U[1] + (double)s.U[2] * s.U[2];   // (harmonic order: same norm)
+      epen = kDielectric * 0.5 * u2 / (double)al;
+    }
+    if (ff.fmax_bits) {
+      const T al = ff.pol[i];
+      T fx, fy, fz;
+      total_field(s, al, ff.Ucart + 3 * i, ff.fld_pair + 3 * i, ff.fld_recip + 3 * i, ff.kappa, fx, fy, fz);
+      ff.field[3 * i] = fx; ff.field[3 * i + 1] = fy; ff.field[3 * i + 2] = fz;
+      if (al > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
+    }
+    if (grad) {
+      int type = top.axis_type[i];
+      const int iz = top.axis_idx[3 * i], ix = top.axis_idx[3 * i + 1], iy = top.axis_idx[3 * i + 2];
+      if (iz < 0) type = NoAxisType;
+      if (type == NoAxisType) {
+        if (dQlocal) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) dQlocal[9 * (size_t)i + q] = P[q];
+        }
+      } else {
+        const bool usex = type != Zonly, usey = (type == ZBisect || type == ThreeFold);
+        const int lz = iz - a0, lx = usex && ix >= 0 ? ix - a0 : -1, ly = usey && iy >= 0 ? iy - a0 : -1;
+        T pz[3] = {0, 0, 0}, px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                                  // (group mates: inside this workgroup by construction)
+          pz[c] = spos[lz][c];
+          if (ix >= 0) px[c] = spos[ix - a0][c];
+          if (iy >= 0) py[c] = spos[iy - a0][c];
+        }
+        FrameWork<T> w;
+        local_frame_fwd(type, box, s.r, pz, px, py, w);
+        T tau[3], gz[3], gx[3], gy[3];
+        multipole_torque(P, s.Q, tau);
+        local_frame_bwd(type, w, tau, gp, gz, gx, gy);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sg[t][c] = gz[c]; sg[t][3 + c] = gx[c]; sg[t][6 + c] = gy[c]; }
+        sidx[t][0] = lz; sidx[t][1] = lx; sidx[t][2] = ly;
+        if (dQlocal) {
+          T dl[9];
+          rot_harm(P, w.X, w.Y, w.Z, dl);
+#pragma unroll
+          for (int q = 0; q < 9; ++q) dQlocal[9 * (size_t)i + q] = dl[q];
+        }
+      }
+    }
+  }
+  if (grad) {                                 // kernel-uniform
+    __syncthreads();
+    if (bits != 0) {
+      const int rec = top.grp_of[i], g0 = (rec >> 2) - a0, gn = (rec & 3) + 1;
+      T acc[3] = {gp[0], gp[1], gp[2]};
+      for (int m = g0; m < g0 + gn; ++m) {     // the frames of the group's sites (its own included: an axis atom may be the site)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (sidx[m][k] == t) { acc[0] += sg[m][3 * k]; acc[1] += sg[m][3 * k + 1]; acc[2] += sg[m][3 * k + 2]; }
+      }
+      grad[3 * (size_t)i] += acc[0]; grad[3 * (size_t)i + 1] += acc[1]; grad[3 * (size_t)i + 2] += acc[2];
+    }
+  }
+  eself = block_reduce_sum<kFinishBlock>(eself);
+  epen = block_reduce_sum<kFinishBlock>(epen);
+  if (threadIdx.x == 0) {
+    atomicAdd(&energies[E_SELF], eself);
+    if (lpol) atomicAdd(&energies[E_PEN], epen);
+  }
+  if (ff.fmax_bits) {
+    fm = block_reduce_max<kFinishBlock>(fm);
+    if (threadIdx.x == 0 && fm > 0.0) atomicMax(ff.fmax_bits, nonneg_bits(fm));
+  }
+}
+
 // Box gradient, local-frame part: the frame vectors site -> axis atom go through the same minimum image as the pairs
 // (admp/spatial.py:88-101), so a molecule that straddles the cell boundary contributes shift (x) dE/d(vector).
 // pot = dE/dQ_global of pair + reciprocal space (the self term is added here, as in the closing kernel).
@@ -598,8 +710,14 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
   const char* gmin_env = getenv("ADMP_FINISH_GROUPS_MIN");
   const int gmin = gmin_env ? atoi(gmin_env) : 8192;
   if ((!list || slab_bits) && top.ngroups > 0 && top.na > gmin) {
-    k_finish_groups<T><<<nblk(top.ngroups), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad, dQlocal,
-                                                                 energies, ff, list ? slab_bits : nullptr);
+    // ADMP_FINISH_ROWS=0: the one-thread-per-group form of round 2 (A/B, tests)
+    const char* rows_env = getenv("ADMP_FINISH_ROWS");
+    if (top.rows_blk && !(rows_env && atoi(rows_env) == 0))
+      k_finish_rows<T><<<top.nrowblk, kFinishBlock, 0, st>>>(top, box, sites, pol, lpol, kappa, pot, grad, dQlocal, energies, ff,
+                                                             list ? slab_bits : nullptr);
+    else
+      k_finish_groups<T><<<nblk(top.ngroups), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
+                                                                   dQlocal, energies, ff, list ? slab_bits : nullptr);
     return;
   }
   if (!list && top.inv_ptr)   // single GPU: pull formulation, no atomics

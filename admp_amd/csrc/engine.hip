@@ -316,6 +316,8 @@ struct EngineBase {
     if (top.inv_ptr) (void)hipFree(top.inv_ptr);
     if (top.inv_idx) (void)hipFree(top.inv_idx);
     if (top.grp_ptr) (void)hipFree(top.grp_ptr);
+    if (top.rows_blk) (void)hipFree(top.rows_blk);
+    if (top.grp_of) (void)hipFree(top.grp_of);
     top = Topology();
     if (!nbr_src) nbr.free_all();
     nbr_src = nullptr; nbr_src_gen = -1;
@@ -437,6 +439,19 @@ struct EngineBase {
         HIP_TRY(hipMalloc(&top.grp_ptr, sizeof(int) * gp.size()));
         HIP_TRY(hipMemcpy(top.grp_ptr, gp.data(), sizeof(int) * gp.size(), hipMemcpyHostToDevice));
         top.ngroups = (int)gp.size() - 1;
+        // row form: workgroups of whole groups (greedy runs of at most kFinishBlock atoms), group record per atom
+        std::vector<int> blk(1, 0), gof((size_t)na);
+        for (int gi = 0; gi < top.ngroups; ++gi) {
+          const int a0 = gp[gi], n = gp[gi + 1] - a0;
+          if (gp[gi + 1] - blk.back() > kFinishBlock) blk.push_back(a0);
+          for (int m = 0; m < n; ++m) gof[(size_t)a0 + m] = (a0 << 2) | (n - 1);
+        }
+        blk.push_back(na);
+        HIP_TRY(hipMalloc(&top.rows_blk, sizeof(int) * blk.size()));
+        HIP_TRY(hipMemcpy(top.rows_blk, blk.data(), sizeof(int) * blk.size(), hipMemcpyHostToDevice));
+        top.nrowblk = (int)blk.size() - 1;
+        HIP_TRY(hipMalloc(&top.grp_of, sizeof(int) * (size_t)na));
+        HIP_TRY(hipMemcpy(top.grp_of, gof.data(), sizeof(int) * (size_t)na, hipMemcpyHostToDevice));
       }
     }
     have_top = true;
@@ -1456,7 +1471,7 @@ struct Engine : EngineBase {
       const bool reuse = ind_bins_eval == eval_seq && ind_bins_n == n_act && ind_bins_gen == act_gen &&
                          ind_bins_at == bins_ind.cell_start;
       int rc = launch_spread<T>(stream, n_act, isites.as<Site<T>>(), 1, ev.g, bins_ind, mesh2.as<T>(), nullptr, nullptr, 1,
-                                reuse ? 1 : 0);
+                                reuse ? 1 : 0, 0);
       ind_bins_eval = eval_seq; ind_bins_n = n_act; ind_bins_gen = act_gen; ind_bins_at = bins_ind.cell_start;
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)}; }
     const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>());

@@ -71,7 +71,14 @@ struct Topology {
   // closing kernel evaluates each frame ONCE, by one thread per group (k_finish_groups); else ngroups = 0 (pull form)
   int* grp_ptr = nullptr;     // ngroups + 1
   int ngroups = 0;
+  // row form of the closing kernel (k_finish_rows, round 4): one thread per ATOM, a workgroup takes a run of whole groups of at
+  // most kFinishBlock atoms -- rows_blk[b] .. rows_blk[b+1]-1 -- so that everything a frame needs of its group mates is
+  // exchanged through LDS; grp_of[i] = (first atom of i's group) << 2 | (group size - 1)
+  int* rows_blk = nullptr;    // nrowblk + 1
+  int nrowblk = 0;
+  int* grp_of = nullptr;      // na
 };
+constexpr int kFinishBlock = 256;
 constexpr int kMaxGroup = 4;
 
 // energies[] slots on the device
@@ -350,7 +357,8 @@ template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
                   T* mesh, const int* list, const int4* bases = nullptr /* from launch_prepare_sites, or recomputed */,
                   int nb = 1 /* batch (scan kernel only): site rows of b at sites + b * na, its mesh at mesh + b * mesh size */,
-                  int reuse_bins = 0 /* binned kernel: positions unchanged since the previous call, keep its brick lists */);
+                  int reuse_bins = 0 /* binned kernel: positions unchanged since the previous call, keep its brick lists */,
+                  int tight = 1 /* binned kernel, f32: fixed-point scale from the stencil-window bound (0: entry count; SCF increments) */);
 size_t spread_scan_bytes(int ncell);
 // k-space layout [K0][ny][K2/2+1] holding mesh rows y0 .. y0+ny-1 (ny = K1, y0 = 0 on one rank).
 // which: 1 = electrostatics (Ck_1, gamma point dropped, x DIELECTRIC), 6/8/10 = dispersion kernels

@@ -133,12 +133,12 @@ __global__ __launch_bounds__(256) void k_bin(int na, const Site<T>* __restrict__
 //                     max |M''| = 1 for order 6 (attained at u = 3; checked numerically): bm_e = 0.1664 |q| + 0.1392 |c1|_1
 //                     + 0.3025 |c2|_1 instead of |q| + |c1|_1 + |c2|_1;
 //                 (b) only entries whose stencil covers a word add to it: the stencil bases of the entries, relative to the
-//                     brick (-5 .. 15 per axis), are histogrammed into 7^3 cells of 3 positions, weighted by bm_e in units
-//                     of 2^-20 bmax (integers, rounded up: the bound does not depend on the order of the adds, so the mesh
-//                     stays bitwise reproducible); the bases that reach a word span 6 positions = at most 3 cells per
-//                     axis, so the largest 3 x 3 x 3 block sum bounds sum_e |term_e| of every word.
-//               Liquid water at 1M atoms: 5.5 x from (a), ~10 x from (b): the quantum drops 50-fold, below f32 round-off
-//               of the values.  Bricks with more than 2048 entries fall back to (a) x cnt.
+//                     brick (-5 .. 15 per axis), are counted into 7^3 cells of 3 positions (integer LDS adds: the bound
+//                     does not depend on their order, so the mesh stays bitwise reproducible); the bases that reach a
+//                     word span 6 positions = at most 3 cells per axis, so the largest 3 x 3 x 3 block count times the
+//                     largest bm_e bounds sum_e |term_e| of every word.
+//               Liquid water at 1M atoms: 5.5 x from (a), ~6 x from (b): the quantum drops 30-fold, below f32 round-off of
+//               the values (force error of the f32 path against f64 at 1M atoms back at 2.0e-5, bench.py precision_check).
 //
 // The kernel is VALU bound (round 3: without its atomics it takes the same time; SQ_ACTIVE_INST_VALU 85 % of the SIMD
 // cycles), so the work per entry is cut by what the entry carries: most sites of a force field are bare charges (the
@@ -272,7 +272,7 @@ __device__ __forceinline__ void brick_add_entry(W* __restrict__ tile, const Site
   }
 }
 
-template <class T>
+template <class T, bool TIGHT>
 __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                        BrickGrid bg, const int* __restrict__ brick_start,
                                                        const int* __restrict__ entries, T* __restrict__ mesh,
@@ -291,6 +291,8 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     n[d] = ((bb[d] + 1) * g.dim(d)) / bg.nb[d] - lo[d];
   }
   for (int t = threadIdx.x; t < 16 * 16 * kBrickRow; t += 256) tile[t] = W(0);
+  if (sizeof(T) == 4 && TIGHT)
+    for (int t = threadIdx.x; t < 344; t += 256) s_hist3[t] = 0u;       // (word 343: the largest block count)
   if (threadIdx.x == 0) s_bmax = 0u;
   __syncthreads();
   const int beg = brick_start[blockIdx.x], cnt = brick_start[blockIdx.x + 1] - beg;
@@ -305,30 +307,19 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
   }
   double bmax, bound;
   if (sizeof(T) == 4) {
-    // (a) + (b) of the header comment.  A thread keeps the bounds and cells of its first kBrickChunk / 256 entries in
-    // registers between the two sub-passes (the unit of the histogram is known only after the maximum)
-    constexpr int kKeep = kBrickChunk / 256;
+    // (a) + (b) of the header comment: per-entry bound with the weight maxima, and a histogram of the entries' stencil bases
+    // (counts: one LDS add per entry in the loop that finds the maximum -- the largest 3 x 3 x 3 block count times the largest
+    // per-entry bound is what a word can receive).  TIGHT = false (the SCF increments: small dipole changes whose rounding
+    // is far below the permanent mesh's) keeps (a) x cnt and skips the histogram.
     constexpr float kW0 = 0.55f * 0.55f * 0.55f, kW1 = 0.46004f * 0.55f * 0.55f, kW2 = 0.55f * 0.55f;   // see (a)
-    for (int t = threadIdx.x; t < 344; t += 256) s_hist3[t] = 0u;       // (word 343: the largest block sum)
-    float bme[kKeep];
-    int cell[kKeep];
     float bm = 0.f;
-    auto bound_of = [&](int e, T r[3]) {
-      T Q[9];
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+      T r[3], Q[9];
       site_qtot(sites[entries[beg + e]], lpol, r, Q);
       const T d1 = m_abs(Q[1]) + m_abs(Q[2]) + m_abs(Q[3]);
       const T q2 = m_abs(Q[4]) + m_abs(Q[5]) + m_abs(Q[6]) + m_abs(Q[7]) + m_abs(Q[8]);
-      return (float)(T(kW0) * m_abs(Q[0]) + T(kW1) * amax * d1 + T(kW2) * T(2) * amax * amax * q2);
-    };
-#pragma unroll
-    for (int k = 0; k < kKeep; ++k) {                      // (compile-time k: the two arrays stay in registers)
-      const int e = threadIdx.x + 256 * k;
-      bme[k] = 0.f;
-      cell[k] = -1;
-      if (e < cnt) {
-        T r[3];
-        bme[k] = bound_of(e, r);
-        bm = fmaxf(bm, bme[k]);
+      bm = fmaxf(bm, (float)(T(kW0) * m_abs(Q[0]) + T(kW1) * amax * d1 + T(kW2) * T(2) * amax * amax * q2));
+      if (TIGHT) {
         int cl = 0;
         bool in = true;
 #pragma unroll
@@ -342,19 +333,13 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
           in = in && o + 5 >= 0 && o < n[d];
           cl = cl * 7 + (o + 5) / 3;
         }
-        if (in) cell[k] = cl;                              // (an entry that misses the brick adds no term)
+        if (in) atomicAdd(&s_hist3[cl], 1u);               // (an entry that misses the brick adds no term)
       }
     }
-    for (int e = threadIdx.x + 256 * kKeep; e < cnt; e += 256) { T r[3]; bm = fmaxf(bm, bound_of(e, r)); }
     if (bm > 0.f) atomicMax(&s_bmax, __float_as_uint(bm * 1.0001f));    // non-negative floats order like their bits
     __syncthreads();
     bmax = (double)__uint_as_float(s_bmax);
-    if (cnt <= kBrickChunk && bmax > 0.0) {
-      const float unit = (float)(1048576.0 / bmax);
-#pragma unroll
-      for (int k = 0; k < kKeep; ++k)
-        if (cell[k] >= 0) atomicAdd(&s_hist3[cell[k]], (unsigned)(bme[k] * unit) + 2u);      // rounded up: <= 2^20 + 2 each
-      __syncthreads();
+    if (TIGHT) {
       if (threadIdx.x < 125) {
         const int wx = threadIdx.x / 25, wy = (threadIdx.x / 5) % 5, wz = threadIdx.x % 5;
         unsigned sum = 0u;
@@ -364,8 +349,8 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
         atomicMax(&s_hist3[343], sum);
       }
       __syncthreads();
-      bound = bmax * (double)s_hist3[343] * (1.0 / 1048576.0);
-      if (bound < bmax) bound = bmax;
+      const unsigned most = s_hist3[343];
+      bound = bmax * (double)(most > 0u ? most : 1u);
     } else {
       bound = bmax * (double)(cnt > 0 ? cnt : 1);
     }
@@ -996,7 +981,7 @@ static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 #define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 template <class T>
 int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, BinScratch& bs,
-                  T* mesh, const int* list, const int4* bases, int nb, int reuse_bins) {
+                  T* mesh, const int* list, const int4* bases, int nb, int reuse_bins, int tight) {
   const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
   const BrickGrid bg = make_bricks(dims);
   if (na <= 0) {      // nothing to spread (a slab rank without atoms of this kind): the mesh is zero
@@ -1021,11 +1006,13 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
   }
   if (nb != 1) return (int)hipErrorInvalidValue;      // batches exist for the scan kernel only
   if (reuse_bins) {   // same positions as the previous call (next dispersion power): the brick lists are still valid
-    k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr);
+    if (tight) k_spread_bricks<T, true><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr);
+    else k_spread_bricks<T, false><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr);
     return 0;
   }
   { const int rc = launch_bin_bricks<T>(st, na, sites, g, bs, list, bases); if (rc != 0) return rc; }
-  k_spread_bricks<T><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
+  if (tight) k_spread_bricks<T, true><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
+  else k_spread_bricks<T, false><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
   bs.counters_zero = true;      // element ncell of both arrays is never written: it stays zero
   return 0;
 }
@@ -1139,7 +1126,7 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
   template int launch_bin_bricks<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, BinScratch&, const int*,   \
                                     const int4*);                                                                     \
   template int launch_spread<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, BinScratch&, T*,          \
-                                const int*, const int4*, int, int);                                                   \
+                                const int*, const int4*, int, int, int);                                              \
   template void launch_gtab<T>(hipStream_t, const int*, int, int, const double*, double, double, int, T*, int,             \
                                const int*, int);                                                                      \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \

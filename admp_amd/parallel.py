@@ -148,6 +148,20 @@ class TorchComm(_CommBase):
                     w.wait()
             recv.copy_(hr)
 
+    def abort(self):
+        """This rank cannot go on (an exception inside a collective's callback): close its side of the group so that peers
+        blocked in a collective fail promptly instead of waiting for the group's timeout (gloo: their pending operations see
+        the connection closed; nccl: the communicator is aborted where torch offers it)."""
+        d = self.dist
+        try:
+            ab = getattr(d.distributed_c10d, '_abort_process_group', None)
+            if self.native and ab is not None:
+                ab(self.group)
+            else:
+                d.destroy_process_group(self.group)
+        except Exception:      # noqa: BLE001 -- already on an error path
+            pass
+
     def shift(self, send, recv, to_next, label='shift'):
         """ring shift: send to rank+1 (to_next) or rank-1, receive from the opposite neighbour."""
         if self.size == 1:
@@ -426,6 +440,11 @@ class _SlabMixin:
         try:
             return fn()
         except _lib.AdmpHipError:
+            # A rank that fails in the middle of a decomposed call leaves its peers inside a collective: release them (they
+            # fail too, promptly) rather than let them wait -- for the group's timeout with torch.distributed, for ever with
+            # raw RCCL.
+            if self.comm.size > 1 and hasattr(self.comm, 'abort'):
+                self.comm.abort()
             if self._binding.error is not None:
                 raise self._binding.error
             raise

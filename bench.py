@@ -19,9 +19,15 @@ dispersion PME + Tang-Toennies on the moving frames with a Verlet list (skin 1 A
 Default workload (N = 1): S1 = BASELINE.json configs[1] -- 1024 polarizable MPID waters, double precision,
 on the seeded synthetic liquid box (the shipped water1024.pdb geometry has 0.67 A contacts on which the
 reference's own Jacobi SCF diverges), plus an `at_scale` leg on S3 (1 048 575 atoms, f32).
-With N > 1 ranks (one process per GPU, launched by torch.distributed.run) every rank steps an independent replica
-of S1 (a 3072-atom box does not strong-scale: "replicas only", weak scaling, `value` = aggregate ns/day of all
-replicas), and `at_scale` runs the 1M-atom box x-slab-decomposed over the N GPUs (admp_amd/parallel.py, RCCL).
+
+N > 1 (`--gpus N`): the path shards, so the value is the SLAB-DECOMPOSED step of BASELINE configs[3]
+(S3: 1 048 575 polarizable atoms, K = 256, f32) over the N GPUs -- x-slabs of the mesh and of space, RCCL issued by the
+library itself (admp_amd/csrc/rccl_comm.hip), every rank keeping its home rows -- `scaling: "strong"`.  A 3072-atom box does
+not strong-scale; the aggregate of N independent S1 replicas is kept only as the labelled extra `replicas_S1`.  When the
+process was not started by a launcher (no WORLD_SIZE in the environment), `--gpus N` makes this process -- which has not
+touched the GPU yet -- start N fresh child ranks (one per device, 127.0.0.1 rendezvous) and relay rank 0's line; a failed
+rank makes the run exit non-zero.  ADMP_BENCH_BACKEND=gloo (+ ADMP_BENCH_SCALE=S2) is the functional rehearsal of several
+ranks on one GPU (host-staged collectives, timings not representative).
 
 One JSON line is printed by rank 0 (contract in the task statement), with `roofline` (real-space pair
 kernel, measured with HIP events inside the timed region) and `cpu_baseline` (the float64 oracle timed on
@@ -242,8 +248,13 @@ def run_timed(f, a, steps, warmup, frames=None, barrier=None, only='pair_full', 
 
 
 def kernel_breakdown(f, a, frames, first, steps=10):
-    """ms per step of every kernel label (all launches bracketed: slightly slower steps than the timed region)."""
+    """(ms per step, launches per step, raw report) of every kernel label.  All launches are bracketed and the side stream is
+    OFF for this pass (admp_set_option ADMP_OPT_SIDE_STREAM): an event pair around a kernel that shares the chip with another
+    stream's kernels does not measure its duration (round-3 verdict: 29 us reported for a 14.7 us pair kernel), so the
+    per-kernel figures -- and the roofline's launch time at S1 -- come from serialised launches and agree with the rocprofv3
+    averages in profiles/; the steps of this pass are slower than the timed region's."""
     U = f.U_ind
+    f.set_side_stream(False)
     f.profile(True)
     f.profile_reset()
     for k in range(steps):
@@ -251,7 +262,9 @@ def kernel_breakdown(f, a, frames, first, steps=10):
         U = f.U_ind
     rep = f.profile_report()
     f.profile(False)
-    return {k: round(v[0] / steps, 5) for k, v in sorted(rep.items())}
+    f.set_side_stream(True)
+    return ({k: round(v[0] / steps, 5) for k, v in sorted(rep.items())},
+            {k: round(v[1] / float(steps), 3) for k, v in sorted(rep.items())}, rep)
 
 
 def time_list_rebuild(f, w, reps=3):
@@ -274,22 +287,34 @@ VALU_PEAK_GINST = 1024 * 2.4 / 2.0     # wave64 VALU instructions per ns the chi
                                        # instruction issues over 2 cycles, 2.4 GHz (MI355X_MICROARCH.md:14-15,34,54) = 1228.8 G/s
 
 
-def roofline_of(rep, w, n_pairs):
-    """The dominant kernel, k_pair_full, is bound by VALU issue, not by HBM (round-2 verdict: its partner rows are served by
-    L2 / MALL, measured HBM traffic is a quarter of the algorithmic bytes).  `achieved` / `peak` / `frac` are therefore the
-    VALU wave-instruction rate: SQ_INSTS_VALU per launch (rocprofv3 PMC pass of this command, profiles/pmc_traffic.json) /
-    the HIP-event launch time measured in this run, against what 1024 SIMDs can issue.  The contract's algorithmic-byte
-    figure (SURVEY.md 8d bytes per pair x pairs / launch time) is kept as `algorithmic_GBs` -- it is NOT a bandwidth: at 1M
-    atoms it exceeds what the memory system can deliver -- next to `hbm_traffic_frac` (measured bytes / time / HBM peak)."""
+def roofline_of(rep, w, n_pairs, rep_serial=None, share=1.0):
+    """Roofline of the dominant kernel, k_pair_full, in the contract's form: `achieved` = ALGORITHMIC bytes per launch
+    (bytes per pair x pairs) / average launch duration, against the HBM peak; `traffic` = measured HBM bytes per
+    launch (rocprofv3 PMC passes of this command, profiles/pmc_traffic.json).
+
+    Launch duration: HIP events around every launch.  On systems that run this kernel on a SIDE stream next to the mesh
+    chain (<= 200 000 atoms) the events of the timed region bracket a kernel that shares the chip -- not its duration -- so
+    the figure is taken from `rep_serial`, the breakdown pass right after the timed region with the side stream off (same
+    process, same frames); the timed region's own figure is kept as `avg_launch_us_timed_region`.  Above that size the kernel
+    runs alone and the timed region's events are used.
+
+    The byte model is not the kernel's limiter (its partner rows come from L2 / MALL: measured traffic is a quarter of the
+    algorithmic bytes, and at 1M atoms the algorithmic rate exceeds what HBM can deliver); `valu_view` gives the view that
+    is: SQ_INSTS_VALU per launch / launch time against the wave-instruction issue rate of 1024 SIMDs.
+    share: fraction of the pairs this rank evaluates (slab ranks: home atoms / atoms; the algorithmic bytes scale with it)."""
     wbytes = 4 if w['prec'] == 'single' else 8
     n_atoms = 3 * w['n_mol']
     total, per_pair = pair_kernel_bytes(n_pairs, n_atoms, wbytes, True)
-    ms, cnt = rep.get('pair_full', (0.0, 0))
+    total *= share
+    ms_t, cnt_t = rep.get('pair_full', (0.0, 0)) if rep else (0.0, 0)
+    concurrent = n_atoms <= int(os.environ.get('ADMP_OVERLAP_MAX', '200000')) and share == 1.0
+    src = rep_serial if (concurrent and rep_serial and rep_serial.get('pair_full', (0, 0))[1]) else rep
+    ms, cnt = src.get('pair_full', (0.0, 0)) if src else (0.0, 0)
     avg_s = (ms / cnt) * 1e-3 if cnt else float('nan')
     alg = total / avg_s / 1e9 if cnt else float('nan')
     traffic = tag = valu = n_trans = n_f64 = None
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and share == 1.0:
         try:
             rec = json.load(open(tfile)).get(w['name'], {})
             traffic = rec.get('pair_full_bytes_per_launch')
@@ -299,28 +324,29 @@ def roofline_of(rep, w, n_pairs):
             tag = rec.get('measured_at')
         except Exception:
             traffic = None
-    out = {'kernel': 'k_pair_full', 'avg_launch_us': round(avg_s * 1e6, 2), 'launches': int(cnt),
+    out = {'kernel': 'k_pair_full', 'bound': 'hbm', 'achieved': round(alg, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': round(alg / HBM_PEAK_GBS, 5), 'traffic': traffic,
+           'avg_launch_us': round(avg_s * 1e6, 2), 'launches': int(cnt),
+           'launch_time_source': ('HIP events, breakdown pass with the side stream off (the kernel shares the chip in the timed '
+                                  'region)' if src is rep_serial and src is not rep else 'HIP events over the timed region'),
            'algorithmic_bytes_per_launch': int(total), 'bytes_per_pair': round(per_pair, 2),
-           'algorithmic_GBs': round(alg, 2), 'algorithmic_frac_of_hbm_peak': round(alg / HBM_PEAK_GBS, 5),
-           'traffic': traffic}
+           'note': 'achieved = algorithmic bytes / launch time (contract); the kernel is not HBM-bound: see traffic, valu_view'}
+    if concurrent and cnt_t:
+        out['avg_launch_us_timed_region'] = round(ms_t / cnt_t * 1e3, 2)
+    if share != 1.0:
+        out['pair_share_of_this_rank'] = round(share, 5)
     if valu and cnt:
         rate = valu / avg_s / 1e9
-        out.update({'bound': 'valu', 'achieved': round(rate, 2), 'peak': VALU_PEAK_GINST, 'unit': 'G wave-instructions/s',
-                    'frac': round(rate / VALU_PEAK_GINST, 5), 'valu_insts_per_launch': int(valu)})
+        vv = {'achieved': round(rate, 2), 'peak': VALU_PEAK_GINST, 'unit': 'G wave-instructions/s',
+              'frac': round(rate / VALU_PEAK_GINST, 5), 'valu_insts_per_launch': int(valu)}
         if n_trans is not None and n_f64 is not None:
             # not every instruction issues in 2 cycles: transcendentals (exp / rcp / rsq / sqrt) take 8, f64 arithmetic 4
             # (MI355X_MICROARCH.md constants table; f64 vector peak = half of f32).  The issue cycles the kernel's instruction
             # mix needs per SIMD against the SIMD cycles of the launch (2.4 GHz):
             cyc = 2.0 * (valu - n_trans - n_f64) + 8.0 * n_trans + 4.0 * n_f64
-            out['valu_issue_cycles_frac'] = round(cyc / 1024.0 / (avg_s * 2.4e9), 5)
-            out['valu_mix'] = {'transcendental': int(n_trans), 'f64': int(n_f64)}
-    else:      # no counter record for this workload: fall back to the contract's byte figure, labelled as such
-        out.update({'bound': 'hbm', 'achieved': round(alg, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(alg / HBM_PEAK_GBS, 5)})
-    if n_atoms <= int(os.environ.get('ADMP_OVERLAP_MAX', '200000')):
-        out['concurrent'] = ('this kernel runs on a side stream next to the spread / convolution kernels of the same step '
-                             '(engine.hip on_side): the HIP-event time brackets it on that stream and includes the time the '
-                             'two streams share the chip; its duration alone is the rocprofv3 average in profiles/')
+            vv['issue_cycles_frac'] = round(cyc / 1024.0 / (avg_s * 2.4e9), 5)
+            vv['mix'] = {'transcendental': int(n_trans), 'f64': int(n_f64)}
+        out['valu_view'] = vv
     if traffic:
         out['traffic_source'] = 'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command%s), not collected in this run' % (
             ', ' + tag if tag else '')
@@ -328,25 +354,42 @@ def roofline_of(rep, w, n_pairs):
     return out
 
 
-def recip_kernel_rooflines(kb, w, grid, evals):
-    """Achieved algorithmic HBM rate of the spread / gather / transform legs (SURVEY.md 8d formulas, ms per launch from the
-    HIP-event breakdown; a step runs `evals` reciprocal passes when the SCF iterates)."""
+TRANSFORM_PREFIXES = ('rocfft_', 'dft_', 'fftx_', 'kspace')
+KSPACE_LABELS = ('kspace', 'dft_x_kspace', 'fftx_kspace')      # exactly one launch of these per mesh convolution
+
+
+def recip_kernel_rooflines(kb, counts, w, grid):
+    """Achieved algorithmic HBM rate of the spread / gather / convolution legs (SURVEY.md 8d formulas).  The labels are taken
+    from the breakdown's own keys (every key with a transform prefix is consumed: a renamed kernel cannot drop out silently,
+    as dft_zy_fwd / dft_yz_inv did in round 3) and the number of launches from the profiler's counts, not from an assumed
+    number of SCF evaluations."""
     wb = 4 if w['prec'] == 'single' else 8
     na = 3 * w['n_mol']
     K3 = grid[0] * grid[1] * grid[2]
     Kh = grid[0] * grid[1] * (grid[2] // 2 + 1)
     out = {}
 
-    def add(name, label_list, nbytes, launches_per_step):
-        ms = sum(kb.get(k, 0.0) for k in label_list) / max(launches_per_step, 1e-9)
-        if ms > 0:
+    def add(name, labels, nbytes, passes, note=None):
+        ms_step = sum(kb.get(k, 0.0) for k in labels)
+        if ms_step > 0 and passes > 0:
+            ms = ms_step / passes
             gbs = nbytes / (ms * 1e-3) / 1e9
-            out[name] = {'algorithmic_bytes': int(nbytes), 'ms_per_pass': round(ms, 5), 'achieved_GBs': round(gbs, 1),
+            out[name] = {'labels': sorted(labels), 'algorithmic_bytes': int(nbytes), 'passes_per_step': round(passes, 3),
+                         'ms_per_pass': round(ms, 5), 'achieved_GBs': round(gbs, 1),
                          'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4)}
-    add('spread', ['spread'], na * 15 * wb + K3 * wb, evals)
-    add('gather', ['gather'], K3 * wb + na * 24 * wb, 1.0)
-    add('transforms+kspace', ['rocfft_r2c', 'rocfft_c2r', 'kspace', 'dft_z_r2c', 'dft_y_fwd', 'dft_x_kspace', 'dft_y_inv',
-                              'dft_z_c2r'], 12 * Kh * 2 * wb + Kh * 5 * wb, evals)
+            if note:
+                out[name]['note'] = note
+    # permanent multipoles + dipoles of all atoms (once per evaluation that spreads them); the SCF increments spread the
+    # dipole changes of the polarizable sites only (a third of the atoms, 3 of the 15 words): their own line
+    add('spread', ['spread'], na * 15 * wb + K3 * wb, counts.get('spread', 0.0))
+    add('spread_scf_increment', ['spread_ind'], (na // 3) * 6 * wb + K3 * wb, counts.get('spread_ind', 0.0))
+    add('gather', ['gather'], K3 * wb + na * 24 * wb, counts.get('gather', 0.0))
+    tl = [k for k in kb if k.startswith(TRANSFORM_PREFIXES)]
+    conv = sum(counts.get(k, 0.0) for k in KSPACE_LABELS)
+    add('transforms+kspace', tl, 12 * Kh * 2 * wb + Kh * 5 * wb, conv,
+        'one pass = one mesh convolution (forward transform, G multiply, inverse transform)')
+    unused = [k for k in kb if k.startswith(TRANSFORM_PREFIXES) and k not in tl]
+    assert not unused, unused
     return out
 
 
@@ -397,7 +440,7 @@ def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10):
 
     def one(k, U, terms=(1, 1, 1)):
         p = seq[k]
-        if k % rebuild == 0:
+        if k >= warmup and (k - warmup) % rebuild == 0:      # the timed region starts with a rebuild: one per `rebuild` steps
             rebuild_lists(p)
         g = None
         if terms[0]:
@@ -411,22 +454,35 @@ def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10):
         return f.U_ind if terms[0] else U
 
     def timed(terms):
+        import gc
         U = None
         rebuild_lists(seq[0])
         for k in range(warmup):
             U = one(k, U, terms)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        upd = 0
-        for k in range(warmup, warmup + steps):
-            U = one(k, U, terms)
-            upd += f.n_cycle if terms[0] else 0
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3, upd / float(steps)
-    ms_all, upd = timed((1, 1, 1))
+        gc.collect()
+        gc.disable()                   # (a generation-2 collection inside a 5-step region would show up as a stall)
+        try:
+            t0 = time.perf_counter()
+            marks = [t0]
+            upd = 0
+            for k in range(warmup, warmup + steps):
+                U = one(k, U, terms)
+                upd += f.n_cycle if terms[0] else 0
+                marks.append(time.perf_counter())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+        finally:
+            gc.enable()
+        per = np.diff(np.asarray(marks)) * 1e3
+        return (t1 - t0) / steps * 1e3, upd / float(steps), [round(float(per.min()), 4), round(float(np.median(per)), 4),
+                                                             round(float(per.max()), 4)]
+    ms_all, upd, spread = timed((1, 1, 1))
     out = {'ms_per_step': round(ms_all, 4), 'ns_per_day': round(0.0864 / (ms_all * 1e-3), 3),
+           'steps': steps, 'step_ms_min_median_max': spread,
            'jacobi_updates_per_step': round(upd, 3), 'n_pairs_with_skin': int(f.n_pairs),
-           'list': 'rc %.1f + skin %.1f A, rebuilt every %d steps inside the timed region' % (RC, SKIN, rebuild),
+           'list': 'rc %.1f + skin %.1f A, rebuilt every %d steps; the timed region of %d steps starts with a rebuild' % (
+               RC, SKIN, rebuild, steps),
            'pme_ms': round(timed((1, 0, 0))[0], 4), 'dispersion_pme_pmax10_ms': round(timed((0, 1, 0))[0], 4),
            'tang_toennies_ms': round(timed((0, 0, 1))[0], 4)}
     f.set_pairs(a['pairs'])          # back to the fixed rc list of the headline
@@ -478,54 +534,154 @@ def aggregate_ns_per_day(t_step_s, world):
     return world * 0.0864 * DT_FS / t_step_s
 
 
-def slab_child(outpath):
-    """One rank of the slab-decomposed strong-scaling leg (spawned by main(), own process group)."""
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this process has not touched the GPU (torch is not even imported yet);
+    it starts N fresh child ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one per device) and
+    relays rank 0's JSON line.  Any rank failing makes the run fail: the others are ended and the exit code is non-zero."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    import threading
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:            # a rank that fails ends the run: its peers would wait in a collective for ever
+            time.sleep(0.2)
+            for pr in list(live):
+                code = pr.poll()
+                if code is not None:
+                    live.remove(pr)
+                    rc = rc or code
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()                  # (the exact processes started above)
+        for pr in procs:
+            pr.wait()
+    reader.join(timeout=10)
+    if rc == 0:
+        sys.stdout.write(b''.join(chunks).decode(errors='replace'))
+        sys.stdout.flush()
+    else:
+        sys.stderr.write('bench.py: a rank exited with code %d; no result line\n' % rc)
+    return rc
+
+
+def selftest_rank(rank, world):
+    """ADMP_BENCH_SELFTEST (CPU test of the launcher, tests/test_distributed_cpu.py): rendezvous over gloo, one barrier, rank 0
+    prints a line; 'failN' makes rank N exit non-zero before the barrier."""
+    mode = os.environ['ADMP_BENCH_SELFTEST']
+    if mode == 'fail%d' % rank:
+        return 3
+    import torch.distributed as dist
+    dist.init_process_group('gloo')
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({'selftest': True, 'n_gpus': world, 'master_port': os.environ.get('MASTER_PORT')}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def main_slab(opt, rank, world):
+    """N > 1: the slab-decomposed step of BASELINE configs[3] over the N ranks (see the module docstring)."""
     import datetime
     import torch
     import torch.distributed as dist
-    from admp_amd.parallel import TorchComm
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)
+    from admp_amd.parallel import make_comm
+    ndev = max(torch.cuda.device_count(), 1)
+    local = int(os.environ.get('LOCAL_RANK', str(rank))) % ndev      # rehearsal on one GPU: the ranks share it (gloo only)
     torch.cuda.set_device(local)
-    backend = os.environ.get('ADMP_BENCH_BACKEND', 'nccl')
+    dev = torch.device('cuda', local)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    backend = os.environ.get('ADMP_BENCH_BACKEND', 'nccl')           # 'gloo' = host-staged rehearsal on one GPU
     if backend == 'nccl':
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(seconds=150))
+        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=300))
     else:
-        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=150))
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
     rdev = 'cuda' if backend == 'nccl' else 'cpu'
-    w3 = make_workload(os.environ.get('ADMP_BENCH_SCALE', 'S3'))
-    comm = TorchComm()
-    # outputs='home': every rank keeps the gradient / dipole rows of its home atoms, as an MD driver that keeps the atoms
-    # distributed would; the reference's calling convention (full arrays to every caller: outputs='replicated') costs one
-    # all-reduce of (Na, 3) per output on top (ADMP_BENCH_OUTPUTS=replicated measures it)
-    f3, a3 = make_force(w3, comm, os.environ.get('ADMP_BENCH_OUTPUTS', 'home'))
-    fr3 = ThermalFrames(w3, torch.device('cuda', local))
-    run_timed(f3, a3, 2, 0, fr3, dist.barrier, only=False)          # warm-up (plans, buffers, RCCL channels)
+    name = os.environ.get('ADMP_BENCH_SCALE', 'S3')
+    w = make_workload(name)
+    comm = make_comm()
+    outputs = os.environ.get('ADMP_BENCH_OUTPUTS', 'home')
+    f, a = make_force(w, comm, outputs)
+    frames = ThermalFrames(w, dev)
+    dt, _, cyc = run_timed(f, a, opt.steps, opt.warmup, frames, dist.barrier, only=False)
+    dt = reduce_max_seconds(dt, dist, rdev)
+    t_step = dt / opt.steps
+    # per-kernel and per-collective times of this rank (HIP events around every launch / collective: a pass of its own)
     comm.reset_stats()
-    comm.profile = True                                              # device events around every collective
-    dt3, rep3, cyc3 = run_timed(f3, a3, 5, 0, fr3, dist.barrier, only=None)
-    dt3 = reduce_max_seconds(dt3, dist, rdev)
+    if hasattr(comm, 'profile'):
+        comm.profile = True
+    nb = min(opt.steps, 5)
+    kb, counts, rep = kernel_breakdown(f, a, frames, opt.warmup + opt.steps, nb)
+    if hasattr(comm, 'refresh_stats'):
+        comm.refresh_stats()
+    sent = {k: int(v / nb) for k, v in sorted(comm.bytes_sent.items())}
+    coll_py = comm.report(nb)
+    n_atoms = 3 * w['n_mol']
+    # the labelled extra: N independent replicas of the single-GPU headline workload (what a 3072-atom box can do with N GPUs)
+    replicas = None
+    if not opt.no_extras:
+        try:
+            w1 = make_workload('S1')
+            f1, a1 = make_force(w1)
+            fr1 = ThermalFrames(w1, dev)
+            k1 = min(opt.steps, 50)
+            dt1, _, _ = run_timed(f1, a1, k1, opt.warmup, fr1, dist.barrier, only=False)
+            dt1 = reduce_max_seconds(dt1, dist, rdev)
+            replicas = {'note': 'EXTRA, not the metric: every rank steps an independent replica of S1 (3072 atoms, f64)',
+                        'aggregate_ns_per_day': round(aggregate_ns_per_day(dt1 / k1, world), 3),
+                        'ms_per_step': round(dt1 / k1 * 1e3, 5), 'scaling': 'weak'}
+        except Exception as e:       # the extra must not take the metric down
+            replicas = {'error': repr(e)}
     if rank == 0:
-        res = {'workload': w3['desc'], 'decomposition': 'x-slab over %d GPUs (RCCL all-to-all transposes, ghost-plane '
-               'shifts, halo exchange of dipoles/gradient); outputs: %s rows' % (world, f3.outputs), 'scaling': 'strong',
-               'n_atoms': 3 * w3['n_mol'], 'n_pairs': int(f3.n_pairs), 'home_atoms_rank0': int(f3.n_home),
-               'ms_per_step': round(dt3 / 5 * 1e3, 3), 'ns_per_day': round(0.0864 / (dt3 / 5), 3),
-               'geometry': 'moving (thermal frames)', 'dtype': 'f32',
-               'rank0_kernel_ms_per_step': {k: round(v[0] / 5, 4) for k, v in sorted(rep3.items())}}
-        res.update(cyc3)
-        res['rank0_collective_ms_per_step'] = comm.report(5)
-        res['rank0_bytes_sent_per_step'] = {k: int(v / 5) for k, v in sorted(comm.bytes_sent.items())}
-        res['rank0_import_atoms'] = int(f3.n_import)
-        with open(outpath, 'w') as fh:
-            json.dump(res, fh)
+        comm_ms = {k: v for k, v in kb.items() if k.startswith('comm_')}
+        kern_ms = {k: v for k, v in kb.items() if not k.startswith('comm_')}
+        cfg = {'workload': w['desc'], 'n_atoms': n_atoms, 'n_pairs': int(f.n_pairs), 'pme_grid': [f.K1, f.K2, f.K3],
+               'kappa': round(float(f.kappa), 6), 'dt_fs': DT_FS, 'geometry': 'MOVING: ' + frames.describe(),
+               'scf': 'Jacobi, warm-started from the previous step\'s dipoles, POL_CONV = 10 kJ/mol/(e A)',
+               'pair_list': 'fixed during the timed steps',
+               'parallelism': 'x-slab decomposition of mesh and space over %d ranks (one process per GPU); collectives: %s; '
+                              'outputs: %s rows' % (world, 'RCCL issued by the library (ncclAllReduce, grouped ncclSend/ncclRecv)'
+                                                    if getattr(comm, 'native_rccl', False) else
+                                                    'torch.distributed %s through the callback interface' % backend, outputs),
+               'home_atoms_rank0': int(f.n_home), 'import_atoms_rank0': int(f.n_import)}
+        cfg.update(cyc)
+        out = {'metric': 'ns/day (electrostatics get_forces per 1 fs step, polarizable PME incl. SCF, moving atoms)',
+               'value': round(0.0864 * DT_FS / t_step, 4), 'unit': 'ns/day', 'n_gpus': world, 'steps': opt.steps,
+               'warmup': opt.warmup, 'ms_per_step': round(t_step * 1e3, 5), 'higher_is_better': True, 'scaling': 'strong',
+               'vs_baseline': None, 'dtype': 'f32' if w['prec'] == 'single' else 'f64', 'data': 'synthetic', 'config': cfg,
+               'roofline': roofline_of(rep, w, f.n_pairs, None, share=f.n_home / float(n_atoms)),
+               'rank0_kernel_ms_per_step': kern_ms,
+               'rank0_kernel_ms_sum': round(sum(kern_ms.values()), 4),
+               'rank0_collective_ms_per_step': comm_ms if comm_ms else coll_py,
+               'rank0_collective_ms_sum': round(sum((comm_ms if comm_ms else coll_py).values()), 4),
+               'rank0_launches_per_step': counts,
+               'rank0_bytes_sent_per_step': sent,
+               'recip_kernels_rank0': None,
+               'cpu_baseline': None}
+        if replicas is not None:
+            out['replicas_S1'] = replicas
+        print(json.dumps(out))
+        sys.stdout.flush()
     dist.barrier()
     dist.destroy_process_group()
+    return 0
 
 
 def main():
-    if len(sys.argv) >= 3 and sys.argv[1] == '--slab-child':
-        return slab_child(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -536,207 +692,152 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='headline only (no scf_tight / static / md_all_terms legs)')
     opt = ap.parse_args()
 
-    import torch
+    if 'WORLD_SIZE' not in os.environ and opt.gpus > 1:
+        return launch_ranks(opt.gpus, sys.argv[1:])           # (nothing in this process has touched the GPU)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)          # rehearsal on one GPU: several ranks share it (gloo backend only)
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    dist = None
+    if os.environ.get('ADMP_BENCH_SELFTEST'):
+        return selftest_rank(rank, world)
     if world > 1:
-        import datetime
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = os.environ.get('ADMP_BENCH_BACKEND', 'nccl')        # 'gloo' = host-staged rehearsal on one GPU
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(seconds=300))
-        else:
-            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
+        return main_slab(opt, rank, world)
 
+    import torch
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
     w = make_workload(opt.workload)
     f, a = make_force(w)
     frames = ThermalFrames(w, dev)
     n_atoms = 3 * w['n_mol']
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    dt, rep, cyc = run_timed(f, a, opt.steps, opt.warmup, frames, barrier if dist is not None else None)
-    rdev = 'cuda' if (dist is None or dist.get_backend() == 'nccl') else 'cpu'
-    dt = reduce_max_seconds(dt, dist, rdev)
+    dt, rep, cyc = run_timed(f, a, opt.steps, opt.warmup, frames)
     t_step = dt / opt.steps
-    value = aggregate_ns_per_day(t_step, world)
+    value = aggregate_ns_per_day(t_step, 1)
     last = opt.warmup + opt.steps            # index of the next frame of the trajectory
     U_last = f.U_ind
+    kb, counts, rep_serial = kernel_breakdown(f, a, frames, last)
     head = dict(n_pairs=int(f.n_pairs), grid=[f.K1, f.K2, f.K3], kappa=round(float(f.kappa), 6),
-                roofline=roofline_of(rep, w, f.n_pairs), kernels=kernel_breakdown(f, a, frames, last))
-    if world == 1:
-        head['rebuild_ms'] = time_list_rebuild(f, w)
-        f.set_pairs(a['pairs'])
+                roofline=roofline_of(rep, w, f.n_pairs, rep_serial), kernels=kb, counts=counts)
+    head['rebuild_ms'] = time_list_rebuild(f, w)
+    f.set_pairs(a['pairs'])
 
-    # Strong-scaling leg of the real multi-GPU path (1M-atom box, x-slab decomposed over all ranks).  It runs in CHILD
-    # processes (one per rank, own process group on MASTER_PORT + 17) so that a failing or hanging collective can
-    # never take the headline line down: the parents only wait, with a time limit, and merge the child's JSON.
-    slab_scale = None
-    if world > 1 and not opt.no_scale and opt.workload == 'S1':
-        import subprocess
-        import tempfile
-        f = None
-        torch.cuda.empty_cache()
-        outpath = os.path.join(tempfile.gettempdir(), 'admp_slab_%s_%d.json' % (os.environ.get('MASTER_PORT', '0'), world))
-        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get('MASTER_PORT', '29500')) + 17))
-        for k in list(env):                      # the children rendezvous on their own store, not on torchrun's agent store
-            if k.startswith('TORCHELASTIC') or k.startswith('TORCH_NCCL') or k == 'GROUP_RANK':
-                env.pop(k)
-        env['TORCHELASTIC_USE_AGENT_STORE'] = 'False'
-        if rank == 0 and os.path.exists(outpath):
-            os.remove(outpath)
-        barrier()
-        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--slab-child', outpath], env=env,
-                                 stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    cfg = {'workload': w['desc'], 'n_atoms': n_atoms, 'n_pairs': head['n_pairs'],
+           'pme_grid': head['grid'], 'kappa': head['kappa'], 'dt_fs': DT_FS,
+           'geometry': 'MOVING: ' + frames.describe(),
+           'scf': 'Jacobi, warm-started from the previous step\'s dipoles, POL_CONV = 10 kJ/mol/(e A) '
+                  '(reference default, admp/settings.py:29)',
+           'pair_list': 'fixed during the timed steps; GPU cell-list search + table compile = %.3f ms per rebuild '
+                        '(value with a rebuild every 10 steps: %.2f ns/day)' % (
+                            head['rebuild_ms'], 0.0864 / (t_step + head['rebuild_ms'] * 1e-4)),
+           'parallelism': 'single GPU'}
+    cfg.update(cyc)
+    out = {
+        'metric': 'ns/day (electrostatics get_forces per 1 fs step, polarizable PME incl. SCF, moving atoms)',
+        'value': round(value, 4), 'unit': 'ns/day', 'n_gpus': 1, 'steps': opt.steps, 'warmup': opt.warmup,
+        'ms_per_step': round(t_step * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f64' if w['prec'] == 'double' else 'f32', 'data': 'synthetic',
+        'config': cfg,
+        'roofline': head['roofline'],
+        'kernel_ms_per_step': head['kernels'],
+        'kernel_launches_per_step': head['counts'],
+        'kernel_ms_note': 'breakdown pass: every launch bracketed by HIP events, side stream off (steps slower than the timed ones)',
+        'recip_kernels': recip_kernel_rooflines(head['kernels'], head['counts'], w, head['grid']),
+    }
+    if not opt.no_extras:
         try:
-            _, err = child.communicate(timeout=360)
-            ok = child.returncode == 0
-        except subprocess.TimeoutExpired:
-            child.kill()
-            _, err = child.communicate()
-            ok = False
-        if rank == 0:
-            if ok and os.path.exists(outpath):
-                slab_scale = json.load(open(outpath))
-            else:
-                slab_scale = {'error': 'slab leg failed or timed out: ' + (err or b'').decode(errors='replace')[-400:]}
-
-    if rank == 0:
-        evals = cyc['scf_field_evaluations_per_step']
-        cfg = {'workload': w['desc'], 'n_atoms': n_atoms, 'n_pairs': head['n_pairs'],
-               'pme_grid': head['grid'], 'kappa': head['kappa'], 'dt_fs': DT_FS,
-               'geometry': 'MOVING: ' + frames.describe(),
-               'scf': 'Jacobi, warm-started from the previous step\'s dipoles, POL_CONV = 10 kJ/mol/(e A) '
-                      '(reference default, admp/settings.py:29)',
-               'pair_list': 'fixed during the timed steps; GPU cell-list search + table compile = %s ms per rebuild '
-                            '(value with a rebuild every 10 steps: %s ns/day)' % (
-                                ('%.3f' % head['rebuild_ms'], '%.2f' % (0.0864 / (t_step + head['rebuild_ms'] * 1e-4)))
-                                if 'rebuild_ms' in head else ('n/a', 'n/a')),
-               'parallelism': 'single GPU' if world == 1 else 'replicas only (%d independent boxes)' % world}
-        cfg.update(cyc)
-        out = {
-            'metric': 'ns/day (electrostatics get_forces per 1 fs step, polarizable PME incl. SCF, moving atoms)',
-            'value': round(value, 4), 'unit': 'ns/day', 'n_gpus': world, 'steps': opt.steps, 'warmup': opt.warmup,
-            'ms_per_step': round(t_step * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64' if w['prec'] == 'double' else 'f32', 'data': 'synthetic',
-            'config': cfg,
-            'roofline': head['roofline'],
-            'kernel_ms_per_step': head['kernels'],
-            'recip_kernels': recip_kernel_rooflines(head['kernels'], w, head['grid'], evals),
-        }
-        if slab_scale is not None:
-            out['at_scale'] = slab_scale
-        if world == 1 and not opt.no_extras:
-            try:
-                k2 = min(opt.steps, 20)
-                dt2, _, cyc2 = run_timed(f, a, k2, opt.warmup, frames, only=False, thresh=1e-2)
-                out['scf_tight'] = dict(thresh=1e-2, ms_per_step=round(dt2 / k2 * 1e3, 5),
-                                        ns_per_day=round(0.0864 / (dt2 / k2), 3), steps=k2, **cyc2)
-                dtp, _, cycp = run_timed(f, a, k2, opt.warmup, frames, only=False, predictor=True)
-                dtq, _, cycq = run_timed(f, a, k2, opt.warmup, frames, only=False, thresh=1e-2, predictor=True)
-                out['scf_predictor'] = dict(note='EXTRA, not the metric: SCF started from the linear extrapolation 2 U(n-1) - U(n-2) '
-                                            'of the two previous steps instead of U(n-1)',
-                                            ms_per_step=round(dtp / k2 * 1e3, 5), ns_per_day=round(0.0864 / (dtp / k2), 3),
-                                            steps=k2, **cycp,
-                                            thresh_1e_2=dict(ms_per_step=round(dtq / k2 * 1e3, 5), **cycq))
-                dt0, _, cyc0 = run_timed(f, a, k2, opt.warmup, None, only=False)
-                out['static_geometry'] = dict(note='UPPER BOUND, not the metric: identical positions every step, the first SCF '
-                                              'check always passes (what round 1 reported as the headline)',
-                                              ms_per_step=round(dt0 / k2 * 1e3, 5), ns_per_day=round(0.0864 / (dt0 / k2), 3),
-                                              steps=k2, **cyc0)
-            except Exception as e:
-                out['scf_tight'] = {'error': repr(e)}
-        if world == 1 and not opt.no_cpu and opt.workload == 'S1':
-            # frame `last` on the GPU from the dipoles of frame last-1, then the oracle on the same frame from the same start
-            p_next = frames.step_frame(last)
-            E, G = step(f, a, U_last, p_next)
-            ncyc_gpu = int(f.n_cycle)
-            cb, ref = cpu_baseline(w, U_last.cpu().numpy() if hasattr(U_last, 'cpu') else U_last, p_next.cpu().numpy())
-            out['cpu_baseline'] = cb
-            Gh = G.cpu().numpy()
-            out['force_rel_l2_vs_oracle'] = float(np.linalg.norm(Gh - ref['grad']) / np.linalg.norm(ref['grad']))
-            out['energy_rel_vs_oracle'] = float(abs(E - ref['E']) / abs(ref['E']))
-            out['scf_cycles_gpu_vs_oracle'] = [ncyc_gpu, int(ref['n_cycle'])]
-        if world == 1 and not opt.no_extras:
-            try:
-                k3 = min(opt.steps, 20)
-                out['md_all_terms'] = {w['name']: md_all_terms(w, f, a, frames, k3, opt.warmup)}
-            except Exception as e:
-                out['md_all_terms'] = {'error': repr(e)}
-        if world == 1 and not opt.no_scale and opt.workload == 'S1':
-            try:
-                f = None
-                frames = None
-                torch.cuda.empty_cache()
-                w3 = make_workload('S3')
-                f3, a3 = make_force(w3)
-                fr3 = ThermalFrames(w3, dev)
-                dt3, rep3, cyc3 = run_timed(f3, a3, 5, 2, fr3)
-                kb3 = kernel_breakdown(f3, a3, fr3, 7, 5)
-                rb3 = time_list_rebuild(f3, w3)
-                f3.set_pairs(a3['pairs'])
-                sc = {'workload': w3['desc'], 'n_atoms': 3 * w3['n_mol'], 'n_pairs': int(f3.n_pairs),
-                      'geometry': 'MOVING: ' + fr3.describe(),
-                      'ms_per_step': round(dt3 / 5 * 1e3, 3), 'ns_per_day': round(0.0864 / (dt3 / 5), 3), 'dtype': 'f32',
-                      'list_rebuild_ms': round(rb3, 3),
-                      'ns_per_day_rebuild_every_10_steps': round(0.0864 / (dt3 / 5 + rb3 * 1e-4), 3),
-                      'roofline': roofline_of(rep3, w3, f3.n_pairs),
-                      'kernel_ms_per_step': kb3,
-                      'recip_kernels': recip_kernel_rooflines(kb3, w3, [f3.K1, f3.K2, f3.K3],
-                                                              cyc3['scf_field_evaluations_per_step'])}
-                sc.update(cyc3)
-                sc['slab_1rank_ms'] = slab_one_rank_ms(w3, fr3)
-                if not opt.no_extras:
-                    dt0, _, cyc0 = run_timed(f3, a3, 5, 2, None, only=False)
-                    sc['static_geometry'] = dict(note='upper bound (identical positions every step)',
-                                                 ms_per_step=round(dt0 / 5 * 1e3, 3), ns_per_day=round(0.0864 / (dt0 / 5), 3))
-                    dt2, _, cyc2 = run_timed(f3, a3, 5, 2, fr3, only=False, thresh=1e-2)
-                    sc['scf_tight'] = dict(thresh=1e-2, ms_per_step=round(dt2 / 5 * 1e3, 3),
-                                           ns_per_day=round(0.0864 / (dt2 / 5), 3), **cyc2)
-                    dtp, _, cycp = run_timed(f3, a3, 5, 3, fr3, only=False, predictor=True)
-                    dtq, _, cycq = run_timed(f3, a3, 5, 3, fr3, only=False, thresh=1e-2, predictor=True)
-                    sc['scf_predictor'] = dict(note='extra: SCF started from 2 U(n-1) - U(n-2)',
-                                               ms_per_step=round(dtp / 5 * 1e3, 3), ns_per_day=round(0.0864 / (dtp / 5), 3), **cycp,
-                                               thresh_1e_2=dict(ms_per_step=round(dtq / 5 * 1e3, 3), **cycq))
-                    sc['precision_check'] = f32_vs_f64_force_error(w3, f3, a3, fr3.frame(3))
-                    out.setdefault('md_all_terms', {})[w3['name']] = md_all_terms(w3, f3, a3, fr3, 5, 2)
-                out['at_scale'] = sc
-            except Exception as e:      # the headline line must still be printed
-                out['at_scale'] = {'error': repr(e)}
+            k2 = min(opt.steps, 20)
+            dt2, _, cyc2 = run_timed(f, a, k2, opt.warmup, frames, only=False, thresh=1e-2)
+            out['scf_tight'] = dict(thresh=1e-2, ms_per_step=round(dt2 / k2 * 1e3, 5),
+                                    ns_per_day=round(0.0864 / (dt2 / k2), 3), steps=k2, **cyc2)
+            dtp, _, cycp = run_timed(f, a, k2, opt.warmup, frames, only=False, predictor=True)
+            dtq, _, cycq = run_timed(f, a, k2, opt.warmup, frames, only=False, thresh=1e-2, predictor=True)
+            out['scf_predictor'] = dict(note='EXTRA, not the metric: SCF started from the linear extrapolation 2 U(n-1) - U(n-2) '
+                                        'of the two previous steps instead of U(n-1)',
+                                        ms_per_step=round(dtp / k2 * 1e3, 5), ns_per_day=round(0.0864 / (dtp / k2), 3),
+                                        steps=k2, **cycp,
+                                        thresh_1e_2=dict(ms_per_step=round(dtq / k2 * 1e3, 5), **cycq))
+            dt0, _, cyc0 = run_timed(f, a, k2, opt.warmup, None, only=False)
+            out['static_geometry'] = dict(note='UPPER BOUND, not the metric: identical positions every step, the first SCF '
+                                          'check always passes (what round 1 reported as the headline)',
+                                          ms_per_step=round(dt0 / k2 * 1e3, 5), ns_per_day=round(0.0864 / (dt0 / k2), 3),
+                                          steps=k2, **cyc0)
+        except Exception as e:
+            out['scf_tight'] = {'error': repr(e)}
+    if not opt.no_cpu and opt.workload == 'S1':
+        # frame `last` on the GPU from the dipoles of frame last-1, then the oracle on the same frame from the same start
+        p_next = frames.step_frame(last)
+        E, G = step(f, a, U_last, p_next)
+        ncyc_gpu = int(f.n_cycle)
+        cb, ref = cpu_baseline(w, U_last.cpu().numpy() if hasattr(U_last, 'cpu') else U_last, p_next.cpu().numpy())
+        out['cpu_baseline'] = cb
+        Gh = G.cpu().numpy()
+        out['force_rel_l2_vs_oracle'] = float(np.linalg.norm(Gh - ref['grad']) / np.linalg.norm(ref['grad']))
+        out['energy_rel_vs_oracle'] = float(abs(E - ref['E']) / abs(ref['E']))
+        out['scf_cycles_gpu_vs_oracle'] = [ncyc_gpu, int(ref['n_cycle'])]
+    if not opt.no_extras:
+        try:
+            k3 = min(opt.steps, 20)
+            out['md_all_terms'] = {w['name']: md_all_terms(w, f, a, frames, k3, opt.warmup)}
+        except Exception as e:
+            out['md_all_terms'] = {'error': repr(e)}
+    if not opt.no_scale and opt.workload == 'S1':
+        try:
+            f = None
+            frames = None
+            torch.cuda.empty_cache()
+            w3 = make_workload('S3')
+            f3, a3 = make_force(w3)
+            fr3 = ThermalFrames(w3, dev)
+            dt3, rep3, cyc3 = run_timed(f3, a3, 5, 2, fr3)
+            kb3, cn3, rs3 = kernel_breakdown(f3, a3, fr3, 7, 5)
+            rb3 = time_list_rebuild(f3, w3)
+            f3.set_pairs(a3['pairs'])
+            sc = {'workload': w3['desc'], 'n_atoms': 3 * w3['n_mol'], 'n_pairs': int(f3.n_pairs),
+                  'geometry': 'MOVING: ' + fr3.describe(),
+                  'ms_per_step': round(dt3 / 5 * 1e3, 3), 'ns_per_day': round(0.0864 / (dt3 / 5), 3), 'dtype': 'f32',
+                  'list_rebuild_ms': round(rb3, 3),
+                  'ns_per_day_rebuild_every_10_steps': round(0.0864 / (dt3 / 5 + rb3 * 1e-4), 3),
+                  'roofline': roofline_of(rep3, w3, f3.n_pairs, rs3),
+                  'kernel_ms_per_step': kb3, 'kernel_launches_per_step': cn3,
+                  'recip_kernels': recip_kernel_rooflines(kb3, cn3, w3, [f3.K1, f3.K2, f3.K3])}
+            sc.update(cyc3)
+            sc['slab_1rank_ms'] = slab_one_rank_ms(w3, fr3)
             if not opt.no_extras:
-                try:      # configs[2] size with the mesh the reference's own rule gives (K = 305: a Bluestein size for rocFFT)
-                    f3 = a3 = fr3 = None
-                    torch.cuda.empty_cache()
-                    w2 = make_workload('S2ref')
-                    f2, a2 = make_force(w2)
-                    fr2 = ThermalFrames(w2, dev)
-                    dtm, _, cycm = run_timed(f2, a2, 10, 3, fr2, only=False)
-                    dts, _, _ = run_timed(f2, a2, 10, 3, None, only=False)
-                    out['reference_rule_mesh'] = dict(
-                        workload=w2['desc'], pme_grid=[f2.K1, f2.K2, f2.K3],
-                        convolution='two-level (Good-Thomas) direct DFT, admp_amd/csrc/pfa_kernels.hip; the rocFFT (Bluestein) '
-                                    'leg of the same step: ADMP_PFA=0, see profiles/README.md',
-                        ms_per_step=round(dtm / 10 * 1e3, 3), ns_per_day=round(0.0864 / (dtm / 10), 3),
-                        static_geometry_ms_per_step=round(dts / 10 * 1e3, 3), **cycm)
-                except Exception as e:
-                    out['reference_rule_mesh'] = {'error': repr(e)}
-        print(json.dumps(out))
-    if dist is not None:
-        try:
-            dist.barrier()
-            dist.destroy_process_group()
-        except Exception:      # a failed collective in the optional at_scale leg must not turn the run into an error
-            pass
+                dt0, _, cyc0 = run_timed(f3, a3, 5, 2, None, only=False)
+                sc['static_geometry'] = dict(note='upper bound (identical positions every step)',
+                                             ms_per_step=round(dt0 / 5 * 1e3, 3), ns_per_day=round(0.0864 / (dt0 / 5), 3))
+                dt2, _, cyc2 = run_timed(f3, a3, 5, 2, fr3, only=False, thresh=1e-2)
+                sc['scf_tight'] = dict(thresh=1e-2, ms_per_step=round(dt2 / 5 * 1e3, 3),
+                                       ns_per_day=round(0.0864 / (dt2 / 5), 3), **cyc2)
+                dtp, _, cycp = run_timed(f3, a3, 5, 3, fr3, only=False, predictor=True)
+                dtq, _, cycq = run_timed(f3, a3, 5, 3, fr3, only=False, thresh=1e-2, predictor=True)
+                sc['scf_predictor'] = dict(note='extra: SCF started from 2 U(n-1) - U(n-2)',
+                                           ms_per_step=round(dtp / 5 * 1e3, 3), ns_per_day=round(0.0864 / (dtp / 5), 3), **cycp,
+                                           thresh_1e_2=dict(ms_per_step=round(dtq / 5 * 1e3, 3), **cycq))
+                sc['precision_check'] = f32_vs_f64_force_error(w3, f3, a3, fr3.frame(3))
+                out.setdefault('md_all_terms', {})[w3['name']] = md_all_terms(w3, f3, a3, fr3, 10, 2)
+            out['at_scale'] = sc
+        except Exception as e:      # the headline line must still be printed
+            out['at_scale'] = {'error': repr(e)}
+        if not opt.no_extras:
+            try:      # configs[2] size with the mesh the reference's own rule gives (K = 305: a Bluestein size for rocFFT)
+                f3 = a3 = fr3 = None
+                torch.cuda.empty_cache()
+                w2 = make_workload('S2ref')
+                f2, a2 = make_force(w2)
+                fr2 = ThermalFrames(w2, dev)
+                dtm, _, cycm = run_timed(f2, a2, 10, 3, fr2, only=False)
+                dts, _, _ = run_timed(f2, a2, 10, 3, None, only=False)
+                out['reference_rule_mesh'] = dict(
+                    workload=w2['desc'], pme_grid=[f2.K1, f2.K2, f2.K3],
+                    convolution='two-level (Good-Thomas) direct DFT, admp_amd/csrc/pfa_kernels.hip; the rocFFT (Bluestein) '
+                                'leg of the same step: ADMP_PFA=0, see profiles/README.md',
+                    ms_per_step=round(dtm / 10 * 1e3, 3), ns_per_day=round(0.0864 / (dtm / 10), 3),
+                    static_geometry_ms_per_step=round(dts / 10 * 1e3, 3), **cycm)
+            except Exception as e:
+                out['reference_rule_mesh'] = {'error': repr(e)}
+    print(json.dumps(out))
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -229,8 +229,10 @@ def test_numpy_pair_list_refilled_in_place(env):
 
 @pytest.mark.parametrize('lpol', [False, True])
 def test_group_closing_kernel_matches_oracle(env, lpol, monkeypatch):
-    """k_finish_groups (one thread per molecule, used above 8192 atoms) forced at a size the oracle can do: energies,
-    gradient, dE/dQ_local; and the pull form on the same inputs gives the same numbers."""
+    """The closing kernels of large molecular systems (used above 8192 atoms) forced at a size the oracle can do: k_finish_rows
+    (round 4: one lane per atom, frames exchanged through LDS inside workgroups of whole frame groups) and k_finish_groups
+    (round 2: one lane per molecule; ADMP_FINISH_ROWS=0): energies, gradient, dE/dQ_local; and the pull form on the same
+    inputs gives the same numbers."""
     from admp_amd.pme import ADMPPmeForce
     from oracle import admp_oracle as O
     n_mol = 125
@@ -239,8 +241,9 @@ def test_group_closing_kernel_matches_oracle(env, lpol, monkeypatch):
     par = S.water_parameters(n_mol, polarizable=lpol)
     pairs = S.build_pairs(pos, box, 4.0)
     out = {}
-    for mode, gmin in (('groups', '0'), ('pull', '100000000')):
+    for mode, gmin, rows in (('rows', '0', '1'), ('groups', '0', '0'), ('pull', '100000000', '1')):
         monkeypatch.setenv('ADMP_FINISH_GROUPS_MIN', gmin)
+        monkeypatch.setenv('ADMP_FINISH_ROWS', rows)
         f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
         if lpol:
             out[mode] = f.get_forces_and_dQ(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
@@ -254,12 +257,12 @@ def test_group_closing_kernel_matches_oracle(env, lpol, monkeypatch):
     else:
         ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], want_dQ=True)
     scale = max(abs(p) for p in ref['parts'])
-    for mode in ('groups', 'pull'):
+    for mode in ('rows', 'groups', 'pull'):
         E, G, dQ, parts = out[mode]
         for got, want in zip(parts, ref['parts']):
             assert abs(got - want) <= 1e-9 * scale, mode
         assert rel(G, ref['grad']) < 1e-8 and rel(dQ, ref['dQ_local']) < 1e-8, mode
-    assert rel(out['groups'][1], out['pull'][1]) < 1e-12
+    assert rel(out['groups'][1], out['pull'][1]) < 1e-12 and rel(out['rows'][1], out['pull'][1]) < 1e-12
 
 
 def test_pscale_gradient_vs_oracle(env):

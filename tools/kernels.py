@@ -12,6 +12,6 @@ f, a = bench.make_force(w)
 fr = bench.ThermalFrames(w, torch.device('cuda', 0))
 for label, frames in (('static', None), ('moving', fr)):
     dt, _, cyc = bench.run_timed(f, a, steps, 3, frames, only=False)
-    kb = bench.kernel_breakdown(f, a, frames, steps + 3, steps)
+    kb = bench.kernel_breakdown(f, a, frames, steps + 3, steps)[0]
     print('%s %s: %.3f ms/step  %s' % (name, label, dt / steps * 1e3, cyc))
     print('   ' + '  '.join('%s %.4f' % (k, v) for k, v in kb.items()))

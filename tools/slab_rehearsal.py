@@ -25,7 +25,7 @@ dev = torch.device('cuda', 0)
 frames = bench.ThermalFrames(w, dev)
 f0, a0 = bench.make_force(w)
 dt0, _, cyc0 = bench.run_timed(f0, a0, steps, 3, frames, only=False)
-kb0 = bench.kernel_breakdown(f0, a0, frames, 3 + steps, steps)
+kb0 = bench.kernel_breakdown(f0, a0, frames, 3 + steps, steps)[0]
 single_ms = dt0 / steps * 1e3
 world = ThreadComm.World(nranks, serialize=True)
 out, errors = [None] * nranks, []
