@@ -49,6 +49,8 @@ PROTOTYPES = {
     'admp_thole_sums': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _vp, _vp]),
     'admp_pscale_grad': (_i32, [_vp, _vp, _dp, _vp, _vp, _vp, _i32, _dp, _dp, _vp, _dp]),
     'admp_mscale_grad': (_i32, [_vp, _i32, _vp, _dp, _vp, _i32, _i32, _dp, _i32]),
+    'admp_md_bonded': (_i32, [_vp, _vp, _dp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    'admp_md_kick_drift': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp]),
     'admp_neighbor_count': (_i32, [_vp, _i32, _vp, _dp, _dbl, _c.POINTER(_i64)]),
     'admp_neighbor_fill': (_i32, [_vp, _vp]),
     'admp_set_pairs_from_positions': (_i32, [_vp, _vp, _dp, _dbl]),

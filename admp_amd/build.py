@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libadmp_hip.so')
-SOURCES = ['engine.hip', 'pair_kernels.hip', 'recip_kernels.hip', 'atom_kernels.hip', 'nbr_kernels.hip', 'cell_kernels.hip', 'dft_kernels.hip', 'pfa_kernels.hip', 'fftx_kernels.hip', 'slab_kernels.hip', 'disp_kernels.hip', 'rccl_comm.hip']
+SOURCES = ['engine.hip', 'pair_kernels.hip', 'recip_kernels.hip', 'atom_kernels.hip', 'nbr_kernels.hip', 'cell_kernels.hip', 'dft_kernels.hip', 'pfa_kernels.hip', 'fftx_kernels.hip', 'slab_kernels.hip', 'disp_kernels.hip', 'rccl_comm.hip', 'md_kernels.hip']
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
 # -fno-slp-vectorize: hipcc's SLP vectoriser packs scalar f32 arithmetic into v_pk_*_f32 pairs, whose operands must sit in

@@ -44,9 +44,14 @@ __global__ __launch_bounds__(kAtomBlock) void k_prepare_sites(Topology top, cons
                                                               RecipGeom<T> g, int4* __restrict__ bases,
                                                               int* __restrict__ act_list, int* __restrict__ act_count,
                                                               const int* __restrict__ cls, int* __restrict__ cls_flags,
-                                                              RQ4<T>* __restrict__ rq, T* __restrict__ Ucopy) {
+                                                              RQ4<T>* __restrict__ rq, T* __restrict__ Ucopy,
+                                                              const int* __restrict__ list, int nlist) {
   int i = blockIdx.x * kAtomBlock + threadIdx.x;
   if (zero_next && i < E_WORDS) zero_next[i] = 0.0;   // the NEXT evaluation's energy words (engine.hip: Ed_cur)
+  if (list) {        // slab rank: the rows of the listed atoms only (its home atoms, or the atoms it reads); no site list here
+    if (i >= nlist) return;
+    i = list[i];
+  }
   if (act_list) {   // kernel-uniform: list of the polarizable sites (pol > 0); ONE counter update per workgroup (every
                     // workgroup of the launch hits the same word: 16k per-wave atomics cost 0.16 ms at 1M atoms), and
                     // a workgroup's sites stay together and in order, which keeps the consumers' gathers local
@@ -487,95 +492,104 @@ __global__ __launch_bounds__(kFinishBlock) void k_finish_rows(Topology top, Box<
                                                               const int* __restrict__ slab_bits) {
   __shared__ T spos[kFinishBlock][3];
   __shared__ T sg[kFinishBlock][9];          // what the frame of site t adds to its z, x, y atoms
-  __shared__ int sidx[kFinishBlock][3];      // ... their indices relative to the workgroup's first atom (-1: none)
-  const int a0 = top.rows_blk[blockIdx.x], na_blk = top.rows_blk[blockIdx.x + 1] - a0;
-  const int t = threadIdx.x, i = a0 + t;
-  const bool live = t < na_blk;
-  // slab rank: a site is served by its owner; the contributions of its frame to atoms of other ranks land in their rows
-  // (zeroed by the caller) and travel to the owners afterwards.  bits == 0: an atom this rank neither owns nor reads.
-  const int bits = live ? (slab_bits ? slab_bits[i] : kSlabHome) : 0;
-  const bool mine = (bits & kSlabHome) != 0;
-  if (slab_bits && !__syncthreads_or(mine)) return;            // (workgroup-uniform) nothing of this rank's here
+  __shared__ int sidx[kFinishBlock][3];      // ... their indices relative to the run's first atom (-1: none)
+  const int t = threadIdx.x;
   double eself = 0.0, epen = 0.0, fm = 0.0;
-  T gp[3] = {T(0), T(0), T(0)};
-  Site<T> s;
-  if (live) {
-    s = sites[i];
-    spos[t][0] = s.r[0]; spos[t][1] = s.r[1]; spos[t][2] = s.r[2];
-  }
-  sidx[t][0] = sidx[t][1] = sidx[t][2] = -1;
-  __syncthreads();
-  if (mine) {
-    T f[3], P[9];
-    self_factors(kappa, f);
-    total_potential(s, pot + 9 * (size_t)i, lpol, f, P, &eself);
-    if (lpol) {
-      T al = pol[i];
-      al = al < T(1e-8) ? T(1e-8) : al;
-      const double u2 = (double)s.U[0] * s.U[0] + (double)s.U[1] * s.U[1] + (double)s.U[2] * s.U[2];   // (harmonic order: same norm)
-      epen = kDielectric * 0.5 * u2 / (double)al;
+  // A workgroup walks several runs (grid-stride) and adds its energy sums ONCE: a launch of one workgroup per run put 8 000
+  // double-precision atomics on the two energy words at 1M atoms, which serialise at the memory side (8 ns each: the first
+  // version of this kernel took 0.116 ms against 0.085 for the form it replaces, all of it waiting there).
+  for (int run = blockIdx.x; run < top.nrowblk; run += gridDim.x) {
+    const int a0 = top.rows_blk[run], na_blk = top.rows_blk[run + 1] - a0;
+    const int i = a0 + t;
+    const bool live = t < na_blk;
+    // slab rank: a site is served by its owner; the contributions of its frame to atoms of other ranks land in their rows
+    // (zeroed by the caller) and travel to the owners afterwards.  bits == 0: an atom this rank neither owns nor reads.
+    const int bits = live ? (slab_bits ? slab_bits[i] : kSlabHome) : 0;
+    const bool mine = (bits & kSlabHome) != 0;
+    if (slab_bits && !__syncthreads_or(mine)) continue;          // (workgroup-uniform) nothing of this rank's in this run
+    T gp[3] = {T(0), T(0), T(0)};
+    Site<T> s;
+    if (live) {
+      s = sites[i];
+      spos[t][0] = s.r[0]; spos[t][1] = s.r[1]; spos[t][2] = s.r[2];
     }
-    if (ff.fmax_bits) {
-      const T al = ff.pol[i];
-      T fx, fy, fz;
-      total_field(s, al, ff.Ucart + 3 * i, ff.fld_pair + 3 * i, ff.fld_recip + 3 * i, ff.kappa, fx, fy, fz);
-      ff.field[3 * i] = fx; ff.field[3 * i + 1] = fy; ff.field[3 * i + 2] = fz;
-      if (al > T(0.001)) fm = fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz)));
-    }
-    if (grad) {
-      int type = top.axis_type[i];
-      const int iz = top.axis_idx[3 * i], ix = top.axis_idx[3 * i + 1], iy = top.axis_idx[3 * i + 2];
-      if (iz < 0) type = NoAxisType;
-      if (type == NoAxisType) {
-        if (dQlocal) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) dQlocal[9 * (size_t)i + q] = P[q];
-        }
-      } else {
-        const bool usex = type != Zonly, usey = (type == ZBisect || type == ThreeFold);
-        const int lz = iz - a0, lx = usex && ix >= 0 ? ix - a0 : -1, ly = usey && iy >= 0 ? iy - a0 : -1;
-        T pz[3] = {0, 0, 0}, px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {                                  // (group mates: inside this workgroup by construction)
-          pz[c] = spos[lz][c];
-          if (ix >= 0) px[c] = spos[ix - a0][c];
-          if (iy >= 0) py[c] = spos[iy - a0][c];
-        }
-        FrameWork<T> w;
-        local_frame_fwd(type, box, s.r, pz, px, py, w);
-        T tau[3], gz[3], gx[3], gy[3];
-        multipole_torque(P, s.Q, tau);
-        local_frame_bwd(type, w, tau, gp, gz, gx, gy);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { sg[t][c] = gz[c]; sg[t][3 + c] = gx[c]; sg[t][6 + c] = gy[c]; }
-        sidx[t][0] = lz; sidx[t][1] = lx; sidx[t][2] = ly;
-        if (dQlocal) {
-          T dl[9];
-          rot_harm(P, w.X, w.Y, w.Z, dl);
-#pragma unroll
-          for (int q = 0; q < 9; ++q) dQlocal[9 * (size_t)i + q] = dl[q];
-        }
-      }
-    }
-  }
-  if (grad) {                                 // kernel-uniform
+    sidx[t][0] = sidx[t][1] = sidx[t][2] = -1;
     __syncthreads();
-    if (bits != 0) {
-      const int rec = top.grp_of[i], g0 = (rec >> 2) - a0, gn = (rec & 3) + 1;
-      T acc[3] = {gp[0], gp[1], gp[2]};
-      for (int m = g0; m < g0 + gn; ++m) {     // the frames of the group's sites (its own included: an axis atom may be the site)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (sidx[m][k] == t) { acc[0] += sg[m][3 * k]; acc[1] += sg[m][3 * k + 1]; acc[2] += sg[m][3 * k + 2]; }
+    if (mine) {
+      T f[3], P[9];
+      double es;
+      self_factors(kappa, f);
+      total_potential(s, pot + 9 * (size_t)i, lpol, f, P, &es);
+      eself += es;
+      if (lpol) {
+        T al = pol[i];
+        al = al < T(1e-8) ? T(1e-8) : al;
+        const double u2 = (double)s.U[0] * s.U[0] + (double)s.U[1] * s.U[1] + (double)s.U[2] * s.U[2];   // (harmonic order: same norm)
+        epen += kDielectric * 0.5 * u2 / (double)al;
       }
-      grad[3 * (size_t)i] += acc[0]; grad[3 * (size_t)i + 1] += acc[1]; grad[3 * (size_t)i + 2] += acc[2];
+      if (ff.fmax_bits) {
+        const T al = ff.pol[i];
+        T fx, fy, fz;
+        total_field(s, al, ff.Ucart + 3 * i, ff.fld_pair + 3 * i, ff.fld_recip + 3 * i, ff.kappa, fx, fy, fz);
+        ff.field[3 * i] = fx; ff.field[3 * i + 1] = fy; ff.field[3 * i + 2] = fz;
+        if (al > T(0.001)) fm = fmax(fm, fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz))));
+      }
+      if (grad) {
+        int type = top.axis_type[i];
+        const int iz = top.axis_idx[3 * i], ix = top.axis_idx[3 * i + 1], iy = top.axis_idx[3 * i + 2];
+        if (iz < 0) type = NoAxisType;
+        if (type == NoAxisType) {
+          if (dQlocal) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) dQlocal[9 * (size_t)i + q] = P[q];
+          }
+        } else {
+          const bool usex = type != Zonly, usey = (type == ZBisect || type == ThreeFold);
+          const int lz = iz - a0, lx = usex && ix >= 0 ? ix - a0 : -1, ly = usey && iy >= 0 ? iy - a0 : -1;
+          T pz[3] = {0, 0, 0}, px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {                                  // (group mates: inside this run by construction)
+            pz[c] = spos[lz][c];
+            if (ix >= 0) px[c] = spos[ix - a0][c];
+            if (iy >= 0) py[c] = spos[iy - a0][c];
+          }
+          FrameWork<T> w;
+          local_frame_fwd(type, box, s.r, pz, px, py, w);
+          T tau[3], gz[3], gx[3], gy[3];
+          multipole_torque(P, s.Q, tau);
+          local_frame_bwd(type, w, tau, gp, gz, gx, gy);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { sg[t][c] = gz[c]; sg[t][3 + c] = gx[c]; sg[t][6 + c] = gy[c]; }
+          sidx[t][0] = lz; sidx[t][1] = lx; sidx[t][2] = ly;
+          if (dQlocal) {
+            T dl[9];
+            rot_harm(P, w.X, w.Y, w.Z, dl);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) dQlocal[9 * (size_t)i + q] = dl[q];
+          }
+        }
+      }
     }
+    if (grad) {                                 // kernel-uniform
+      __syncthreads();
+      if (bits != 0) {
+        const int rec = top.grp_of[i], g0 = (rec >> 2) - a0, gn = (rec & 3) + 1;
+        T acc[3] = {gp[0], gp[1], gp[2]};
+        for (int m = g0; m < g0 + gn; ++m) {     // the frames of the group's sites (its own included: an axis atom may be the site)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (sidx[m][k] == t) { acc[0] += sg[m][3 * k]; acc[1] += sg[m][3 * k + 1]; acc[2] += sg[m][3 * k + 2]; }
+        }
+        grad[3 * (size_t)i] += acc[0]; grad[3 * (size_t)i + 1] += acc[1]; grad[3 * (size_t)i + 2] += acc[2];
+      }
+    }
+    __syncthreads();                            // the LDS rows are rewritten by the next run
   }
   eself = block_reduce_sum<kFinishBlock>(eself);
   epen = block_reduce_sum<kFinishBlock>(epen);
   if (threadIdx.x == 0) {
-    atomicAdd(&energies[E_SELF], eself);
-    if (lpol) atomicAdd(&energies[E_PEN], epen);
+    if (eself != 0.0) atomicAdd(&energies[E_SELF], eself);
+    if (lpol && epen != 0.0) atomicAdd(&energies[E_PEN], epen);
   }
   if (ff.fmax_bits) {
     fm = block_reduce_max<kFinishBlock>(fm);
@@ -678,9 +692,12 @@ template <class T>
 void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, const T* Qlocal, const T* Ucart,
                           const T* pol, const T* thole, const Box<T>& box, Site<T>* sites, double* zero_next,
                           const RecipGeom<T>& g, int4* bases, int* act_list, int* act_count, const int* cls,
-                          int* cls_flags, RQ4<T>* rq, T* Ucopy) {
-  k_prepare_sites<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, Qlocal, Ucart, pol, thole, box, sites, zero_next, g,
-                                                          bases, act_list, act_count, cls, cls_flags, rq, Ucopy);
+                          int* cls_flags, RQ4<T>* rq, T* Ucopy, const int* list, int nlist) {
+  const int n = list ? nlist : top.na;
+  if (n <= 0 && !zero_next) return;
+  k_prepare_sites<T><<<nblk(n > E_WORDS || !zero_next ? (n > 0 ? n : 1) : E_WORDS), kAtomBlock, 0, st>>>(
+      top, pos, Qlocal, Ucart, pol, thole, box, sites, zero_next, g, bases, list ? nullptr : act_list,
+      list ? nullptr : act_count, cls, cls_flags, rq, Ucopy, list, nlist);
 }
 template <class T>
 void launch_site_classes(hipStream_t st, int na, const Site<T>* sites, int* cls) {
@@ -713,8 +730,9 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
     // ADMP_FINISH_ROWS=0: the one-thread-per-group form of round 2 (A/B, tests)
     const char* rows_env = getenv("ADMP_FINISH_ROWS");
     if (top.rows_blk && !(rows_env && atoi(rows_env) == 0))
-      k_finish_rows<T><<<top.nrowblk, kFinishBlock, 0, st>>>(top, box, sites, pol, lpol, kappa, pot, grad, dQlocal, energies, ff,
-                                                             list ? slab_bits : nullptr);
+      k_finish_rows<T><<<top.nrowblk < 1024 ? top.nrowblk : 1024, kFinishBlock, 0, st>>>(top, box, sites, pol, lpol, kappa, pot, grad,
+                                                                                         dQlocal, energies, ff,
+                                                                                         list ? slab_bits : nullptr);
     else
       k_finish_groups<T><<<nblk(top.ngroups), kAtomBlock, 0, st>>>(top, pos, box, sites, pol, Ucart, lpol, kappa, pot, grad,
                                                                    dQlocal, energies, ff, list ? slab_bits : nullptr);
@@ -772,7 +790,7 @@ void launch_scale_add(hipStream_t st, int na, const T* vals, int stride, int cha
                                              double*, const RecipGeom<T>*, int4*);                                      \
   template void launch_prepare_sites<T>(hipStream_t, const Topology&, const T*, const T*, const T*, const T*, const T*, \
                                         const Box<T>&, Site<T>*, double*, const RecipGeom<T>&, int4*, int*, int*,       \
-                                        const int*, int*, RQ4<T>*, T*);                                                 \
+                                        const int*, int*, RQ4<T>*, T*, const int*, int);                                \
   template void launch_site_classes<T>(hipStream_t, int, const Site<T>*, int*);                                         \
   template void launch_field_finish<T>(hipStream_t, int, const Site<T>*, const T*, const T*, const T*, const T*, T, T*,  \
                                        unsigned long long*, const int*, const int*);                                    \

@@ -206,7 +206,32 @@ int launch_spread_scalar(hipStream_t st, int nch, const T* pos, const T* vals, i
 // 32 atoms once into LDS, six lanes per atom sum their z-index over the 36 (x, y) points) over NCH meshes at once.
 constexpr int kSgAtoms = 32, kSgBlock = 6 * kSgAtoms, kSgRow = 19;
 
+template <class T, int NCH> struct ChanVec { T v[NCH]; };
+
 template <class T, int NCH>
+__global__ __launch_bounds__(256) void k_interleave(long n, const T* __restrict__ src, long stride, T* __restrict__ dst) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    ChanVec<T, NCH> o;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) o.v[c] = src[(long)c * stride + i];
+    reinterpret_cast<ChanVec<T, NCH>*>(dst)[i] = o;
+  }
+}
+template <class T>
+void launch_interleave(hipStream_t st, int nch, long n, const T* src, long stride, T* dst) {
+  if (n <= 0) return;
+  long blocks = (n + 255) / 256;
+  if (blocks > 32768) blocks = 32768;
+  if (nch == 3) k_interleave<T, 3><<<(unsigned)blocks, 256, 0, st>>>(n, src, stride, dst);
+  else if (nch == 2) k_interleave<T, 2><<<(unsigned)blocks, 256, 0, st>>>(n, src, stride, dst);
+  else k_interleave<T, 1><<<(unsigned)blocks, 256, 0, st>>>(n, src, stride, dst);
+}
+
+// IL: phi holds the NCH channels of every mesh point side by side (k_interleave).  The gather is bound by the number of
+// load INSTRUCTIONS its lanes issue (36 per lane and mesh: the address unit of the CU, round-3 counters), not by the bytes
+// they return -- so the channels of a point are fetched with one 4 NCH-byte load and folded with the atom's coefficients at
+// once: sum_c q_c phi_c takes the place of phi in the separable sums (they are linear in phi).
+template <class T, int NCH, bool IL>
 __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __restrict__ pos, const T* __restrict__ vals,
                                                             int stride, RecipGeom<T> g, const T* __restrict__ phi,
                                                             long mesh_stride, T* __restrict__ grad,
@@ -243,14 +268,28 @@ __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __r
     const int base[3] = {sbase[s][0], sbase[s][1], sbase[s][2]};
     const W4<T> wz = w[s][12 + c];
     const int ic = wrap_add(base[2], c, g.K[2]);
-    // one channel at a time (its 36 loads in flight together), the channels' sums combined with the atom's coefficients
+    if (IL) {
+      T q[NCH];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const T* __restrict__ ph = phi + (long)ch * mesh_stride;
-      T fc[3];
-      gather_zcol_field_w(g, base, &w[s][0], &w[s][6], wz, ic, [&](long idx) { return ph[idx]; }, fc);
-      const T q = vals[(long)stride * i + ch];
-      f[0] += q * fc[0]; f[1] += q * fc[1]; f[2] += q * fc[2];
+      for (int ch = 0; ch < NCH; ++ch) q[ch] = vals[(long)stride * i + ch];
+      const ChanVec<T, NCH>* __restrict__ ph = reinterpret_cast<const ChanVec<T, NCH>*>(phi);
+      gather_zcol_field_w(g, base, &w[s][0], &w[s][6], wz, ic, [&](long idx) {
+        const ChanVec<T, NCH> p = ph[idx];
+        T v = q[0] * p.v[0];
+#pragma unroll
+        for (int ch = 1; ch < NCH; ++ch) v += q[ch] * p.v[ch];
+        return v;
+      }, f);
+    } else {
+      // one channel at a time (its 36 loads in flight together), the channels' sums combined with the atom's coefficients
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const T* __restrict__ ph = phi + (long)ch * mesh_stride;
+        T fc[3];
+        gather_zcol_field_w(g, base, &w[s][0], &w[s][6], wz, ic, [&](long idx) { return ph[idx]; }, fc);
+        const T q = vals[(long)stride * i + ch];
+        f[0] += q * fc[0]; f[1] += q * fc[1]; f[2] += q * fc[2];
+      }
     }
   }
   part[0][threadIdx.x] = f[0]; part[1][threadIdx.x] = f[1]; part[2][threadIdx.x] = f[2];
@@ -286,12 +325,18 @@ __global__ __launch_bounds__(256) void k_scalar_self(int na, int nch, const T* _
 
 template <class T>
 void launch_gather_scalar(hipStream_t st, int nch, int na, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
-                          const T* phi, long mesh_stride, T* grad, const int* list) {
+                          const T* phi, long mesh_stride, T* grad, const int* list, int interleaved) {
   if (na <= 0) return;
   const unsigned grid = xcd_grid((unsigned)((na + kSgAtoms - 1) / kSgAtoms));
-  if (nch == 3) k_gather_scalar<T, 3><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
-  else if (nch == 2) k_gather_scalar<T, 2><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
-  else k_gather_scalar<T, 1><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+  if (interleaved) {
+    if (nch == 3) k_gather_scalar<T, 3, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+    else if (nch == 2) k_gather_scalar<T, 2, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+    else k_gather_scalar<T, 1, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+    return;
+  }
+  if (nch == 3) k_gather_scalar<T, 3, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+  else if (nch == 2) k_gather_scalar<T, 2, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+  else k_gather_scalar<T, 1, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
 }
 template <class T>
 void launch_scalar_self(hipStream_t st, int nch, int na, const T* vals, int stride, const int* list, const double* self_coefs,
@@ -346,7 +391,8 @@ void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, in
   template int launch_spread_scalar<T>(hipStream_t, int, const T*, const T*, int, const RecipGeom<T>&, const BinScratch&, \
                                        T*, long);                                                                        \
   template void launch_gather_scalar<T>(hipStream_t, int, int, const T*, const T*, int, const RecipGeom<T>&, const T*,    \
-                                        long, T*, const int*);                                                           \
+                                        long, T*, const int*, int);                                                      \
+  template void launch_interleave<T>(hipStream_t, int, long, const T*, long, T*);                                        \
   template void launch_scalar_self<T>(hipStream_t, int, int, const T*, int, const int*, const double*, double*);         \
   template void launch_gather_value<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, const T*,     \
                                        double, T*);

@@ -301,6 +301,10 @@ struct EngineBase {
                            const double* mS, const double* pS, const void* U, double* out) = 0;
   virtual void mscale_grad(int kind, const void* pos, const double* box, const void* par, int pmax, int ns, double* out,
                            int on_device) = 0;
+  virtual void md_bonded(const void* pos, const double* box, int nb, const int32_t* bidx, const void* bpar, int na,
+                         const int32_t* aidx, const void* apar, double* E_dev, void* grad) = 0;
+  virtual void md_kick_drift(int n, void* pos, void* vel, const void* grad, const void* inv_mass, double half_dt_acc, double dt,
+                             double* ekin_dev) = 0;
   virtual void nbr_count(int na, const void* pos, const double* box, double rc, int64_t* n_pairs) = 0;
   virtual void nbr_fill(int32_t* pairs) = 0;
   virtual void nbr_table(const void* pos, const double* box, double rc) = 0;
@@ -323,6 +327,7 @@ struct EngineBase {
     nbr_src = nullptr; nbr_src_gen = -1;
     nbr = NbrTable();
     cls_pending = false; cls_quiet = 1 << 20;
+    slab_sites_na = -1;
     have_top = have_pairs = false;
     ++nbr_gen;
   }
@@ -349,6 +354,8 @@ struct EngineBase {
   // sets does not pay a recompilation per call.
   bool cls_pending = false;
   int cls_quiet = 1 << 20;      // evaluations since the last CLS_STALE
+  int slab_sites_na = -1;       // slab rank: every row of the site table (at slab_sites_ptr) has been prepared at least once
+  const void* slab_sites_ptr = nullptr;   //     for a system of this many atoms (Engine::stage_begin)
   void cls_seen(int flags) {
     if (flags & CLS_STALE) { cls_pending = true; cls_quiet = 0; }
     else if ((flags & CLS_BETTER) && cls_quiet > 8) cls_pending = true;
@@ -588,6 +595,11 @@ struct Engine : EngineBase {
     if (plan_xb) rocfft_plan_destroy(plan_xb);
     if (plan2_f) rocfft_plan_destroy(plan2_f);
     if (plan2_b) rocfft_plan_destroy(plan2_b);
+    for (int k = 0; k < 4; ++k) {
+      if (plan2n_f[k]) rocfft_plan_destroy(plan2n_f[k]);
+      if (plan2n_b[k]) rocfft_plan_destroy(plan2n_b[k]);
+      plan2n_f[k] = plan2n_b[k] = nullptr;
+    }
     if (info_f) rocfft_execution_info_destroy(info_f);
     plan_f = plan_b = plan_xf = plan_xb = plan2_f = plan2_b = nullptr;
     use_fx = false;
@@ -644,24 +656,34 @@ struct Engine : EngineBase {
     const bool track = with_dipoles && sl.prev_na == na && sl.owner_prev.p;
     sl.owner_prev.need(sizeof(int) * (size_t)na);
     if (track) sl.mig.need(sizeof(int) * (size_t)na);
+    // Columns of the ordered compaction.  Only `rows` (the home rows in the table's order: a different sequence) takes a pass
+    // of its own; home / polarizable home / the per-peer import, export and migrant columns are bins of ONE pass over the atoms
+    // (slab_kernels.hip k_slab_bins; ADMP_SLAB_BINS=0: a pass per column as in round 3, for A/B and tests).
+    static const bool bins_on = [] { const char* e = getenv("ADMP_SLAB_BINS"); return !(e && atoi(e) == 0); }();
     SlabCols cs;
-    auto col = [&](const int* seq, int len, int mask, int want, const int* src = nullptr) {
+    SlabBins sb;
+    sb.N = bins_on ? N : 0; sb.me = me;
+    auto col = [&](const int* seq, int len, int mask, int want, const int* src = nullptr, bool binned = false) {
       cs.seq[cs.ncols] = seq; cs.len[cs.ncols] = len; cs.mask[cs.ncols] = mask; cs.want[cs.ncols] = want; cs.src[cs.ncols] = src;
+      cs.binned[cs.ncols] = binned && bins_on ? 1 : 0;
       return cs.ncols++;
     };
-    const int c_home = col(nullptr, na, kSlabHome, kSlabHome);
+    const int c_home = col(nullptr, na, kSlabHome, kSlabHome, nullptr, true);
     const int c_rows = col(order, na, kSlabHome, kSlabHome);
-    const int c_act = col(nullptr, na, kSlabHome | kSlabPolar, kSlabHome | kSlabPolar);
+    const int c_act = col(nullptr, na, kSlabHome | kSlabPolar, kSlabHome | kSlabPolar, nullptr, true);
+    sb.c_home = c_home; sb.c_act = c_act;
     int c_imp[kSlabMaxRanks], c_exp[kSlabMaxRanks], c_min[kSlabMaxRanks], c_mout[kSlabMaxRanks];
+    for (int t = 0; t < kSlabMaxRanks; ++t) sb.c_imp[t] = sb.c_exp[t] = sb.c_min[t] = sb.c_mout[t] = -1;
     for (int t = 0; t < N; ++t) {
       c_imp[t] = c_exp[t] = c_min[t] = c_mout[t] = -1;
       if (t == me) continue;
-      c_imp[t] = col(nullptr, na, kSlabHome | (1 << t), 1 << t);
-      c_exp[t] = col(nullptr, na, kSlabHome | (1 << t), kSlabHome | (1 << t));
+      c_imp[t] = col(nullptr, na, kSlabHome | (1 << t), 1 << t, nullptr, true);
+      c_exp[t] = col(nullptr, na, kSlabHome | (1 << t), kSlabHome | (1 << t), nullptr, true);
       if (track) {
-        c_min[t] = col(nullptr, na, kSlabHome | (1 << t), 1 << t, sl.mig.as<int>());
-        c_mout[t] = col(nullptr, na, kSlabHome | (1 << t), kSlabHome | (1 << t), sl.mig.as<int>());
+        c_min[t] = col(nullptr, na, kSlabHome | (1 << t), 1 << t, sl.mig.as<int>(), true);
+        c_mout[t] = col(nullptr, na, kSlabHome | (1 << t), kSlabHome | (1 << t), sl.mig.as<int>(), true);
       }
+      sb.c_imp[t] = c_imp[t]; sb.c_exp[t] = c_exp[t]; sb.c_min[t] = c_min[t]; sb.c_mout[t] = c_mout[t];
     }
     sl.counts.need(sizeof(int) * (size_t)cs.ncols * (size_t)std::max(1, slab_compact_blocks(na)));
     sl.totals.need(sizeof(int) * kSlabMaxCols);
@@ -669,7 +691,7 @@ struct Engine : EngineBase {
     {
       TIMED("slab_decompose");
       int rc = launch_slab_decompose(stream, na, nbr, top, ev.bases, ev.pol, (int)sizeof(T), X1v - X0v, K0v, X0v, N, me,
-                                     sl.owner.as<int>(), sl.bits.as<int>(), cs, sl.counts.as<int>(), sl.totals.as<int>(),
+                                     sl.owner.as<int>(), sl.bits.as<int>(), cs, sb, sl.counts.as<int>(), sl.totals.as<int>(),
                                      sl.lists.as<int>(), track ? sl.owner_prev.as<int>() : nullptr, track ? sl.mig.as<int>() : nullptr);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("slab decomposition: ") + hipGetErrorString((hipError_t)rc)};
     }
@@ -1027,6 +1049,48 @@ struct Engine : EngineBase {
     return false;
   }
 
+  // Batched y-z plans of the fused-x path for nb meshes at once (dispersion PME: C6 / C8 / C10): the same 2-D r2c / c2r
+  // plans with batch nb * K0 over meshes / spectra stored back to back -- two rocFFT executions per call instead of 2 nb.
+  rocfft_plan plan2n_f[4] = {nullptr, nullptr, nullptr, nullptr}, plan2n_b[4] = {nullptr, nullptr, nullptr, nullptr};
+  void ensure_batched_plans(int nb) {
+    ARG_CHECK(nb >= 2 && nb <= 3 && use_fx && snranks == 1, "internal: batched y-z plans");
+    if (plan2n_f[nb]) return;
+    const rocfft_precision pr = sizeof(T) == 4 ? rocfft_precision_single : rocfft_precision_double;
+    const size_t len2[2] = {(size_t)K[2], (size_t)K[1]};
+    const size_t rs[2] = {1, (size_t)K[2]}, cs[2] = {1, (size_t)fx_khp};
+    const size_t rdist = (size_t)K[1] * K[2], cdist = (size_t)K[1] * fx_khp;
+    rocfft_plan_description df = nullptr, db = nullptr;
+    FFT_TRY(rocfft_plan_description_create(&df));
+    FFT_TRY(rocfft_plan_description_set_data_layout(df, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr,
+                                                    nullptr, 2, rs, rdist, 2, cs, cdist));
+    FFT_TRY(rocfft_plan_description_create(&db));
+    FFT_TRY(rocfft_plan_description_set_data_layout(db, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr,
+                                                    nullptr, 2, cs, cdist, 2, rs, rdist));
+    FFT_TRY(rocfft_plan_create(&plan2n_f[nb], rocfft_placement_notinplace, rocfft_transform_type_real_forward, pr, 2, len2,
+                               (size_t)nb * K[0], df));
+    FFT_TRY(rocfft_plan_create(&plan2n_b[nb], rocfft_placement_notinplace, rocfft_transform_type_real_inverse, pr, 2, len2,
+                               (size_t)nb * K[0], db));
+    rocfft_plan_description_destroy(df);
+    rocfft_plan_description_destroy(db);
+    size_t w = 0, wmax = 0;
+    FFT_TRY(rocfft_plan_get_work_buffer_size(plan2n_f[nb], &w)); if (w > wmax) wmax = w;
+    FFT_TRY(rocfft_plan_get_work_buffer_size(plan2n_b[nb], &w)); if (w > wmax) wmax = w;
+    if (wmax + 16 > fft_work.bytes) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      fft_work.need(wmax + 16);
+    }
+    if (fft_work.bytes > 16) FFT_TRY(rocfft_execution_info_set_work_buffer(info_f, fft_work.p, fft_work.bytes - 16));
+  }
+  // nb meshes at mesh_p + b * nreal -> phi_b in place; energies of all channels summed into energies[slot]
+  void convolve_batch(T* mesh_p, T* spec_p, const DftTabs<T>& tabs, int nb, size_t nreal, size_t nspec, int slot) {
+    ensure_batched_plans(nb);
+    run_plan("rocfft_r2c_yz", plan2n_f[nb], mesh_p, spec_p);
+    { TIMED("fftx_kspace");
+      launch_fftx_conv_batch<T>(stream, K, fx_tw.as<T>(), spec_p, tabs, nb, (long)nspec, Ed_cur(), slot, fx_khp); }
+    run_plan("rocfft_c2r_yz", plan2n_b[nb], spec_p, mesh_p);
+    (void)nreal;
+  }
+
   void run_plan(const char* label, rocfft_plan plan, void* in, void* out) {
     TIMED(label);
     FFT_TRY(rocfft_execution_info_set_stream(info_f, stream));
@@ -1177,6 +1241,35 @@ struct Engine : EngineBase {
     other_clean = false;
     fmax_clean = true;
     for (bool& c : slot_clean) c = true;
+    // Slab rank, steady state: only the rows this rank reads are prepared -- its home atoms and its imports (round 3 prepared
+    // the rows of ALL atoms on every rank: 0.056 ms at 1M atoms whatever the rank count).  The ownership rule needs the stencil
+    // base planes of all atoms first: a 28-byte-per-atom pass (k_atom_bases).  The first evaluation of a handle / topology /
+    // buffer, and evaluations that recompile the table's site classes, take the all-atom pass below, so that every row of
+    // `sites` has held valid data at least once (the class compilation reads all of them).  ADMP_SLAB_SUBSET=0: always all.
+    static const bool subset_on = [] { const char* e = getenv("ADMP_SLAB_SUBSET"); return !(e && atoi(e) == 0); }();
+    if (snranks > 1 && subset_on && slab_sites_na == na && slab_sites_ptr == sites.p && !cls_pending && have_pairs) {
+      { TIMED("atom_bases"); launch_atom_bases<T>(stream, na, ev.pos, ev.g, bases_d.as<int4>()); }
+      ev.bases = bases_d.as<int4>();
+      cls_sites_na = na;
+      ++cls_quiet;
+      const bool tracked = lpol && sl.prev_na == na;
+      decompose();
+      {
+        TIMED("prepare_sites");
+        const int* lists[2] = {sl.home, sl.imp.as<int>()};
+        const int counts[2] = {sl.n_home, sl.n_imp};
+        for (int k = 0; k < 2; ++k)
+          launch_prepare_sites<T>(stream, top, ev.pos, ev.Ql, U_first, ev.pol, ev.thole, ev.bx, sites.as<Site<T>>(),
+                                  k == 0 ? energies_d.as<double>() + (size_t)(ehalf ^ 1) * E_WORDS : nullptr, ev.g, nullptr,
+                                  nullptr, nullptr, nbr.cls, cls_flags_dev(), rq_p(), U_first != ev.U ? ev.U : nullptr, lists[k],
+                                  counts[k]);
+      }
+      other_clean = true;
+      if (tracked) exchange_migrants();
+      if (lpol) exchange_U(0);
+      ev.active = true;
+      return ev.n_home;
+    }
     {
       TIMED("prepare_sites");
       // list of the polarizable sites for the incremental SCF: rebuilt by this kernel unless the caller vouches that the
@@ -1218,6 +1311,7 @@ struct Engine : EngineBase {
     }
     other_clean = true;
     if (snranks > 1) {
+      slab_sites_na = na; slab_sites_ptr = sites.p;        // every row of `sites` is valid from here on
       const bool tracked = lpol && sl.prev_na == na;       // (decompose() then lists the atoms that changed hands)
       decompose();
       if (tracked) exchange_migrants();
@@ -1892,7 +1986,7 @@ struct Engine : EngineBase {
     double* acc = vir_begin();
     launch_disp_pair<T>(stream, na, nbr, pack_srows(pos, cl, 3), bx, tab, (T)kappa, pmax, grad.as<T>(), Ed);
     launch_scalar_pair_virial<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, acc + V_XW);
-    cls_sites_na = -1;   // other rows than an electrostatics evaluation's
+    cls_sites_na = slab_sites_na = -1;   // other rows than an electrostatics evaluation's
     sites.need(sizeof(Site<T>) * (size_t)na);
     ensure_bins(na);
     const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
@@ -1936,6 +2030,25 @@ struct Engine : EngineBase {
     HIP_TRY(hipStreamSynchronize(stream));
     E[0] = Eh2[E_REAL];
     vir_assemble(inv, 0.0, dbox);      // only the xw sums are non-zero here
+  }
+
+  // ---- MD-driver helpers (md_kernels.hip): device pointers, nothing read back -----------------------------
+  void md_bonded(const void* pos, const double* box, int nb, const int32_t* bidx, const void* bpar, int na, const int32_t* aidx,
+                 const void* apar, double* E_dev, void* grad_) override {
+    ARG_CHECK(pos && box && E_dev && grad_ && nb >= 0 && na >= 0, "bad argument");
+    ARG_CHECK((nb == 0 || (bidx && bpar)) && (na == 0 || (aidx && apar)), "bond / angle lists missing");
+    double inv[9], vol;
+    Box<T> bx = make_box(box, inv, &vol);
+    TIMED("md_bonded");
+    launch_md_bonded<T>(stream, nb, bidx, reinterpret_cast<const T*>(bpar), na, aidx, reinterpret_cast<const T*>(apar),
+                        reinterpret_cast<const T*>(pos), bx, reinterpret_cast<T*>(grad_), E_dev);
+  }
+  void md_kick_drift(int n, void* pos, void* vel, const void* grad_, const void* inv_mass, double half_dt_acc, double dt,
+                     double* ekin_dev) override {
+    ARG_CHECK(n >= 0 && vel && grad_ && inv_mass && (dt == 0.0 || pos), "bad argument");
+    TIMED("md_kick_drift");
+    launch_md_kick_drift<T>(stream, n, reinterpret_cast<T*>(pos), reinterpret_cast<T*>(vel), reinterpret_cast<const T*>(grad_),
+                            reinterpret_cast<const T*>(inv_mass), half_dt_acc, dt, ekin_dev);
   }
 
   // ---- neighbour search (cell list) ------------------------------------------------------------------
@@ -2051,7 +2164,7 @@ struct Engine : EngineBase {
     HIP_TRY(hipMemsetAsync(Ed, 0, E_WORDS * sizeof(double), stream));
     const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
     const int nch = (pmax - 4) / 2;
-    cls_sites_na = -1;   // other rows than an electrostatics evaluation's
+    cls_sites_na = slab_sites_na = -1;   // other rows than an electrostatics evaluation's
     // At scale (brick regime) and on every slab rank the channels go through ONE binning, ONE spread and ONE gather straight
     // from the caller's position / coefficient arrays (disp_kernels.hip); small single-GPU systems keep the batched
     // scan-spread / direct-DFT path below (dispatch-bound: nine launches for the three powers).
@@ -2072,6 +2185,22 @@ struct Engine : EngineBase {
       // per lane, whatever it sums: 0.175 ms per channel at 1M atoms in every form tried (one pass over the three meshes
       // 0.52-0.61 ms; one pass per channel from its own or from a shared, cache-resident phi buffer 0.525; round 2's
       // k_gather_field_staged on site rows 0.525) -- what the fused path saves is the site rows and the scale-add pass.
+      // Round 4, one rank on a fused-x mesh: the nch meshes go through ONE batched r2c, ONE x pass (a G table per channel)
+      // and ONE batched c2r; then the channels of every mesh point are laid side by side (one streaming pass) and ONE gather
+      // fetches them with a single load per stencil point -- the gather is bound by its load instructions (36 per lane and
+      // mesh), not by the bytes they return.  ADMP_DISP_BATCH=0: the per-channel loop (A/B, tests).
+      static const bool batch_on = [] { const char* e = getenv("ADMP_DISP_BATCH"); return !(e && atoi(e) == 0); }();
+      if (batch_on && snranks == 1 && use_fx && nch >= 2) {
+        const size_t nspec = 2 * (size_t)K[0] * K[1] * fx_khp;
+        spec.need(nch * nspec * sizeof(T));
+        mesh2.need(nch * nreal * sizeof(T));
+        DftTabs<T> tabs;
+        for (int c = 0; c < nch; ++c) { ensure_gtab(box, inv, vol, 6 + 2 * c); tabs.p[c] = gtab_cur; }
+        convolve_batch(mesh.as<T>(), spec.as<T>(), tabs, nch, nreal, nspec, E_RECIP);
+        { TIMED("interleave"); launch_interleave<T>(stream, nch, (long)nreal, mesh.as<T>(), (long)nreal, mesh2.as<T>()); }
+        { TIMED("gather_field");
+          launch_gather_scalar<T>(stream, nch, sr.n, pos, cl, 3, g, mesh2.as<T>(), (long)nreal, dpos, sr.home, 1); }
+      } else
       for (int c = 0; c < nch; ++c) {
         ensure_gtab(box, inv, vol, 6 + 2 * c);
         convolve(mesh.as<T>() + c * nreal, spec.as<T>(), gtab_cur, E_RECIP);
@@ -2223,7 +2352,7 @@ struct Engine : EngineBase {
     HIP_TRY(hipMemsetAsync(Ed, 0, E_WORDS * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(out, 0, 3 * (size_t)na * sizeof(T), stream));
     launch_scalar_pair_pgrad<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, out);
-    cls_sites_na = -1;
+    cls_sites_na = slab_sites_na = -1;
     sites.need(sizeof(Site<T>) * (size_t)na);
     ensure_bins(na);
     const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
@@ -2348,7 +2477,7 @@ struct Engine : EngineBase {
     HIP_TRY(hipMemsetAsync(cls, 0, 16 * sizeof(double), stream));
     if (kind == 0) {
       ARG_CHECK(have_ewald, "ewald parameters must be set first");
-      cls_sites_na = -1;   // other rows than an electrostatics evaluation's
+      cls_sites_na = slab_sites_na = -1;   // other rows than an electrostatics evaluation's
       sites.need(sizeof(Site<T>) * (size_t)na);
       RecipGeom<T> g = make_geom(inv);
       launch_prepare_sites<T>(stream, top, pos, par, nullptr, nullptr, nullptr, bx, sites.as<Site<T>>(), nullptr, g, nullptr);
@@ -2583,6 +2712,18 @@ int admp_thole_sums(admp_handle* h, const void* positions, const double* box, co
                     const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
                     void* sumX, void* sumXw) {
   return guarded(h, [&](EngineBase& e) { e.thole_sums(positions, box, Q_local, pol, tholes, n_scales, mScales, pScales, U, sumX, sumXw); });
+}
+
+int admp_md_bonded(admp_handle* h, const void* positions, const double* box, int n_bonds, const int32_t* bond_idx,
+                   const void* bond_par, int n_angles, const int32_t* angle_idx, const void* angle_par, double* E_dev,
+                   void* grad_inout) {
+  return guarded(h, [&](EngineBase& e) {
+    e.md_bonded(positions, box, n_bonds, bond_idx, bond_par, n_angles, angle_idx, angle_par, E_dev, grad_inout);
+  });
+}
+int admp_md_kick_drift(admp_handle* h, int n_atoms, void* positions, void* velocities, const void* grad, const void* inv_mass,
+                       double half_dt_acc, double dt, double* ekin_dev) {
+  return guarded(h, [&](EngineBase& e) { e.md_kick_drift(n_atoms, positions, velocities, grad, inv_mass, half_dt_acc, dt, ekin_dev); });
 }
 
 int admp_neighbor_count(admp_handle* h, int n_atoms, const void* positions, const double* box, double rc, int64_t* n_pairs) {

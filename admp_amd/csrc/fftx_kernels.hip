@@ -20,8 +20,11 @@ constexpr int kFftxGMax = 16;      // G values a thread keeps in registers: N * 
 template <class T>
 __global__ __launch_bounds__(kFftxBlock) void k_fftx_conv(int N, int logN, int ncols, int nfix, int NC, long jstride, long fixstride,
                                                           long gjstride, long gfixstride, int K3, Cx<T>* __restrict__ spec,
-                                                          const T* __restrict__ gtab, const Cx<T>* __restrict__ twg,
+                                                          DftTabs<T> tabs, long spec_bstride, const Cx<T>* __restrict__ twg,
                                                           double* energies, int slot) {
+  // blockIdx.y = channel of a batch (dispersion PME: the C6 / C8 / C10 meshes, one G table each)
+  const T* __restrict__ gtab = tabs.p[blockIdx.y];
+  spec += (long)blockIdx.y * spec_bstride;
   Cx<T>* tw = reinterpret_cast<Cx<T>*>(fftx_smem);      // [N / 2]: (cos, sin)(2 pi k / N)
   Cx<T>* D = tw + N / 2;                                 // [N][NC]
   // tiles of one row of columns share their 128-B lines: neighbours on the same XCD (same L2)
@@ -169,6 +172,15 @@ bool fftx_usable(int N) { return N >= 32 && N <= 1024 && (N & (N - 1)) == 0; }
 template <class T>
 void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot, int khp,
                       int ny) {
+  DftTabs<T> tabs;
+  tabs.p[0] = gtab;
+  launch_fftx_conv_batch<T>(st, K, tw, spec, tabs, 1, 0, energies, slot, khp, ny);
+}
+// nb channels: spec of channel b at spec + b * spec_stride (in reals), its table tabs.p[b]; the energies of all channels
+// are summed into energies[slot]
+template <class T>
+void launch_fftx_conv_batch(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, int nb, long spec_stride,
+                            double* energies, int slot, int khp, int ny) {
   const int N = K[0], Kh = K[2] / 2 + 1;
   if (khp < Kh) khp = Kh;
   if (ny <= 0) ny = K[1];
@@ -178,12 +190,16 @@ void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, cons
   while (NC > 1 && sizeof(Cx<T>) * ((size_t)N / 2 + (size_t)N * NC) > 60 * 1024) NC >>= 1;
   const size_t sh = sizeof(Cx<T>) * ((size_t)N / 2 + (size_t)N * NC);
   const int ntile = (Kh + NC - 1) / NC;
-  k_fftx_conv<T><<<xcd_grid((unsigned)(ntile * ny)), kFftxBlock, sh, st>>>(N, logN, Kh, ny, NC, (long)ny * khp, (long)khp,
-                                                                        (long)ny * Kh, (long)Kh, K[2],
-                                                                          reinterpret_cast<Cx<T>*>(spec), gtab,
-                                                                          reinterpret_cast<const Cx<T>*>(tw), energies, slot);
+  k_fftx_conv<T><<<dim3(xcd_grid((unsigned)(ntile * ny)), (unsigned)nb), kFftxBlock, sh, st>>>(
+      N, logN, Kh, ny, NC, (long)ny * khp, (long)khp, (long)ny * Kh, (long)Kh, K[2], reinterpret_cast<Cx<T>*>(spec), tabs,
+      spec_stride / 2, reinterpret_cast<const Cx<T>*>(tw), energies, slot);
 }
-template void launch_fftx_conv<float>(hipStream_t, const int*, const float*, float*, const float*, double*, int, int, int);
-template void launch_fftx_conv<double>(hipStream_t, const int*, const double*, double*, const double*, double*, int, int, int);
+#define INST(T)                                                                                                            \
+  template void launch_fftx_conv<T>(hipStream_t, const int*, const T*, T*, const T*, double*, int, int, int);               \
+  template void launch_fftx_conv_batch<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, int, long, double*, int, \
+                                          int, int);
+INST(float)
+INST(double)
+#undef INST
 
 }  // namespace admp

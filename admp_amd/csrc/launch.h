@@ -119,7 +119,8 @@ void launch_prepare_sites(hipStream_t st, const Topology& top, const T* pos, con
                           const int* cls = nullptr /* NbrTable::cls, checked against the sites: flags OR-ed into ... */,
                           int* cls_flags = nullptr /* ... this word (CLS_STALE / CLS_BETTER) */,
                           RQ4<T>* rq = nullptr /* optional: compact copy (position, charge) of every row */,
-                          T* Ucopy = nullptr /* optional: Ucart is read-only; this array receives a copy of it */);
+                          T* Ucopy = nullptr /* optional: Ucart is read-only; this array receives a copy of it */,
+                          const int* list = nullptr /* optional: only the rows of these atoms ... */, int nlist = 0 /* ... this many */);
 template <class T>
 void launch_local_frames(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, T* out /* (na,3,3) */);
 // field (Cartesian dE/dU) = pair (harmonic order) + recip (cartesian) + self + penalty; also max |field| over
@@ -217,6 +218,10 @@ template <class T>
 void launch_fftx_conv(hipStream_t st, const int K[3], const T* tw, T* spec, const T* gtab, double* energies, int slot,
                       int khp = 0 /* row pitch of spec in complex numbers (0: K[2]/2+1) */,
                       int ny = 0 /* y rows held: spec and gtab are [K0][ny][..] (0: K[1]; a slab rank holds its own rows) */);
+template <class T>
+void launch_fftx_conv_batch(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, int nb,
+                            long spec_stride /* reals between the spectra of consecutive channels */, double* energies, int slot,
+                            int khp = 0, int ny = 0);
 
 // ---- pair_kernels.hip
 template <class T>
@@ -402,7 +407,12 @@ int launch_spread_scalar(hipStream_t st, int nch, const T* pos, const T* vals, i
 // grad[i] += sum_c vals[i][c] Jac . grad phi_c(r_i) for the n listed atoms
 template <class T>
 void launch_gather_scalar(hipStream_t st, int nch, int na, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
-                          const T* phi, long mesh_stride, T* grad, const int* list);
+                          const T* phi, long mesh_stride, T* grad, const int* list,
+                          int interleaved = 0 /* phi = [mesh point][nch]: the channels of a point side by side (launch_interleave) */);
+// dst[i * nch + c] = src[c * stride + i], i < n: the nch meshes of a dispersion call side by side per mesh point, so that the
+// gather fetches all channels of a stencil point with ONE load instruction
+template <class T>
+void launch_interleave(hipStream_t st, int nch, long n, const T* src, long stride, T* dst);
 // energies[E_SELF] += sum over the n listed atoms and the nch channels of self_coefs[c] vals[i][c]^2
 template <class T>
 void launch_scalar_self(hipStream_t st, int nch, int na, const T* vals, int stride, const int* list, const double* self_coefs,
@@ -451,6 +461,16 @@ struct SlabCols {
   const int* src[kSlabMaxCols];    // the flag words this column tests (nullptr: the `bits` array of the decomposition)
   int mask[kSlabMaxCols];
   int want[kSlabMaxCols];
+  int binned[kSlabMaxCols];        // 1: the column is filled by the one-pass bin compaction (SlabBins), not by its own pass
+};
+// The per-peer columns of a decomposition -- imports from / exports to / atoms taken over from / given away to every rank --
+// plus the home and polarizable-home columns, as BINS of one ordered compaction pass over the atoms (round 3 ran one pass over
+// all atoms per column: 7 passes on 2 ranks, 31 on 8 -- the part of a rank's step that GREW with the rank count).  c_*: the
+// column (index into SlabCols / totals / lists) a bin writes, -1 = absent.
+struct SlabBins {
+  int N = 0, me = 0;
+  int c_home = -1, c_act = -1;
+  int c_imp[kSlabMaxRanks], c_exp[kSlabMaxRanks], c_min[kSlabMaxRanks], c_mout[kSlabMaxRanks];
 };
 // segments of a joined per-peer list: segment s = column col[s] of the compaction, entries off[s] .. off[s+1]-1 of the result
 struct SlabSegs {
@@ -464,8 +484,8 @@ struct SlabSegs {
 // 1 << previous owner (atoms this rank took over) or kSlabHome | 1 << new owner (atoms it gave away), else 0
 int launch_slab_decompose(hipStream_t st, int na, const NbrTable& nb, const Topology& top, const int4* bases, const void* pol,
                           int prec, int width, int K0, int X0, int nranks, int me, int* owner, int* bits,
-                          const SlabCols& cs, int* counts, int* totals, int* lists, const int* owner_prev = nullptr,
-                          int* mig = nullptr);
+                          const SlabCols& cs, const SlabBins& sb, int* counts, int* totals, int* lists,
+                          const int* owner_prev = nullptr, int* mig = nullptr);
 int slab_compact_blocks(int maxlen);
 void launch_slab_concat(hipStream_t st, const SlabSegs& segs, const int* lists, long col_stride, int* out);
 template <class T>
@@ -495,5 +515,13 @@ int launch_class_partition(hipStream_t st, int na, NbrTable& nb);
 // builds nb from (n_rows, 2) device pairs; scratch (deg/cursor) is managed inside. Returns hipError_t as int.
 int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, const int* pairs_dev, NbrTable& nb,
                           void** scratch, size_t* scratch_bytes);
+
+// ---- md_kernels.hip: harmonic bonded terms and velocity-Verlet half steps of the MD drivers
+template <class T>
+void launch_md_bonded(hipStream_t st, int nb, const int* bidx, const T* bpar, int na, const int* aidx, const T* apar, const T* pos,
+                      const Box<T>& box, T* grad, double* E);
+template <class T>
+void launch_md_kick_drift(hipStream_t st, int n, T* pos, T* vel, const T* grad, const T* inv_mass, double half_dt_acc, double dt,
+                          double* ekin);
 
 }  // namespace admp

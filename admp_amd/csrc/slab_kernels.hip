@@ -13,6 +13,7 @@
 // reader -- all ascending, so both ends of an exchange agree on the order) are ordered compactions of that array.
 #include "dft_math.h"
 #include "launch.h"
+#include "reduce.h"
 
 namespace admp {
 
@@ -28,7 +29,7 @@ __device__ __forceinline__ int slab_owner(int gx, int K0, int N) {
 template <class T>
 __global__ __launch_bounds__(256) void k_slab_owner(int na, const int4* __restrict__ bases, const T* __restrict__ pol, int width,
                                                     int K0, int X0, int N, int me, int* __restrict__ owner,
-                                                    int* __restrict__ bits) {
+                                                    int* __restrict__ bits, const int* __restrict__ prev, int* __restrict__ mig) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= na) return;
   const int b = bases[i].x;                        // local plane index of the stencil base, relative to this rank's X0
@@ -42,15 +43,10 @@ __global__ __launch_bounds__(256) void k_slab_owner(int na, const int4* __restri
   }
   owner[i] = o;
   bits[i] = w;
-}
-
-// atoms that changed hands since the previous evaluation (see launch_slab_decompose)
-__global__ __launch_bounds__(256) void k_slab_migrants(int na, const int* __restrict__ owner, const int* __restrict__ prev, int me,
-                                                       int* __restrict__ mig) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= na) return;
-  const int o = owner[i], q = prev[i];
-  mig[i] = (o == me && q != me) ? (1 << q) : ((q == me && o != me) ? (kSlabHome | (1 << o)) : 0);
+  if (mig) {      // atoms that changed hands since the previous evaluation (see launch_slab_decompose)
+    const int q = prev[i];
+    mig[i] = (o == me && q != me) ? (1 << q) : ((q == me && o != me) ? (kSlabHome | (1 << o)) : 0);
+  }
 }
 
 // import marks on the atoms other ranks own, export masks on the rank's own atoms; 8 lanes per row, every atom's row is
@@ -105,6 +101,7 @@ __global__ __launch_bounds__(kCompactBlock) void k_compact_count(SlabCols cs, co
                                                                  int* __restrict__ counts) {
   __shared__ int wsum[kCompactBlock / 64];
   const int c = blockIdx.y, p0 = blockIdx.x * kCompactSpan;
+  if (cs.binned[c]) return;                 // (workgroup-uniform) filled by k_slab_bins
   int n = 0;
   if (p0 < cs.len[c]) {
 #pragma unroll
@@ -156,7 +153,7 @@ __global__ __launch_bounds__(kCompactBlock) void k_compact_write(SlabCols cs, co
                                                                  long col_stride) {
   __shared__ int wcnt[kCompactPer][kCompactBlock / 64];
   const int c = blockIdx.y, p0 = blockIdx.x * kCompactSpan;
-  if (p0 >= cs.len[c]) return;
+  if (cs.binned[c] || p0 >= cs.len[c]) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int x[kCompactPer];
   bool keep[kCompactPer];
@@ -180,22 +177,104 @@ __global__ __launch_bounds__(kCompactBlock) void k_compact_write(SlabCols cs, co
   }
 }
 
+// ---- all per-peer columns in one ordered pass --------------------------------------------------------------------------------
+// A workgroup takes kCompactSpan consecutive atoms as 16 chunks of 64 (chunk q = r * 4 + wave holds atoms p0 + r * 256 + wave *
+// 64 + lane: ascending in q).  visit() enumerates, wave-uniformly, the bins the 64 atoms of a chunk fall into (ballot per bin:
+// a wave of a liquid holds home atoms and the imports / exports of one or two neighbours); rank inside the chunk = number of
+// lower lanes in the same bin, so every bin's list comes out in ascending atom order -- the order both ends of an exchange
+// rely on.  WRITE = false: per-workgroup counts of every bin; WRITE = true (after the scan): the lists.
+template <class F>
+__device__ __forceinline__ void slab_visit_bins(int w, int g, const SlabBins& sb, F&& f) {
+  const bool home = (w & kSlabHome) != 0;
+  const int peers = w & ((1 << kSlabMaxRanks) - 1);
+  { const bool m = home; const unsigned long long b = __ballot(m); if (b) f(sb.c_home, m, b); }
+  { const bool m = home && (w & kSlabPolar); const unsigned long long b = __ballot(m); if (b) f(sb.c_act, m, b); }
+  const int imp = home ? 0 : peers, ex = home ? peers : 0;
+  const bool gout = (g & kSlabHome) != 0;
+  const int gp = g & ((1 << kSlabMaxRanks) - 1), gin = gout ? 0 : gp, go = gout ? gp : 0;
+  // (which peers occur at all in this chunk: one OR over the wave, then one ballot per peer that does)
+  int any = imp | ex | gp;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) any |= __shfl_xor(any, off, 64);
+  while (any) {
+    const int t = __builtin_ctz(any);
+    any &= any - 1;
+    { const bool m = (imp >> t) & 1; const unsigned long long b = __ballot(m); if (b) f(sb.c_imp[t], m, b); }
+    { const bool m = (ex >> t) & 1; const unsigned long long b = __ballot(m); if (b) f(sb.c_exp[t], m, b); }
+    { const bool m = (gin >> t) & 1; const unsigned long long b = __ballot(m); if (b && sb.c_min[t] >= 0) f(sb.c_min[t], m, b); }
+    { const bool m = (go >> t) & 1; const unsigned long long b = __ballot(m); if (b && sb.c_mout[t] >= 0) f(sb.c_mout[t], m, b); }
+  }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kCompactBlock) void k_slab_bins(int na, int ncols, const int* __restrict__ bits,
+                                                             const int* __restrict__ mig, SlabBins sb, int nblocks,
+                                                             int* __restrict__ counts, int* __restrict__ lists, long col_stride) {
+  __shared__ int cnt[kCompactPer * (kCompactBlock / 64)][kSlabMaxCols];
+  constexpr int kChunks = kCompactPer * (kCompactBlock / 64);
+  const int p0 = blockIdx.x * kCompactSpan, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = threadIdx.x; t < kChunks * kSlabMaxCols; t += kCompactBlock) (&cnt[0][0])[t] = 0;
+  __syncthreads();
+  int w[kCompactPer], g[kCompactPer];
+#pragma unroll
+  for (int r = 0; r < kCompactPer; ++r) {
+    const int p = p0 + r * kCompactBlock + (int)threadIdx.x;
+    w[r] = p < na ? bits[p] : 0;
+    g[r] = (mig && p < na) ? mig[p] : 0;
+    const int q = r * (kCompactBlock / 64) + wave;
+    slab_visit_bins(w[r], g[r], sb, [&](int c, bool, unsigned long long b) { if (lane == 0 && c >= 0) cnt[q][c] = __popcll(b); });
+  }
+  __syncthreads();
+  if (!WRITE) {
+    for (int c = threadIdx.x; c < ncols; c += kCompactBlock) {
+      int tot = 0;
+      for (int q = 0; q < kChunks; ++q) tot += cnt[q][c];
+      // (only the bins' columns: the others belong to k_compact_count)
+      bool mine = c == sb.c_home || c == sb.c_act;
+      for (int t = 0; t < sb.N && !mine; ++t) mine = c == sb.c_imp[t] || c == sb.c_exp[t] || c == sb.c_min[t] || c == sb.c_mout[t];
+      if (mine) counts[(size_t)c * nblocks + blockIdx.x] = tot;
+    }
+    return;
+  }
+  for (int c = threadIdx.x; c < ncols; c += kCompactBlock) {      // chunk counts -> offsets of the chunks inside this workgroup
+    int run = counts[(size_t)c * nblocks + blockIdx.x];           // (scanned: this workgroup's offset in column c)
+    for (int q = 0; q < kChunks; ++q) { const int v = cnt[q][c]; cnt[q][c] = run; run += v; }
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < kCompactPer; ++r) {
+    const int p = p0 + r * kCompactBlock + (int)threadIdx.x;
+    const int q = r * (kCompactBlock / 64) + wave;
+    slab_visit_bins(w[r], g[r], sb, [&](int c, bool member, unsigned long long b) {
+      if (member && c >= 0) lists[(size_t)c * col_stride + cnt[q][c] + __popcll(b & lt)] = p;
+    });
+  }
+}
+
 int launch_slab_decompose(hipStream_t st, int na, const NbrTable& nb, const Topology& top, const int4* bases, const void* pol,
                           int prec, int width, int K0, int X0, int nranks, int me, int* owner, int* bits,
-                          const SlabCols& cs, int* counts, int* totals, int* lists, const int* owner_prev, int* mig) {
+                          const SlabCols& cs, const SlabBins& sb, int* counts, int* totals, int* lists, const int* owner_prev,
+                          int* mig) {
   if (na <= 0) return 0;
   const unsigned g1 = (unsigned)((na + 255) / 256);
-  if (prec == 4) k_slab_owner<float><<<g1, 256, 0, st>>>(na, bases, (const float*)pol, width, K0, X0, nranks, me, owner, bits);
-  else k_slab_owner<double><<<g1, 256, 0, st>>>(na, bases, (const double*)pol, width, K0, X0, nranks, me, owner, bits);
-  if (owner_prev && mig) k_slab_migrants<<<g1, 256, 0, st>>>(na, owner, owner_prev, me, mig);
+  const int* pv = (owner_prev && mig) ? owner_prev : nullptr;
+  int* mg = pv ? mig : nullptr;
+  if (prec == 4) k_slab_owner<float><<<g1, 256, 0, st>>>(na, bases, (const float*)pol, width, K0, X0, nranks, me, owner, bits, pv, mg);
+  else k_slab_owner<double><<<g1, 256, 0, st>>>(na, bases, (const double*)pol, width, K0, X0, nranks, me, owner, bits, pv, mg);
   k_slab_marks<<<(unsigned)(((long)na * 8 + 255) / 256), 256, 0, st>>>(na, nb.rowptr, nb.col, top, owner, me, bits);
   int maxlen = 0;
   for (int c = 0; c < cs.ncols; ++c) maxlen = cs.len[c] > maxlen ? cs.len[c] : maxlen;
   const int nblocks = (maxlen + kCompactSpan - 1) / kCompactSpan;
   if (nblocks <= 0) return (int)hipMemsetAsync(totals, 0, sizeof(int) * cs.ncols, st);
-  k_compact_count<<<dim3(nblocks, cs.ncols), kCompactBlock, 0, st>>>(cs, bits, nblocks, counts);
+  int generic = 0;
+  for (int c = 0; c < cs.ncols; ++c) generic += cs.binned[c] ? 0 : 1;
+  const int* migp = (owner_prev && mig) ? mig : nullptr;
+  if (generic) k_compact_count<<<dim3(nblocks, cs.ncols), kCompactBlock, 0, st>>>(cs, bits, nblocks, counts);
+  if (sb.N > 0) k_slab_bins<false><<<nblocks, kCompactBlock, 0, st>>>(na, cs.ncols, bits, migp, sb, nblocks, counts, lists, (long)na);
   k_compact_scan<<<cs.ncols, 1024, 0, st>>>(nblocks, counts, totals);
-  k_compact_write<<<dim3(nblocks, cs.ncols), kCompactBlock, 0, st>>>(cs, bits, nblocks, counts, lists, (long)na);
+  if (generic) k_compact_write<<<dim3(nblocks, cs.ncols), kCompactBlock, 0, st>>>(cs, bits, nblocks, counts, lists, (long)na);
+  if (sb.N > 0) k_slab_bins<true><<<nblocks, kCompactBlock, 0, st>>>(na, cs.ncols, bits, migp, sb, nblocks, counts, lists, (long)na);
   return (int)hipGetLastError();
 }
 int slab_compact_blocks(int maxlen) { return (maxlen + kCompactSpan - 1) / kCompactSpan; }
@@ -296,32 +375,38 @@ void launch_halo_u_unpack(hipStream_t st, int n, int what, const int* idx, const
 // x-slab layout spec[nx][K1][pitch >= nh] (rows padded to whole cache lines) <-> send / receive buffer: the block for peer t
 // holds [nx][ny_t][nh] with ny_t = the y rows of rank t; one complex number per thread, z fastest (coalesced both sides).
 // dir 0: spec -> buf (pack), dir 1: buf -> spec (unpack)
+// A workgroup takes kPackRows consecutive y rows of one x plane: 16 lanes look up the rows' peers and offsets once (round 3
+// did two integer divisions and the owner search per ELEMENT), then all threads sweep the rows' elements flat (row index by
+// a float-reciprocal division), z fastest on both sides.
+constexpr int kPackRows = 16;
 template <class T>
 __global__ __launch_bounds__(256) void k_transpose_pack(int nx, int K1, int nh, int pitch, int N, int dir, Cx<T>* __restrict__ spec,
                                                         Cx<T>* __restrict__ buf) {
-  const long n = (long)nx * K1 * nh;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
-    const int z = (int)(t % nh);
-    const long r = t / nh;
-    const int y = (int)(r % K1), x = (int)(r / K1);
+  __shared__ long boff[kPackRows];
+  const int ya = blockIdx.x * kPackRows, x = blockIdx.y, rows = min(kPackRows, K1 - ya);
+  if (threadIdx.x < rows) {
+    const int y = ya + threadIdx.x;
     int p = (int)(((long)y * N) / K1);                                   // owner of row y: floor(s K1 / N) <= y
     while ((int)(((long)p * K1) / N) > y) --p;
     while ((int)(((long)(p + 1) * K1) / N) <= y) ++p;
     const int y0 = (int)(((long)p * K1) / N), ny = (int)(((long)(p + 1) * K1) / N) - y0;
-    const long o = (long)nx * y0 * nh + ((long)x * ny + (y - y0)) * nh + z;   // blocks of lower peers hold nx * y0 rows
-    const long si = r * pitch + z;
-    if (dir == 0) buf[o] = spec[si];
-    else spec[si] = buf[o];
+    boff[threadIdx.x] = (long)nx * y0 * nh + ((long)x * ny + (y - y0)) * nh;   // blocks of lower peers hold nx * y0 rows
+  }
+  __syncthreads();
+  Cx<T>* __restrict__ s = spec + ((long)x * K1 + ya) * pitch;
+  const int n = rows * nh;
+  const float inv = 1.0f / (float)nh;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int r = fast_div(e, nh, inv), z = e - r * nh;
+    if (dir == 0) buf[boff[r] + z] = s[(long)r * pitch + z];
+    else s[(long)r * pitch + z] = buf[boff[r] + z];
   }
 }
 template <class T>
 void launch_transpose_pack(hipStream_t st, int nx, int K1, int nh, int pitch, int nranks, int dir, T* spec, T* buf) {
-  const long n = (long)nx * K1 * nh;
-  if (n <= 0) return;
-  long blocks = (n + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  k_transpose_pack<T><<<(unsigned)blocks, 256, 0, st>>>(nx, K1, nh, pitch, nranks, dir, reinterpret_cast<Cx<T>*>(spec),
-                                                        reinterpret_cast<Cx<T>*>(buf));
+  if (nx <= 0 || K1 <= 0 || nh <= 0) return;
+  k_transpose_pack<T><<<dim3((unsigned)((K1 + kPackRows - 1) / kPackRows), (unsigned)nx), 256, 0, st>>>(
+      nx, K1, nh, pitch, nranks, dir, reinterpret_cast<Cx<T>*>(spec), reinterpret_cast<Cx<T>*>(buf));
 }
 
 // the four energy parts of an evaluation in one block of words (what a SUM all-reduce over the ranks then takes)

@@ -1,11 +1,18 @@
 #!/usr/bin/env python
 """Velocity-Verlet NVE loop on the full MPID-style water potential: multipolar (optionally polarizable) PME +
 dispersion PME + Tang-Toennies damping from libadmp_hip, harmonic bonds / angles (examples' mpidwater.xml:16-21)
-from a few torch ops.  The reference has no integrator; this driver turns the hot path into a
-real MD loop: it reports the energy drift (a direct check that the hand-coded adjoints are the gradient of the
-energies) and the achieved ns/day including neighbour rebuilds.
+and the integrator as HIP kernels too (admp_amd/md.py: one kernel for the bonded terms, one per half step; round 3 spent
+~60 torch launches per step on them).  The reference has no integrator; this driver turns the hot
+path into a real MD loop: it reports the energy drift (a direct check that the hand-coded adjoints are the gradient of the
+energies) and the achieved ns/day including neighbour rebuilds.  Per step the host waits only where the calculators
+themselves do (each returns its energy as a number, like the reference's get_forces); the bonded and kinetic energies
+stay on the device until a line is logged.
 
-    python examples/md/nve_water.py [--waters 1024] [--steps 200] [--dt 0.5] [--pol] [--single]
+    python examples/md/nve_water.py [--waters 1024] [--steps 200] [--dt 0.5] [--pol] [--single] [--mesh K] [--log 10]
+
+--mesh K: K1 = K2 = K3 = K instead of the reference's rule (admp/pme.py:146-172), e.g. 128 for the 98 304-atom box of
+BASELINE configs[2] (the rule gives 305 = 5 * 61 there: every convolution then runs on the two-level DFT kernels, 0.7 ms
+each -- with a tight SCF that, not the host, is most of a step).
 """
 import argparse
 import os
@@ -26,6 +33,7 @@ K_ANG, TH0 = 460.24, 1.82421813418
 
 
 def bonded(pos, n_mol):
+    """torch restatement of the bonded terms (the checker of tests/test_gpu_examples.py; the loop uses admp_amd.md)"""
     m = pos.reshape(n_mol, 3, 3)
     a, b = m[:, 1] - m[:, 0], m[:, 2] - m[:, 0]
     ra, rb = a.norm(dim=1), b.norm(dim=1)
@@ -43,14 +51,18 @@ def main():
     ap.add_argument('--rebuild', type=int, default=10)
     ap.add_argument('--minimize', type=int, default=200)
     ap.add_argument('--temp', type=float, default=300.0)
+    ap.add_argument('--mesh', type=int, default=0, help='PME mesh size per dimension (0: the reference rule)')
+    ap.add_argument('--log', type=int, default=10, help='steps between energy records (each costs two host reads)')
+    ap.add_argument('--thresh', type=float, default=1e-2, help='SCF threshold of --pol (the reference default 10 does not conserve energy)')
     opt = ap.parse_args()
     settings.PRECISION = 'single' if opt.single else 'double'
     if opt.pol:
-        settings.POL_CONV = 1e-2      # a tight SCF: the reference's default (10) is too loose for energy conservation
+        settings.POL_CONV = opt.thresh      # a tight SCF: the reference's default (10) is too loose for energy conservation
         settings.MAX_N_POL = 60
     from admp_amd.pme import ADMPPmeForce
     from admp_amd.disp_pme import ADMPDispPmeForce
     from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
+    from admp_amd.md import HarmonicBonded, VelocityVerlet
 
     n_mol = opt.waters
     pos0, box = S.synthetic_water_box(n_mol, seed=20240)
@@ -61,8 +73,16 @@ def main():
     rc, skin = 4.0, 1.0
     pme = ADMPPmeForce(box, at, ai, cov, rc, 1e-4, 2, lpol=opt.pol)
     disp = ADMPDispPmeForce(box, cov, rc, 1e-4, 10)
+    if opt.mesh:
+        for obj in (pme, disp):
+            for k in ('K1', 'K2', 'K3'):
+                obj.update_env(k, opt.mesh)
     tt_obj = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
     tt = value_and_grad(tt_obj)
+    o = 3 * np.arange(n_mol)
+    bonds = np.stack([np.concatenate([o, o]), np.concatenate([o + 1, o + 2])], axis=1)
+    angles = np.stack([o + 1, o, o + 2], axis=1)
+    bond = HarmonicBonded(3 * n_mol, bonds, np.tile([K_BOND, R0], (2 * n_mol, 1)), angles, np.tile([K_ANG, TH0], (n_mol, 1)))
 
     class Lists:
         """Verlet lists with a skin, rebuilt every --rebuild steps (the pair kernels have no cutoff test of their own,
@@ -84,49 +104,55 @@ def main():
     state = {'U': None}
 
     def forces(p, pairs):
+        """(potential energy of the three calculators -- numbers they return anyway --, +dE/dr of everything); the bonded
+        energy of this evaluation is in bond.energy_words (read by epot_now() when a line is logged)"""
         if opt.pol:
-            e1, g1 = pme.get_forces(p, box, pairs, Q, pol, thole, mS, pS, dS, U_init=state['U'])
+            e1, g = pme.get_forces(p, box, pairs, Q, pol, thole, mS, pS, dS, U_init=state['U'])
             state['U'] = pme.U_ind
             state['cyc'] = state.get('cyc', 0) + pme.n_cycle + 1
             state['n'] = state.get('n', 0) + 1
         else:
-            e1, g1 = pme.get_forces(p, box, pairs, Q, mS)
+            e1, g = pme.get_forces(p, box, pairs, Q, mS)
         e2, g2 = disp.get_forces(p, box, pairs, cl, mS)
         e3, g3 = tt(p, box, pairs, mS, a_, b_, q_, c6)
-        pb = p.detach().clone().requires_grad_(True)
-        e4 = bonded(pb, n_mol)
-        g4, = torch.autograd.grad(e4, pb)
-        return float(e1) + float(e2) + float(e3) + float(e4.detach()), -(g1 + g2 + g3 + g4)
+        g.add_(g2).add_(g3)
+        bond.reset_energy()
+        bond.add_forces(p, box, g)
+        return e1 + e2 + e3, g
+
+    def epot_now(e123):
+        return float(e123) + bond.energy()
 
     g = torch.Generator(device=dev).manual_seed(1)
     # units: A, fs, amu, kJ/mol.  1 kJ/mol/amu = (1e-2 A/fs)^2;  1 (kJ/mol/A)/amu = 1e-4 A/fs^2
     vel = torch.randn(pos.shape, generator=g, device=dev, dtype=dt) * torch.sqrt(KB * opt.temp / mass) * 1e-2
     acc_unit = 1e-4
     h = opt.dt
+    vv = VelocityVerlet(pme, np.tile(MASS, n_mol), h)
     pairs = nbl.allocate(pos)
-    epot, f = forces(pos, pairs)
+    e123, grad = forces(pos, pairs)
     for it in range(opt.minimize):          # the synthetic box is not equilibrated: capped steepest descent first
-        stepv = f * (0.02 / max(float(f.norm(dim=1).max()), 1e-12))
-        pos = pos + stepv
+        pos = pos - grad * (0.02 / max(float(grad.norm(dim=1).max()), 1e-12))
         if (it + 1) % opt.rebuild == 0:
             pairs = nbl.allocate(pos)
-        e_new, f = forces(pos, pairs)
+        e123, grad = forces(pos, pairs)
         if it % 50 == 0 or it == opt.minimize - 1:
-            print('minimize %4d  Epot %14.4f' % (it, e_new))
+            print('minimize %4d  Epot %14.4f' % (it, epot_now(e123)))
     pairs = nbl.allocate(pos)
-    epot, f = forces(pos, pairs)
+    e123, grad = forces(pos, pairs)
+    pos, vel = pos.contiguous(), vel.contiguous()
     log = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for step in range(opt.steps):
-        vel = vel + 0.5 * h * acc_unit * f / mass
-        pos = pos + h * vel
+        vv.kick_drift(pos, vel, grad)                                  # v(t + h/2), r(t + h): in place, one kernel
         if (step + 1) % opt.rebuild == 0:
             pairs = nbl.allocate(pos)
-        epot, f = forces(pos, pairs)
-        vel = vel + 0.5 * h * acc_unit * f / mass
-        if step % 10 == 0 or step == opt.steps - 1:
-            ekin = float(0.5 * (mass * vel ** 2).sum()) / acc_unit
+        e123, grad = forces(pos, pairs)
+        rec = step % opt.log == 0 or step == opt.steps - 1
+        vv.kick(pos, vel, grad, want_ekin=rec)                         # v(t + h)
+        if rec:
+            epot, ekin = epot_now(e123), vv.kinetic_energy()
             log.append((step, epot, ekin, epot + ekin))
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0

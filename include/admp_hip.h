@@ -231,6 +231,23 @@ int admp_neighbor_fill(admp_handle* h, int32_t* pairs_out);
  * from DEVICE positions (n_atoms of admp_set_topology), without materialising the pair array. */
 int admp_set_pairs_from_positions(admp_handle* h, const void* positions, const double* box, double rc);
 
+/* ---- MD-driver helpers ("next" row f2 of SURVEY.md 8f; the reference has no integrator) -------------------
+ * replaces: nothing in the reference -- its drivers stop at get_forces.  What an MD loop around the hot path needs besides
+ * it, as device kernels so that a step does not pay dozens of framework launches: the harmonic bonded terms of the drivers'
+ * force field (examples/water_1024/mpidwater.xml:16-21: HarmonicBondForce E = k/2 (r - r0)^2, HarmonicAngleForce E = k/2
+ * (theta - theta0)^2) over explicit lists, and the half steps of velocity Verlet.  All pointers are DEVICE pointers
+ * (box: host); nothing is read back -- energies accumulate into device words the caller reads when it logs.
+ *   admp_md_bonded      bond_idx (n_bonds,2) int32, bond_par (n_bonds,2) real = (k, r0); angle_idx (n_angles,3) int32 = (i,
+ *                       centre, k), angle_par (n_angles,2) real = (k, theta0 in rad); minimum-image vectors;
+ *                       E_dev[0] += bond energy, E_dev[1] += angle energy (doubles); grad_inout (Na,3) real += dE/dr
+ *   admp_md_kick_drift  v -= half_dt_acc * grad / m (grad = +dE/dr, inv_mass (Na) real); then, if dt != 0, r += dt * v;
+ *                       ekin_dev (optional) += sum m v^2 / 2 after the kick, in the caller's units */
+int admp_md_bonded(admp_handle* h, const void* positions, const double* box, int n_bonds, const int32_t* bond_idx,
+                   const void* bond_par, int n_angles, const int32_t* angle_idx, const void* angle_par, double* E_dev,
+                   void* grad_inout);
+int admp_md_kick_drift(admp_handle* h, int n_atoms, void* positions, void* velocities, const void* grad, const void* inv_mass,
+                       double half_dt_acc, double dt, double* ekin_dev);
+
 /* ---- multi-GPU: x-slab decomposition ---------------------------------------------------------------------
  * (no counterpart in the reference, which is single-device)  One process per GPU, SPMD: every rank makes
  * the same admp_pme_energy_grad / admp_disp_energy_grad / admp_tt_energy_grad call with the same full input arrays.  Rank s

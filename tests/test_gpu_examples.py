@@ -71,3 +71,53 @@ def test_nve_water_conserves_energy(pol):
     assert m, out[-500:]
     assert abs(float(m.group(1))) < 2e-4, out[-800:]
     assert 'ns/day' in out
+
+
+@pytest.mark.parametrize('prec,tol', [('double', 1e-11), ('single', 2e-5)])
+def test_md_bonded_and_integrator_kernels(prec, tol):
+    """admp_amd.md (admp_md_bonded, admp_md_kick_drift): the harmonic bond / angle kernel against torch autograd through the
+    driver's own torch restatement (wrapped molecules: minimum-image vectors), and one velocity-Verlet step against the
+    formulas; energies accumulate on the device."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'examples', 'md'))
+    import nve_water as drv
+    from admp_amd import settings, systems as S
+    from admp_amd.md import HarmonicBonded, VelocityVerlet
+    old = settings.PRECISION
+    settings.PRECISION = prec
+    try:
+        n_mol = 300
+        pos0, box = S.synthetic_water_box(n_mol, seed=3)
+        rng = np.random.default_rng(1)
+        pos0 = pos0 + 0.05 * rng.normal(size=pos0.shape)                 # off the equilibrium geometry
+        o = 3 * np.arange(n_mol)
+        bonds = np.stack([np.concatenate([o, o]), np.concatenate([o + 1, o + 2])], axis=1)
+        angles = np.stack([o + 1, o, o + 2], axis=1)
+        hb = HarmonicBonded(3 * n_mol, bonds, np.tile([drv.K_BOND, drv.R0], (2 * n_mol, 1)), angles,
+                            np.tile([drv.K_ANG, drv.TH0], (n_mol, 1)))
+        pt = torch.tensor(pos0, dtype=torch.float64, requires_grad=True)
+        e_ref = drv.bonded(pt, n_mol)
+        g_ref, = torch.autograd.grad(e_ref, pt)
+        wrapped = np.mod(pos0, box[0, 0])                                 # atoms of a molecule on opposite faces of the cell
+        for p in (pos0, wrapped):
+            E, G = hb.get_forces(p, box)
+            assert abs(E - float(e_ref)) < max(tol, 1e-12) * abs(float(e_ref))
+            assert np.linalg.norm(G - g_ref.numpy()) < tol * np.linalg.norm(g_ref.numpy())
+        # integrator: one full step with a constant gradient
+        dt = torch.float32 if prec == 'single' else torch.float64
+        mass = np.tile(drv.MASS, n_mol)
+        vv = VelocityVerlet(hb, mass, 0.5)
+        r = torch.as_tensor(pos0, dtype=dt, device='cuda').contiguous()
+        v = torch.as_tensor(rng.normal(size=pos0.shape) * 1e-2, dtype=dt, device='cuda').contiguous()
+        g = torch.as_tensor(rng.normal(size=pos0.shape) * 50.0, dtype=dt, device='cuda').contiguous()
+        r0, v0 = r.double().cpu().numpy(), v.double().cpu().numpy()
+        gh = g.double().cpu().numpy()
+        vv.kick_drift(r, v, g)
+        vh = v0 - 0.25e-4 * gh / mass[:, None]
+        assert np.abs(v.double().cpu().numpy() - vh).max() < tol and np.abs(r.double().cpu().numpy() - (r0 + 0.5 * vh)).max() < 50 * tol
+        vv.kick(r, v, g, want_ekin=True)
+        v1 = vh - 0.25e-4 * gh / mass[:, None]
+        ek = 0.5 * (mass[:, None] * v1 ** 2).sum() / 1e-4
+        assert abs(vv.kinetic_energy() - ek) < 10 * tol * ek
+    finally:
+        settings.PRECISION = old

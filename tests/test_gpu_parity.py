@@ -175,12 +175,20 @@ dref = None
 for prec, tol in (('double', 1e-9), ('single', 5e-4)):
     settings.PRECISION = prec
     d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
-    for K in ((d.K1, d.K2, d.K3), (60, 60, 60)):          # direct-DFT mesh (58 = 2 * 29) and a rocFFT one
+    # direct-DFT mesh (58 = 2 * 29), a rocFFT one, and a power-of-two one: there the channels go through the batched y-z plans,
+    # one x pass with a table per channel, the interleave pass and ONE gather (round 4)
+    for K in ((d.K1, d.K2, d.K3), (60, 60, 60), (64, 64, 64)):
         d.K1, d.K2, d.K3 = K
         d.refresh_calculators()
         E, G = d.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
         dref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d.kappa, K, 10)
         assert abs(E - dref['E']) < tol * max(abs(p) for p in dref['parts']) and rel(G, dref['grad']) < max(tol, 1e-8), (prec, K)
+    d8 = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 8)          # two channels through the batched path
+    d8.K1 = d8.K2 = d8.K3 = 64
+    d8.refresh_calculators()
+    E, G = d8.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
+    dref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d8.kappa, (64, 64, 64), 8)
+    assert abs(E - dref['E']) < tol * max(abs(p) for p in dref['parts']) and rel(G, dref['grad']) < max(tol, 1e-8), (prec, 'pmax 8')
 print('BRICK-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ADMP_SPREAD_BRICK_MIN='0')
