@@ -1984,8 +1984,8 @@ struct Engine : EngineBase {
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     double* acc = vir_begin();
-    launch_disp_pair<T>(stream, na, nbr, pack_srows(pos, cl, 3), bx, tab, (T)kappa, pmax, grad.as<T>(), Ed);
-    launch_scalar_pair_virial<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, acc + V_XW);
+    launch_disp_pair<T>(stream, na, nbr, pack_srows(pos, cl, 3), bx, tab, (T)kappa, pmax, grad.as<T>(), Ed, nullptr, 0, cutoff);
+    launch_scalar_pair_virial<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, acc + V_XW, cutoff);
     cls_sites_na = slab_sites_na = -1;   // other rows than an electrostatics evaluation's
     sites.need(sizeof(Site<T>) * (size_t)na);
     ensure_bins(na);
@@ -2023,8 +2023,8 @@ struct Engine : EngineBase {
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
     double* acc = vir_begin();
-    launch_tt_pair<T>(stream, na, nbr, pack_srows(pos, par, 4), bx, tab, grad.as<T>(), Ed);
-    launch_scalar_pair_virial<T>(stream, 1, na, nbr, pos, par, bx, tab, T(0), 0, acc + V_XW);
+    launch_tt_pair<T>(stream, na, nbr, pack_srows(pos, par, 4), bx, tab, grad.as<T>(), Ed, nullptr, 0, cutoff);
+    launch_scalar_pair_virial<T>(stream, 1, na, nbr, pos, par, bx, tab, T(0), 0, acc + V_XW, cutoff);
     double Eh2[E_SLOTS];
     HIP_TRY(hipMemcpyAsync(Eh2, Ed, sizeof(Eh2), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -2351,7 +2351,7 @@ struct Engine : EngineBase {
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_WORDS * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(out, 0, 3 * (size_t)na * sizeof(T), stream));
-    launch_scalar_pair_pgrad<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, out);
+    launch_scalar_pair_pgrad<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, out, cutoff);
     cls_sites_na = slab_sites_na = -1;
     sites.need(sizeof(Site<T>) * (size_t)na);
     ensure_bins(na);
@@ -2376,7 +2376,7 @@ struct Engine : EngineBase {
     Box<T> bx = make_box(box, inv, &vol);
     ScaleTab<T> tab = make_tab(ns, mS, nullptr);
     launch_scalar_pair_pgrad<T>(stream, 1, top.na, nbr, reinterpret_cast<const T*>(pos_), reinterpret_cast<const T*>(abqc_), bx,
-                                tab, T(0), 0, reinterpret_cast<T*>(out_));
+                                tab, T(0), 0, reinterpret_cast<T*>(out_), cutoff);
     HIP_TRY(hipStreamSynchronize(stream));
   }
 
@@ -2482,7 +2482,7 @@ struct Engine : EngineBase {
       RecipGeom<T> g = make_geom(inv);
       launch_prepare_sites<T>(stream, top, pos, par, nullptr, nullptr, nullptr, bx, sites.as<Site<T>>(), nullptr, g, nullptr);
     }
-    { TIMED("mscale_grad"); launch_mscale_sums<T>(stream, kind, na, nbr, sites.as<Site<T>>(), pos, par, bx, pmax, cls); }
+    { TIMED("mscale_grad"); launch_mscale_sums<T>(stream, kind, na, nbr, sites.as<Site<T>>(), pos, par, bx, pmax, cls, cutoff); }
     double h16[16];
     HIP_TRY(hipMemcpyAsync(h16, cls, sizeof(h16), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));

@@ -265,7 +265,8 @@ void launch_thole_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>
 // 1: dispersion (pos, par = c6/c8/c10 per atom, pmax), 2: Tang-Toennies (pos, par = a/b/q/c6 per atom)
 template <class T>
 void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, const Site<T>* sites, const T* pos,
-                        const T* par, const Box<T>& box, int pmax, double* cls16);
+                        const T* par, const Box<T>& box, int pmax, double* cls16,
+                        double cutoff = 0.0 /* kinds 1, 2: listed pairs beyond it are skipped (admp_set_cutoff) */);
 // cls16[nb] += sum over the pairs of covalent class nb of d(pair energy)/d(pscale) (pme_math.h pair_pscale_deriv)
 template <class T>
 void launch_pscale_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
@@ -295,7 +296,7 @@ void launch_pair_virial(hipStream_t st, int na, const NbrTable& nb, const Site<T
                         const ScaleTab<T>& tab, T kappa, int lpol, double* vir);
 template <class T>
 void launch_scalar_pair_virial(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par,
-                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir);
+                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir, double cutoff = 0.0);
 // vir[9] += shift (x) dE/d(frame vector) of the local frames whose axis vectors cross the cell boundary
 template <class T>
 void launch_frame_virial(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
@@ -425,7 +426,7 @@ void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, in
 // tt = 1 Tang-Toennies, out (na,4) = dE/d(a, b, q, c6)
 template <class T>
 void launch_scalar_pair_pgrad(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par, const Box<T>& box,
-                              const ScaleTab<T>& tab, T kappa, int pmax, T* out);
+                              const ScaleTab<T>& tab, T kappa, int pmax, T* out, double cutoff = 0.0);
 // ---- cell_kernels.hip: positions -> half pair list (cell list), two phases so that the caller can size `pairs`
 struct CellScratch {
   int n[3] = {0, 0, 0};

@@ -322,12 +322,23 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar(int na, const int* _
   if (threadIdx.x == 0) atomicAdd(&energies[E_REAL], 0.5 * e);
 }
 
+// admp_set_cutoff in the on-request kernels below (parameter gradients, dE/dmScales, box gradient of the scalar pair terms):
+// a listed pair beyond the cutoff contributes nothing, exactly as in the energy / gradient kernels -- with a skin list the
+// derivatives are then those of the energy the calculator returns (advisor, round 3).  rc2 = 0: every listed pair.
+template <class T>
+__device__ __forceinline__ bool pair_inside(const Box<T>& box, const T ri[3], const T rj[3], T rc2) {
+  if (rc2 <= T(0)) return true;
+  T d[3] = {ri[0] - rj[0], ri[1] - rj[1], ri[2] - rj[2]};
+  min_image(box, d);
+  return d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2;
+}
+
 // per-atom parameter derivatives of the scalar pair terms (disp_math.h): out[row][0..NP) = sum over the row's partners
 template <class T, bool TT>
 __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_pgrad(int na, const int* __restrict__ rowptr,
                                                                   const int* __restrict__ col, const T* __restrict__ pos,
                                                                   const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
-                                                                  T kappa, int pmax, T* __restrict__ out) {
+                                                                  T kappa, int pmax, T* __restrict__ out, T rc2) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   constexpr int LPR = 8, NP = TT ? 4 : 3;
@@ -344,6 +355,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_pgrad(int na, const 
       const int c = col[k];
       const int nb = col_nb(c), j = c & kColMask;
       const T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]};
+      if (!pair_inside(box, ri, rj, rc2)) continue;
       T pj[4] = {0, 0, 0, 0};
       for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
       if (TT) tt_pair_dparams(box, ri, rj, pi, pj, s_tab[nb] + T(1), acc);
@@ -357,11 +369,12 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_pgrad(int na, const 
 }
 template <class T>
 void launch_scalar_pair_pgrad(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par, const Box<T>& box,
-                              const ScaleTab<T>& tab, T kappa, int pmax, T* out) {
+                              const ScaleTab<T>& tab, T kappa, int pmax, T* out, double cutoff) {
   if (na <= 0) return;
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
-  if (tt) k_pair_scalar_pgrad<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out);
-  else k_pair_scalar_pgrad<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out);
+  const T rc2 = (T)(cutoff * cutoff);
+  if (tt) k_pair_scalar_pgrad<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out, rc2);
+  else k_pair_scalar_pgrad<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out, rc2);
 }
 
 // dE/dmScales (the parameter gradient the reference's examples/openmm_api/run.py:41-46 prints): per covalent class
@@ -372,7 +385,7 @@ template <class T, int KIND>
 __global__ __launch_bounds__(kPairBlock) void k_pair_mgrad(int na, const int* __restrict__ rowptr,
                                                            const int* __restrict__ col, const Site<T>* __restrict__ sites,
                                                            const T* __restrict__ pos, const T* __restrict__ par, Box<T> box,
-                                                           int pmax, double* __restrict__ cls) {
+                                                           int pmax, double* __restrict__ cls, T rc2) {
   __shared__ double s_cls[16];
   if (threadIdx.x < 16) s_cls[threadIdx.x] = 0.0;
   __syncthreads();
@@ -398,6 +411,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_mgrad(int na, const int* __
         v = pair_bare_energy<T>(box, I, sites[j]);
       } else {
         T rj[3] = {pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]}, pj[4] = {0, 0, 0, 0}, g[3] = {0, 0, 0};
+        if (!pair_inside(box, ri, rj, rc2)) continue;      // (the multipolar kernels evaluate every listed pair: KIND 0 has no cutoff)
         for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
         if (KIND == 1) {   // disp_pair is linear in mm: E(mm = 1) - E(mm = 0)
           v = disp_pair(box, ri, rj, pi, pj, T(1), T(0), pmax, g) - disp_pair(box, ri, rj, pi, pj, T(0), T(0), pmax, g);
@@ -495,11 +509,12 @@ void launch_thole_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>
 
 template <class T>
 void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, const Site<T>* sites, const T* pos,
-                        const T* par, const Box<T>& box, int pmax, double* cls16) {
+                        const T* par, const Box<T>& box, int pmax, double* cls16, double cutoff) {
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
-  if (kind == 0) k_pair_mgrad<T, 0><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16);
-  else if (kind == 1) k_pair_mgrad<T, 1><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16);
-  else k_pair_mgrad<T, 2><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16);
+  const T rc2 = (T)(cutoff * cutoff);
+  if (kind == 0) k_pair_mgrad<T, 0><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, T(0));
+  else if (kind == 1) k_pair_mgrad<T, 1><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, rc2);
+  else k_pair_mgrad<T, 2><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, rc2);
 }
 
 // ---- box gradient, real-space part (jax.grad(get_energy, argnums=1) in the reference) -----------------------
@@ -552,7 +567,7 @@ template <class T, bool TT>
 __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_virial(int na, const int* __restrict__ rowptr,
                                                                    const int* __restrict__ col, const T* __restrict__ pos,
                                                                    const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
-                                                                   T kappa, int pmax, double* vir) {
+                                                                   T kappa, int pmax, double* vir, T rc2) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   constexpr int LPR = 8, NP = TT ? 4 : 3;
@@ -571,6 +586,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_virial(int na, const
       const T d[3] = {ri[0] - rj[0], ri[1] - rj[1], ri[2] - rj[2]};
       T sh[3];
       if (!image_shift(box, d, sh)) continue;
+      if (!pair_inside(box, ri, rj, rc2)) continue;
       for (int q = 0; q < NP; ++q) pj[q] = par[NP * j + q];
       T g[3] = {0, 0, 0};
       if (TT) (void)tt_pair(box, ri, rj, pi, pj, s_tab[nb] + T(1), g);
@@ -593,10 +609,11 @@ void launch_pair_virial(hipStream_t st, int na, const NbrTable& nb, const Site<T
 }
 template <class T>
 void launch_scalar_pair_virial(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par,
-                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir) {
+                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir, double cutoff) {
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
-  if (tt) k_pair_scalar_virial<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir);
-  else k_pair_scalar_virial<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir);
+  const T rc2 = (T)(cutoff * cutoff);
+  if (tt) k_pair_scalar_virial<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir, rc2);
+  else k_pair_scalar_virial<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir, rc2);
 }
 
 // lanes of a wavefront that share one row.  Few lanes = fewer idle lanes at the row tail and less shuffle
@@ -759,15 +776,15 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* s
   template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const SRow<T>*, const Box<T>&,                 \
                                   const ScaleTab<T>&, T*, double*, const int*, int, double);                        \
   template void launch_mscale_sums<T>(hipStream_t, int, int, const NbrTable&, const Site<T>*, const T*, const T*,   \
-                                      const Box<T>&, int, double*);                                                 \
+                                      const Box<T>&, int, double*, double);                                         \
   template void launch_thole_sums<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
                                      const ScaleTab<T>&, T*, T*);                                                   \
   template void launch_pair_virial<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,             \
                                       const ScaleTab<T>&, T, int, double*);                                         \
   template void launch_scalar_pair_virial<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,            \
-                                             const Box<T>&, const ScaleTab<T>&, T, int, double*);                   \
+                                             const Box<T>&, const ScaleTab<T>&, T, int, double*, double);           \
   template void launch_scalar_pair_pgrad<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,             \
-                                            const Box<T>&, const ScaleTab<T>&, T, int, T*);
+                                            const Box<T>&, const ScaleTab<T>&, T, int, T*, double);
 INST(float)
 INST(double)
 #undef INST

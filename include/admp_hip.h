@@ -97,8 +97,10 @@ int64_t admp_num_pairs(const admp_handle* h);   /* pairs kept (i < j) */
  * minimum-image distance is >= rc are skipped by the pair kernels, so that the result is the one of the exact-rc list
  * whatever the skin.  rc = 0 (default): every listed pair is evaluated -- what the reference does with whatever list it is
  * handed (admp/pme.py:671-729 has no distance test).  Not a speed option (the kernels wait on the partner fetches, not on
- * the pair arithmetic).  Honoured by the dispersion and Tang-Toennies pair kernels
- * (admp_disp_energy_grad, admp_tt_energy_grad); the multipolar PME kernels evaluate every listed pair. */
+ * the pair arithmetic).  Honoured by the dispersion and Tang-Toennies pair kernels and by everything derived from them
+ * (admp_disp_energy_grad, admp_tt_energy_grad, their box gradients, admp_disp_param_grad, admp_tt_param_grad, admp_mscale_grad
+ * kinds 1 and 2: the derivatives are those of the energy the calculator returns); the multipolar PME kernels evaluate
+ * every listed pair. */
 int admp_set_cutoff(admp_handle* h, double rc);
 /* One shot, device pointers only: the NEXT admp_pme_energy_grad reads its initial dipoles from U_init ((Na,3), read-only) and
  * uses U_inout purely as output (it starts as a copy made by the first kernel of the evaluation).  The reference's callers

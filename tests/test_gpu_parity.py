@@ -1101,6 +1101,30 @@ def test_cutoff_on_skin_list_equals_exact_list(precision):
         if prec == 'double':
             ref = O.tt_energy_and_grad(pos, box, pairs, par['mScales'], cov, par['a_list'], par['b_list'], par['q_list'], c6)
             assert abs(E1 - ref['E']) < 1e-9 * abs(ref['E']) and rel(G1, ref['grad']) < 1e-9
+    # everything derived from the pair terms honours the cutoff too (advisor, round 3): on the skin list with the cutoff set,
+    # parameter gradients, dE/dmScales and the box gradient are those of the exact-rc list
+    settings.PRECISION = 'double'
+    d0 = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+    d1 = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+    d1.set_cutoff(4.0)
+    t0 = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+    t1 = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+    t1.set_cutoff(4.0)
+    ta = (par['a_list'], par['b_list'], par['q_list'], c6)
+    for a, b in ((d0.get_param_gradient(pos, box, pairs, par['c_list'], par['mScales']),
+                  d1.get_param_gradient(pos, box, wide, par['c_list'], par['mScales'])),
+                 (d0.get_mscale_gradient(pos, box, pairs, par['c_list'], par['mScales']),
+                  d1.get_mscale_gradient(pos, box, wide, par['c_list'], par['mScales'])),
+                 (d0.get_box_gradient(pos, box, pairs, par['c_list'], par['mScales']),
+                  d1.get_box_gradient(pos, box, wide, par['c_list'], par['mScales'])),
+                 (t0.get_param_gradient(pos, box, pairs, par['mScales'], *ta),
+                  t1.get_param_gradient(pos, box, wide, par['mScales'], *ta)),
+                 (t0.get_mscale_gradient(pos, box, pairs, par['mScales'], *ta),
+                  t1.get_mscale_gradient(pos, box, wide, par['mScales'], *ta)),
+                 (t0.get_box_gradient(pos, box, pairs, par['mScales'], *ta),
+                  t1.get_box_gradient(pos, box, wide, par['mScales'], *ta))):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        assert np.abs(a - b).max() <= 1e-10 * max(np.abs(a).max(), 1e-30), (a, b)
     from admp_amd._lib import AdmpHipError
     with pytest.raises(AdmpHipError):
         d.set_cutoff(-1.0)
