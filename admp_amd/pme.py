@@ -296,6 +296,14 @@ class ADMPPmeForce(HipForceBase):
         self.U_ind = self._like(r['U'], like)
         self.lconverg = r['flag']
         self.n_cycle = r['i']
+        self._warn_unconverged(r)
+
+    def _warn_unconverged(self, r):
+        """The reference returns `lconverg = False` silently (admp/pme.py:139-143); a drop-in user whose SCF diverges -- e.g.
+        the literal k-point order on an unequal mesh, where the reference's own iteration has a growing mode -- gets told."""
+        if not r['flag']:
+            warnings.warn('induced-dipole SCF did not converge within %d cycles (lconverg = False); energies and gradients '
+                          'are those of the unconverged dipoles, as in the reference' % (r['i'] + 1))
 
     def _generate_get_forces(self):
         if not self.lpol:
@@ -429,4 +437,5 @@ class ADMPPmeForce(HipForceBase):
             raise RuntimeError('optimize_Uind needs lpol=True')
         r = self._evaluate(positions, box, pairs, Q_local, mScales, pol, tholes, pScales, dScales, U_init,
                            want_grad=False, maxiter=maxiter, thresh=thresh)
+        self._warn_unconverged(r)
         return self._like(r['U'], positions), r['flag'], r['i']

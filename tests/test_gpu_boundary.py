@@ -227,6 +227,33 @@ def test_numpy_pair_list_refilled_in_place(env):
     assert f.n_pairs == keep - 1
 
 
+def test_literal_kpoint_order_divergence_is_the_references(env):
+    """GPU twin of tests/test_oracle_physics.py::test_literal_kpoint_order_makes_the_scf_diverge_on_an_unequal_mesh: on the
+    96 x 100 x 45 mesh the default (literal) k-point order makes the reference's own Jacobi SCF diverge; the drop-in must
+    return what the reference returns -- all 30 cycles, lconverg False, the same (huge) dipoles -- and say so."""
+    import warnings
+    from admp.pme import ADMPPmeForce
+    from oracle import admp_oracle as O
+    n_mol = 216
+    pos, box = S.synthetic_water_box(n_mol, seed=5)
+    at, ai, cov = S.water_topology(n_mol)
+    par = S.water_parameters(n_mol, True)
+    pairs = S.build_pairs(pos, box, 4.0)
+    f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+    for k, v in zip(('K1', 'K2', 'K3'), (96, 100, 45)):
+        f.update_env(k, v)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        U, flag, i = f.optimize_Uind(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'],
+                                     par['dScales'])
+    assert any('did not converge' in str(x.message) for x in w)
+    sysm = O.PmeSystem(at, ai, cov, f.kappa, (96, 100, 45), 2, True)
+    Ur, flag_r, i_r = O.optimize_Uind(sysm, pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
+                                      par['pScales'])
+    assert (flag, i) == (flag_r, i_r) == (False, 29)
+    assert rel(U, Ur.numpy()) < 1e-8 and np.abs(U).max() > 1e20
+
+
 @pytest.mark.parametrize('lpol', [False, True])
 def test_group_closing_kernel_matches_oracle(env, lpol, monkeypatch):
     """The closing kernels of large molecular systems (used above 8192 atoms) forced at a size the oracle can do: k_finish_rows
