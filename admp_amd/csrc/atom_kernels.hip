@@ -603,10 +603,13 @@ __global__ __launch_bounds__(kFinishBlock) void k_finish_rows(Topology top, Box<
 template <class T>
 __global__ __launch_bounds__(kAtomBlock) void k_frame_virial(Topology top, const T* __restrict__ pos, Box<T> box,
                                                              const Site<T>* __restrict__ sites, int lpol, T kappa,
-                                                             const T* __restrict__ pot, double* vir) {
-  const int i = blockIdx.x * kAtomBlock + threadIdx.x;
+                                                             const T* __restrict__ pot, double* vir,
+                                                             const int* __restrict__ list, int nlist) {
+  const int slot = blockIdx.x * kAtomBlock + threadIdx.x;
+  const int n = list ? nlist : top.na;
+  const int i = (list && slot < n) ? list[slot] : slot;      // (slab rank: the frames of its home sites)
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < top.na) {
+  if (slot < n) {
     int type, iz, ix, iy;
     FrameWork<T> w;
     frame_of(top, pos, box, i, type, iz, ix, iy, w);
@@ -755,13 +758,14 @@ void launch_finish(hipStream_t st, const Topology& top, const T* pos, const Box<
 
 template <class T>
 void launch_frame_virial(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
-                         int lpol, T kappa, const T* pot, double* vir) {
-  k_frame_virial<T><<<nblk(top.na), kAtomBlock, 0, st>>>(top, pos, box, sites, lpol, kappa, pot, vir);
+                         int lpol, T kappa, const T* pot, double* vir, const int* list, int nlist) {
+  const int n = list ? nlist : top.na;
+  if (n > 0) k_frame_virial<T><<<nblk(n), kAtomBlock, 0, st>>>(top, pos, box, sites, lpol, kappa, pot, vir, list, nlist);
 }
 template void launch_frame_virial<float>(hipStream_t, const Topology&, const float*, const Box<float>&, const Site<float>*,
-                                         int, float, const float*, double*);
+                                         int, float, const float*, double*, const int*, int);
 template void launch_frame_virial<double>(hipStream_t, const Topology&, const double*, const Box<double>&,
-                                          const Site<double>*, int, double, const double*, double*);
+                                          const Site<double>*, int, double, const double*, double*, const int*, int);
 
 template <class T>
 void launch_scalar_sites(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, double self_coef,

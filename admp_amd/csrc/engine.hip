@@ -1932,10 +1932,72 @@ struct Engine : EngineBase {
     HIP_TRY(hipStreamSynchronize(stream));   // `inv` is a caller stack array
   }
 
+  // The same on a slab rank (round 4): the pair / gather / frame sums run over the rank's home rows and atoms, the k-tensor
+  // sums over the y rows it holds of the transposed spectrum (between the x transforms of the distributed convolution, which
+  // therefore takes the unfused x passes here), and the 24 device words are summed over the ranks before the host folds
+  // them -- every rank returns the full dE/dbox.
+  void convolve_slab_virial(T* mesh_p, T* spec_p, const T* gtab, int slot, int which, double vol, double* acc) {
+    double* Ed = Ed_cur();
+    const size_t plane = (size_t)K[1] * K[2];
+    const int nx = nxown(), ny = nyown(), nh = K[2] / 2 + 1;
+    sl.ghost.need(kGhost * plane * sizeof(T));
+    sl.pack.need((size_t)nx * K[1] * nh * 2 * sizeof(T));
+    sl.tbuf.need((size_t)K[0] * ny * nh * 2 * sizeof(T));
+    { TIMED("comm_ghost"); c_shift(mesh_p + (size_t)nx * plane, sl.ghost.p, (int64_t)(kGhost * plane), real_dtype(), 1, ADMP_TAG_GHOST); }
+    { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)(kGhost * plane), mesh_p, sl.ghost.as<T>()); }
+    fft_forward(mesh_p, spec_p);
+    { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, fx_khp, snranks, 0, spec_p, sl.pack.as<T>()); }
+    { TIMED("comm_transpose"); c_all_to_all_v(sl.pack.p, sl.tr_send, sl.tbuf.p, sl.tr_recv, real_dtype(), ADMP_TAG_TRANSPOSE); }
+    fft_x(sl.tbuf.as<T>(), 0);
+    launch_kspace_virial<T>(stream, K, binv_d.as<double>(), std::fabs(vol), kappa, which, ref_korder, sl.tbuf.as<T>(), acc + V_TK,
+                            Y0, ny);
+    { TIMED("kspace"); launch_kspace<T>(stream, K, ny, gtab, sl.tbuf.as<T>(), Ed, slot); }
+    fft_x(sl.tbuf.as<T>(), 1);
+    { TIMED("comm_transpose"); c_all_to_all_v(sl.tbuf.p, sl.tr_recv, sl.pack.p, sl.tr_send, real_dtype(), ADMP_TAG_TRANSPOSE); }
+    { TIMED("transpose_pack"); launch_transpose_pack<T>(stream, nx, K[1], nh, fx_khp, snranks, 1, spec_p, sl.pack.as<T>()); }
+    fft_inverse(spec_p, mesh_p);
+    { TIMED("comm_ghost"); c_shift(mesh_p, mesh_p + (size_t)nx * plane, (int64_t)(kGhost * plane), real_dtype(), 0, ADMP_TAG_GHOST); }
+  }
+  void pme_box_grad_slab(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
+                         const double* mS, const double* pS, const void* U_, double* E, double* dbox) {
+    const int na = top.na;
+    grad.need(3 * (size_t)na * sizeof(T));
+    T* gbuf = grad.as<T>();
+    mono_ok = true;
+    stage_begin(pos_, box, Ql_, pol_, thole_, ns, mS, pS, const_cast<void*>(U_));
+    double inv[9], vol;
+    make_box(box, inv, &vol);
+    upload_binv(inv);
+    double* acc = vir_begin();
+    stage_pair_full(gbuf);
+    launch_pair_virial<T>(stream, na, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, lpol, acc + V_XW, pair_rows(), ev.n_home);
+    stage_spread(mesh.as<T>());
+    if (!slot_clean[E_RECIP]) HIP_TRY(hipMemsetAsync(Ed_cur() + E_RECIP, 0, sizeof(double), stream));
+    slot_clean[E_RECIP] = false;
+    convolve_slab_virial(mesh.as<T>(), spec.as<T>(), gtab_cur, E_RECIP, 1, vol, acc);
+    stage_gather(mesh.as<T>(), gbuf);
+    launch_gather_virial<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh.as<T>(), acc + V_XW, acc + V_Y, ev.home);
+    if (lmax > 0)
+      launch_frame_virial<T>(stream, top, ev.pos, ev.bx, sites.as<Site<T>>(), lpol, (T)kappa, pot.as<T>(), acc + V_XW, ev.home,
+                             ev.n_home);
+    // (the frame sums need the TOTAL potential of the home sites: pot holds pair + reciprocal space, the self term is added
+    // by the kernel itself, as on one rank)
+    stage_finish(nullptr, nullptr, E_RECIP, E);
+    { TIMED("comm_energies"); c_all_reduce(acc, V_WORDS, ADMP_T_F64, ADMP_OP_SUM, ADMP_TAG_ENERGIES); }
+    vir_assemble(inv, E[1], dbox);
+    warm_regime = false;
+    scf_last = -1.0;
+    scf_nobs[0] = scf_nobs[1] = 0;
+  }
+
   void pme_box_grad(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
                     const double* mS, const double* pS, const void* U_, double* E, double* dbox) override {
-    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
     ARG_CHECK(pos_ && box && Ql_ && E && dbox, "null argument");
+    if (snranks > 1) {
+      if (lpol) ARG_CHECK(U_, "polarizable handle needs the induced dipoles");
+      pme_box_grad_slab(pos_, box, Ql_, pol_, thole_, ns, mS, pS, U_, E, dbox);
+      return;
+    }
     if (lpol) ARG_CHECK(U_, "polarizable handle needs the induced dipoles");
     const int na = top.na;
     grad.need(3 * (size_t)na * sizeof(T));
@@ -2021,14 +2083,22 @@ struct Engine : EngineBase {
     energies_d.need(2 * E_WORDS * sizeof(double));
     ehalf = 0; other_clean = false;
     double* Ed = energies_d.as<double>();
-    HIP_TRY(hipMemsetAsync(Ed, 0, E_SLOTS * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(Ed, 0, E_WORDS * sizeof(double), stream));
     double* acc = vir_begin();
-    launch_tt_pair<T>(stream, na, nbr, pack_srows(pos, par, 4), bx, tab, grad.as<T>(), Ed, nullptr, 0, cutoff);
-    launch_scalar_pair_virial<T>(stream, 1, na, nbr, pos, par, bx, tab, T(0), 0, acc + V_XW, cutoff);
-    double Eh2[E_SLOTS];
-    HIP_TRY(hipMemcpyAsync(Eh2, Ed, sizeof(Eh2), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    E[0] = Eh2[E_REAL];
+    ScalarRows sr{nullptr, na, nullptr};
+    if (snranks > 1) {     // ownership by x-slabs of a virtual mesh, as in tt(); the sums are added over the ranks
+      ARG_CHECK(have_comm, "slab-decomposed handle without a communicator (admp_set_comm)");
+      RecipGeom<T> g;
+      const int Kv = 64 * snranks;
+      g.K[0] = Kv; g.K[1] = g.K[2] = 32;
+      for (int k = 0; k < 9; ++k) { g.hinv[k] = (T)inv[k]; g.Aop[k] = g.Jac[k] = T(0); }
+      g.xoff = 64 * srank; g.nloc0 = 64 + kGhost; g.wrap0 = 1 << 30;
+      sr = scalar_rows(pos, g, Kv, 64 * srank, 64 * (srank + 1), true);
+    }
+    launch_tt_pair<T>(stream, na, nbr, pack_srows(pos, par, 4), bx, tab, grad.as<T>(), Ed, sr.rows, sr.n, cutoff);
+    launch_scalar_pair_virial<T>(stream, 1, na, nbr, pos, par, bx, tab, T(0), 0, acc + V_XW, cutoff, sr.rows, sr.n);
+    read_scalar_energies(Ed, E, 1);
+    if (snranks > 1) { TIMED("comm_energies"); c_all_reduce(acc, V_WORDS, ADMP_T_F64, ADMP_OP_SUM, ADMP_TAG_ENERGIES); }
     vir_assemble(inv, 0.0, dbox);      // only the xw sums are non-zero here
   }
 

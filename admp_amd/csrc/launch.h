@@ -293,22 +293,25 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* s
 // vir[9] += 1/2 sum_entries shift (x) dE_pair/dr_I over the pairs whose minimum image crosses the cell boundary
 template <class T>
 void launch_pair_virial(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                        const ScaleTab<T>& tab, T kappa, int lpol, double* vir);
+                        const ScaleTab<T>& tab, T kappa, int lpol, double* vir,
+                        const int* rows = nullptr /* slab rank: its n_rows home rows */, int n_rows = 0);
 template <class T>
 void launch_scalar_pair_virial(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par,
-                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir, double cutoff = 0.0);
+                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir, double cutoff = 0.0,
+                               const int* rows = nullptr /* slab rank: its n_rows home rows */, int n_rows = 0);
 // vir[9] += shift (x) dE/d(frame vector) of the local frames whose axis vectors cross the cell boundary
 template <class T>
 void launch_frame_virial(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const Site<T>* sites,
-                         int lpol, T kappa, const T* pot, double* vir);
+                         int lpol, T kappa, const T* pot, double* vir, const int* list = nullptr /* home sites */, int nlist = 0);
 // tk[6] += sum_k w dG/dk^2 |S_k|^2 k (x) k (xx, yy, zz, xy, xz, yz), spectrum NOT yet multiplied by G (single rank)
 template <class T>
 void launch_kspace_virial(hipStream_t st, const int K[3], const double* box_inv, double volume, double kappa, int which,
-                          int ref_order, const T* spec, double* tk);
+                          int ref_order, const T* spec, double* tk,
+                          int y0 = 0, int ny = 0 /* spec holds the y rows y0 .. y0+ny-1 as [K0][ny][K2/2+1] (0: all K[1] rows) */);
 // xw[9] += sum_atoms x (x) dE_recip/dx ; yy[9] += sum_atoms dE_recip/dAop (recip_box_terms)
 template <class T>
 void launch_gather_virial(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi,
-                          double* xw, double* yy);
+                          double* xw, double* yy, const int* list = nullptr /* the na atoms to gather at (nullptr: 0 .. na-1) */);
 
 // Mesh bricks for the LDS-tiled spread: dimension d is cut into nb[d] = ceil(K/16) bricks of 15..16
 // (>= 6) points, brick b covering [b*K/nb, (b+1)*K/nb).  An atom is binned by the brick of its

@@ -533,14 +533,16 @@ __device__ __forceinline__ void block_add9(double acc[9], double scale, double* 
 template <class T, bool LPOL>
 __global__ __launch_bounds__(kPairBlock) void k_pair_virial(int na, const int* __restrict__ rowptr,
                                                             const int* __restrict__ col, const Site<T>* __restrict__ sites,
-                                                            Box<T> box, ScaleTab<T> tab, T kappa, double* vir) {
+                                                            Box<T> box, ScaleTab<T> tab, T kappa, double* vir,
+                                                            const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   constexpr int LPR = 8;
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (row < na) {
+  if (slot < na) {
+    const int row = rows ? rows[slot] : slot;           // (slab rank: its home rows)
     const Site<T> I = sites[row];
     const int end = rowptr[row + 1];
 #pragma unroll 1
@@ -567,14 +569,16 @@ template <class T, bool TT>
 __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_virial(int na, const int* __restrict__ rowptr,
                                                                    const int* __restrict__ col, const T* __restrict__ pos,
                                                                    const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
-                                                                   T kappa, int pmax, double* vir, T rc2) {
+                                                                   T kappa, int pmax, double* vir, T rc2,
+                                                                   const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   constexpr int LPR = 8, NP = TT ? 4 : 3;
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (row < na) {
+  if (slot < na) {
+    const int row = rows ? rows[slot] : slot;           // (slab rank: its home rows)
     T ri[3] = {pos[3 * row], pos[3 * row + 1], pos[3 * row + 2]}, pi[4] = {0, 0, 0, 0};
     for (int k = 0; k < NP; ++k) pi[k] = par[NP * row + k];
     const int end = rowptr[row + 1];
@@ -602,18 +606,23 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_virial(int na, const
 
 template <class T>
 void launch_pair_virial(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                        const ScaleTab<T>& tab, T kappa, int lpol, double* vir) {
+                        const ScaleTab<T>& tab, T kappa, int lpol, double* vir, const int* rows, int n_rows) {
+  if (rows) na = n_rows;
+  if (na <= 0) return;
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
-  if (lpol) k_pair_virial<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, vir);
-  else k_pair_virial<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, vir);
+  if (lpol) k_pair_virial<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, vir, rows);
+  else k_pair_virial<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, kappa, vir, rows);
 }
 template <class T>
 void launch_scalar_pair_virial(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par,
-                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir, double cutoff) {
+                               const Box<T>& box, const ScaleTab<T>& tab, T kappa, int pmax, double* vir, double cutoff,
+                               const int* rows, int n_rows) {
+  if (rows) na = n_rows;
+  if (na <= 0) return;
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
   const T rc2 = (T)(cutoff * cutoff);
-  if (tt) k_pair_scalar_virial<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir, rc2);
-  else k_pair_scalar_virial<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir, rc2);
+  if (tt) k_pair_scalar_virial<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir, rc2, rows);
+  else k_pair_scalar_virial<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, vir, rc2, rows);
 }
 
 // lanes of a wavefront that share one row.  Few lanes = fewer idle lanes at the row tail and less shuffle
@@ -780,9 +789,10 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* s
   template void launch_thole_sums<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
                                      const ScaleTab<T>&, T*, T*);                                                   \
   template void launch_pair_virial<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,             \
-                                      const ScaleTab<T>&, T, int, double*);                                         \
+                                      const ScaleTab<T>&, T, int, double*, const int*, int);                        \
   template void launch_scalar_pair_virial<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,            \
-                                             const Box<T>&, const ScaleTab<T>&, T, int, double*, double);           \
+                                             const Box<T>&, const ScaleTab<T>&, T, int, double*, double,            \
+                                             const int*, int);                                                      \
   template void launch_scalar_pair_pgrad<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,             \
                                             const Box<T>&, const ScaleTab<T>&, T, int, T*, double);
 INST(float)

@@ -276,13 +276,15 @@ template <class T, bool TIGHT>
 __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
                                                        BrickGrid bg, const int* __restrict__ brick_start,
                                                        const int* __restrict__ entries, T* __restrict__ mesh,
-                                                       int* __restrict__ clear_a, int* __restrict__ clear_b) {
+                                                       int* __restrict__ clear_a, int* __restrict__ clear_b,
+                                                       const int4* __restrict__ bases) {
   using W = typename BrickWord<T>::type;
   __shared__ W tile[16 * 16 * kBrickRow];
   __shared__ unsigned s_bmax;
   __shared__ unsigned short s_order[kBrickChunk];
   __shared__ int s_hist[4];
   __shared__ unsigned s_hist3[344];
+  __shared__ unsigned char s_kind[kBrickChunk];     // class of the first chunk's entries, found while pass 1 has their rows
   const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
   const int bb[3] = {bx, by, bz};
   int lo[3], n[3];
@@ -315,17 +317,25 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
     float bm = 0.f;
     for (int e = threadIdx.x; e < cnt; e += 256) {
       T r[3], Q[9];
-      site_qtot(sites[entries[beg + e]], lpol, r, Q);
+      const int atom = entries[beg + e];
+      site_qtot(sites[atom], lpol, r, Q);
       const T d1 = m_abs(Q[1]) + m_abs(Q[2]) + m_abs(Q[3]);
       const T q2 = m_abs(Q[4]) + m_abs(Q[5]) + m_abs(Q[6]) + m_abs(Q[7]) + m_abs(Q[8]);
+      if (e < kBrickChunk)      // (site_kind of the row: Q already holds Q + U)
+        s_kind[e] = (unsigned char)((q2 == T(0) && d1 == T(0)) ? SK_CHARGE : ((q2 == T(0) && Q[0] == T(0)) ? SK_DIPOLE : SK_GENERAL));
       bm = fmaxf(bm, (float)(T(kW0) * m_abs(Q[0]) + T(kW1) * amax * d1 + T(kW2) * T(2) * amax * amax * q2));
       if (TIGHT) {
         int cl = 0;
         bool in = true;
+        // (the stencil record of the atom when the caller has them -- k_prepare_sites / k_atom_bases wrote them with the same
+        // grid_ref: 16 bytes the binning has just read, instead of the position words of the 80-byte row)
+        int4 rec = make_int4(0, 0, 0, 0);
+        if (bases) rec = bases[atom];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {                      // the stencil's base relative to the brick, as brick_add_entry sees it
           int base;
-          (void)grid_ref(g, r, d, base);
+          if (bases) base = d == 0 ? rec.x : (d == 1 ? rec.y : rec.z);
+          else (void)grid_ref(g, r, d, base);
           const int period = d == 0 ? g.wrap0 : g.K[d];
           int o = base - lo[d];
           if (o + 5 < 0) o += period;
@@ -362,6 +372,8 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
       const T d1 = m_abs(Q[1]) + m_abs(Q[2]) + m_abs(Q[3]);
       const T q2 = m_abs(Q[4]) + m_abs(Q[5]) + m_abs(Q[6]) + m_abs(Q[7]) + m_abs(Q[8]);
       bm = fmaxf(bm, (float)(m_abs(Q[0]) + amax * d1 + T(2) * amax * amax * q2));
+      if (e < kBrickChunk)
+        s_kind[e] = (unsigned char)((q2 == T(0) && d1 == T(0)) ? SK_CHARGE : ((q2 == T(0) && Q[0] == T(0)) ? SK_DIPOLE : SK_GENERAL));
     }
     if (bm > 0.f) atomicMax(&s_bmax, __float_as_uint(bm * 1.0001f));    // non-negative floats order like their bits
     __syncthreads();
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(256) void k_spread_bricks(const Site<T>* __restrict
       const int e = threadIdx.x + 256 * k;
       kind[k] = 0; slot[k] = 0;
       if (e < nch) {
-        kind[k] = ADMP_SPREAD_CLASSES ? site_kind(sites[entries[beg + c0 + e]], lpol) : SK_GENERAL;
+        kind[k] = !ADMP_SPREAD_CLASSES ? SK_GENERAL : (c0 == 0 ? (int)s_kind[e] : site_kind(sites[entries[beg + c0 + e]], lpol));
         slot[k] = atomicAdd(&s_hist[kind[k]], 1);
       }
     }
@@ -703,14 +715,15 @@ __device__ inline double gprime_at(int i0, int i1, int i2, int K0, int K1, int K
 template <class T>
 __global__ __launch_bounds__(256) void k_kspace_virial(int K0, int K1, int K2, const double* __restrict__ binv,
                                                        double volume, double kappa, int which, int ref_order,
-                                                       const T* __restrict__ spec, double* tk) {
+                                                       const T* __restrict__ spec, double* tk, int y0, int ny) {
+  // spec = [K0][ny][K2/2+1] holding the y rows y0 .. y0+ny-1 (one rank: all of them; a slab rank: its own, transposed layout)
   const int nh = K2 / 2 + 1;
-  const long n = (long)K0 * K1 * nh;
+  const long n = (long)K0 * ny * nh;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) {
     const int i2 = (int)(t % nh);
-    const int i1 = (int)((t / nh) % K1);
-    const int i0 = (int)(t / ((long)nh * K1));
+    const int i1 = y0 + (int)((t / nh) % ny);
+    const int i0 = (int)(t / ((long)nh * ny));
     const double re = (double)spec[2 * t], im = (double)spec[2 * t + 1];
     const double w = ((i2 == 0 || ((K2 & 1) == 0 && i2 == K2 / 2)) ? 0.5 : 1.0) * (re * re + im * im);
     double kv[3];
@@ -736,10 +749,12 @@ __global__ __launch_bounds__(256) void k_kspace_virial(int K0, int K1, int K2, c
 // (spline_math.h): xw[9] and y[9].  On request only -- the plain loop over the 216 stencil points is good enough.
 template <class T>
 __global__ __launch_bounds__(128) void k_gather_virial(int na, const Site<T>* __restrict__ sites, int lpol, RecipGeom<T> g,
-                                                       const T* __restrict__ phi, double* xw, double* yy) {
-  const int i = blockIdx.x * 128 + threadIdx.x;
+                                                       const T* __restrict__ phi, double* xw, double* yy,
+                                                       const int* __restrict__ list) {
+  const int slot = blockIdx.x * 128 + threadIdx.x;
+  const int i = (list && slot < na) ? list[slot] : slot;      // (slab rank: its home atoms)
   double ax[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ay[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < na) {
+  if (slot < na) {
     T r[3], Q[9], F[NF];
     site_qtot(sites[i], lpol, r, Q);
     gather_atom(g, r, [&](long idx) { return phi[idx]; }, F);
@@ -1006,13 +1021,13 @@ int launch_spread(hipStream_t st, int na, const Site<T>* sites, int lpol, const 
   }
   if (nb != 1) return (int)hipErrorInvalidValue;      // batches exist for the scan kernel only
   if (reuse_bins) {   // same positions as the previous call (next dispersion power): the brick lists are still valid
-    if (tight) k_spread_bricks<T, true><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr);
-    else k_spread_bricks<T, false><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr);
+    if (tight) k_spread_bricks<T, true><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr, bases);
+    else k_spread_bricks<T, false><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, nullptr, nullptr, nullptr);
     return 0;
   }
   { const int rc = launch_bin_bricks<T>(st, na, sites, g, bs, list, bases); if (rc != 0) return rc; }
-  if (tight) k_spread_bricks<T, true><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
-  else k_spread_bricks<T, false><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur);
+  if (tight) k_spread_bricks<T, true><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur, bases);
+  else k_spread_bricks<T, false><<<bg.ncell, 256, 0, st>>>(sites, lpol, g, bg, bs.cell_start, bs.sorted, mesh, bs.cursor, bs.fillcur, nullptr);
   bs.counters_zero = true;      // element ncell of both arrays is never written: it stays zero
   return 0;
 }
@@ -1092,17 +1107,18 @@ void launch_kspace(hipStream_t st, const int K[3], int ny, const T* gtab, T* spe
 
 template <class T>
 void launch_kspace_virial(hipStream_t st, const int K[3], const double* box_inv, double volume, double kappa, int which,
-                          int ref_order, const T* spec, double* tk) {
-  const long n = (long)K[0] * K[1] * (K[2] / 2 + 1);
+                          int ref_order, const T* spec, double* tk, int y0, int ny) {
+  if (ny <= 0) { y0 = 0; ny = K[1]; }
+  const long n = (long)K[0] * ny * (K[2] / 2 + 1);
   int blocks = (int)((n + 2047) / 2048);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  k_kspace_virial<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], box_inv, volume, kappa, which, ref_order, spec, tk);
+  k_kspace_virial<T><<<blocks, 256, 0, st>>>(K[0], K[1], K[2], box_inv, volume, kappa, which, ref_order, spec, tk, y0, ny);
 }
 template <class T>
 void launch_gather_virial(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi,
-                          double* xw, double* yy) {
-  k_gather_virial<T><<<(na + 127) / 128, 128, 0, st>>>(na, sites, lpol, g, phi, xw, yy);
+                          double* xw, double* yy, const int* list) {
+  if (na > 0) k_gather_virial<T><<<(na + 127) / 128, 128, 0, st>>>(na, sites, lpol, g, phi, xw, yy, list);
 }
 
 template <class T>
@@ -1135,9 +1151,9 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
                                        const int*, int, const int*, const int*, const FieldFin<T>&);                  \
   template void launch_kspace_virial<T>(hipStream_t, const int*, const double*, double, double, int, int, const T*,   \
-                                        double*);                                                                     \
+                                        double*, int, int);                                                           \
   template void launch_gather_virial<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, double*, \
-                                        double*);
+                                        double*, const int*);
 INST(float)
 INST(double)
 #undef INST

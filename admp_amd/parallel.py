@@ -496,6 +496,12 @@ class SlabPme(_SlabMixin, ADMPPmeForce):
         return out
 
 
+    def get_energy_and_box_gradient(self, *a, **k):
+        """(E, dE/dbox) on the slab ranks (round 4): pair / gather / frame sums over the rank's home rows, k-tensor sums over
+        its rows of the transposed spectrum, the 24 sums added over the ranks -- every rank returns the full 3 x 3 gradient."""
+        return self._checked(lambda: ADMPPmeForce.get_energy_and_box_gradient(self, *a, **k))
+
+
 class SlabDispPme(_SlabMixin, ADMPDispPmeForce):
     """ADMPDispPmeForce decomposed over the same x-slabs (real-space pairs over the home rows, the C6 / C8 / C10 meshes
     through the distributed transform, gathers at the home atoms)."""
@@ -529,3 +535,7 @@ class SlabPairInteraction(_SlabMixin, _PairInteraction):
         E, grad = self._checked(lambda: _PairInteraction._evaluate(self, positions, box, pairs, mScales, atomic_params, True))
         self._fetch_home()
         return E, (self._assemble(grad) if want_grad else None)
+
+    def get_energy_and_box_gradient(self, *a, **k):
+        """(E, dE/dbox) on the slab ranks: the pair sums over the rank's home rows, added over the ranks"""
+        return self._checked(lambda: _PairInteraction.get_energy_and_box_gradient(self, *a, **k))

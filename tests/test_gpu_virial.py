@@ -187,3 +187,75 @@ def test_box_gradient_finite_strain_at_config_size(env):
         bm[a, b] -= h
         fd = (f.get_energy(p, bp, None, Q, par['mScales']) - f.get_energy(p, bm, None, Q, par['mScales'])) / (2 * h)
         assert abs(fd - dbox[a, b]) < 2e-4 * np.abs(dbox).max(), ((a, b), fd, dbox[a, b])
+
+
+@pytest.mark.parametrize('lpol', [False, True])
+def test_slab_box_gradient_matches_single_gpu(lpol):
+    """dE/dbox of the multipolar PME on a slab-decomposed handle (round 4: admp_pme_box_grad no longer refuses it): 2 and 3
+    thread ranks on wrapped molecules (frames and pairs across the cell and slab faces) return the single-GPU gradient."""
+    import threading
+    from admp_amd import settings
+    from admp_amd import systems as S
+    from admp_amd.parallel import SlabPme, ThreadComm
+    from admp_amd.pme import ADMPPmeForce
+    old = settings.PRECISION
+    settings.PRECISION = 'double'
+    try:
+        n_mol = 1000
+        pos, box = S.synthetic_water_box(n_mol, seed=23)
+        pos = np.mod(pos, box[0, 0])
+        at, ai, cov = S.water_topology(n_mol)
+        par = S.water_parameters(n_mol, lpol)
+        pairs = S.build_pairs(pos, box, 4.0)
+        args = (par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales']) if lpol else \
+            (par['Q_local'], par['mScales'])
+        f0 = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+        E0, dB0 = f0.get_energy_and_box_gradient(pos, box, pairs, *args)
+        for nranks in (2, 3):
+            world = ThreadComm.World(nranks)
+            out, errors = [None] * nranks, []
+
+            def work(rank):
+                try:
+                    f = SlabPme(ThreadComm(world, rank), box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
+                    out[rank] = f.get_energy_and_box_gradient(pos, box, pairs, *args)
+                except Exception as e:      # noqa: BLE001
+                    errors.append((rank, repr(e)))
+                    try:
+                        world.barrier.abort()
+                    except Exception:
+                        pass
+            ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+            [t.start() for t in ts]
+            [t.join(timeout=600) for t in ts]
+            assert not errors, errors
+            for E, dB in out:
+                assert abs(E - E0) < 1e-10 * max(abs(p) for p in f0.energy_parts)
+                assert np.abs(dB - dB0).max() < 1e-9 * np.abs(dB0).max(), (nranks, dB, dB0)
+        if lpol:      # the Tang-Toennies pair term on slab ranks too
+            from admp_amd.parallel import SlabPairInteraction
+            from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel
+            ta = (par['mScales'], par['a_list'], par['b_list'], par['q_list'], np.ascontiguousarray(par['c_list'][:, 0]))
+            t0 = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+            Et0, dBt0 = t0.get_energy_and_box_gradient(pos, box, pairs, *ta)
+            world = ThreadComm.World(2)
+            out, errors = [None] * 2, []
+
+            def work_tt(rank):
+                try:
+                    t = SlabPairInteraction(ThreadComm(world, rank), TT_damping_qq_c6_kernel, cov)
+                    out[rank] = t.get_energy_and_box_gradient(pos, box, pairs, *ta)
+                except Exception as e:      # noqa: BLE001
+                    errors.append((rank, repr(e)))
+                    try:
+                        world.barrier.abort()
+                    except Exception:
+                        pass
+            ts = [threading.Thread(target=work_tt, args=(r,)) for r in range(2)]
+            [t.start() for t in ts]
+            [t.join(timeout=600) for t in ts]
+            assert not errors, errors
+            for E, dB in out:
+                assert abs(E - Et0) < 1e-10 * abs(Et0) and np.abs(dB - dBt0).max() < 1e-9 * np.abs(dBt0).max()
+    finally:
+        settings.PRECISION = old

@@ -23,6 +23,7 @@ for wl in ('S1', 'S2', 'S3'):
         f = glob.glob(os.path.join(src, 'pmc_%s_%s' % (wl, c), '**', '*counter_collection.csv'), recursive=True)
         if not f:
             continue
+        f.sort(key=os.path.getmtime, reverse=True)      # gpurun merges into gpurun_out/: the newest pass counts
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f[0])):
             if r['Counter_Name'] == c:
@@ -30,7 +31,8 @@ for wl in ('S1', 'S2', 'S3'):
         for k, v in agg.items():
             per[k][c] = (sum(v) / len(v), len(v))
     mix = collections.defaultdict(lambda: collections.defaultdict(list))      # instruction classes of the pair kernel
-    for f in glob.glob(os.path.join(src, 'pmc_%s_MIX' % wl, '**', '*counter_collection.csv'), recursive=True):
+    for f in sorted(glob.glob(os.path.join(src, 'pmc_%s_MIX' % wl, '**', '*counter_collection.csv'), recursive=True),
+                    key=os.path.getmtime, reverse=True)[:1]:
         for r in csv.DictReader(open(f)):
             if 'k_pair_full' in r['Kernel_Name']:
                 mix[r['Counter_Name']]['v'].append(float(r['Counter_Value']))
