@@ -634,6 +634,22 @@ def main_slab(opt, rank, world):
     sent = {k: int(v / nb) for k, v in sorted(comm.bytes_sent.items())}
     coll_py = comm.report(nb)
     n_atoms = 3 * w['n_mol']
+    # what the reference's calling convention (every caller receives the full gradient / dipole arrays) costs on top: one SUM
+    # all-reduce of (Na, 3) per output array and call -- the same object with outputs='replicated', a short leg of its own
+    replicated = None
+    if not opt.no_extras and outputs == 'home':
+        try:
+            f.outputs = 'replicated'
+            kr = min(opt.steps, 5)
+            dtr, _, _ = run_timed(f, a, kr, 1, frames, dist.barrier, only=False)
+            dtr = reduce_max_seconds(dtr, dist, rdev)
+            replicated = {'note': 'EXTRA: the same step with outputs=\'replicated\' (full arrays on every rank, as the reference\'s '
+                                  'single-device API returns them)', 'ms_per_step': round(dtr / kr * 1e3, 5),
+                          'ns_per_day': round(0.0864 / (dtr / kr), 3), 'steps': kr}
+        except Exception as e:
+            replicated = {'error': repr(e)}
+        finally:
+            f.outputs = outputs
     # the labelled extra: N independent replicas of the single-GPU headline workload (what a 3072-atom box can do with N GPUs)
     replicas = None
     if not opt.no_extras:
@@ -675,6 +691,8 @@ def main_slab(opt, rank, world):
                'rank0_bytes_sent_per_step': sent,
                'recip_kernels_rank0': None,
                'cpu_baseline': None}
+        if replicated is not None:
+            out['outputs_replicated'] = replicated
         if replicas is not None:
             out['replicas_S1'] = replicas
         print(json.dumps(out))
