@@ -2026,12 +2026,63 @@ struct Engine : EngineBase {
     scf_nobs[0] = scf_nobs[1] = 0;
   }
 
+  // dispersion PME box gradient on a slab rank (round 4): the pair sums over its home rows, the channels spread / gathered on
+  // its home atoms through the distributed convolution with the k-tensor sums between the x transforms, the self term over
+  // its home atoms; the 24 device sums are added over the ranks
+  void disp_box_grad_slab(const T* pos, const double* box, const T* cl, int pmax, int ns, const double* mS, double* E,
+                          double* dbox) {
+    const int na = top.na;
+    double inv[9], vol;
+    Box<T> bx = make_box(box, inv, &vol);
+    ensure_mesh();
+    RecipGeom<T> g = make_geom(inv);
+    ScaleTab<T> tab = make_tab(ns, mS, nullptr);
+    ARG_CHECK(spread_uses_bricks(1 << 30, g), "slab-decomposed dispersion PME needs at least 17 local mesh planes and K2, K3 >= 17");
+    grad.need(3 * (size_t)na * sizeof(T));
+    energies_d.need(2 * E_WORDS * sizeof(double));
+    ehalf = 0; other_clean = false;
+    double* Ed = energies_d.as<double>();
+    HIP_TRY(hipMemsetAsync(Ed, 0, 2 * E_WORDS * sizeof(double), stream));
+    double* acc = vir_begin();
+    cls_sites_na = slab_sites_na = -1;
+    const ScalarRows sr = scalar_rows(pos, g, K[0], X0, X1, true);
+    launch_disp_pair<T>(stream, na, nbr, pack_srows(pos, cl, 3), bx, tab, (T)kappa, pmax, grad.as<T>(), Ed, sr.rows, sr.n, cutoff);
+    launch_scalar_pair_virial<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, acc + V_XW, cutoff, sr.rows, sr.n);
+    const double kp[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
+    const int nch = (pmax - 4) / 2;
+    const size_t nreal = nreal_local();
+    mesh.need(nch * nreal * sizeof(T));
+    sites.need(sizeof(Site<T>) * (size_t)na);
+    ensure_bins(std::max(sr.n, 1));
+    {
+      int rc = launch_bin_bricks<T>(stream, sr.n, (const Site<T>*)nullptr, g, bins, sr.home, bases_d.as<int4>());
+      if (rc == 0) rc = launch_spread_scalar<T>(stream, nch, pos, cl, 3, g, bins, mesh.as<T>(), (long)nreal);
+      if (rc != 0) throw Err{ADMP_E_HIP, std::string("dispersion spread: ") + hipGetErrorString((hipError_t)rc)};
+      bins.counters_zero = true;
+    }
+    double* scratchE = Ed + E_WORDS;              // (the all-atom self sums of launch_scalar_sites are not this rank's: discarded)
+    for (int c = 0; c < nch; ++c) {
+      ensure_gtab(box, inv, vol, 6 + 2 * c);
+      upload_binv(inv);
+      convolve_slab_virial(mesh.as<T>() + c * nreal, spec.as<T>(), gtab_cur, E_RECIP, 6 + 2 * c, vol, acc);
+      launch_scalar_sites<T>(stream, na, pos, cl, 3, c, 0.0, sites.as<Site<T>>(), scratchE);
+      launch_gather_virial<T>(stream, sr.n, sites.as<Site<T>>(), 0, g, mesh.as<T>() + c * nreal, acc + V_XW, acc + V_Y, sr.home);
+    }
+    launch_scalar_self<T>(stream, nch, sr.n, cl, 3, sr.home, kp, Ed);
+    read_scalar_energies(Ed, E, 3);
+    { TIMED("comm_energies"); c_all_reduce(acc, V_WORDS, ADMP_T_F64, ADMP_OP_SUM, ADMP_TAG_ENERGIES); }
+    vir_assemble(inv, E[1], dbox);
+  }
+
   void disp_box_grad(const void* pos_, const double* box, const void* clist_, int pmax, int ns, const double* mS, double* E,
                      double* dbox) override {
     ARG_CHECK(have_top && have_ewald && have_pairs, "topology, ewald parameters and pairs must be set first");
-    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
     ARG_CHECK(pos_ && box && clist_ && E && dbox, "null argument");
     ARG_CHECK(pmax == 6 || pmax == 8 || pmax == 10, "pmax must be 6, 8 or 10");
+    if (snranks > 1) {
+      disp_box_grad_slab(reinterpret_cast<const T*>(pos_), box, reinterpret_cast<const T*>(clist_), pmax, ns, mS, E, dbox);
+      return;
+    }
     const int na = top.na;
     double inv[9], vol;
     Box<T> bx = make_box(box, inv, &vol);

@@ -521,6 +521,11 @@ class SlabDispPme(_SlabMixin, ADMPDispPmeForce):
         return E, self._assemble(grad)
 
 
+    def get_energy_and_box_gradient(self, *a, **k):
+        """(E, dE/dbox) of dispersion PME on the slab ranks (round 4); every rank returns the full gradient"""
+        return self._checked(lambda: ADMPDispPmeForce.get_energy_and_box_gradient(self, *a, **k))
+
+
 class SlabPairInteraction(_SlabMixin, _PairInteraction):
     """generate_pairwise_interaction(kernel, covalent_map, static_args) for the kernels of libadmp_hip (Tang-Toennies),
     decomposed over x-slabs: every rank evaluates the rows of its home atoms; one SUM all-reduce of the energy."""

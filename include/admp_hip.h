@@ -140,9 +140,8 @@ int admp_pme_energy_fixed_dipoles(admp_handle* h, const void* positions, const d
  * admp/disp_pme.py:76 with argnums).  dE_dbox is 9 doubles (host), row-major like `box` (lattice vectors in rows).
  * Positions / parameters are DEVICE pointers.  For a polarizable handle U holds the induced dipoles to evaluate at (the
  * converged ones: the reference differentiates energy_fn at stop_gradient(U_ind), admp/pme.py:81-85).
- * E_out as in the corresponding energy_grad call.  admp_pme_box_grad also runs on a slab-decomposed handle (round 4: every rank
- * returns the full gradient, the device sums are added over the ranks); the dispersion / pair-potential variants do not
- * (ADMP_E_ARG). */
+ * E_out as in the corresponding energy_grad call.  All three also run on a slab-decomposed handle (round 4: every rank returns
+ * the full gradient; the device sums are added over the ranks). */
 int admp_pme_box_grad(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
                       const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
                       double* E_out, double* dE_dbox);

@@ -232,6 +232,31 @@ def test_slab_box_gradient_matches_single_gpu(lpol):
             for E, dB in out:
                 assert abs(E - E0) < 1e-10 * max(abs(p) for p in f0.energy_parts)
                 assert np.abs(dB - dB0).max() < 1e-9 * np.abs(dB0).max(), (nranks, dB, dB0)
+        if lpol:      # dispersion PME (pmax 10) on slab ranks
+            from admp_amd.disp_pme import ADMPDispPmeForce
+            from admp_amd.parallel import SlabDispPme
+            d0 = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+            Ed0, dBd0 = d0.get_energy_and_box_gradient(pos, box, pairs, par['c_list'], par['mScales'])
+            world = ThreadComm.World(2)
+            out, errors = [None] * 2, []
+
+            def work_d(rank):
+                try:
+                    d = SlabDispPme(ThreadComm(world, rank), box, cov, 4.0, 1e-4, 10)
+                    out[rank] = d.get_energy_and_box_gradient(pos, box, pairs, par['c_list'], par['mScales'])
+                except Exception as e:      # noqa: BLE001
+                    errors.append((rank, repr(e)))
+                    try:
+                        world.barrier.abort()
+                    except Exception:
+                        pass
+            ts = [threading.Thread(target=work_d, args=(r,)) for r in range(2)]
+            [t.start() for t in ts]
+            [t.join(timeout=600) for t in ts]
+            assert not errors, errors
+            for E, dB in out:
+                assert abs(E - Ed0) < 1e-10 * max(abs(p) for p in d0.energy_parts)
+                assert np.abs(dB - dBd0).max() < 1e-9 * np.abs(dBd0).max(), (dB, dBd0)
         if lpol:      # the Tang-Toennies pair term on slab ranks too
             from admp_amd.parallel import SlabPairInteraction
             from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel
