@@ -355,9 +355,10 @@ void launch_scalar_self(hipStream_t st, int nch, int na, const T* vals, int stri
 template <class T>
 __global__ __launch_bounds__(128) void k_gather_value(int na, const T* __restrict__ pos, const T* __restrict__ vals, int stride,
                                                       int chan, RecipGeom<T> g, const T* __restrict__ phi, T extra,
-                                                      T* __restrict__ out) {
-  const int i = blockIdx.x * 128 + threadIdx.x;
-  if (i >= na) return;
+                                                      T* __restrict__ out, const int* __restrict__ list) {
+  const int slot = blockIdx.x * 128 + threadIdx.x;
+  if (slot >= na) return;
+  const int i = list ? list[slot] : slot;                 // (slab rank: its home atoms)
   const T r[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
   int base[3];
   T M[3][6];
@@ -382,8 +383,8 @@ __global__ __launch_bounds__(128) void k_gather_value(int na, const T* __restric
 }
 template <class T>
 void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, const RecipGeom<T>& g,
-                         const T* phi, double extra, T* out) {
-  if (na > 0) k_gather_value<T><<<(na + 127) / 128, 128, 0, st>>>(na, pos, vals, stride, chan, g, phi, (T)extra, out);
+                         const T* phi, double extra, T* out, const int* list) {
+  if (na > 0) k_gather_value<T><<<(na + 127) / 128, 128, 0, st>>>(na, pos, vals, stride, chan, g, phi, (T)extra, out, list);
 }
 
 #define INST(T)                                                                                                          \
@@ -395,7 +396,7 @@ void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, in
   template void launch_interleave<T>(hipStream_t, int, long, const T*, long, T*);                                        \
   template void launch_scalar_self<T>(hipStream_t, int, int, const T*, int, const int*, const double*, double*);         \
   template void launch_gather_value<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, const T*,     \
-                                       double, T*);
+                                       double, T*, const int*);
 INST(float)
 INST(double)
 #undef INST

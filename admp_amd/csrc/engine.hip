@@ -2455,7 +2455,6 @@ struct Engine : EngineBase {
   void disp_param_grad(const void* pos_, const double* box, const void* clist_, int pmax, int ns, const double* mS,
                        void* out_) override {
     ARG_CHECK(have_top && have_ewald && have_pairs, "topology, ewald parameters and pairs must be set first");
-    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
     ARG_CHECK(pos_ && box && clist_ && out_, "null argument");
     ARG_CHECK(pmax == 6 || pmax == 8 || pmax == 10, "pmax must be 6, 8 or 10");
     const int na = top.na;
@@ -2472,6 +2471,28 @@ struct Engine : EngineBase {
     double* Ed = energies_d.as<double>();
     HIP_TRY(hipMemsetAsync(Ed, 0, E_WORDS * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(out, 0, 3 * (size_t)na * sizeof(T), stream));
+    if (snranks > 1) {      // slab rank (round 4): pair sums over its home rows, the channels' mesh potentials at its home atoms
+      ARG_CHECK(spread_uses_bricks(1 << 30, g), "slab-decomposed dispersion PME needs at least 17 local mesh planes and K2, K3 >= 17");
+      cls_sites_na = slab_sites_na = -1;
+      const ScalarRows sr = scalar_rows(pos, g, K[0], X0, X1, true);
+      launch_scalar_pair_pgrad<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, out, cutoff, sr.rows, sr.n);
+      const double kq[3] = {-std::pow(kappa, 6) / 12.0, -std::pow(kappa, 8) / 48.0, -std::pow(kappa, 10) / 240.0};
+      const int nc = (pmax - 4) / 2;
+      const size_t nreal = nreal_local();
+      mesh.need(nc * nreal * sizeof(T));
+      ensure_bins(std::max(sr.n, 1));
+      int rc = launch_bin_bricks<T>(stream, sr.n, (const Site<T>*)nullptr, g, bins, sr.home, bases_d.as<int4>());
+      if (rc == 0) rc = launch_spread_scalar<T>(stream, nc, pos, cl, 3, g, bins, mesh.as<T>(), (long)nreal);
+      if (rc != 0) throw Err{ADMP_E_HIP, std::string("dispersion spread: ") + hipGetErrorString((hipError_t)rc)};
+      bins.counters_zero = true;
+      for (int c = 0; c < nc; ++c) {
+        ensure_gtab(box, inv, vol, 6 + 2 * c);
+        convolve(mesh.as<T>() + c * nreal, spec.as<T>(), gtab_cur, E_RECIP);
+        launch_gather_value<T>(stream, sr.n, pos, cl, 3, c, g, mesh.as<T>() + c * nreal, 2.0 * kq[c], out, sr.home);
+      }
+      HIP_TRY(hipStreamSynchronize(stream));
+      return;
+    }
     launch_scalar_pair_pgrad<T>(stream, 0, na, nbr, pos, cl, bx, tab, (T)kappa, pmax, out, cutoff);
     cls_sites_na = slab_sites_na = -1;
     sites.need(sizeof(Site<T>) * (size_t)na);
@@ -2491,13 +2512,23 @@ struct Engine : EngineBase {
   // dE/d(a, b, q, c6) (Na,4) of the Tang-Toennies pair term (admp/pairwise.py:94-113).  Device pointers; on request only.
   void tt_param_grad(const void* pos_, const double* box, const void* abqc_, int ns, const double* mS, void* out_) override {
     ARG_CHECK(have_top && have_pairs, "topology and pairs must be set first");
-    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
     ARG_CHECK(pos_ && box && abqc_ && out_, "null argument");
     double inv[9], vol;
     Box<T> bx = make_box(box, inv, &vol);
     ScaleTab<T> tab = make_tab(ns, mS, nullptr);
-    launch_scalar_pair_pgrad<T>(stream, 1, top.na, nbr, reinterpret_cast<const T*>(pos_), reinterpret_cast<const T*>(abqc_), bx,
-                                tab, T(0), 0, reinterpret_cast<T*>(out_), cutoff);
+    const T* pos = reinterpret_cast<const T*>(pos_);
+    ScalarRows sr{nullptr, top.na, nullptr};
+    if (snranks > 1) {      // the rows of the rank's home atoms (per-atom outputs: home rows are this rank's results)
+      ARG_CHECK(have_comm, "slab-decomposed handle without a communicator (admp_set_comm)");
+      RecipGeom<T> gv;
+      const int Kv = 64 * snranks;
+      gv.K[0] = Kv; gv.K[1] = gv.K[2] = 32;
+      for (int k = 0; k < 9; ++k) { gv.hinv[k] = (T)inv[k]; gv.Aop[k] = gv.Jac[k] = T(0); }
+      gv.xoff = 64 * srank; gv.nloc0 = 64 + kGhost; gv.wrap0 = 1 << 30;
+      sr = scalar_rows(pos, gv, Kv, 64 * srank, 64 * (srank + 1), true);
+    }
+    launch_scalar_pair_pgrad<T>(stream, 1, top.na, nbr, pos, reinterpret_cast<const T*>(abqc_), bx,
+                                tab, T(0), 0, reinterpret_cast<T*>(out_), cutoff, sr.rows, sr.n);
     HIP_TRY(hipStreamSynchronize(stream));
   }
 
@@ -2549,11 +2580,12 @@ struct Engine : EngineBase {
   void thole_sums(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                   const double* mS, const double* pS, const void* U, void* sumX, void* sumXw) override {
     ARG_CHECK(lpol, "polarizable handle required");
-    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
     ARG_CHECK(sumX && sumXw && U, "null argument");
     HIP_TRY(hipSetDevice(device));
     stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, const_cast<void*>(U));
-    { TIMED("thole_sums"); launch_thole_sums<T>(stream, top.na, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T*)sumX, (T*)sumXw); }
+    // (slab rank: the sums of its home rows -- per-atom outputs like the gradient: the home rows are this rank's results)
+    { TIMED("thole_sums"); launch_thole_sums<T>(stream, top.na, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T*)sumX, (T*)sumXw,
+                                                snranks > 1 ? pair_rows() : nullptr, ev.n_home); }
     ev.active = false;
     HIP_TRY(hipStreamSynchronize(stream));
   }
@@ -2562,13 +2594,14 @@ struct Engine : EngineBase {
   void pscale_grad(const void* pos, const double* box, const void* Ql, const void* pol, const void* thole, int ns,
                    const double* mS, const double* pS, const void* U, double* out) override {
     ARG_CHECK(lpol, "polarizable handle required");
-    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
     ARG_CHECK(out && U && ns >= 1 && ns <= 16, "bad argument");
     stage_begin(pos, box, Ql, pol, thole, ns, mS, pS, const_cast<void*>(U));
     vir_d.need(V_WORDS * sizeof(double));
     double* cls = vir_d.as<double>();
     HIP_TRY(hipMemsetAsync(cls, 0, 16 * sizeof(double), stream));
-    { TIMED("pscale_grad"); launch_pscale_sums<T>(stream, top.na, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, cls); }
+    { TIMED("pscale_grad"); launch_pscale_sums<T>(stream, top.na, nbr, sites.as<Site<T>>(), ev.bx, ev.tab, cls,
+                                                  snranks > 1 ? pair_rows() : nullptr, ev.n_home); }
+    if (snranks > 1) { TIMED("comm_energies"); c_all_reduce(cls, 16, ADMP_T_F64, ADMP_OP_SUM, ADMP_TAG_ENERGIES); }
     ev.active = false;
     double h16[16];
     HIP_TRY(hipMemcpyAsync(h16, cls, sizeof(h16), hipMemcpyDeviceToHost, stream));
@@ -2584,7 +2617,7 @@ struct Engine : EngineBase {
     ARG_CHECK(have_top && have_pairs, "topology and pairs must be set first");
     ARG_CHECK(pos_ && box && par_ && out && ns >= 1 && ns <= 16, "bad argument");
     ARG_CHECK(kind >= 0 && kind <= 2, "kind must be 0 (multipolar PME), 1 (dispersion) or 2 (Tang-Toennies)");
-    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
+    ARG_CHECK(snranks == 1 || on_device, "a slab-decomposed handle takes device pointers");
     const int na = top.na;
     HIP_TRY(hipSetDevice(device));
     double inv[9], vol;
@@ -2603,7 +2636,22 @@ struct Engine : EngineBase {
       RecipGeom<T> g = make_geom(inv);
       launch_prepare_sites<T>(stream, top, pos, par, nullptr, nullptr, nullptr, bx, sites.as<Site<T>>(), nullptr, g, nullptr);
     }
-    { TIMED("mscale_grad"); launch_mscale_sums<T>(stream, kind, na, nbr, sites.as<Site<T>>(), pos, par, bx, pmax, cls, cutoff); }
+    ScalarRows sr{nullptr, na, nullptr};
+    if (snranks > 1) {      // the class sums of the rank's home rows, added over the ranks
+      ARG_CHECK(have_comm, "slab-decomposed handle without a communicator (admp_set_comm)");
+      RecipGeom<T> gv;
+      if (have_ewald) { update_slab(); gv = make_geom(inv); sr = scalar_rows(pos, gv, K[0], X0, X1, true); }
+      else {                // a pair potential has no mesh: x-slabs of a virtual one, as in tt()
+        const int Kv = 64 * snranks;
+        gv.K[0] = Kv; gv.K[1] = gv.K[2] = 32;
+        for (int k = 0; k < 9; ++k) { gv.hinv[k] = (T)inv[k]; gv.Aop[k] = gv.Jac[k] = T(0); }
+        gv.xoff = 64 * srank; gv.nloc0 = 64 + kGhost; gv.wrap0 = 1 << 30;
+        sr = scalar_rows(pos, gv, Kv, 64 * srank, 64 * (srank + 1), true);
+      }
+    }
+    { TIMED("mscale_grad"); launch_mscale_sums<T>(stream, kind, na, nbr, sites.as<Site<T>>(), pos, par, bx, pmax, cls, cutoff,
+                                                  sr.rows, sr.n); }
+    if (snranks > 1) { TIMED("comm_energies"); c_all_reduce(cls, 16, ADMP_T_F64, ADMP_OP_SUM, ADMP_TAG_ENERGIES); }
     double h16[16];
     HIP_TRY(hipMemcpyAsync(h16, cls, sizeof(h16), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));

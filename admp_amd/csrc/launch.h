@@ -260,17 +260,18 @@ int pair_lanes_per_row(int n_rows);   // 4/8/16 by row count; env ADMP_PAIR_LPR 
 // sumX[i] = sum_j dE_ij/d ln(au_ij), sumXw[i] = sum_j (same) * d ln(au_ij)/d thole_i  (pme_math.h pair_thole_logderiv)
 template <class T>
 void launch_thole_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                       const ScaleTab<T>& tab, T* sumX, T* sumXw);
+                       const ScaleTab<T>& tab, T* sumX, T* sumXw, const int* rows = nullptr, int n_rows = 0);
 // cls16[nb] += sum over the pairs of covalent class nb of d(pair energy)/d(mscale); kind 0: multipolar PME (sites),
 // 1: dispersion (pos, par = c6/c8/c10 per atom, pmax), 2: Tang-Toennies (pos, par = a/b/q/c6 per atom)
 template <class T>
 void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, const Site<T>* sites, const T* pos,
                         const T* par, const Box<T>& box, int pmax, double* cls16,
-                        double cutoff = 0.0 /* kinds 1, 2: listed pairs beyond it are skipped (admp_set_cutoff) */);
+                        double cutoff = 0.0 /* kinds 1, 2: listed pairs beyond it are skipped (admp_set_cutoff) */,
+                        const int* rows = nullptr /* slab rank: its n_rows home rows */, int n_rows = 0);
 // cls16[nb] += sum over the pairs of covalent class nb of d(pair energy)/d(pscale) (pme_math.h pair_pscale_deriv)
 template <class T>
 void launch_pscale_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                        const ScaleTab<T>& tab, double* cls16);
+                        const ScaleTab<T>& tab, double* cls16, const int* rows = nullptr, int n_rows = 0);
 // packed rows of the scalar pair kernels: position (3) + up to 4 per-atom parameters + pad, one aligned 8-real row per atom
 template <class T>
 struct alignas(8 * sizeof(T)) SRow {
@@ -424,12 +425,13 @@ void launch_scalar_self(hipStream_t st, int nch, int na, const T* vals, int stri
 // out[i * stride + chan] += phi(r_i) + extra * vals[i * stride + chan]  (mesh potential at the atoms: dE_recip/dc_i)
 template <class T>
 void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, int stride, int chan, const RecipGeom<T>& g,
-                         const T* phi, double extra, T* out);
+                         const T* phi, double extra, T* out, const int* list = nullptr /* the na atoms (nullptr: 0 .. na-1) */);
 // (pair_kernels.hip) per-atom parameter derivatives of the scalar pair terms: tt = 0 dispersion, out (na,3) = dE/dc6,c8,c10;
 // tt = 1 Tang-Toennies, out (na,4) = dE/d(a, b, q, c6)
 template <class T>
 void launch_scalar_pair_pgrad(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par, const Box<T>& box,
-                              const ScaleTab<T>& tab, T kappa, int pmax, T* out, double cutoff = 0.0);
+                              const ScaleTab<T>& tab, T kappa, int pmax, T* out, double cutoff = 0.0,
+                              const int* rows = nullptr, int n_rows = 0);
 // ---- cell_kernels.hip: positions -> half pair list (cell list), two phases so that the caller can size `pairs`
 struct CellScratch {
   int n[3] = {0, 0, 0};

@@ -338,14 +338,16 @@ template <class T, bool TT>
 __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_pgrad(int na, const int* __restrict__ rowptr,
                                                                   const int* __restrict__ col, const T* __restrict__ pos,
                                                                   const T* __restrict__ par, Box<T> box, ScaleTab<T> tab,
-                                                                  T kappa, int pmax, T* __restrict__ out, T rc2) {
+                                                                  T kappa, int pmax, T* __restrict__ out, T rc2,
+                                                                  const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   constexpr int LPR = 8, NP = TT ? 4 : 3;
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
+  const int row = (rows && slot < na) ? rows[slot] : slot;      // (slab rank: the rows of its home atoms)
   T acc[4] = {0, 0, 0, 0};
-  if (row < na) {
+  if (slot < na) {
     const T ri[3] = {pos[3 * row], pos[3 * row + 1], pos[3 * row + 2]};
     T pi[4] = {0, 0, 0, 0};
     for (int k = 0; k < NP; ++k) pi[k] = par[NP * row + k];
@@ -364,17 +366,18 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_scalar_pgrad(int na, const 
   }
 #pragma unroll
   for (int k = 0; k < NP; ++k) acc[k] = row_reduce<T, LPR>(acc[k]);
-  if (row < na && sub == 0)
+  if (slot < na && sub == 0)
     for (int k = 0; k < NP; ++k) out[NP * row + k] = acc[k];
 }
 template <class T>
 void launch_scalar_pair_pgrad(hipStream_t st, int tt, int na, const NbrTable& nb, const T* pos, const T* par, const Box<T>& box,
-                              const ScaleTab<T>& tab, T kappa, int pmax, T* out, double cutoff) {
+                              const ScaleTab<T>& tab, T kappa, int pmax, T* out, double cutoff, const int* rows, int n_rows) {
+  if (rows) na = n_rows;
   if (na <= 0) return;
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
   const T rc2 = (T)(cutoff * cutoff);
-  if (tt) k_pair_scalar_pgrad<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out, rc2);
-  else k_pair_scalar_pgrad<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out, rc2);
+  if (tt) k_pair_scalar_pgrad<T, true><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out, rc2, rows);
+  else k_pair_scalar_pgrad<T, false><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, pos, par, box, tab, kappa, pmax, out, rc2, rows);
 }
 
 // dE/dmScales (the parameter gradient the reference's examples/openmm_api/run.py:41-46 prints): per covalent class
@@ -385,15 +388,17 @@ template <class T, int KIND>
 __global__ __launch_bounds__(kPairBlock) void k_pair_mgrad(int na, const int* __restrict__ rowptr,
                                                            const int* __restrict__ col, const Site<T>* __restrict__ sites,
                                                            const T* __restrict__ pos, const T* __restrict__ par, Box<T> box,
-                                                           int pmax, double* __restrict__ cls, T rc2) {
+                                                           int pmax, double* __restrict__ cls, T rc2,
+                                                           const int* __restrict__ rows) {
   __shared__ double s_cls[16];
   if (threadIdx.x < 16) s_cls[threadIdx.x] = 0.0;
   __syncthreads();
   constexpr int LPR = 8;
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
+  const int row = (rows && slot < na) ? rows[slot] : slot;      // (slab rank: its home rows; the class sums are added over the ranks)
   double e0 = 0.0;
-  if (row < na) {
+  if (slot < na) {
     Site<T> I;
     T ri[3] = {0, 0, 0}, pi[4] = {0, 0, 0, 0};
     constexpr int NP = KIND == 2 ? 4 : 3;
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_mgrad(int na, const int* __
 template <class T>
 __global__ __launch_bounds__(kPairBlock) void k_pair_pgrad(int na, const int* __restrict__ rowptr, const int* __restrict__ col,
                                                            const Site<T>* __restrict__ sites, Box<T> box, ScaleTab<T> tab,
-                                                           double* __restrict__ cls) {
+                                                           double* __restrict__ cls, const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   __shared__ double s_cls[16];
   stage_tab(tab, s_tab);
@@ -441,9 +446,10 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_pgrad(int na, const int* __
   __syncthreads();
   constexpr int LPR = 8;
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
+  const int row = (rows && slot < na) ? rows[slot] : slot;
   double e0 = 0.0;
-  if (row < na) {
+  if (slot < na) {
     const Site<T> I = sites[row];
     const int end = rowptr[row + 1];
     for (int k = rowptr[row] + sub; k < end; k += LPR) {
@@ -462,28 +468,32 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_pgrad(int na, const int* __
 }
 template <class T>
 void launch_pscale_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                        const ScaleTab<T>& tab, double* cls16) {
+                        const ScaleTab<T>& tab, double* cls16, const int* rows, int n_rows) {
+  if (rows) na = n_rows;
+  if (na <= 0) return;
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
-  k_pair_pgrad<T><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, cls16);
+  k_pair_pgrad<T><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, cls16, rows);
 }
 template void launch_pscale_sums<float>(hipStream_t, int, const NbrTable&, const Site<float>*, const Box<float>&,
-                                        const ScaleTab<float>&, double*);
+                                        const ScaleTab<float>&, double*, const int*, int);
 template void launch_pscale_sums<double>(hipStream_t, int, const NbrTable&, const Site<double>*, const Box<double>&,
-                                         const ScaleTab<double>&, double*);
+                                         const ScaleTab<double>&, double*, const int*, int);
 
 // per-atom sums of d(pair energy)/d ln(au) (pair_thole_logderiv): sumX[i] = sum_j X_ij, sumXw[i] = sum_j X_ij wth_ij
 template <class T>
 __global__ __launch_bounds__(kPairBlock) void k_pair_tholegrad(int na, const int* __restrict__ rowptr,
                                                                const int* __restrict__ col,
                                                                const Site<T>* __restrict__ sites, Box<T> box,
-                                                               ScaleTab<T> tab, T* __restrict__ sumX, T* __restrict__ sumXw) {
+                                                               ScaleTab<T> tab, T* __restrict__ sumX, T* __restrict__ sumXw,
+                                                               const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   constexpr int LPR = 8;
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  const int row = (int)(t / LPR), sub = (int)(t % LPR);
+  const int slot = (int)(t / LPR), sub = (int)(t % LPR);
+  const int row = (rows && slot < na) ? rows[slot] : slot;      // (slab rank: the sums of its home rows)
   T sx = 0, sw = 0;
-  if (row < na) {
+  if (slot < na) {
     const Site<T> I = sites[row];
     const int end = rowptr[row + 1];
     for (int k = rowptr[row] + sub; k < end; k += LPR) {
@@ -498,23 +508,27 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_tholegrad(int na, const int
   }
   sx = row_reduce<T, LPR>(sx);
   sw = row_reduce<T, LPR>(sw);
-  if (row < na && sub == 0) { sumX[row] = sx; sumXw[row] = sw; }
+  if (slot < na && sub == 0) { sumX[row] = sx; sumXw[row] = sw; }
 }
 template <class T>
 void launch_thole_sums(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
-                       const ScaleTab<T>& tab, T* sumX, T* sumXw) {
+                       const ScaleTab<T>& tab, T* sumX, T* sumXw, const int* rows, int n_rows) {
+  if (rows) na = n_rows;
+  if (na <= 0) return;
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
-  k_pair_tholegrad<T><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, sumX, sumXw);
+  k_pair_tholegrad<T><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, box, tab, sumX, sumXw, rows);
 }
 
 template <class T>
 void launch_mscale_sums(hipStream_t st, int kind, int na, const NbrTable& nb, const Site<T>* sites, const T* pos,
-                        const T* par, const Box<T>& box, int pmax, double* cls16, double cutoff) {
+                        const T* par, const Box<T>& box, int pmax, double* cls16, double cutoff, const int* rows, int n_rows) {
+  if (rows) na = n_rows;
+  if (na <= 0) return;
   const unsigned grid = (unsigned)(((long)na * 8 + kPairBlock - 1) / kPairBlock);
   const T rc2 = (T)(cutoff * cutoff);
-  if (kind == 0) k_pair_mgrad<T, 0><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, T(0));
-  else if (kind == 1) k_pair_mgrad<T, 1><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, rc2);
-  else k_pair_mgrad<T, 2><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, rc2);
+  if (kind == 0) k_pair_mgrad<T, 0><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, T(0), rows);
+  else if (kind == 1) k_pair_mgrad<T, 1><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, rc2, rows);
+  else k_pair_mgrad<T, 2><<<grid, kPairBlock, 0, st>>>(na, nb.rowptr, nb.col, sites, pos, par, box, pmax, cls16, rc2, rows);
 }
 
 // ---- box gradient, real-space part (jax.grad(get_energy, argnums=1) in the reference) -----------------------
@@ -785,16 +799,16 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* s
   template void launch_tt_pair<T>(hipStream_t, int, const NbrTable&, const SRow<T>*, const Box<T>&,                 \
                                   const ScaleTab<T>&, T*, double*, const int*, int, double);                        \
   template void launch_mscale_sums<T>(hipStream_t, int, int, const NbrTable&, const Site<T>*, const T*, const T*,   \
-                                      const Box<T>&, int, double*, double);                                         \
+                                      const Box<T>&, int, double*, double, const int*, int);                        \
   template void launch_thole_sums<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,              \
-                                     const ScaleTab<T>&, T*, T*);                                                   \
+                                     const ScaleTab<T>&, T*, T*, const int*, int);                                  \
   template void launch_pair_virial<T>(hipStream_t, int, const NbrTable&, const Site<T>*, const Box<T>&,             \
                                       const ScaleTab<T>&, T, int, double*, const int*, int);                        \
   template void launch_scalar_pair_virial<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,            \
                                              const Box<T>&, const ScaleTab<T>&, T, int, double*, double,            \
                                              const int*, int);                                                      \
   template void launch_scalar_pair_pgrad<T>(hipStream_t, int, int, const NbrTable&, const T*, const T*,             \
-                                            const Box<T>&, const ScaleTab<T>&, T, int, T*, double);
+                                            const Box<T>&, const ScaleTab<T>&, T, int, T*, double, const int*, int);
 INST(float)
 INST(double)
 #undef INST

@@ -472,6 +472,15 @@ class _SlabMixin:
         return full
 
 
+    def _assemble_any(self, x):
+        """_assemble for a per-atom output in whatever container the base class returned it (torch tensor or numpy array)"""
+        if x is None or self.comm.size == 1:
+            return x
+        if isinstance(x, torch.Tensor):
+            return self._assemble(x.to(self._device))
+        return self._assemble(torch.as_tensor(np.ascontiguousarray(x), device=self._device)).cpu().numpy()
+
+
 class SlabPme(_SlabMixin, ADMPPmeForce):
     """ADMPPmeForce whose evaluation is spread over the ranks of `comm` (SPMD: every rank makes the same
     get_energy / get_forces call with the same full input arrays).  outputs='home' (default): only the rows of `home_atoms`
@@ -501,6 +510,19 @@ class SlabPme(_SlabMixin, ADMPPmeForce):
         its rows of the transposed spectrum, the 24 sums added over the ranks -- every rank returns the full 3 x 3 gradient."""
         return self._checked(lambda: ADMPPmeForce.get_energy_and_box_gradient(self, *a, **k))
 
+    # parameter gradients on the slab ranks (round 4): class sums (dE/dmScales, dE/dpScales) are added over the ranks inside the
+    # library -- every rank returns the full vector; per-atom ones (dE/dpol, dE/dtholes) are outputs like the gradient
+    def get_mscale_gradient(self, *a, **k):
+        return self._checked(lambda: ADMPPmeForce.get_mscale_gradient(self, *a, **k))
+
+    def get_pscale_gradient(self, *a, **k):
+        return self._checked(lambda: ADMPPmeForce.get_pscale_gradient(self, *a, **k))
+
+    def get_pol_thole_gradients(self, *a, **k):
+        dpol, dth = self._checked(lambda: ADMPPmeForce.get_pol_thole_gradients(self, *a, **k))
+        self._fetch_home()
+        return self._assemble_any(dpol), self._assemble_any(dth)
+
 
 class SlabDispPme(_SlabMixin, ADMPDispPmeForce):
     """ADMPDispPmeForce decomposed over the same x-slabs (real-space pairs over the home rows, the C6 / C8 / C10 meshes
@@ -525,6 +547,14 @@ class SlabDispPme(_SlabMixin, ADMPDispPmeForce):
         """(E, dE/dbox) of dispersion PME on the slab ranks (round 4); every rank returns the full gradient"""
         return self._checked(lambda: ADMPDispPmeForce.get_energy_and_box_gradient(self, *a, **k))
 
+    def get_mscale_gradient(self, *a, **k):
+        return self._checked(lambda: ADMPDispPmeForce.get_mscale_gradient(self, *a, **k))
+
+    def get_param_gradient(self, *a, **k):
+        g = self._checked(lambda: ADMPDispPmeForce.get_param_gradient(self, *a, **k))
+        self._fetch_home()
+        return self._assemble_any(g)
+
 
 class SlabPairInteraction(_SlabMixin, _PairInteraction):
     """generate_pairwise_interaction(kernel, covalent_map, static_args) for the kernels of libadmp_hip (Tang-Toennies),
@@ -544,3 +574,11 @@ class SlabPairInteraction(_SlabMixin, _PairInteraction):
     def get_energy_and_box_gradient(self, *a, **k):
         """(E, dE/dbox) on the slab ranks: the pair sums over the rank's home rows, added over the ranks"""
         return self._checked(lambda: _PairInteraction.get_energy_and_box_gradient(self, *a, **k))
+
+    def get_mscale_gradient(self, *a, **k):
+        return self._checked(lambda: _PairInteraction.get_mscale_gradient(self, *a, **k))
+
+    def get_param_gradient(self, *a, **k):
+        gs = self._checked(lambda: _PairInteraction.get_param_gradient(self, *a, **k))
+        self._fetch_home()
+        return tuple(self._assemble_any(g) for g in gs)

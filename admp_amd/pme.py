@@ -347,8 +347,8 @@ class ADMPPmeForce(HipForceBase):
             U = self._real(self.U_ind, (na, 3))
             mS = self._host64(mScales)
             pS = self._host64(pScales, len(mS))
-            sx = torch.empty(na, dtype=self._dtype, device=self._device)
-            sw = torch.empty(na, dtype=self._dtype, device=self._device)
+            sx = torch.zeros(na, dtype=self._dtype, device=self._device)      # (a slab rank fills its home rows only)
+            sw = torch.zeros(na, dtype=self._dtype, device=self._device)
             rc = self._L.admp_thole_sums(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), self._ptr(Q),
                                          self._ptr(pol_t), self._ptr(th_t), len(mS), _lib.darr(mS), _lib.darr(pS),
                                          self._ptr(U), self._ptr(sx), self._ptr(sw))

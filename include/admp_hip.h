@@ -195,7 +195,8 @@ int admp_mscale_grad(admp_handle* h, int kind, const void* positions, const doub
  *   admp_disp_param_grad   dE_dc (Na,3) real = d(E_real + E_recip + E_self)/dc_list of admp_disp_energy_grad
  *   admp_tt_param_grad     dE_dabqc (Na,4) real = dE/d(a, b, q, c6) of admp_tt_energy_grad; an atom whose a or b is zero gets 0
  *                          for that entry (the geometric mean sqrt(a_i a_j) has no finite derivative there: NaN in autodiff)
- * All array arguments are DEVICE pointers.  Not available on a slab-decomposed handle. */
+ * All array arguments are DEVICE pointers.  On a slab-decomposed handle (round 4) the rows of the rank's home atoms are filled
+ * (per-atom outputs, like the gradient); the class sums of admp_mscale_grad / admp_pscale_grad are added over the ranks. */
 int admp_disp_param_grad(admp_handle* h, const void* positions, const double* box, const void* c_list, int pmax, int n_scales,
                          const double* mScales, void* dE_dc);
 int admp_tt_param_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,
