@@ -1837,7 +1837,6 @@ struct Engine : EngineBase {
   // CALLER supplies -- no SCF.  Device pointers only.  dU = dE/dUind_global (Cartesian, incl. the self and penalty terms).
   void pme_at_U(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
                 const double* mS, const double* pS, const void* U_, double* E, void* dpos_, void* dU_, void* dQl_) override {
-    ARG_CHECK(snranks == 1, "not available on a slab-decomposed handle");
     ARG_CHECK(lpol, "polarizable handle required (the non-polarizable energy is admp_pme_energy_grad)");
     ARG_CHECK(pos_ && box && Ql_ && U_ && E, "null argument");
     ARG_CHECK(!dQl_ || dpos_, "dE_dQlocal requires dE_dpos");
@@ -1845,6 +1844,11 @@ struct Engine : EngineBase {
     grad.need(3 * (size_t)na * sizeof(T));
     T* gbuf = dpos_ ? reinterpret_cast<T*>(dpos_) : grad.as<T>();
     mono_ok = (dQl_ == nullptr);
+    if (snranks > 1) {      // slab rank: the rows of the atoms it reads are filled in from their owners -- in a copy, the caller's
+      s_U.need(3 * (size_t)na * sizeof(T));                            // array is an input here (its home rows must be valid)
+      HIP_TRY(hipMemcpyAsync(s_U.p, U_, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      U_ = s_U.p;
+    }
     stage_begin(pos_, box, Ql_, pol_, thole_, ns, mS, pS, const_cast<void*>(U_));
     const bool wantU = dU_ != nullptr;
     stage_pair_full(gbuf, wantU ? fld_pair.as<T>() : nullptr);

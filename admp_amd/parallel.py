@@ -510,6 +510,13 @@ class SlabPme(_SlabMixin, ADMPPmeForce):
         its rows of the transposed spectrum, the 24 sums added over the ranks -- every rank returns the full 3 x 3 gradient."""
         return self._checked(lambda: ADMPPmeForce.get_energy_and_box_gradient(self, *a, **k))
 
+    def _at_U(self, *a, **k):
+        """the bare calculators at caller-supplied dipoles (energy_fn / grad_U_fn / grad_pos_fn) on the slab ranks: the energy
+        is global, the two gradients are per-atom outputs (home rows, assembled like the others)"""
+        E, gpos, gU = self._checked(lambda: ADMPPmeForce._at_U(self, *a, **k))
+        self._fetch_home()
+        return E, self._assemble_any(gpos), self._assemble_any(gU)
+
     # parameter gradients on the slab ranks (round 4): class sums (dE/dmScales, dE/dpScales) are added over the ranks inside the
     # library -- every rank returns the full vector; per-atom ones (dE/dpol, dE/dtholes) are outputs like the gradient
     def get_mscale_gradient(self, *a, **k):

@@ -130,7 +130,9 @@ int admp_pme_energy_grad(admp_handle* h, const void* positions, const double* bo
 /* replaces: ADMPPmeForce.energy_fn / grad_U_fn / grad_pos_fn (admp/pme.py:69-78): the bare polarizable energy with the
  * induced dipoles as an explicit input (no SCF), and its derivatives with respect to positions, dipoles and Q_local.
  * All array arguments are DEVICE pointers; U (Na,3) global Cartesian; dE_dpos / dE_dU / dE_dQlocal may each be NULL.
- * dE_dU is the "field" of optimize_Uind (admp/pme.py:133): real + reciprocal + self + polarization-penalty terms. */
+ * dE_dU is the "field" of optimize_Uind (admp/pme.py:133): real + reciprocal + self + polarization-penalty terms.
+ * On a slab-decomposed handle (round 4): U must be valid on the rank's home rows (the rows it reads of other ranks are fetched
+ * from their owners into a copy); dE_dpos / dE_dU / dE_dQlocal hold the home rows, E_out the global energies. */
 int admp_pme_energy_fixed_dipoles(admp_handle* h, const void* positions, const double* box, const void* Q_local, const void* pol,
                          const void* tholes, int n_scales, const double* mScales, const double* pScales, const void* U,
                          double* E_out, void* dE_dpos, void* dE_dU, void* dE_dQlocal);

@@ -316,7 +316,12 @@ def test_slab_parameter_gradients_match_single_gpu():
                         m_disp=d.get_mscale_gradient(pos, box, pairs, par['c_list'], par['mScales']),
                         c_disp=d.get_param_gradient(pos, box, pairs, par['c_list'], par['mScales']),
                         m_tt=t.get_mscale_gradient(pos, box, pairs, *ta),
-                        p_tt=np.stack(t.get_param_gradient(pos, box, pairs, *ta)))
+                        p_tt=np.stack(t.get_param_gradient(pos, box, pairs, *ta)),
+                        # the bare calculators at given dipoles (admp/pme.py:69-78)
+                        e_fix=np.atleast_1d(f.energy_fn(pos, box, pairs, par['Q_local'], U_fix, *pa[1:])),
+                        g_U=f.grad_U_fn(pos, box, pairs, par['Q_local'], U_fix, *pa[1:]),
+                        g_pos=f.grad_pos_fn(pos, box, pairs, par['Q_local'], U_fix, *pa[1:]))
+        U_fix = np.random.default_rng(3).normal(size=(3 * n_mol, 3)) * 0.02 * (par['pol'] > 0)[:, None]
         ref = all_grads(ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True), ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10),
                         generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={}))
         world = ThreadComm.World(2)
