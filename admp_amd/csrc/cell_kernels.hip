@@ -145,14 +145,31 @@ template <class T, int MODE>
 __global__ __launch_bounds__(256) void k_cell_rows(Topology top, const T* __restrict__ pos, Box<T> box, CellGrid cg, T rc2,
                                                    const int* __restrict__ start, const CellAtom<T>* __restrict__ spos,
                                                    int* __restrict__ deg, int* __restrict__ deg4,
-                                                   const int* __restrict__ rowptr, int* __restrict__ col, long cap) {
+                                                   const int* __restrict__ rowptr, int* __restrict__ col, long cap,
+                                                   RowFilter rf, unsigned char* __restrict__ built) {
   // rows are visited in cell-sorted order: the lanes of a wavefront then sweep the same few cells (L1-resident)
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int slot = (int)(t >> 2), l = (int)(t & 3);
   int n = 0;
   long w = 0;
-  const bool live = slot < top.na;
+  bool live = slot < top.na;
   int i = 0;
+  bool skip = false;
+  if (live && rf.on) {      // slab rank: only the rows of the atoms near its slab (RowFilter); the others stay empty
+    const CellAtom<T> me = spos[slot];
+    T f = me.x * box.hinv[0] + me.y * box.hinv[3] + me.z * box.hinv[6];
+    f -= m_floor(f);
+    int b = (int)(f * (T)rf.K0) - 2 - rf.lo;
+    b %= rf.K0;
+    if (b < 0) b += rf.K0;
+    skip = b >= rf.width;
+    if (!MODE && l == 0) built[me.id] = skip ? 0 : 1;
+    if (skip) {
+      i = me.id;
+      if (!MODE) deg4[4 * i + l] = 0;
+      live = false;
+    }
+  }
   if (live) {
     const CellAtom<T> me = spos[slot];
     i = me.id;
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(256) void k_cell_rows(Topology top, const T* __rest
     if (live) deg4[4 * i + l] = n;
     n += __shfl_xor(n, 1, 64);
     n += __shfl_xor(n, 2, 64);
-    if (live && l == 0) deg[i] = n;
+    if ((live || skip) && l == 0) deg[i] = n;
   }
 }
 
@@ -328,8 +345,12 @@ int cell_fill_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, dou
 // positions -> i-grouped neighbour table of the pair kernels in one go (no pair array, no atomics, no sort)
 template <class T>
 int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const double* heights,
-                     double rc, CellScratch& cs, NbrTable& nb) {
+                     double rc, CellScratch& cs, NbrTable& nb, const RowFilter& rf_in) {
   const int na = top.na;
+  RowFilter rf = rf_in;
+  if (na <= kBruteMax) rf.on = 0;                       // (tiny systems: every row)
+  if (rf.on) { if (!nb.built) CK(hipMalloc(&nb.built, (size_t)na)); }
+  else if (nb.built) { (void)hipFree(nb.built); nb.built = nullptr; }
   if (na <= kBruteMax) {
     if (cs.ensure(na, 1) != 0) return (int)hipErrorOutOfMemory;
     if (!nb.rowptr) CK(hipMalloc(&nb.rowptr, sizeof(int) * (na + 1)));
@@ -376,7 +397,8 @@ int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Bo
   int* deg = reinterpret_cast<int*>(cs.count);        // na + 1 ints fit in the (na + 1) long long scratch
   CK(hipMemsetAsync(deg + na, 0, sizeof(int), st));   // the scan's last element (the total)
   const int rblocks = (int)(((long)na * 4 + 255) / 256);
-  k_cell_rows<T, 0><<<rblocks, 256, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, spos, deg, cs.deg4, nullptr, nullptr, 0);
+  k_cell_rows<T, 0><<<rblocks, 256, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, spos, deg, cs.deg4, nullptr, nullptr, 0,
+                                             rf, nb.built);
   need = cs.scan_bytes;
   CK(hipcub::DeviceScan::ExclusiveSum(cs.scan_tmp, need, deg, nb.rowptr, na + 1, st));
   // The fill is enqueued optimistically with the buffer of the previous build (entries beyond it are dropped) and the
@@ -384,7 +406,7 @@ int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Bo
   int total = 0;
   if (nb.cap > 0)
     k_cell_rows<T, 1><<<rblocks, 256, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, spos, nullptr, cs.deg4, nb.rowptr,
-                                               nb.col, (long)nb.cap);
+                                               nb.col, (long)nb.cap, rf, nb.built);
   CK(hipMemcpyAsync(&total, nb.rowptr + na, sizeof(int), hipMemcpyDeviceToHost, st));
   CK(hipStreamSynchronize(st));
   if (total > nb.cap) {
@@ -392,7 +414,7 @@ int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Bo
     nb.cap = (int64_t)total + total / 8 + 1024;
     CK(hipMalloc(&nb.col, sizeof(int) * nb.cap));
     k_cell_rows<T, 1><<<rblocks, 256, 0, st>>>(top, pos, box, cg, (T)(rc * rc), cs.start, spos, nullptr, cs.deg4, nb.rowptr,
-                                               nb.col, (long)nb.cap);
+                                               nb.col, (long)nb.cap, rf, nb.built);
     CK(hipStreamSynchronize(st));
   }
   nb.n_half = total / 2;
@@ -441,7 +463,7 @@ void CellScratch::release() {
                                    long long*);                                                                   \
   template int cell_fill_pairs<T>(hipStream_t, int, const T*, const Box<T>&, double, CellScratch&, int*);                \
   template int cell_build_table<T>(hipStream_t, const Topology&, const T*, const Box<T>&, const double*, double,   \
-                                   CellScratch&, NbrTable&);
+                                   CellScratch&, NbrTable&, const RowFilter&);
 INST(float)
 INST(double)
 #undef INST

@@ -477,6 +477,7 @@ struct EngineBase {
     }
     {
       TIMED("nbr_build");
+      if (nbr.built) { (void)hipFree(nbr.built); nbr.built = nullptr; }      // (a table from an explicit list holds every row)
       int rc = build_neighbour_table(stream, top, n_rows, dev, nbr, &scan_scratch.p, &scan_bytes);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("build_neighbour_table: ") + hipGetErrorString((hipError_t)rc)};
       apply_classes();
@@ -686,7 +687,7 @@ struct Engine : EngineBase {
       sb.c_imp[t] = c_imp[t]; sb.c_exp[t] = c_exp[t]; sb.c_min[t] = c_min[t]; sb.c_mout[t] = c_mout[t];
     }
     sl.counts.need(sizeof(int) * (size_t)cs.ncols * (size_t)std::max(1, slab_compact_blocks(na)));
-    sl.totals.need(sizeof(int) * kSlabMaxCols);
+    sl.totals.need(sizeof(int) * (kSlabMaxCols + 1));
     sl.lists.need(sizeof(int) * (size_t)cs.ncols * (size_t)na);
     {
       TIMED("slab_decompose");
@@ -695,9 +696,13 @@ struct Engine : EngineBase {
                                      sl.lists.as<int>(), track ? sl.owner_prev.as<int>() : nullptr, track ? sl.mig.as<int>() : nullptr);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("slab decomposition: ") + hipGetErrorString((hipError_t)rc)};
     }
-    int tot[kSlabMaxCols];
-    HIP_TRY(hipMemcpyAsync(tot, sl.totals.p, sizeof(int) * cs.ncols, hipMemcpyDeviceToHost, stream));
+    int tot[kSlabMaxCols + 1];
+    HIP_TRY(hipMemcpyAsync(tot, sl.totals.p, sizeof(int) * (cs.ncols + 1), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (tot[cs.ncols])
+      throw Err{ADMP_E_STATE, "an atom entered this rank's slab whose row the neighbour table does not hold: the table of a slab "
+                              "rank covers its slab plus a margin of half the list cutoff (admp_set_pairs_from_positions) -- "
+                              "rebuild the pair list"};
     const int* L = sl.lists.as<int>();
     sl.n_home = tot[c_home]; sl.home = L + (size_t)c_home * na;
     sl.rows = L + (size_t)c_rows * na;
@@ -2212,8 +2217,19 @@ struct Engine : EngineBase {
     for (int d = 0; d < 3; ++d)
       heights[d] = 1.0 / std::sqrt(inv[0 + d] * inv[0 + d] + inv[3 + d] * inv[3 + d] + inv[6 + d] * inv[6 + d]);
     for (int d = 0; d < 3; ++d) ARG_CHECK(rc <= 0.5 * heights[d] * (1 + 1e-12), "rc exceeds half the box height (minimum image)");
+    // Slab rank with a mesh (round 4): only the rows of the atoms whose stencil base plane lies within the rank's slab plus a
+    // margin -- half the list cutoff (far more than half a skin) plus 4 planes for the pair potentials' slab rule -- are built:
+    // the search then costs the rank its share of the box, not the box.  ADMP_SLAB_ROWS=0: every row on every rank.
+    RowFilter rf;
+    static const bool rows_on = [] { const char* e = getenv("ADMP_SLAB_ROWS"); return !(e && atoi(e) == 0); }();
+    if (rows_on && snranks > 1 && have_ewald && have_comm) {
+      update_slab();
+      const int mp = (int)std::ceil(0.5 * rc / (heights[0] / K[0])) + 4;
+      const int width = (X1 - X0) + 2 * mp;
+      if (width < K[0]) { rf.on = 1; rf.K0 = K[0]; rf.lo = ((X0 - mp) % K[0] + K[0]) % K[0]; rf.width = width; }
+    }
     TIMED("neighbor_table");
-    int r = cell_build_table<T>(stream, top, reinterpret_cast<const T*>(pos), b, heights, rc, cells, nbr);
+    int r = cell_build_table<T>(stream, top, reinterpret_cast<const T*>(pos), b, heights, rc, cells, nbr, rf);
     if (r != 0) throw Err{ADMP_E_HIP, std::string("cell_build_table: ") + hipGetErrorString((hipError_t)r)};
     apply_classes();
     order_rows();

@@ -43,9 +43,14 @@ struct NbrTable {
   int64_t cap_alt = 0;
   int* deg = nullptr;
   int deg_na = 0;
+  // Slab ranks (round 4): a table built from positions holds the rows of the atoms near the rank's slab only (RowFilter);
+  // built[i] = 1 for the atoms whose row exists (nullptr: every row).  The ownership pass refuses an evaluation in which an
+  // atom without a row has become a home atom (the list is older than its skin allows).
+  unsigned char* built = nullptr;
   void free_all() {             // the owner's buffers (a borrowed table is a copy of the lender's struct: never freed)
     for (int** p : {&rowptr, &col, &order, &cls, &order_plain, &col_alt, &deg})
       if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (built) { (void)hipFree(built); built = nullptr; }
     n_half = cap = cap_alt = 0; deg_na = 0;
   }
 };
@@ -450,9 +455,15 @@ int cell_count_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, co
 template <class T>
 int cell_fill_pairs(hipStream_t st, int na, const T* pos, const Box<T>& box, double rc, CellScratch& cs, int* pairs);
 // positions -> the pair kernels' neighbour table directly (both directions, nbonds packed), no pair array in between
+// rows to build (slab ranks): the atoms whose approximate stencil base plane floor(frac_x K0) - 2 lies in the periodic
+// interval [lo, lo + width) of the K0 planes along x; on == 0: every row
+struct RowFilter {
+  int on = 0;
+  int K0 = 0, lo = 0, width = 0;
+};
 template <class T>
 int cell_build_table(hipStream_t st, const Topology& top, const T* pos, const Box<T>& box, const double* heights,
-                     double rc, CellScratch& cs, NbrTable& nb);
+                     double rc, CellScratch& cs, NbrTable& nb, const RowFilter& rf = RowFilter());
 
 // ---- slab_kernels.hip: x-slab decomposition (multi-GPU) ------------------------------------------------------------------
 // per-atom word of a rank's view of the decomposition (see slab_kernels.hip)
@@ -488,6 +499,7 @@ struct SlabSegs {
 // (the caller reads them once).  counts: ncols * slab_compact_blocks(max len) ints of scratch.  hipError_t as int.
 // owner_prev (optional): the owners of the previous evaluation; mig[na] then receives, for the atoms that changed hands,
 // 1 << previous owner (atoms this rank took over) or kSlabHome | 1 << new owner (atoms it gave away), else 0
+// totals[cs.ncols] (one word past the columns' totals) comes back non-zero when a home atom has no row in a filtered table
 int launch_slab_decompose(hipStream_t st, int na, const NbrTable& nb, const Topology& top, const int4* bases, const void* pol,
                           int prec, int width, int K0, int X0, int nranks, int me, int* owner, int* bits,
                           const SlabCols& cs, const SlabBins& sb, int* counts, int* totals, int* lists,

@@ -29,13 +29,17 @@ __device__ __forceinline__ int slab_owner(int gx, int K0, int N) {
 template <class T>
 __global__ __launch_bounds__(256) void k_slab_owner(int na, const int4* __restrict__ bases, const T* __restrict__ pol, int width,
                                                     int K0, int X0, int N, int me, int* __restrict__ owner,
-                                                    int* __restrict__ bits, const int* __restrict__ prev, int* __restrict__ mig) {
+                                                    int* __restrict__ bits, const int* __restrict__ prev, int* __restrict__ mig,
+                                                    const unsigned char* __restrict__ built, int* __restrict__ missing) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= na) return;
   const int b = bases[i].x;                        // local plane index of the stencil base, relative to this rank's X0
   int o = me, w = 0;
   if (b < width) {
     w = kSlabHome | ((pol && pol[i] > T(0)) ? kSlabPolar : 0);
+    // a filtered table (RowFilter) holds the rows of the atoms that were near this slab when it was built: a home atom
+    // without a row means the list is older than its margin allows -- the evaluation is refused, not silently short a row
+    if (built && !built[i] && !*(volatile int*)missing) atomicOr(missing, 1);
   } else {
     int gx = b + X0;
     if (gx >= K0) gx -= K0;
@@ -260,8 +264,12 @@ int launch_slab_decompose(hipStream_t st, int na, const NbrTable& nb, const Topo
   const unsigned g1 = (unsigned)((na + 255) / 256);
   const int* pv = (owner_prev && mig) ? owner_prev : nullptr;
   int* mg = pv ? mig : nullptr;
-  if (prec == 4) k_slab_owner<float><<<g1, 256, 0, st>>>(na, bases, (const float*)pol, width, K0, X0, nranks, me, owner, bits, pv, mg);
-  else k_slab_owner<double><<<g1, 256, 0, st>>>(na, bases, (const double*)pol, width, K0, X0, nranks, me, owner, bits, pv, mg);
+  int* missing = totals + cs.ncols;                // (one word past the columns' totals)
+  { const hipError_t e = hipMemsetAsync(missing, 0, sizeof(int), st); if (e != hipSuccess) return (int)e; }
+  if (prec == 4) k_slab_owner<float><<<g1, 256, 0, st>>>(na, bases, (const float*)pol, width, K0, X0, nranks, me, owner, bits, pv, mg,
+                                                         nb.built, missing);
+  else k_slab_owner<double><<<g1, 256, 0, st>>>(na, bases, (const double*)pol, width, K0, X0, nranks, me, owner, bits, pv, mg,
+                                                nb.built, missing);
   k_slab_marks<<<(unsigned)(((long)na * 8 + 255) / 256), 256, 0, st>>>(na, nb.rowptr, nb.col, top, owner, me, bits);
   int maxlen = 0;
   for (int c = 0; c < cs.ncols; ++c) maxlen = cs.len[c] > maxlen ? cs.len[c] : maxlen;
