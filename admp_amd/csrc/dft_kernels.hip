@@ -389,10 +389,133 @@ struct ZyLayout {          // LDS carve-up of the plane kernels (bytes); the sam
 // its half of the outputs of every z line and transforms its own columns along y; inverse by halves of the y output pairs
 // (y, N-y) -- each workgroup transforms every column along y for its pairs only and then the z lines of those y.  Both
 // load the whole plane.
-template <class T, int KQ>
+// SPREAD (round 4, small systems in double precision): the plane is not read from a mesh -- the workgroup builds it in LDS from
+// the sites (PlaneSpread: the scan spread of recip_kernels.hip, one x plane instead of one brick): it scans the stencil bases
+// of all atoms, keeps those whose six x planes include this one (~6 na / K0 of them) and adds their 6 x 6 (y, z) patches with
+// LDS atomics, straight into the slots of the z pair sums (element (l, j) is the real part of slot (j - 1, l) for j <= H3, the
+// imaginary part of slot (N3 - 1 - j, l) above, x0[l] for j = 0): one in-place pass then turns (a, b) into (a + b, a - b).
+// The spread kernel (17 us at 3072 atoms: 375 workgroups each scanning every atom), its dispatch and the mesh round trip through
+// L2 go away; both workgroups of a plane build the whole plane (they both need it).  Weights: 4 threads per kept atom stage
+// the three axes' splines and the folded multipoles (spread_entry_list's arithmetic), then one task per stencil point.
+constexpr int kZyW = 42;                       // staged words per kept atom: 6 folded coefficients, 18 y and 18 z weights
+constexpr int kZyScan = 3;                     // atoms a thread tests per scan round (their records are fetched together)
+constexpr int kZySpreadMaxAtoms = 8192;        // a hit is 16 bits: atom (13) | x offset (3)
+template <class T>
+__host__ __device__ inline int zy_spread_sub(int N2, int N3) {      // kept atoms whose weights fit in the spectrum region (free
+  const int Kh = N3 / 2 + 1;                                         // until the z lines write it) next to the hit list
+  const long spare = (long)sizeof(Cx<T>) * N2 * Kh - (long)sizeof(unsigned short) * kZyScan * kZyBlock;
+  const long n = spare / (long)(kZyW * sizeof(T) + 2 * sizeof(int));
+  return n > kZyBlock / 3 ? kZyBlock / 3 : (int)n;                   // (three staging threads per kept atom)
+}
+template <class T>
+__device__ __forceinline__ void zy_plane_spread(const PlaneSpread<T>& sp, int px, int N2, int N3, Cx<T>* p, T* x0, T* xn,
+                                                unsigned char* scratch, int SUB) {
+  __shared__ int s_nhit;
+  unsigned short* hits = reinterpret_cast<unsigned short*>(scratch);             // [kZyScan * kZyBlock]
+  T* wts = reinterpret_cast<T*>(hits + kZyScan * kZyBlock);                      // [SUB][kZyW]
+  int* ebase = reinterpret_cast<int*>(wts + (size_t)SUB * kZyW);                 // [SUB][2]: stencil bases along y and z
+  const int H3 = (N3 - 1) / 2;
+  const Site<T>* sites = sp.sites + (size_t)blockIdx.y * sp.na;
+  for (int t = threadIdx.x; t < H3 * N2; t += kZyBlock) p[t] = Cx<T>{T(0), T(0)};
+  for (int t = threadIdx.x; t < 2 * N2; t += kZyBlock) x0[t] = T(0);                 // (x0 and xn are one array)
+  const RecipGeom<T>& g = sp.g;
+  for (int c0 = 0; c0 < sp.na; c0 += kZyScan * kZyBlock) {
+    if (threadIdx.x == 0) s_nhit = 0;
+    __syncthreads();                                                                   // (also: the zeroes above are in place)
+    int bx[kZyScan];
+#pragma unroll
+    for (int r = 0; r < kZyScan; ++r) {                                               // independent loads, all in flight
+      const int i = c0 + (int)threadIdx.x + r * kZyBlock;
+      bx[r] = -1000;
+      if (i < sp.na) {
+        if (sp.bases) bx[r] = sp.bases[i].x;
+        else {
+          const T rr[3] = {sites[i].r[0], sites[i].r[1], sites[i].r[2]};
+          (void)grid_ref(g, rr, 0, bx[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kZyScan; ++r) {
+      int a = px - bx[r];
+      if (a < 0) a += g.K[0];
+      if (bx[r] >= 0 && a < 6)
+        hits[atomicAdd(&s_nhit, 1)] = (unsigned short)((c0 + (int)threadIdx.x + r * kZyBlock) | (a << 13));
+    }
+    __syncthreads();
+    const int nhit = s_nhit;
+    const int nsub = (nhit + SUB - 1) / SUB, per = nsub > 0 ? (nhit + nsub - 1) / nsub : 0;      // balanced sub-rounds
+    for (int sub = 0; sub < nhit; sub += per) {
+      const int cnt = min(per, nhit - sub);
+      if ((int)threadIdx.x < 3 * cnt) {
+        const int e = threadIdx.x / 3, part = threadIdx.x - 3 * e;
+        const int h = hits[sub + e];
+        const Site<T>& site = sites[h & 0x1fff];
+        T* w = wts + e * kZyW;
+        const T r[3] = {site.r[0], site.r[1], site.r[2]};
+        int base;
+        T M[6], D1[6], D2[6], D3[6];
+        const T f = grid_ref(g, r, part, base);
+        bspline6(f, M, D1, D2, D3);
+        if (part == 0) {
+          // x factors of this plane folded into the multipole coefficients: c1 = (x, y, z), c2 = (xx, yy, zz, xy, xz, yz)
+          const int a = h >> 13;
+          T m0 = T(0), d0 = T(0), e0 = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            if (k == a) { m0 = M[k]; d0 = D1[k]; e0 = D2[k]; }
+          T Q[9], c1[3], c2[6];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Q[k] = site.Q[k];
+          if (sp.lpol) { Q[1] += site.U[0]; Q[2] += site.U[1]; Q[3] += site.U[2]; }       // Q_global_tot, admp/pme.py:236
+          fold_multipole(g, Q, c1, c2);
+          w[0] = Q[0] * m0 + c1[0] * d0 + c2[0] * e0;      // P0 = w0 My + w1 My' + w2 My''   (times Mz)
+          w[1] = c1[1] * m0 + c2[3] * d0;
+          w[2] = c2[1] * m0;
+          w[3] = c1[2] * m0 + c2[4] * d0;                  // P1 = w3 My + w4 My'             (times Mz')
+          w[4] = c2[5] * m0;
+          w[5] = c2[2] * m0;                               // P2 = w5 My                      (times Mz'')
+        } else {
+          const int o = part == 1 ? 6 : 24;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { w[o + k] = M[k]; w[o + 6 + k] = D1[k]; w[o + 12 + k] = D2[k]; }
+          ebase[2 * e + part - 1] = base;
+        }
+      }
+      __syncthreads();
+      for (int task = threadIdx.x; task < cnt * 6; task += kZyBlock) {      // (kept atom, y point): six z adds
+        const int e = task / 6, b = task - e * 6;
+        const T* w = wts + e * kZyW;
+        const T m1 = w[6 + b], d1 = w[12 + b], e1 = w[18 + b];
+        const T P0 = w[0] * m1 + w[1] * d1 + w[2] * e1;
+        const T P1 = w[3] * m1 + w[4] * d1;
+        const T P2 = w[5] * m1;
+        const int jb = wrap_add(ebase[2 * e], b, N2), bz = ebase[2 * e + 1];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const T v = P0 * w[24 + c] + P1 * w[30 + c] + P2 * w[36 + c];
+          const int jc = wrap_add(bz, c, N3);
+          T* dst;
+          if (jc == 0) dst = &x0[jb];
+          else if (jc <= H3) dst = &p[(jc - 1) * N2 + jb].re;
+          else if (2 * jc == N3) dst = &xn[jb];
+          else dst = &p[(N3 - 1 - jc) * N2 + jb].im;
+          atomicAdd(dst, v);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < H3 * N2; t += kZyBlock) {
+    const Cx<T> ab = p[t];
+    p[t] = Cx<T>{ab.re + ab.im, ab.re - ab.im};
+  }
+}
+
+template <class T, int KQ, bool SPREAD>
 __global__ __launch_bounds__(kZyBlock) void k_dft_zy_fwd(int N2, int N3, const T* __restrict__ mesh, Cx<T>* __restrict__ spec,
                                                          const Cx<T>* __restrict__ tw2g, const Cx<T>* __restrict__ tw3g,
-                                                         long mesh_stride, long spec_stride) {
+                                                         long mesh_stride, long spec_stride, PlaneSpread<T> sp) {
   const ZyLayout<T> L(N2, N3);
   const int H3 = (N3 - 1) / 2, Kh = N3 / 2 + 1, H2 = (N2 - 1) / 2;
   const int kz0 = (int)(((long)Kh * blockIdx.z) / gridDim.z), kz1 = (int)(((long)Kh * (blockIdx.z + 1)) / gridDim.z);
@@ -407,15 +530,19 @@ __global__ __launch_bounds__(kZyBlock) void k_dft_zy_fwd(int N2, int N3, const T
   Cx<T>* out = spec + blockIdx.y * spec_stride + (long)blockIdx.x * N2 * Kh;
   for (int t = threadIdx.x; t < N3; t += kZyBlock) tw3[t] = tw3g[t];
   for (int t = threadIdx.x; t < N2; t += kZyBlock) tw2[t] = tw2g[t];
-  for (int t = threadIdx.x; t < H3 * N2; t += kZyBlock) {
-    const int l = t / H3, jj = t - l * H3;
-    const T* x = plane + (long)l * N3;
-    const T a = x[1 + jj], b = x[N3 - 1 - jj];
-    p[jj * N2 + l] = Cx<T>{a + b, a - b};
-  }
-  for (int l = threadIdx.x; l < N2; l += kZyBlock) {
-    x0[l] = plane[(long)l * N3];
-    xn[l] = (N3 & 1) ? T(0) : plane[(long)l * N3 + N3 / 2];
+  if (SPREAD) {
+    zy_plane_spread<T>(sp, (int)blockIdx.x, N2, N3, p, x0, xn, dft_smem + L.b, zy_spread_sub<T>(N2, N3));
+  } else {
+    for (int t = threadIdx.x; t < H3 * N2; t += kZyBlock) {
+      const int l = t / H3, jj = t - l * H3;
+      const T* x = plane + (long)l * N3;
+      const T a = x[1 + jj], b = x[N3 - 1 - jj];
+      p[jj * N2 + l] = Cx<T>{a + b, a - b};
+    }
+    for (int l = threadIdx.x; l < N2; l += kZyBlock) {
+      x0[l] = plane[(long)l * N3];
+      xn[l] = (N3 & 1) ? T(0) : plane[(long)l * N3 + N3 / 2];
+    }
   }
   __syncthreads();
   // z lines: task = (line l, group g of KQ of this workgroup's outputs)
@@ -601,9 +728,16 @@ bool dft_zy_fits(const int K[3]) {
   // two workgroups per plane must fit the chip in one round (one workgroup per CU): with more planes the separate passes win
   return !off && 2 * K[0] <= 256 && ZyLayout<T>(K[1], K[2]).total + 2048 <= 160 * 1024;      // (+ the kernels' static LDS)
 }
+// can the forward plane kernel build its planes from the sites (zy_plane_spread)?  double precision only: LDS float atomics
+// run at a twentieth of the f64 rate on this chip (tools/ubench/lds_atomics.hip)
+template <class T>
+bool dft_zy_spread_fits(const int K[3], int na) {
+  static const int mx = [] { const char* e = getenv("ADMP_FUSE_SPREAD_MAX"); return e ? atoi(e) : 8192; }();
+  return sizeof(T) == 8 && na > 0 && na <= mx && na <= kZySpreadMaxAtoms && dft_zy_fits<T>(K) && zy_spread_sub<T>(K[1], K[2]) >= 16;
+}
 template <class T>
 bool launch_dft_zy(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb, long mesh_stride,
-                   long spec_stride, T* accum) {
+                   long spec_stride, T* accum, const PlaneSpread<T>* sp) {
   const size_t sh = ZyLayout<T>(K[1], K[2]).total;
   const Cx<T>* t1 = reinterpret_cast<const Cx<T>*>(tw) + K[0];
   const Cx<T>* t2 = t1 + K[1];
@@ -616,15 +750,24 @@ bool launch_dft_zy(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec
                                      nb == 1 ? accum : nullptr);
     return accum != nullptr && nb == 1;
   }
-  auto kern = k_dft_zy_fwd<T, 2>;
+  if (sp) {
+    static size_t attr_sp = 0;
+    auto kern = k_dft_zy_fwd<T, 2, true>;
+    if (attr_sp < sh) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_sp = sh; }
+    kern<<<grid, kZyBlock, sh, st>>>(K[1], K[2], mesh, reinterpret_cast<Cx<T>*>(spec), t1, t2, mesh_stride, spec_stride / 2, *sp);
+    return false;
+  }
+  auto kern = k_dft_zy_fwd<T, 2, false>;
   if (attr_set[0] < sh) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr_set[0] = sh; }
-  kern<<<grid, kZyBlock, sh, st>>>(K[1], K[2], mesh, reinterpret_cast<Cx<T>*>(spec), t1, t2, mesh_stride, spec_stride / 2);
+  kern<<<grid, kZyBlock, sh, st>>>(K[1], K[2], mesh, reinterpret_cast<Cx<T>*>(spec), t1, t2, mesh_stride, spec_stride / 2,
+                                   PlaneSpread<T>());
   return false;
 }
 #undef KQ_SWITCH
 #define INST(T)                                                                                   \
   template bool dft_zy_fits<T>(const int*);                                                       \
-  template bool launch_dft_zy<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*); \
+  template bool dft_zy_spread_fits<T>(const int*, int);                                           \
+  template bool launch_dft_zy<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*, const PlaneSpread<T>*); \
   template bool launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*); \
   template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int, int, long);           \
   template void launch_dft_x_conv<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long);

@@ -22,6 +22,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/admp_hip.h"
@@ -322,6 +323,7 @@ struct EngineBase {
     if (top.grp_ptr) (void)hipFree(top.grp_ptr);
     if (top.rows_blk) (void)hipFree(top.rows_blk);
     if (top.grp_of) (void)hipFree(top.grp_of);
+    if (top.gath_blk) (void)hipFree(top.gath_blk);
     top = Topology();
     if (!nbr_src) nbr.free_all();
     nbr_src = nullptr; nbr_src_gen = -1;
@@ -454,6 +456,15 @@ struct EngineBase {
           for (int m = 0; m < n; ++m) gof[(size_t)a0 + m] = (a0 << 2) | (n - 1);
         }
         blk.push_back(na);
+        {   // runs of at most kGatherRun atoms for the gather with the closing epilogue
+          std::vector<int> gb(1, 0);
+          for (int gi = 0; gi < top.ngroups; ++gi)
+            if (gp[gi + 1] - gb.back() > kGatherRun) gb.push_back(gp[gi]);
+          gb.push_back(na);
+          HIP_TRY(hipMalloc(&top.gath_blk, sizeof(int) * gb.size()));
+          HIP_TRY(hipMemcpy(top.gath_blk, gb.data(), sizeof(int) * gb.size(), hipMemcpyHostToDevice));
+          top.ngathblk = (int)gb.size() - 1;
+        }
         HIP_TRY(hipMalloc(&top.rows_blk, sizeof(int) * blk.size()));
         HIP_TRY(hipMemcpy(top.rows_blk, blk.data(), sizeof(int) * blk.size(), hipMemcpyHostToDevice));
         top.nrowblk = (int)blk.size() - 1;
@@ -979,9 +990,21 @@ struct Engine : EngineBase {
   // accum (optional): a second mesh the result is to be ADDED to; returns true when the last pass did that itself (the direct
   // DFT writes every word once anyway), false when the caller still has to add
   // out (optional, rocFFT paths): phi is written there instead of over mesh_p
-  bool convolve(T* mesh_p, T* spec_p, const T* gtab, int slot, T* accum = nullptr, T* out = nullptr) {
+  // sp: the forward transform builds its planes from these sites (no spread kernel ran, mesh_p holds nothing yet): small
+  // double-precision systems on the direct-DFT plane kernels (spread_fused())
+  bool spread_fused(int n) const {
+    return use_dft && !use_pfa && snranks == 1 && !ev.home && dft_zy_spread_fits<T>(K, n);
+  }
+  PlaneSpread<T> plane_spread(int n, const Site<T>* rows, int lp, const int4* bases) const {
+    PlaneSpread<T> sp;
+    sp.na = n; sp.lpol = lp; sp.sites = rows; sp.bases = bases; sp.g = ev.g;
+    return sp;
+  }
+  bool convolve(T* mesh_p, T* spec_p, const T* gtab, int slot, T* accum = nullptr, T* out = nullptr,
+                const PlaneSpread<T>* sp = nullptr) {
     double* Ed = Ed_cur();
     T* mesh_o = out ? out : mesh_p;
+    ARG_CHECK(!sp || (use_dft && !use_pfa && snranks == 1), "internal: plane spread on a transform path without it");
     if (snranks > 1) {
       // x-slab ranks: the stencils of the home atoms overhang into kGhost planes of the next rank (added there before the
       // transform), the 3-D transform is batched 2-D r2c on the owned planes -> transpose (all-to-all over the ranks: every
@@ -1026,7 +1049,9 @@ struct Engine : EngineBase {
     if (use_dft) {
       const T* tw = dft_tw.as<T>();
       const bool planes = dft_zy_fits<T>(K);         // z and y lines of a plane in one workgroup (dft_kernels.hip)
-      if (planes) { TIMED("dft_zy_fwd"); launch_dft_zy<T>(stream, K, tw, mesh_p, spec_p, 0); }
+      ARG_CHECK(!sp || planes, "internal: plane spread without the plane kernels");
+      if (planes && sp) { TIMED("dft_spread_zy_fwd"); launch_dft_zy<T>(stream, K, tw, mesh_p, spec_p, 0, 1, 0, 0, nullptr, sp); }
+      else if (planes) { TIMED("dft_zy_fwd"); launch_dft_zy<T>(stream, K, tw, mesh_p, spec_p, 0); }
       else {
         { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh_p, spec_p, 0); }
         { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec_p, 0); }
@@ -1377,6 +1402,13 @@ struct Engine : EngineBase {
     side_busy = false;
     ev.active = false;
   }
+  // Order of submission around a fork: dispatch-bound systems (<= 16384 atoms) submit the side work AFTER the first kernel of
+  // the main chain that follows (see recip_pass); larger ones first -- there the pair kernel is long and wants the early start.
+  // ADMP_SIDE_FIRST = 0 / 1 forces one order (A/B).
+  bool side_first() const {
+    static const int mode = [] { const char* e = getenv("ADMP_SIDE_FIRST"); return e ? atoi(e) : -1; }();
+    return mode >= 0 ? mode != 0 : top.na > 16384;
+  }
   template <class F>
   void on_side(F&& f) {
     if (!overlap_ok()) { f(); return; }
@@ -1415,8 +1447,21 @@ struct Engine : EngineBase {
                         Ed_cur(), pair_rows(), fld_out, mono_ok ? 1 : 0, cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole);
   }
   // with_field_finish: the gather also forms the total dE/dU and its maximum (launch_field_finish's work, fused)
+  // Small single-rank systems with frame groups: the closing kernel's work rides in the gather's epilogue (recip_kernels.hip,
+  // k_gather_staged<.., FIN>); the launch_finish_only that follows is then a no-op.  ADMP_FUSE_FIN_MAX = 0 turns it off (A/B).
+  bool fin_fused = false;
+  bool fuse_fin_ok() const {
+    const char* e = getenv("ADMP_FUSE_FIN_MAX");       // (read per call: the parity tests run both forms in one process)
+    const int fin_max = e ? atoi(e) : 8192;
+    return snranks == 1 && !ev.home && top.gath_blk && top.na <= fin_max;
+  }
+  FinishArgs<T> finish_args(bool want_grad, T* dQl) {
+    FinishArgs<T> f;
+    f.pol = ev.pol; f.kappa = (T)kappa; f.dQlocal = dQl; f.energies = Ed_cur(); f.want_grad = want_grad ? 1 : 0;
+    return f;
+  }
   void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr, bool with_field_finish = false,
-                    double* e_recip = nullptr) {
+                    double* e_recip = nullptr, const FinishArgs<T>* fin = nullptr) {
     need_eval();
     FieldFin<T> ff;
     if (with_field_finish) {
@@ -1427,6 +1472,12 @@ struct Engine : EngineBase {
     }
     join_side();                       // the gather adds to the rows the pair kernel has set
     TIMED("gather");
+    if (fin && fuse_fin_ok()) {
+      launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff,
+                       e_recip, &top, &ev.bx, *fin);
+      fin_fused = true;
+      return;
+    }
     launch_gather<T>(stream, ev.n_home, sites.as<Site<T>>(), lpol, ev.g, mesh_p, pot.as<T>(), grad_p, ev.home, fld_out, ff,
                      e_recip);
   }
@@ -1434,6 +1485,7 @@ struct Engine : EngineBase {
   // with_field_finish (single rank, pull kernel): the SCF residual and its maximum are formed by this kernel too
   void launch_finish_only(T* grad_p, T* dQl, bool with_field_finish = false) {
     need_eval();
+    if (fin_fused) { fin_fused = false; return; }      // (the gather just before did this work)
     FieldFin<T> ff;
     if (with_field_finish) {
       if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
@@ -1548,22 +1600,34 @@ struct Engine : EngineBase {
   }
   size_t nreal_local() const { return (size_t)nloc0() * K[1] * K[2]; }
   // check_word: the zero word the check after this increment writes (its residual then rides in the field gather)
-  void scf_increment(int n_act, unsigned long long* check_word = nullptr) {   // fld_pair / fld_recip / phi <- their values for the dipoles after scf_jacobi
-    if (n_act <= 0 && snranks == 1) return;
+  // extra_side: more work for the side stream of this increment (the closing pair kernel of a chained call, whose dipoles are final)
+  void scf_increment(int n_act, unsigned long long* check_word = nullptr,   // fld_pair / fld_recip / phi <- their values for the dipoles after scf_jacobi
+                     const std::function<void()>& extra_side = nullptr) {
+    if (n_act <= 0 && snranks == 1) {
+      if (extra_side) on_side(extra_side);
+      return;
+    }
+    const bool first = side_first();
+    auto side_work = [&] {
+      on_side([&] {
+        TIMED("pair_field_ind");
+        launch_pair_field_ind<T>(stream, n_act, ind, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
+                                 act_list());
+      });
+      if (extra_side) on_side(extra_side);
+    };
     if (ind_nbr_gen != nbr_gen || ind_act_gen != act_gen) {      // neighbour table or polarizable set changed
       TIMED("ind_table");
       int rc = build_ind_table<T>(stream, top.na, nbr, sites.as<Site<T>>(), ind, &scan_scratch.p, &scan_bytes);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("build_ind_table: ") + hipGetErrorString((hipError_t)rc)};
       ind_nbr_gen = nbr_gen; ind_act_gen = act_gen;
     }
-    on_side([&] {
-      TIMED("pair_field_ind");
-      launch_pair_field_ind<T>(stream, n_act, ind, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                               act_list());
-    });
+    if (first) side_work();
     const size_t nreal = nreal_local();
     mesh2.need(nreal * sizeof(T));
-    { TIMED("spread_ind");
+    const bool fused = spread_fused(n_act);
+    if (fused) { if (!first) side_work(); }
+    else { TIMED("spread_ind");
       // the compact rows keep their positions and their order through the SCF cycles of one evaluation: the brick lists of
       // its first increment serve the later ones (two binning passes and a scan less per cycle)
       ensure_bins(std::max(n_act, 1), bins_ind, bin_cells_ind, bin_sorted_ind);
@@ -1573,7 +1637,9 @@ struct Engine : EngineBase {
                                 reuse ? 1 : 0, 0);
       ind_bins_eval = eval_seq; ind_bins_n = n_act; ind_bins_gen = act_gen; ind_bins_at = bins_ind.cell_start;
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)}; }
-    const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>());
+    if (!first && !fused) side_work();
+    const PlaneSpread<T> sp = plane_spread(n_act, isites.as<Site<T>>(), 1, nullptr);
+    const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>(), nullptr, fused ? &sp : nullptr);
     join_side();
     { TIMED("gather_field_ind");
       launch_gather_field<T>(stream, n_act, isites.as<Site<T>>(), ev.g, mesh2.as<T>(), fld_recip.as<T>(), nullptr, 1, nullptr,
@@ -1618,13 +1684,25 @@ struct Engine : EngineBase {
   }
 
   // full reciprocal pass on one rank: spread -> r2c -> G multiply (+energy) -> c2r ; mesh then holds phi
-  void recip_pass(int slot) {
-    stage_spread(mesh.as<T>());
+  // side_work: real-space kernels that run NEXT to the convolution (on_side).  They are submitted after the spread: the host
+  // needs ~10 us for the event record / stream wait / launch of a fork, and submitted first (round 3) that time stood between
+  // the site pass and the spread on the main stream as well (kernel trace of the S1 loop: 10-12 us idle there, every
+  // evaluation); behind the spread it is hidden by a running kernel and the side kernels still have the three transform
+  // passes to hide behind (side_first()).
+  template <class F>
+  void recip_pass(int slot, F&& side_work) {
     need_eval();
+    const bool fused = spread_fused(ev.n_home);      // the forward transform spreads (dft_kernels.hip, zy_plane_spread)
+    const bool first = side_first() || fused;
+    if (first) side_work();
+    if (!fused) stage_spread(mesh.as<T>());
+    if (!first) side_work();
     if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(Ed_cur() + slot, 0, sizeof(double), stream));
     slot_clean[slot] = false;
-    convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, slot);
+    const PlaneSpread<T> sp = plane_spread(ev.n_home, sites.as<Site<T>>(), lpol, ev.bases);
+    convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, slot, nullptr, nullptr, fused ? &sp : nullptr);
   }
+  void recip_pass(int slot) { recip_pass(slot, [] {}); }
 
   void pme(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
            const double* mS, const double* pS, void* U_, int max_cycle, double thresh, double* E, void* dpos_,
@@ -1710,8 +1788,7 @@ struct Engine : EngineBase {
       ++scf_stats[chain ? 3 : (speculate ? 1 : 0)];
       if (chain) {
         n_act = nact_known();
-        on_side([&] { first_pair_field(); });
-        recip_pass(E_SCF_RECIP);
+        recip_pass(E_SCF_RECIP, [&] { on_side([&] { first_pair_field(); }); });
         auto word = [&](int k) {      // residual of check k: E_FMAX, then the (still zero) chain words of this evaluation
           return k == 0 ? fmax_word() : reinterpret_cast<unsigned long long*>(Ed_cur() + E_FMAX1 + (k - 1));
         };
@@ -1721,12 +1798,15 @@ struct Engine : EngineBase {
         const bool early_full = overlap_ok();       // the closing pair kernel next to the last increment's mesh chain
         for (int c = 0; c < nhat; ++c) {
           scf_jacobi(n_act, word(c), thresh);        // a zero step once a check has passed: later residuals repeat it
-          if (early_full && c == nhat - 1) on_side([&] { stage_pair_full(gbuf); });      // (the dipoles are final now)
-          scf_increment(n_act, word(c + 1));
+          if (early_full && c == nhat - 1)      // (the dipoles are final now)
+            scf_increment(n_act, word(c + 1), [&] { stage_pair_full(gbuf); });
+          else
+            scf_increment(n_act, word(c + 1));
           launch_field_check(word(c + 1));
         }
         if (!early_full) stage_pair_full(gbuf);
-        stage_gather(mesh.as<T>(), gbuf, nullptr, false, Ed_cur() + E_SLOTS);
+        const FinishArgs<T> fin_c = finish_args(dpos != nullptr, dQl);
+        stage_gather(mesh.as<T>(), gbuf, nullptr, false, Ed_cur() + E_SLOTS, &fin_c);
         launch_finish_only(dpos ? gbuf : nullptr, dQl);
         read_energies(E_PARTS_SUM, E);
         nact_seen();
@@ -1757,14 +1837,14 @@ struct Engine : EngineBase {
         // again, the step is already finished (no separate field kernels, no second pass).  Same arithmetic and
         // same (U, flag, i) as the plain loop; a failed check only costs the difference between the kernels.
         // The closing kernel is enqueued speculatively as well, so the step has ONE host synchronisation.
-        on_side([&] { stage_pair_full(gbuf, fld_pair.as<T>()); });
-        recip_pass(E_SCF_RECIP);
+        recip_pass(E_SCF_RECIP, [&] { on_side([&] { stage_pair_full(gbuf, fld_pair.as<T>()); }); });
         // small systems are dispatch-bound: the field finish rides in the gather's epilogue; larger ones keep the two
         // kernels (98k atoms: gather 26 -> 47 us fused against 9 us saved; 1M atoms: 0.40 vs 0.31 + 0.056 ms)
         static const int fuse_max = [] { const char* e = getenv("ADMP_FUSE_FF_MAX"); return e ? atoi(e) : 16384; }();
         const bool fuse_ff = top.na <= fuse_max;
         const bool fuse_g = fuse_ff && snranks == 1;
-        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), fuse_g);
+        const FinishArgs<T> fin_s = finish_args(dpos != nullptr, dQl);
+        stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), fuse_g, nullptr, fuse_g ? &fin_s : nullptr);
         const bool pull = !ev.home && top.inv_ptr;          // the atomics-free closing kernel can carry the field finish
         if (!fuse_g && !pull) launch_field_finish_only();
         launch_finish_only(dpos ? gbuf : nullptr, dQl, !fuse_g && pull);
@@ -1785,8 +1865,7 @@ struct Engine : EngineBase {
       }
       for (; !done && i < max_cycle; ++i) {     // admp/pme.py:132-138
         if (!have_base) {        // first field evaluation of the call: everything, at the polarizable sites
-          on_side([&] { first_pair_field(); });
-          recip_pass(E_SCF_RECIP);
+          recip_pass(E_SCF_RECIP, [&] { on_side([&] { first_pair_field(); }); });
           unsigned long long* w = fuse_ok() ? next_check_word() : nullptr;
           first_gather_field(field_epilogue(w));
           have_base = true;
@@ -1819,10 +1898,11 @@ struct Engine : EngineBase {
 
     const bool atoms_energy = phi_valid && phi_accum;
     if (!done) {
-      if (!phi_valid) { on_side([&] { stage_pair_full(gbuf); }); recip_pass(E_RECIP); }
+      if (!phi_valid) recip_pass(E_RECIP, [&] { on_side([&] { stage_pair_full(gbuf); }); });
       else stage_pair_full(gbuf);
       // (the partial words are zero: nothing else of this evaluation writes them)
-      stage_gather(mesh.as<T>(), gbuf, nullptr, false, atoms_energy ? Ed_cur() + E_SLOTS : nullptr);
+      const FinishArgs<T> fin_t = finish_args(dpos != nullptr, dQl);
+      stage_gather(mesh.as<T>(), gbuf, nullptr, false, atoms_energy ? Ed_cur() + E_SLOTS : nullptr, finished ? nullptr : &fin_t);
     }
     if (!finished)
       stage_finish(dpos ? gbuf : nullptr, dQl, atoms_energy ? (int)E_PARTS_SUM : (phi_valid ? (int)E_SCF_RECIP : (int)E_RECIP), E);

@@ -82,8 +82,22 @@ struct Topology {
   int* rows_blk = nullptr;    // nrowblk + 1
   int nrowblk = 0;
   int* grp_of = nullptr;      // na
+  // the same cut into runs of at most kGatherRun atoms: one workgroup of the gather each when the closing work rides in its
+  // epilogue (small systems: one dispatch fewer per step)
+  int* gath_blk = nullptr;    // ngathblk + 1
+  int ngathblk = 0;
 };
 constexpr int kFinishBlock = 256;
+constexpr int kGatherRun = 32;
+// closing work in the gather's epilogue (k_gather_staged<.., FIN>): what launch_finish takes besides the gather's arguments
+template <class T>
+struct FinishArgs {
+  const T* pol = nullptr;
+  T kappa = 0;
+  T* dQlocal = nullptr;
+  double* energies = nullptr;   // nullptr = epilogue off
+  int want_grad = 1;            // 0: energies only (the frame adjoint is skipped)
+};
 constexpr int kMaxGroup = 4;
 
 // energies[] slots on the device
@@ -181,9 +195,19 @@ struct DftTabs {
 // z and y lines of every x plane in one kernel (dft_kernels.hip, round 3); dft_zy_fits: the plane and its spectrum fit the LDS
 template <class T>
 bool dft_zy_fits(const int K[3]);
+// what the forward plane kernel needs to build its planes itself (no spread kernel, no mesh): nb channels of na site rows back to back
+template <class T>
+struct PlaneSpread {
+  int na = 0, lpol = 0;
+  const Site<T>* sites = nullptr;
+  const int4* bases = nullptr;      // stencil records of the atoms (k_prepare_sites), or nullptr: from the positions
+  RecipGeom<T> g;
+};
+template <class T>
+bool dft_zy_spread_fits(const int K[3], int na);
 template <class T>
 bool launch_dft_zy(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb = 1, long mesh_stride = 0,
-                   long spec_stride = 0, T* accum = nullptr);
+                   long spec_stride = 0, T* accum = nullptr, const PlaneSpread<T>* sp = nullptr /* forward only */);
 template <class T>
 bool launch_dft_z(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec, int inverse, int nb = 1,
                   long mesh_stride = 0, long spec_stride = 0,                                     // r2c / c2r along z
@@ -391,7 +415,9 @@ template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
                    T* grad, const int* list, T* fld_recip /* optional: cartesian reciprocal dE/dU */,
                    const FieldFin<T>& ff = FieldFin<T>(),
-                   double* e_recip = nullptr /* optional: += 1/2 sum_i Q_tot,i . dE_recip/dQ_i = the reciprocal energy */);
+                   double* e_recip = nullptr /* optional: += 1/2 sum_i Q_tot,i . dE_recip/dQ_i = the reciprocal energy */,
+                   const Topology* top = nullptr /* with fin: the workgroups take the runs of whole frame groups top->gath_blk */,
+                   const Box<T>* box = nullptr, const FinishArgs<T>& fin = FinishArgs<T>());
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi,
                          T* fld_recip, const int* list, int nb = 1 /* batch: phi of b at phi + b * mesh size, fld + b * 3 * na */,

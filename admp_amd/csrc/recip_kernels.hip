@@ -872,16 +872,29 @@ __device__ __forceinline__ void convert_sums(int i, const T* __restrict__ sums, 
   }
 }
 
-template <class T, bool ERECIP>
+// FIN (small molecular systems, round 4): the workgroup takes a run of WHOLE frame groups (Topology::gath_blk, <= 32 atoms) and
+// its epilogue does the closing kernel's work for them -- self + penalty energies, frame adjoint, dE/dQ_local (k_finish_rows'
+// arithmetic: every frame once, by its own site; positions in and gradient contributions out through LDS) -- so a step of a
+// 3072-atom system has one dispatch fewer (the closing kernel took 10 us of a 0.21 ms step, all of it latency).
+template <class T>
+struct GatherFin {
+  T spos[kGsAtoms][3];
+  T sg[kGsAtoms][9];
+  int sidx[kGsAtoms][3];
+};
+template <class T, bool ERECIP, bool FIN>
 __global__ __launch_bounds__(kGsBlock) void k_gather_staged(int na, const Site<T>* __restrict__ sites, int lpol,
                                                             RecipGeom<T> g, const T* __restrict__ phi,
                                                             T* __restrict__ pot, T* __restrict__ grad,
                                                             const int* __restrict__ list, T* __restrict__ fld,
-                                                            FieldFin<T> ff, double* e_recip) {
+                                                            FieldFin<T> ff, double* e_recip, Topology top, Box<T> box,
+                                                            FinishArgs<T> fin) {
   __shared__ GatherStage<T> L;
-  const long blk = xcd_block(blockIdx.x, (unsigned)((na + kGsAtoms - 1) / kGsAtoms));
+  __shared__ GatherFin<T> LF;
+  const long blk = xcd_block(blockIdx.x, (unsigned)(FIN ? top.ngathblk : (na + kGsAtoms - 1) / kGsAtoms));
   if (blk < 0) return;                                   // workgroup-uniform
-  const int slot0 = (int)blk * kGsAtoms;
+  int slot0 = (int)blk * kGsAtoms;
+  if (FIN) { slot0 = top.gath_blk[blk]; na = top.gath_blk[blk + 1]; }      // this run's atoms: slot0 .. na - 1 (list == nullptr)
   stage_splines<T, 4>(g, sites, list, slot0, na, L.w, L.base);
   const int s = threadIdx.x / 6, c = threadIdx.x - 6 * s;
   T F[NF];
@@ -902,12 +915,121 @@ __global__ __launch_bounds__(kGsBlock) void k_gather_staged(int na, const Site<T
     L.sum[a][k] = ((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5]);
   }
   __syncthreads();
-  if (threadIdx.x >= 64) return;                          // step 3: one wave, lanes 0..31
+  if (!FIN && threadIdx.x >= 64) return;                  // step 3: one wave, lanes 0..31
   const int slot = slot0 + (int)threadIdx.x;
   const bool on = threadIdx.x < kGsAtoms && slot < na;
   T er = T(0);
   double fm = 0.0;
-  if (on) convert_sums<T, ERECIP>(list ? list[slot] : slot, L.sum[threadIdx.x], sites, lpol, g, pot, grad, fld, ff, er, fm);
+  if (!FIN) {
+    if (on) convert_sums<T, ERECIP>(list ? list[slot] : slot, L.sum[threadIdx.x], sites, lpol, g, pot, grad, fld, ff, er, fm);
+  } else {
+    // the closing epilogue: the whole workgroup stays (barriers below), lanes 0 .. n-1 of the first wave work
+    const int t = threadIdx.x, i = slot;
+    double eself = 0.0, epen = 0.0;
+    T gacc[3] = {T(0), T(0), T(0)};
+    Site<T> st;
+    if (t < kGsAtoms) LF.sidx[t][0] = LF.sidx[t][1] = LF.sidx[t][2] = -1;
+    if (on) {
+      st = sites[i];
+      LF.spos[t][0] = st.r[0]; LF.spos[t][1] = st.r[1]; LF.spos[t][2] = st.r[2];
+    }
+    __syncthreads();
+    if (on) {
+      T r[3], Q[9], S[NF];
+      site_qtot(st, lpol, r, Q);
+#pragma unroll
+      for (int k = 0; k < NF; ++k) S[k] = L.sum[t][k];
+      T P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      unfold_potential(g, Q, S, P, gacc);               // reciprocal part of dE/dQ_global and of the gradient
+      if (fld) { fld[3 * i] = P[2]; fld[3 * i + 1] = P[3]; fld[3 * i + 2] = P[1]; }
+      if (ERECIP) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) er += Q[k] * P[k];
+      }
+      if (ff.fmax_bits) {
+        const T al = ff.pol[i];
+        T fx, fy, fz;
+        const T fr[3] = {P[2], P[3], P[1]};
+        total_field(st, al, ff.Ucart + 3 * i, ff.fld_pair + 3 * i, fr, ff.kappa, fx, fy, fz);
+        ff.field[3 * i] = fx; ff.field[3 * i + 1] = fy; ff.field[3 * i + 2] = fz;
+        if (al > T(0.001)) fm = fmax(fm, fmax(fabs((double)fx), fmax(fabs((double)fy), fabs((double)fz))));
+      }
+      // total potential: pair part (in pot) + reciprocal part + self term; self and penalty energies (k_finish_rows)
+      T f[3];
+      self_factors(fin.kappa, f);
+      double es = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const T fl = k == 0 ? f[0] : (k < 4 ? f[1] : f[2]);
+        es += (double)(fl * Q[k] * Q[k]);
+        P[k] += pot[9 * (size_t)i + k];
+        pot[9 * (size_t)i + k] = P[k];                   // (pair + reciprocal, as the separate gather leaves it)
+        P[k] -= T(2.0 * kDielectric) * fl * Q[k];
+      }
+      eself = -kDielectric * es;
+      if (lpol) {
+        T al = fin.pol[i];
+        al = al < T(1e-8) ? T(1e-8) : al;
+        const double u2 = (double)st.U[0] * st.U[0] + (double)st.U[1] * st.U[1] + (double)st.U[2] * st.U[2];
+        epen = kDielectric * 0.5 * u2 / (double)al;
+      }
+      if (fin.want_grad) {
+        int type = top.axis_type[i];
+        const int iz = top.axis_idx[3 * i], ix = top.axis_idx[3 * i + 1], iy = top.axis_idx[3 * i + 2];
+        if (iz < 0) type = NoAxisType;
+        if (type == NoAxisType) {
+          if (fin.dQlocal) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) fin.dQlocal[9 * (size_t)i + q] = P[q];
+          }
+        } else {
+          const bool usex = type != Zonly, usey = (type == ZBisect || type == ThreeFold);
+          const int lz = iz - slot0, lx = usex && ix >= 0 ? ix - slot0 : -1, ly = usey && iy >= 0 ? iy - slot0 : -1;
+          T pz[3] = {0, 0, 0}, px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+#pragma unroll
+          for (int c2 = 0; c2 < 3; ++c2) {
+            pz[c2] = LF.spos[lz][c2];
+            if (ix >= 0) px[c2] = LF.spos[ix - slot0][c2];
+            if (iy >= 0) py[c2] = LF.spos[iy - slot0][c2];
+          }
+          FrameWork<T> w;
+          local_frame_fwd(type, box, st.r, pz, px, py, w);
+          T tau[3], gp[3], gz[3], gx[3], gy[3];
+          multipole_torque(P, st.Q, tau);
+          local_frame_bwd(type, w, tau, gp, gz, gx, gy);
+#pragma unroll
+          for (int c2 = 0; c2 < 3; ++c2) {
+            gacc[c2] += gp[c2];
+            LF.sg[t][c2] = gz[c2]; LF.sg[t][3 + c2] = gx[c2]; LF.sg[t][6 + c2] = gy[c2];
+          }
+          LF.sidx[t][0] = lz; LF.sidx[t][1] = lx; LF.sidx[t][2] = ly;
+          if (fin.dQlocal) {
+            T dl[9];
+            rot_harm(P, w.X, w.Y, w.Z, dl);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) fin.dQlocal[9 * (size_t)i + q] = dl[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (on && fin.want_grad && grad) {
+      const int rec = top.grp_of[i], g0 = (rec >> 2) - slot0, gn = (rec & 3) + 1;
+      for (int m = g0; m < g0 + gn; ++m) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (LF.sidx[m][k] == t) { gacc[0] += LF.sg[m][3 * k]; gacc[1] += LF.sg[m][3 * k + 1]; gacc[2] += LF.sg[m][3 * k + 2]; }
+      }
+      grad[3 * (size_t)i] += gacc[0]; grad[3 * (size_t)i + 1] += gacc[1]; grad[3 * (size_t)i + 2] += gacc[2];
+    }
+    if (threadIdx.x >= 64) return;
+    eself = wave_reduce_sum(eself);
+    epen = wave_reduce_sum(epen);
+    if (threadIdx.x == 0) {
+      if (eself != 0.0) atomicAdd(&fin.energies[E_SELF], eself);
+      if (lpol && epen != 0.0) atomicAdd(&fin.energies[E_PEN], epen);
+    }
+  }
   if (ERECIP) {
     const double e = wave_reduce_sum((double)er);
     if (threadIdx.x == 0) atomicAdd(&e_recip[(blockIdx.x >> 3) & (E_PARTS - 1)], 0.5 * e);
@@ -1123,13 +1245,24 @@ void launch_gather_virial(hipStream_t st, int na, const Site<T>* sites, int lpol
 
 template <class T>
 void launch_gather(hipStream_t st, int na, const Site<T>* sites, int lpol, const RecipGeom<T>& g, const T* phi, T* pot,
-                   T* grad, const int* list, T* fld, const FieldFin<T>& ff, double* e_recip) {
+                   T* grad, const int* list, T* fld, const FieldFin<T>& ff, double* e_recip, const Topology* top,
+                   const Box<T>* box, const FinishArgs<T>& fin) {
   if (na <= 0) return;
+  if (fin.energies && top && box && top->gath_blk && !list) {      // closing work in the epilogue: one workgroup per run of groups
+    const unsigned gs = xcd_grid((unsigned)top->ngathblk);
+    if (e_recip)
+      k_gather_staged<T, true, true><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip, *top, *box, fin);
+    else
+      k_gather_staged<T, false, true><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip, *top, *box, fin);
+    return;
+  }
   const unsigned gs = xcd_grid((unsigned)nblk(na, kGsAtoms));
+  const Topology t0;
+  const Box<T> b0 = Box<T>();
   if (e_recip)
-    k_gather_staged<T, true><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
+    k_gather_staged<T, true, false><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip, t0, b0, FinishArgs<T>());
   else
-    k_gather_staged<T, false><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip);
+    k_gather_staged<T, false, false><<<gs, kGsBlock, 0, st>>>(na, sites, lpol, g, phi, pot, grad, list, fld, ff, e_recip, t0, b0, FinishArgs<T>());
 }
 template <class T>
 void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const RecipGeom<T>& g, const T* phi, T* fld,
@@ -1147,7 +1280,8 @@ void launch_gather_field(hipStream_t st, int na, const Site<T>* sites, const Rec
                                const int*, int);                                                                      \
   template void launch_kspace<T>(hipStream_t, const int*, int, const T*, T*, double*, int);                           \
   template void launch_gather<T>(hipStream_t, int, const Site<T>*, int, const RecipGeom<T>&, const T*, T*, T*,        \
-                                 const int*, T*, const FieldFin<T>&, double*);                                         \
+                                 const int*, T*, const FieldFin<T>&, double*, const Topology*, const Box<T>*,          \
+                                 const FinishArgs<T>&);                                                                \
   template void launch_gather_field<T>(hipStream_t, int, const Site<T>*, const RecipGeom<T>&, const T*, T*,           \
                                        const int*, int, const int*, const int*, const FieldFin<T>&);                  \
   template void launch_kspace_virial<T>(hipStream_t, const int*, const double*, double, double, int, int, const T*,   \

@@ -268,9 +268,13 @@ def test_group_closing_kernel_matches_oracle(env, lpol, monkeypatch):
     par = S.water_parameters(n_mol, polarizable=lpol)
     pairs = S.build_pairs(pos, box, 4.0)
     out = {}
-    for mode, gmin, rows in (('rows', '0', '1'), ('groups', '0', '0'), ('pull', '100000000', '1')):
+    # 'gather': the form small systems take by default since round 4 -- the closing work in the epilogue of the gather
+    # (k_gather_staged<.., FIN>, one workgroup per run of whole frame groups); ADMP_FUSE_FIN_MAX=0 gives the separate kernels
+    for mode, gmin, rows, fin in (('rows', '0', '1', '0'), ('groups', '0', '0', '0'), ('pull', '100000000', '1', '0'),
+                                  ('gather', '100000000', '1', '8192')):
         monkeypatch.setenv('ADMP_FINISH_GROUPS_MIN', gmin)
         monkeypatch.setenv('ADMP_FINISH_ROWS', rows)
+        monkeypatch.setenv('ADMP_FUSE_FIN_MAX', fin)
         f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=lpol)
         if lpol:
             out[mode] = f.get_forces_and_dQ(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'],
@@ -284,12 +288,13 @@ def test_group_closing_kernel_matches_oracle(env, lpol, monkeypatch):
     else:
         ref = O.pme_energy_and_grad(sysm, pos, box, pairs, par['Q_local'], par['mScales'], want_dQ=True)
     scale = max(abs(p) for p in ref['parts'])
-    for mode in ('rows', 'groups', 'pull'):
+    for mode in ('rows', 'groups', 'pull', 'gather'):
         E, G, dQ, parts = out[mode]
         for got, want in zip(parts, ref['parts']):
             assert abs(got - want) <= 1e-9 * scale, mode
         assert rel(G, ref['grad']) < 1e-8 and rel(dQ, ref['dQ_local']) < 1e-8, mode
     assert rel(out['groups'][1], out['pull'][1]) < 1e-12 and rel(out['rows'][1], out['pull'][1]) < 1e-12
+    assert rel(out['gather'][1], out['pull'][1]) < 1e-12 and rel(out['gather'][2], out['pull'][2]) < 1e-12
 
 
 def test_pscale_gradient_vs_oracle(env):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Steady-state kernel timeline of one bench step from a `rocprofv3 --kernel-trace --output-format csv` run:
 prints, for the last complete step, every dispatch with its duration and the idle gap before it.
-    python tools/timeline.py <dir with *_kernel_trace.csv> [anchor-kernel-substring]"""
+    python tools/timeline.py <dir with *_kernel_trace.csv> [anchor-kernel-substring] [steps]"""
 import csv
 import glob
 import os
@@ -19,7 +19,8 @@ def main():
     idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
     if len(idx) < 3:
         print('anchor not found often enough'); return
-    a, b = idx[-3], idx[-2]
+    nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    a, b = idx[-2 - nsteps], idx[-2]
     prev_end = int(rows[a - 1]['End_Timestamp'])
     busy = 0
     for r in rows[a:b]:
