@@ -587,7 +587,7 @@ struct Engine : EngineBase {
                       &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw, &bin_cells_ind, &bin_sorted_ind, &srow_d})
       b->release();
     free_topology();
-    if (ind.rowptr) (void)hipFree(ind.rowptr);
+    if (ind.end) (void)hipFree(ind.end);
     if (ind.col) (void)hipFree(ind.col);
     cells.release();
     sl.release();
@@ -1618,7 +1618,7 @@ struct Engine : EngineBase {
     };
     if (ind_nbr_gen != nbr_gen || ind_act_gen != act_gen) {      // neighbour table or polarizable set changed
       TIMED("ind_table");
-      int rc = build_ind_table<T>(stream, top.na, nbr, sites.as<Site<T>>(), ind, &scan_scratch.p, &scan_bytes);
+      int rc = build_ind_table<T>(stream, top.na, nbr, sites.as<Site<T>>(), ind);
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("build_ind_table: ") + hipGetErrorString((hipError_t)rc)};
       ind_nbr_gen = nbr_gen; ind_act_gen = act_gen;
     }

@@ -240,17 +240,17 @@ int build_neighbour_table(hipStream_t st, const Topology& top, int64_t n_rows, c
   return 0;
 }
 
-// sub-table of the polarizable-polarizable entries: mode 0 counts per atom row (cnt[i]; 0 for non-polarizable atoms),
-// mode 1 copies the entries to icol at irow[i] (row order preserved).  8 lanes per row.
-template <class T, int MODE>
+// sub-table of the polarizable-polarizable entries: the kept entries of row i go to icol at the row's own offset rowptr[i]
+// (row order preserved), iend[i] = one past the last (= rowptr[i] for non-polarizable atoms).  8 lanes per row.
+template <class T>
 __global__ __launch_bounds__(256) void k_ind_table(int na, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                          const Site<T>* __restrict__ sites, int* __restrict__ cnt,
-                                                          const int* __restrict__ irow, int* __restrict__ icol) {
+                                                   const Site<T>* __restrict__ sites, int* __restrict__ iend,
+                                                   int* __restrict__ icol) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int row = (int)(t >> 3), sub = (int)(t & 7);
   const bool live = row < na && sites[row].p6 > T(0);
-  const int beg = live ? rowptr[row] : 0, end = live ? rowptr[row + 1] : 0;
-  int base = (MODE == 1 && live) ? irow[row] : 0, total = 0;
+  const int beg = row < na ? rowptr[row] : 0, end = live ? rowptr[row + 1] : beg;
+  int base = beg;
   for (int k0 = beg; k0 < end; k0 += 8) {      // the 8 lanes of a row share the trip count; the ballot is read per group
     const int k = k0 + sub;
     const int c = k < end ? col[k] : 0;
@@ -259,52 +259,39 @@ __global__ __launch_bounds__(256) void k_ind_table(int na, const int* __restrict
     const unsigned long long m = __ballot(keep);
     const int g0 = (threadIdx.x & 63) & ~7;
     const unsigned grp = (unsigned)((m >> g0) & 0xffull);
-    if (MODE == 1 && keep) icol[base + __popc(grp & ((1u << sub) - 1u))] = c;
+    if (keep) icol[base + __popc(grp & ((1u << sub) - 1u))] = c;
     base += __popc(grp);
-    total += __popc(grp);
   }
-  if (MODE == 0 && row < na && sub == 0) cnt[row] = total;
+  if (row < na && sub == 0) iend[row] = base;
 }
 
-// it <- the polarizable-polarizable entries of nb (rows keyed by atom).  One host synchronisation (the entry count).
+// it <- the polarizable-polarizable entries of nb (rows keyed by atom, row order preserved), one pass, nothing read back
 template <class T>
-int build_ind_table(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, IndTable& it, void** scratch,
-                    size_t* scratch_bytes) {
-  if (!it.rowptr) NB_CHECK(hipMalloc(&it.rowptr, sizeof(int) * (na + 1)));
-  DevTmp cntbuf;
-  NB_CHECK(hipMalloc(&cntbuf.p, sizeof(int) * (na + 1)));
-  int* cnt = (int*)cntbuf.p;
-  NB_CHECK(hipMemsetAsync(cnt + na, 0, sizeof(int), st));
-  const unsigned grid = (unsigned)(((long)na * 8 + 255) / 256);
-  k_ind_table<T, 0><<<grid, 256, 0, st>>>(na, nb.rowptr, nb.col, sites, cnt, nullptr, nullptr);
-  NB_CHECK(hipGetLastError());
-  size_t need = 0;
-  NB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, cnt, it.rowptr, na + 1, st));
-  if (need > *scratch_bytes) {
-    if (*scratch) NB_CHECK(hipFree(*scratch));
-    *scratch = nullptr; *scratch_bytes = 0;
-    NB_CHECK(hipMalloc(scratch, need));
-    *scratch_bytes = need;
+int build_ind_table(hipStream_t st, int na, const NbrTable& nb, const Site<T>* sites, IndTable& it) {
+  if (na > it.na_cap) {
+    if (it.end) NB_CHECK(hipFree(it.end));
+    it.end = nullptr; it.na_cap = 0;
+    NB_CHECK(hipMalloc(&it.end, sizeof(int) * (size_t)na));
+    it.na_cap = na;
   }
-  NB_CHECK(hipcub::DeviceScan::ExclusiveSum(*scratch, need, cnt, it.rowptr, na + 1, st));
-  int total = 0;
-  NB_CHECK(hipMemcpyAsync(&total, it.rowptr + na, sizeof(int), hipMemcpyDeviceToHost, st));
-  NB_CHECK(hipStreamSynchronize(st));
-  it.n = total;
-  if (total > it.cap) {
+  const int64_t need = 2 * nb.n_half;
+  if (need > it.cap) {
     if (it.col) NB_CHECK(hipFree(it.col));
     it.col = nullptr; it.cap = 0;
-    NB_CHECK(hipMalloc(&it.col, sizeof(int) * ((size_t)total + 1024)));
-    it.cap = (int64_t)total + 1024;
+    const int64_t cap = need + need / 8 + 1024;                   // (a rebuilt list is a little longer or shorter: no regrowth)
+    NB_CHECK(hipMalloc(&it.col, sizeof(int) * (size_t)cap));
+    it.cap = cap;
   }
-  if (total > 0) {
-    k_ind_table<T, 1><<<grid, 256, 0, st>>>(na, nb.rowptr, nb.col, sites, nullptr, it.rowptr, it.col);
+  it.beg = nb.rowptr;
+  if (na > 0) {
+    const unsigned grid = (unsigned)(((long)na * 8 + 255) / 256);
+    k_ind_table<T><<<grid, 256, 0, st>>>(na, nb.rowptr, nb.col, sites, it.end, it.col);
     NB_CHECK(hipGetLastError());
   }
   return 0;
 }
-template int build_ind_table<float>(hipStream_t, int, const NbrTable&, const Site<float>*, IndTable&, void**, size_t*);
-template int build_ind_table<double>(hipStream_t, int, const NbrTable&, const Site<double>*, IndTable&, void**, size_t*);
+template int build_ind_table<float>(hipStream_t, int, const NbrTable&, const Site<float>*, IndTable&);
+template int build_ind_table<double>(hipStream_t, int, const NbrTable&, const Site<double>*, IndTable&);
 
 // ascending sort of n ints in place (keys_tmp: n ints of scratch); returns a hipError_t as int
 int sort_ints(hipStream_t st, int* keys, int* keys_tmp, int n, void** scratch, size_t* scratch_bytes) {

@@ -213,10 +213,11 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __
 
 // Incremental SCF (engine.hip): fld[row] += sum over the polarizable partners of T_ij . dU_j, rows = the polarizable
 // sites.  dU_j (global harmonic order) rides in the pad words of the partner's site row (k_jacobi_delta).  The kernel
-// walks the polarizable-polarizable SUB-table (irow / icol, rows keyed by atom, built by build_ind_table when the
+// walks the polarizable-polarizable SUB-table (irow / iend / icol, rows keyed by atom, built by build_ind_table when the
 // neighbour table or the set of polarizable sites changes): for water the O-O pairs, 1/9 of the directed entries.
 template <class T, int LPR>
 __global__ __launch_bounds__(kPairBlock) void k_pair_field_ind(int na, const int* __restrict__ irow,
+                                                               const int* __restrict__ iend,
                                                                const int* __restrict__ icol,
                                                                const Site<T>* __restrict__ sites, Box<T> box,
                                                                ScaleTab<T> tab, T kappa, T* __restrict__ fld,
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field_ind(int na, const int
   if (row >= 0) {
     const T rI[3] = {sites[row].r[0], sites[row].r[1], sites[row].r[2]};
     const T p6I = sites[row].p6, thI = sites[row].thole;
-    const int end = irow[row + 1];
+    const int end = iend[row];
 #pragma unroll 1
     for (int k = irow[row] + sub; k < end; k += LPR) {
       const int c = icol[k];
@@ -669,6 +670,28 @@ static int field_lanes_per_row(int n_rows, bool ind) {
   return ind ? (n_rows >= 32768 ? 4 : (n_rows >= 8192 ? 8 : 16)) : (n_rows >= 8192 ? 8 : 16);
 }
 
+// the scalar pair kernels (dispersion, Tang-Toennies; k_pair_scalar): env ADMP_SCALAR_LPR / ADMP_TT_LPR override
+static int scalar_lanes_per_row(int n_rows, bool tt, double avg_row) {
+  static const int forced[2] = {
+      [] { const char* s = getenv("ADMP_SCALAR_LPR"); const int x = s ? atoi(s) : -1;
+           return (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32) ? x : -1; }(),
+      [] { const char* s = getenv("ADMP_TT_LPR"); const int x = s ? atoi(s) : -1;
+           return (x == 1 || x == 2 || x == 4 || x == 8 || x == 16 || x == 32) ? x : -1; }()};
+  if (forced[tt ? 1 : 0] > 0) return forced[tt ? 1 : 0];
+  // round 4, packed 32-byte partner rows and the two-ahead prefetch: few lanes per row win as soon as the rows fill the chip
+  // (a lane walks ~14 partners with its fetches in flight; more lanes only add row_reduce steps and idle tail lanes).
+  // 1M rows (f32) LPR 1/2/4/8/16: dispersion 0.251/0.171/0.227/0.422/0.810 ms, TT call 0.383/0.220/0.268/0.457/0.847;
+  // 98k rows: 0.033/0.030/0.040/0.053/0.086 and 0.075/0.064/0.069/0.088/0.121; 3072 rows (f64): 0.031/0.020/0.018/0.013/0.014
+  // and 0.076/0.058/0.049/0.051/0.045.  (Rounds 2-3 ran dispersion with the field kernels' rule: 8 lanes at 1M rows.)
+  // On a Verlet list with a skin the rows are twice as long (rc 4 + 1 A: 55 partners) and the best width doubles (1M rows,
+  // skin list, cutoff test, LPR 1/2/4/8: dispersion 0.938/0.407/0.301/0.432 ms, TT call 1.22/0.50/0.37/0.48): the rule is
+  // ~14 partners per lane, from the table's average row length.
+  if (n_rows < 8192) return tt ? 16 : 8;
+  const double lanes = avg_row / 14.0;
+  const int lpr = lanes < 1.4 ? 1 : (lanes < 2.8 ? 2 : (lanes < 5.6 ? 4 : 8));
+  return n_rows >= 32768 ? lpr : 2 * lpr;
+}
+
 // minimum waves per SIMD requested from the register allocator for the polarizable kernel
 // (env ADMP_PAIR_MINW: 1 = no constraint, 2 = at most 256 registers).  Defaults from measurement:
 //   f32: 2 (242 VGPRs, no spill; S2 0.110 ms vs 0.161 ms at 1 wave/SIMD)
@@ -743,7 +766,7 @@ void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const
   if (n_rows <= 0) return;
   const int lpr = field_lanes_per_row(n_rows, true);
 #define CALL(L)                                                                                                          \
-  k_pair_field_ind<T, L><<<xcd_grid(grid_for(n_rows, L)), kPairBlock, 0, st>>>(n_rows, it.rowptr, it.col, sites, box, tab, \
+  k_pair_field_ind<T, L><<<xcd_grid(grid_for(n_rows, L)), kPairBlock, 0, st>>>(n_rows, it.beg, it.end, it.col, sites, box, tab, \
                                                                                kappa, fld, rows)
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
@@ -754,7 +777,7 @@ void launch_disp_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>*
                       double cutoff) {
   if (!rows) { rows = nb.order_plain ? nb.order_plain : nb.order; n_rows = na; }
   if (n_rows <= 0) return;
-  const int lpr = field_lanes_per_row(n_rows, false);      // light arithmetic per partner: more lanes = more fetches in flight
+  const int lpr = scalar_lanes_per_row(n_rows, false, na > 0 ? 2.0 * (double)nb.n_half / na : 0.0);
   const T rc2 = (T)(cutoff * cutoff);
 #define CALL(L)                                                                                                        \
   if (cutoff > 0.0)                                                                                                    \
@@ -771,7 +794,7 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* s
                     const ScaleTab<T>& tab, T* grad, double* energies, const int* rows, int n_rows, double cutoff) {
   if (!rows) { rows = nb.order_plain ? nb.order_plain : nb.order; n_rows = na; }
   if (n_rows <= 0) return;
-  const int lpr = pair_lanes_per_row(n_rows);             // (8 lanes per row measured slower here: 0.44 against 0.35 ms at 1M atoms)
+  const int lpr = scalar_lanes_per_row(n_rows, true, na > 0 ? 2.0 * (double)nb.n_half / na : 0.0);
   const T rc2 = (T)(cutoff * cutoff);
 #define CALL(L)                                                                                                       \
   if (cutoff > 0.0)                                                                                                   \

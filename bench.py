@@ -386,6 +386,12 @@ def recip_kernel_rooflines(kb, counts, w, grid):
     # dipole changes of the polarizable sites only (a third of the atoms, 3 of the 15 words): their own line
     add('spread', ['spread'], na * 15 * wb + K3 * wb, counts.get('spread', 0.0))
     add('spread_scf_increment', ['spread_ind'], (na // 3) * 6 * wb + K3 * wb, counts.get('spread_ind', 0.0))
+    if 'dft_spread_zy_fwd' in kb:
+        # small double-precision systems on the direct-DFT plane kernels (round 4): no spread kernel and no charge mesh in
+        # memory -- the forward transform's workgroups build their x planes in LDS from the site rows (dft_kernels.hip)
+        out['spread'] = {'fused_into': 'dft_spread_zy_fwd', 'launches_per_step': counts.get('dft_spread_zy_fwd', 0.0),
+                         'note': 'the spread is the first phase of the forward plane transform; its time is part of '
+                                 'transforms+kspace, which moves no spread bytes through HBM'}
     add('gather', ['gather'], K3 * wb + na * 24 * wb, counts.get('gather', 0.0))
     tl = [k for k in kb if k.startswith(TRANSFORM_PREFIXES)]
     conv = sum(counts.get(k, 0.0) for k in KSPACE_LABELS)

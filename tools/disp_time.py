@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the dispersion-PME and Tang-Toennies calculators (ms per get_forces, per-kernel breakdown).
-usage: python tools/disp_time.py [S1|S2|S3]"""
+usage: python tools/disp_time.py [S1|S2|S3] [skin]       (skin: on the Verlet list of rc + 1 A, cutoff honoured, as in an MD loop)"""
 import os
 import sys
 import time
@@ -29,6 +29,14 @@ if w['K'] is not None:
         disp.update_env(k, w['K'])
 pairs = w['pairs']
 mS = par['mScales']
+tt_obj = generate_pairwise_interaction(TT_damping_qq_c6_kernel, w['cov'], static_args={})
+if len(sys.argv) > 2 and sys.argv[2] == 'skin':
+    f, a = bench.make_force(w)
+    f.update_neighbors(pos, w['box'], rc=bench.RC + bench.SKIN)
+    for obj in (disp, tt_obj):
+        obj.share_neighbors(f)
+    pairs = None
+    name += ' (skin list, %d pairs)' % f.n_pairs
 
 
 def timeit(fn, n=20):
@@ -51,7 +59,7 @@ rep = disp.profile_report()
 disp.profile(False)
 print('%s dispersion pmax=10: %.3f ms per get_forces; kernels (ms/call): %s' % (
     name, t_disp, {k: round(v[0] / 5, 4) for k, v in sorted(rep.items())}))
-tt = value_and_grad(generate_pairwise_interaction(TT_damping_qq_c6_kernel, w['cov'], static_args={}))
+tt = value_and_grad(tt_obj)
 T = lambda k: torch.as_tensor(par[k], dtype=dt, device=dev)      # noqa: E731
 a_, b_, q_, c6 = T('a_list'), T('b_list'), T('q_list'), cl[:, 0].contiguous()
 print('%s Tang-Toennies: %.3f ms per call' % (name, timeit(lambda: tt(pos, w['box'], pairs, mS, a_, b_, q_, c6))))
