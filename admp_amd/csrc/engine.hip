@@ -1460,11 +1460,13 @@ struct Engine : EngineBase {
     f.pol = ev.pol; f.kappa = (T)kappa; f.dQlocal = dQl; f.energies = Ed_cur(); f.want_grad = want_grad ? 1 : 0;
     return f;
   }
+  // ff_given: a field epilogue on a word of the caller's choice (field_epilogue(word); the chained SCF's last residual)
   void stage_gather(const T* mesh_p, T* grad_p, T* fld_out = nullptr, bool with_field_finish = false,
-                    double* e_recip = nullptr, const FinishArgs<T>* fin = nullptr) {
+                    double* e_recip = nullptr, const FinishArgs<T>* fin = nullptr, const FieldFin<T>* ff_given = nullptr) {
     need_eval();
     FieldFin<T> ff;
-    if (with_field_finish) {
+    if (ff_given) ff = *ff_given;
+    else if (with_field_finish) {
       if (!fmax_clean) HIP_TRY(hipMemsetAsync(fmax_word(), 0, sizeof(unsigned long long), stream));
       fmax_clean = false;
       ff.pol = ev.pol; ff.Ucart = ev.U; ff.fld_pair = fld_pair.as<T>(); ff.kappa = (T)kappa;
@@ -1601,8 +1603,10 @@ struct Engine : EngineBase {
   size_t nreal_local() const { return (size_t)nloc0() * K[1] * K[2]; }
   // check_word: the zero word the check after this increment writes (its residual then rides in the field gather)
   // extra_side: more work for the side stream of this increment (the closing pair kernel of a chained call, whose dipoles are final)
+  // field_from_total_phi: do not gather the increment's field -- the caller's next kernel is a full gather of the accumulated
+  // phi with a field epilogue, which yields the same reciprocal field (and the residual) for every atom
   void scf_increment(int n_act, unsigned long long* check_word = nullptr,   // fld_pair / fld_recip / phi <- their values for the dipoles after scf_jacobi
-                     const std::function<void()>& extra_side = nullptr) {
+                     const std::function<void()>& extra_side = nullptr, bool field_from_total_phi = false) {
     if (n_act <= 0 && snranks == 1) {
       if (extra_side) on_side(extra_side);
       return;
@@ -1641,7 +1645,8 @@ struct Engine : EngineBase {
     const PlaneSpread<T> sp = plane_spread(n_act, isites.as<Site<T>>(), 1, nullptr);
     const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>(), nullptr, fused ? &sp : nullptr);
     join_side();
-    { TIMED("gather_field_ind");
+    if (!field_from_total_phi) {
+      TIMED("gather_field_ind");
       launch_gather_field<T>(stream, n_act, isites.as<Site<T>>(), ev.g, mesh2.as<T>(), fld_recip.as<T>(), nullptr, 1, nullptr,
                              act_list(), check_word ? field_epilogue(check_word) : FieldFin<T>()); }
     if (!added) { TIMED("mesh_add"); launch_mesh_add<T>(stream, (long)nreal, mesh.as<T>(), mesh2.as<T>()); }
@@ -1796,17 +1801,28 @@ struct Engine : EngineBase {
         first_gather_field(field_epilogue(word(0)));
         launch_field_check(word(0));
         const bool early_full = overlap_ok();       // the closing pair kernel next to the last increment's mesh chain
+        // the last residual rides in the closing gather (it reads the accumulated phi anyway): the field gather of the last
+        // increment is not run (small single-rank systems; ADMP_CHAIN_LAST_FIELD=1 keeps it: A/B, tests)
+        static const bool keep_last = [] { const char* e = getenv("ADMP_CHAIN_LAST_FIELD"); return e && atoi(e) != 0; }();
+        const bool last_in_gather = fuse_ok() && !keep_last && n_act > 0;
         for (int c = 0; c < nhat; ++c) {
           scf_jacobi(n_act, word(c), thresh);        // a zero step once a check has passed: later residuals repeat it
-          if (early_full && c == nhat - 1)      // (the dipoles are final now)
-            scf_increment(n_act, word(c + 1), [&] { stage_pair_full(gbuf); });
+          const bool last = c == nhat - 1;
+          if (early_full && last)      // (the dipoles are final now)
+            scf_increment(n_act, word(c + 1), [&] { stage_pair_full(gbuf); }, last_in_gather);
           else
-            scf_increment(n_act, word(c + 1));
-          launch_field_check(word(c + 1));
+            scf_increment(n_act, word(c + 1), nullptr, last && last_in_gather);
+          if (!(last && last_in_gather)) launch_field_check(word(c + 1));
         }
         if (!early_full) stage_pair_full(gbuf);
         const FinishArgs<T> fin_c = finish_args(dpos != nullptr, dQl);
-        stage_gather(mesh.as<T>(), gbuf, nullptr, false, Ed_cur() + E_SLOTS, &fin_c);
+        if (last_in_gather) {
+          const FieldFin<T> ffl = field_epilogue(word(nhat));
+          stage_gather(mesh.as<T>(), gbuf, fld_recip.as<T>(), false, Ed_cur() + E_SLOTS, &fin_c, &ffl);
+          launch_field_check(word(nhat));            // (done by the epilogue: clears the mark)
+        } else {
+          stage_gather(mesh.as<T>(), gbuf, nullptr, false, Ed_cur() + E_SLOTS, &fin_c);
+        }
         launch_finish_only(dpos ? gbuf : nullptr, dQl);
         read_energies(E_PARTS_SUM, E);
         nact_seen();
