@@ -717,8 +717,10 @@ def main_slab(opt, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    # defaults: the S1 loop settles within ~60 steps of a fresh process (clocks, caches, the SCF-form history: tools/s1_settle.py
+    # -- steps 20-59 run 2 % slower than the steady state); 20 + 200 steps of 0.2 ms keep the default run short
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='S1', choices=sorted(WORKLOADS))
     ap.add_argument('--no-scale', action='store_true', help='skip the extra 1M-atom measurement (N=1 only)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')

@@ -226,6 +226,17 @@ for prec in ('double', 'single'):
         key = '%%s_%%d_%%d_%%d' %% ((prec,) + (f.K1, f.K2, f.K3))
         out[key + '_parts'] = np.asarray(f.energy_parts); out[key + '_G'] = np.asarray(G); out[key + '_U'] = np.asarray(f.U_ind)
         out[key + '_dparts'] = np.asarray(d.energy_parts); out[key + '_Gd'] = np.asarray(Gd)
+# a denser case for the spread that the forward plane kernel does itself (double precision, dft_kernels.hip zy_plane_spread):
+# 4500 atoms on 31 x planes = ~870 kept atoms per plane (several staging sub-rounds) and two scan rounds of 3072 atoms
+settings.PRECISION = 'double'
+from admp_amd.pme import ADMPPmeForce
+pos, box, at, ai, cov, par, pairs = water_system(1500, 7, True)
+f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+f.K1, f.K2, f.K3 = 31, 97, 97
+f.refresh_calculators()
+E, G = f.get_forces(pos, box, pairs, par['Q_local'], par['pol'], par['tholes'], par['mScales'], par['pScales'], par['dScales'])
+out['double_dense_parts'] = np.asarray(f.energy_parts); out['double_dense_G'] = np.asarray(G); out['double_dense_U'] = np.asarray(f.U_ind)
+out['double_dense_cycles'] = np.asarray([f.n_cycle])
 np.savez(sys.argv[1], **out)
 print('DFT-RUN-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -234,7 +245,11 @@ print('DFT-RUN-OK')
     # 'pfa': the two-level (Good-Thomas) kernels of pfa_kernels.hip forced onto these small meshes, every dimension split
     # that has a coprime split (34 = 2 * 17, 38 = 2 * 19, 96 = 32 * 3, 100 = 4 * 25, 45 = 9 * 5, 51 = 3 * 17; 31, 97, 64 plain)
     # 'dft' runs the z and y lines of a plane in one kernel where the plane fits the LDS; 'dft_passes' keeps them apart
+    # 'dft_nospread': the plane kernels reading a mesh the spread kernel wrote (round 4: by default the forward plane kernel of a
+    # double-precision system of <= 8192 atoms builds its planes from the sites); ADMP_FUSE_FIN_MAX=0 there as well: the
+    # closing kernel on its own instead of in the gather's epilogue
     modes = {'rocfft': dict(ADMP_DFT='0'), 'dft': dict(ADMP_DFT='1'), 'dft_passes': dict(ADMP_DFT='1', ADMP_DFT_PLANES='0'),
+             'dft_nospread': dict(ADMP_DFT='1', ADMP_FUSE_SPREAD_MAX='0', ADMP_FUSE_FIN_MAX='0'),
              'pfa': dict(ADMP_DFT='2', ADMP_PFA_MIN='0')}
     for mode, extra in modes.items():
         path = str(tmp_path / ('%s.npz' % mode))
@@ -242,9 +257,9 @@ print('DFT-RUN-OK')
                            env=dict(os.environ, **extra), timeout=900)
         assert r.returncode == 0 and 'DFT-RUN-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
         res[mode] = dict(np.load(path))
-    assert len(res['rocfft']) == 2 * 4 * 5
+    assert len(res['rocfft']) == 2 * 4 * 5 + 4
     for key, a in res['rocfft'].items():
-        for mode in ('dft', 'dft_passes', 'pfa'):
+        for mode in ('dft', 'dft_passes', 'dft_nospread', 'pfa'):
             b = res[mode][key]
             tol = 1e-10 if key.startswith('double') else 2e-4
             scale = np.abs(a).max()
