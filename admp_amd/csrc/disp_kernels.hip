@@ -180,6 +180,144 @@ __global__ __launch_bounds__(256) void k_spread_bricks_scalar(const T* __restric
   if (threadIdx.x == 0 && clear_a) { clear_a[blockIdx.x] = 0; clear_b[blockIdx.x] = 0; }
 }
 
+// ---- typed form (round 4) -------------------------------------------------------------------------------------------------
+// When the coefficient rows (C6, C8, C10) of the atoms take only a few distinct values -- atom TYPES: water has two -- the
+// structure factor of channel p is a combination of the types' structure factors, S_p = sum_t c_p,t S_t, and what an atom of
+// type t gathers is the potential psi_t = sum_p c_p,t phi_p.  So the meshes are per TYPE: an atom spreads its bare stencil
+// weights into the mesh of its type (216 LDS atomics instead of 216 per channel), NT meshes go through the transforms
+// instead of one per channel, the x pass combines them at every k (fftx_kernels.hip k_fftx_mix), and an atom gathers from
+// its type's mesh alone.  Same sums regrouped (the reference spreads c_p,i per channel: admp/disp_pme.py:80-123).
+template <class T, int NT>
+__global__ __launch_bounds__(256) void k_spread_bricks_typed(const T* __restrict__ pos, const int* __restrict__ types,
+                                                             RecipGeom<T> g, BrickGrid bg, const int* __restrict__ brick_start,
+                                                             const int* __restrict__ entries, T* __restrict__ mesh,
+                                                             long mesh_stride, int* __restrict__ clear_a,
+                                                             int* __restrict__ clear_b) {
+  using W = typename ScalarWord<T>::type;
+  W* tile = reinterpret_cast<W*>(scalar_smem);          // [NT][kScalarTile]
+  const int bz = blockIdx.x % bg.nb[2], by = (blockIdx.x / bg.nb[2]) % bg.nb[1], bx = blockIdx.x / (bg.nb[2] * bg.nb[1]);
+  const int bb[3] = {bx, by, bz};
+  int lo[3], n[3];
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = (bb[d] * g.dim(d)) / bg.nb[d];
+    n[d] = ((bb[d] + 1) * g.dim(d)) / bg.nb[d] - lo[d];
+  }
+  for (int t = threadIdx.x; t < NT * kScalarTile; t += 256) tile[t] = W(0);
+  __syncthreads();
+  const int beg = brick_start[blockIdx.x], cnt = brick_start[blockIdx.x + 1] - beg;
+  // unit sources: a word receives at most cnt * 0.17 (the largest product of three order-6 spline values)
+  int ex;
+  {
+    const double bound = 0.17 * (double)(cnt > 0 ? cnt : 1);
+    ex = sizeof(T) == 4 ? 29 - ilogb(bound) : 49;
+  }
+  const T scale = (T)ldexp(1.0, ex);
+  const double inv_scale = ldexp(1.0, -ex);
+  const int rows = (cnt + 63) >> 6, lane = threadIdx.x & 63;
+  for (int pass = threadIdx.x >> 6; pass < rows; pass += 4) {
+    const int e = lane * rows + pass;
+    if (e >= cnt) continue;
+    const int i = entries[beg + e];
+    const T r[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+    int ty = types[i];
+    ty = ty < 0 ? 0 : (ty >= NT ? NT - 1 : ty);            // (the host checks the table; never index outside the tiles)
+    W* mytile = tile + ty * kScalarTile;
+    int base[3];
+    T M[3][6];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      T D1[6], D2[6], D3[6];
+      const T f = grid_ref(g, r, d, base[d]);
+      bspline6(f, M[d], D1, D2, D3);
+    }
+    int off[3], ok[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int period = d == 0 ? g.wrap0 : g.K[d];
+      int o = base[d] - lo[d];
+      if (o + 5 < 0) o += period;
+      else if (o >= n[d]) o -= period;
+      off[d] = o;
+      int m = 0;
+#pragma unroll
+      for (int p6 = 0; p6 < 6; ++p6) m |= ((unsigned)(o + p6) < (unsigned)n[d]) << p6;
+      ok[d] = m;
+    }
+    if (!(ok[0] && ok[1] && ok[2])) continue;
+    T wz[6];
+    int jz[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      wz[c] = ((ok[2] >> c) & 1) ? scale * M[2][c] : T(0);
+      const int j = off[2] + c;
+      jz[c] = j < 0 ? 0 : (j >= n[2] ? n[2] - 1 : j);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (!((ok[0] >> a) & 1)) continue;
+      const int ja = off[0] + a;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        if (!((ok[1] >> b) & 1)) continue;
+        const int jb = off[1] + b;
+        const T mm = M[0][a] * M[1][b];
+        const int rowo = (ja * 16 + jb) * kScalarRow;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomicAdd(&mytile[rowo + jz[c]], scalar_fixed(mm * wz[c]));
+      }
+    }
+  }
+  __syncthreads();
+  const int nyz = n[1] * n[2], ntot = n[0] * nyz;
+  const float inv_yz = 1.0f / (float)nyz, inv_z = 1.0f / (float)n[2];
+  for (int t = threadIdx.x; t < ntot; t += 256) {
+    int ja, jb, jc;
+    if (n[1] == 16 && n[2] == 16) { ja = t >> 8; jb = (t >> 4) & 15; jc = t & 15; }
+    else { ja = fast_div(t, nyz, inv_yz); const int rem = t - ja * nyz; jb = fast_div(rem, n[2], inv_z); jc = rem - jb * n[2]; }
+    const long mi = ((long)(lo[0] + ja) * g.K[1] + (lo[1] + jb)) * g.K[2] + lo[2] + jc;
+    const int ti = (ja * 16 + jb) * kScalarRow + jc;
+#pragma unroll
+    for (int ty = 0; ty < NT; ++ty) mesh[(long)ty * mesh_stride + mi] = scalar_value(tile[ty * kScalarTile + ti], inv_scale);
+  }
+  if (threadIdx.x == 0 && clear_a) { clear_a[blockIdx.x] = 0; clear_b[blockIdx.x] = 0; }
+}
+// the caller's type table against the coefficient rows it stands for (admp_disp_set_types): any row that is not bit for bit
+// its type's row bumps *bad (read back with the energies; the call then fails instead of returning a wrong energy)
+template <class T>
+__global__ __launch_bounds__(256) void k_types_check(int na, const T* __restrict__ vals, int stride, const int* __restrict__ types,
+                                                     MixTab mix, double* bad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool wrong = false;
+  if (i < na) {
+    const int ty = types[i];
+    wrong = ty < 0 || ty >= mix.nt;
+    if (!wrong)
+      for (int ch = 0; ch < mix.nch; ++ch) wrong = wrong || vals[(long)stride * i + ch] != (T)mix.c[ch][ty];
+  }
+  if (__syncthreads_or(wrong) && threadIdx.x == 0) atomicAdd(bad, 1.0);
+}
+template <class T>
+void launch_types_check(hipStream_t st, int na, const T* vals, int stride, const int* types, const MixTab& mix, double* bad) {
+  if (na > 0) k_types_check<T><<<(na + 255) / 256, 256, 0, st>>>(na, vals, stride, types, mix, bad);
+}
+// nt = 1..3 type meshes (single precision: three 17 KB tiles per workgroup)
+template <class T>
+int launch_spread_typed(hipStream_t st, int nt, const T* pos, const int* types, const RecipGeom<T>& g, const BinScratch& bs,
+                        T* mesh, long mesh_stride) {
+  const int dims[3] = {g.nloc0, g.K[1], g.K[2]};
+  const BrickGrid bg = make_bricks(dims);
+  using W = typename ScalarWord<T>::type;
+  const size_t sh = (size_t)nt * kScalarTile * sizeof(W);
+  if (sh > 64 * 1024 || nt < 1 || nt > 3) return (int)hipErrorInvalidValue;
+  if (nt == 3)
+    k_spread_bricks_typed<T, 3><<<bg.ncell, 256, sh, st>>>(pos, types, g, bg, bs.cell_start, bs.sorted, mesh, mesh_stride, bs.cursor, bs.fillcur);
+  else if (nt == 2)
+    k_spread_bricks_typed<T, 2><<<bg.ncell, 256, sh, st>>>(pos, types, g, bg, bs.cell_start, bs.sorted, mesh, mesh_stride, bs.cursor, bs.fillcur);
+  else
+    k_spread_bricks_typed<T, 1><<<bg.ncell, 256, sh, st>>>(pos, types, g, bg, bs.cell_start, bs.sorted, mesh, mesh_stride, bs.cursor, bs.fillcur);
+  return (int)hipGetLastError();
+}
+
 template <class T>
 int launch_spread_scalar(hipStream_t st, int nch, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
                          const BinScratch& bs, T* mesh, long mesh_stride) {
@@ -235,7 +373,8 @@ template <class T, int NCH, bool IL>
 __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __restrict__ pos, const T* __restrict__ vals,
                                                             int stride, RecipGeom<T> g, const T* __restrict__ phi,
                                                             long mesh_stride, T* __restrict__ grad,
-                                                            const int* __restrict__ list) {
+                                                            const int* __restrict__ list, const int* __restrict__ types) {
+  // types (NCH = 1, not interleaved): atom i gathers from the mesh of its type, which already carries the coefficients
   __shared__ W4<T> w[kSgAtoms][kSgRow];                   // the four orders of the 18 stencil indices of every atom
   __shared__ int sbase[kSgAtoms][4];
   __shared__ T part[3][kSgBlock];
@@ -284,10 +423,10 @@ __global__ __launch_bounds__(kSgBlock) void k_gather_scalar(int na, const T* __r
       // one channel at a time (its 36 loads in flight together), the channels' sums combined with the atom's coefficients
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-        const T* __restrict__ ph = phi + (long)ch * mesh_stride;
+        const T* __restrict__ ph = phi + (long)(types ? types[i] : ch) * mesh_stride;
         T fc[3];
         gather_zcol_field_w(g, base, &w[s][0], &w[s][6], wz, ic, [&](long idx) { return ph[idx]; }, fc);
-        const T q = vals[(long)stride * i + ch];
+        const T q = types ? T(1) : vals[(long)stride * i + ch];
         f[0] += q * fc[0]; f[1] += q * fc[1]; f[2] += q * fc[2];
       }
     }
@@ -325,18 +464,22 @@ __global__ __launch_bounds__(256) void k_scalar_self(int na, int nch, const T* _
 
 template <class T>
 void launch_gather_scalar(hipStream_t st, int nch, int na, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
-                          const T* phi, long mesh_stride, T* grad, const int* list, int interleaved) {
+                          const T* phi, long mesh_stride, T* grad, const int* list, int interleaved, const int* types) {
   if (na <= 0) return;
   const unsigned grid = xcd_grid((unsigned)((na + kSgAtoms - 1) / kSgAtoms));
-  if (interleaved) {
-    if (nch == 3) k_gather_scalar<T, 3, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
-    else if (nch == 2) k_gather_scalar<T, 2, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
-    else k_gather_scalar<T, 1, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+  if (types) {      // one mesh per atom, chosen by its type
+    k_gather_scalar<T, 1, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, types);
     return;
   }
-  if (nch == 3) k_gather_scalar<T, 3, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
-  else if (nch == 2) k_gather_scalar<T, 2, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
-  else k_gather_scalar<T, 1, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list);
+  if (interleaved) {
+    if (nch == 3) k_gather_scalar<T, 3, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, nullptr);
+    else if (nch == 2) k_gather_scalar<T, 2, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, nullptr);
+    else k_gather_scalar<T, 1, true><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, nullptr);
+    return;
+  }
+  if (nch == 3) k_gather_scalar<T, 3, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, nullptr);
+  else if (nch == 2) k_gather_scalar<T, 2, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, nullptr);
+  else k_gather_scalar<T, 1, false><<<grid, kSgBlock, 0, st>>>(na, pos, vals, stride, g, phi, mesh_stride, grad, list, nullptr);
 }
 template <class T>
 void launch_scalar_self(hipStream_t st, int nch, int na, const T* vals, int stride, const int* list, const double* self_coefs,
@@ -392,7 +535,10 @@ void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, in
   template int launch_spread_scalar<T>(hipStream_t, int, const T*, const T*, int, const RecipGeom<T>&, const BinScratch&, \
                                        T*, long);                                                                        \
   template void launch_gather_scalar<T>(hipStream_t, int, int, const T*, const T*, int, const RecipGeom<T>&, const T*,    \
-                                        long, T*, const int*, int);                                                      \
+                                        long, T*, const int*, int, const int*);                                          \
+  template int launch_spread_typed<T>(hipStream_t, int, const T*, const int*, const RecipGeom<T>&, const BinScratch&, T*, \
+                                      long);                                                                             \
+  template void launch_types_check<T>(hipStream_t, int, const T*, int, const int*, const MixTab&, double*);              \
   template void launch_interleave<T>(hipStream_t, int, long, const T*, long, T*);                                        \
   template void launch_scalar_self<T>(hipStream_t, int, int, const T*, int, const int*, const double*, double*);         \
   template void launch_gather_value<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, const T*,     \

@@ -289,6 +289,7 @@ struct EngineBase {
                              double* E, double* dbox) = 0;
   virtual void tt_box_grad(const void* pos, const double* box, const void* abqc, int ns, const double* mS, double* E,
                            double* dbox) = 0;
+  virtual void disp_set_types(int nt, const void* types, const double* ctab) = 0;
   virtual void disp(const void* pos, const double* box, const void* clist, int pmax, int ns, const double* mS, double* E,
                     void* dpos, int on_device) = 0;
   virtual void tt(const void* pos, const double* box, const void* abqc, int ns, const double* mS, double* E, void* dpos,
@@ -2346,7 +2347,7 @@ struct Engine : EngineBase {
     return srow_d.as<SRow<T>>();
   }
   // energies of a dispersion / pair-potential call: (real, recip, self) of all ranks
-  void read_scalar_energies(double* Ed, double* E, int n) {
+  void read_scalar_energies(double* Ed, double* E, int n, bool types_checked = false) {
     double Eh2[E_WORDS];
     if (snranks > 1) {
       TIMED("comm_energies");
@@ -2356,6 +2357,8 @@ struct Engine : EngineBase {
     HIP_TRY(hipMemcpyAsync(Eh2, Ed, sizeof(Eh2), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     const double* src = snranks > 1 ? Eh2 + E_RED : Eh2;      // (E_REAL, E_RECIP, E_SELF are words 0, 1, 2 either way)
+    if (types_checked && Eh2[E_FMAX] != 0.0)      // (k_types_check counted rows that differ from their type's coefficients)
+      throw Err{ADMP_E_ARG, "admp_disp_set_types: c_list rows differ from the coefficients of their types"};
     for (int k = 0; k < n; ++k) E[k] = src[k];
   }
   // rows of a scalar pair / dispersion call: all atoms in the table's length-sorted order, or -- on a slab rank -- the
@@ -2375,6 +2378,21 @@ struct Engine : EngineBase {
     return {sl.rows, sl.n_home, sl.home};
   }
 
+  // admp_disp_set_types: the atoms' coefficient rows take nt <= 3 distinct values; types (device int32[Na], the caller's) picks
+  // the row ctab[type][3] of every atom.  Used by the single-rank fused-x path in single precision (typed meshes: one spread
+  // and one gather per ATOM instead of per channel, nt transforms instead of one per channel); verified against c_list in
+  // every call that uses it.  nt = 0: forget.
+  int disp_nt = 0;
+  const int* disp_types = nullptr;
+  double disp_ctab[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  void disp_set_types(int nt, const void* types, const double* ctab) override {
+    if (nt <= 0 || !types || !ctab) { disp_nt = 0; disp_types = nullptr; return; }
+    ARG_CHECK(nt <= 3, "admp_disp_set_types: at most 3 types");
+    disp_nt = nt;
+    disp_types = reinterpret_cast<const int*>(types);
+    for (int t = 0; t < nt; ++t)
+      for (int c = 0; c < 3; ++c) disp_ctab[t][c] = ctab[3 * t + c];
+  }
   // dispersion PME (admp/disp_pme.py:80-123): real-space pairs + one scalar reciprocal pass per power
   void disp(const void* pos_, const double* box, const void* clist_, int pmax, int ns, const double* mS, double* E,
             void* dpos_, int on_device) override {
@@ -2413,6 +2431,42 @@ struct Engine : EngineBase {
       const size_t nreal = nreal_local();
       mesh.need(nch * nreal * sizeof(T));
       ensure_bins(std::max(sr.n, 1));
+      static const bool typed_on = [] { const char* e = getenv("ADMP_DISP_TYPES"); return !(e && atoi(e) == 0); }();
+      static const bool batch_on_t = [] { const char* e = getenv("ADMP_DISP_BATCH"); return !(e && atoi(e) == 0); }();
+      const bool typed = typed_on && batch_on_t && snranks == 1 && use_fx && sizeof(T) == 4 && disp_nt >= 1 && disp_types;
+      if (typed) {
+        // Typed meshes (disp_kernels.hip): nt type meshes through the transforms, combined per k in the x pass
+        const int nt = disp_nt;
+        MixTab mix;
+        mix.nch = nch; mix.nt = nt;
+        for (int c = 0; c < 3; ++c)
+          for (int t = 0; t < 4; ++t) mix.c[c][t] = (c < nch && t < nt) ? (float)disp_ctab[t][c] : 0.f;
+        launch_types_check<T>(stream, na, cl, 3, disp_types, mix, Ed + E_FMAX);
+        const size_t nspec = 2 * (size_t)K[0] * K[1] * fx_khp;
+        mesh.need((size_t)std::max(nt, nch) * nreal * sizeof(T));
+        spec.need((size_t)nt * nspec * sizeof(T));
+        { TIMED("spread");
+          int rc = launch_bin_bricks<T>(stream, sr.n, (const Site<T>*)nullptr, g, bins, sr.home, bases_d.as<int4>());
+          if (rc == 0) rc = launch_spread_typed<T>(stream, nt, pos, disp_types, g, bins, mesh.as<T>(), (long)nreal);
+          if (rc != 0) throw Err{ADMP_E_HIP, std::string("dispersion spread (typed): ") + hipGetErrorString((hipError_t)rc)};
+          bins.counters_zero = true; }
+        DftTabs<T> tabs;
+        for (int c = 0; c < nch; ++c) { ensure_gtab(box, inv, vol, 6 + 2 * c); tabs.p[c] = gtab_cur; }
+        if (nt >= 2) ensure_batched_plans(nt);
+        run_plan("rocfft_r2c_yz", nt >= 2 ? plan2n_f[nt] : plan2_f, mesh.p, spec.p);
+        { TIMED("fftx_kspace");
+          launch_fftx_mix<T>(stream, K, fx_tw.as<T>(), spec.as<T>(), tabs, mix, (long)nspec, Ed, E_RECIP, fx_khp); }
+        run_plan("rocfft_c2r_yz", nt >= 2 ? plan2n_b[nt] : plan2_b, spec.p, mesh.p);
+        { TIMED("gather_field");
+          launch_gather_scalar<T>(stream, 1, sr.n, pos, cl, 3, g, mesh.as<T>(), (long)nreal, dpos, sr.home, 0, disp_types); }
+        { TIMED("scalar_self"); launch_scalar_self<T>(stream, nch, sr.n, cl, 3, sr.home, kp, Ed); }
+        read_scalar_energies(Ed, E, 3, true);
+        if (dpos_ && !on_device) {
+          HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
+          HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return;
+      }
       { TIMED("spread");
         int rc = launch_bin_bricks<T>(stream, sr.n, (const Site<T>*)nullptr, g, bins, sr.home, bases_d.as<int4>());
         if (rc == 0) rc = launch_spread_scalar<T>(stream, nch, pos, cl, 3, g, bins, mesh.as<T>(), (long)nreal);
@@ -2964,6 +3018,10 @@ int admp_set_option(admp_handle* h, int option, int value) {
 int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* box, const void* c_list, int pmax,
                           int n_scales, const double* mScales, double* E_out, void* dE_dpos, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.disp(positions, box, c_list, pmax, n_scales, mScales, E_out, dE_dpos, on_device); });
+}
+
+int admp_disp_set_types(admp_handle* h, int n_types, const void* type_of_atom, const double* coefficients) {
+  return guarded(h, [&](EngineBase& e) { e.disp_set_types(n_types, type_of_atom, coefficients); });
 }
 
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,

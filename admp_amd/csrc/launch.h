@@ -449,7 +449,20 @@ int launch_spread_scalar(hipStream_t st, int nch, const T* pos, const T* vals, i
 template <class T>
 void launch_gather_scalar(hipStream_t st, int nch, int na, const T* pos, const T* vals, int stride, const RecipGeom<T>& g,
                           const T* phi, long mesh_stride, T* grad, const int* list,
-                          int interleaved = 0 /* phi = [mesh point][nch]: the channels of a point side by side (launch_interleave) */);
+                          int interleaved = 0 /* phi = [mesh point][nch]: the channels of a point side by side (launch_interleave) */,
+                          const int* types = nullptr /* typed form: atom i gathers, with weight 1, from mesh types[i] */);
+// typed dispersion meshes (disp_kernels.hip k_spread_bricks_typed): unit sources into mesh types[i]; nt = 1..3
+template <class T>
+int launch_spread_typed(hipStream_t st, int nt, const T* pos, const int* types, const RecipGeom<T>& g, const BinScratch& bs,
+                        T* mesh, long mesh_stride);
+// x pass of the typed form (fftx_kernels.hip k_fftx_mix): spec holds nt type meshes; at every k the channel structure
+// factors S_p = sum_t ctab[p][t] S_t are formed, E += w G_p |S_p|^2, and the types get back psi_t = sum_p ctab[p][t] G_p S_p
+struct MixTab { float c[3][4]; int nch, nt; };
+template <class T>
+void launch_types_check(hipStream_t st, int na, const T* vals, int stride, const int* types, const MixTab& mix, double* bad);
+template <class T>
+void launch_fftx_mix(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, const MixTab& mix,
+                     long spec_stride, double* energies, int slot, int khp);
 // dst[i * nch + c] = src[c * stride + i], i < n: the nch meshes of a dispersion call side by side per mesh point, so that the
 // gather fetches all channels of a stencil point with ONE load instruction
 template <class T>

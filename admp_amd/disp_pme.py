@@ -75,6 +75,7 @@ class ADMPDispPmeForce(HipForceBase):
             key = (id(c_list), c_list.data_ptr(), c_list._version)
             hit = getattr(self, '_c_cache', None)
             if hit is not None and hit[0] == key:
+                self._type_misses = 0
                 return hit[1]
             c = c_list.detach().to(device=self._device, dtype=self._dtype)
         else:
@@ -84,7 +85,29 @@ class ADMPDispPmeForce(HipForceBase):
         c3 = torch.zeros((na, 3), dtype=self._dtype, device=self._device)
         c3[:, :nc] = c[:, :nc]
         self._c_cache = (key, c3, c_list) if key is not None else None      # (the tensor stays alive: its id stays unique)
+        self._update_types(c3 if key is not None else None)
         return c3
+
+    def _update_types(self, c3):
+        """Atom types for the library's typed meshes (include/admp_hip.h admp_disp_set_types): when the rows of c_list take at
+        most 3 distinct values the reciprocal part keeps one mesh per type instead of one per power.  Found once per c_list
+        tensor (torch.unique on the device: milliseconds at 1M atoms, so only for a tensor that is kept from call to call --
+        a caller who hands in new coefficients every call, e.g. while fitting them, gets the per-power path)."""
+        misses = getattr(self, '_type_misses', 0)
+        types = None
+        if c3 is not None and self._dtype == torch.float32 and misses < 3 and settings.DISP_TYPED_MESHES:
+            rows, inv = torch.unique(c3, dim=0, return_inverse=True)
+            if rows.shape[0] <= 3:
+                types = (inv.to(torch.int32).contiguous(), rows.double().cpu().numpy())
+        self._type_misses = misses + 1          # (reset by every call that finds its tensor in the cache: _evaluate_on_stream)
+        if types is None:
+            if getattr(self, '_types', None) is not None:
+                _lib.check(self._h, self._L.admp_disp_set_types(self._h, 0, None, None), 'admp_disp_set_types')
+            self._types = None
+            return
+        self._types = types                      # (the library reads the index array of every later call: keep it alive)
+        _lib.check(self._h, self._L.admp_disp_set_types(self._h, int(types[1].shape[0]), self._ptr(types[0]),
+                                                         _lib.darr(types[1])), 'admp_disp_set_types')
 
     def get_energy_and_box_gradient(self, positions, box, pairs, c_list, mScales):
         """(E, dE/dbox (3,3)) at fixed Cartesian positions: `value_and_grad(get_energy, argnums=1)` of the reference."""

@@ -37,3 +37,8 @@ def precision_bytes():
     if PRECISION not in ('single', 'double'):
         raise ValueError("settings.PRECISION must be 'single' or 'double'")
     return 4 if PRECISION == 'single' else 8
+
+# Dispersion PME: when the (C6, C8, C10) rows of the atoms take at most three distinct values (atom types), the reciprocal part
+# keeps one mesh per type instead of one per power (include/admp_hip.h admp_disp_set_types).  Same sums regrouped; False keeps
+# the reference's per-power meshes (admp/disp_pme.py:80-123).
+DISP_TYPED_MESHES = True

@@ -162,6 +162,16 @@ int admp_local_frames(admp_handle* h, const void* positions, const double* box, 
 int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* box, const void* c_list, int pmax,
                           int n_scales, const double* mScales, double* E_out, void* dE_dpos, int on_device);
 
+/* Optional hint for admp_disp_energy_grad (no counterpart in the reference, which spreads every channel's coefficients,
+ * admp/disp_pme.py:80-123): the rows of c_list take only n_types <= 3 distinct values (atom types: water has two).
+ *   type_of_atom  (Na) int32, DEVICE pointer owned by the caller (must stay valid until replaced): row index of every atom
+ *   coefficients  (n_types,3) host doubles: the distinct rows (C6, C8, C10)
+ * A single-rank handle on a power-of-two mesh in single precision then keeps one mesh per TYPE instead of one per channel
+ * (S_p(k) = sum_t c_p,t S_t(k): one spread and one gather per atom, n_types transforms each way, the channels combined per k
+ * point) -- the same sums regrouped.  Every call that uses the table checks it against c_list and fails with ADMP_E_ARG on a
+ * mismatch.  n_types = 0 (or NULL): forget the table.  Other handles ignore it. */
+int admp_disp_set_types(admp_handle* h, int n_types, const void* type_of_atom, const double* coefficients);
+
 /* replaces: generate_pairwise_interaction(TT_damping_qq_c6_kernel, ...) (admp/pairwise.py:45-113).
  *   abqc (Na,4) real: a, b, q, c6 per atom */
 int admp_tt_energy_grad(admp_handle* h, const void* positions, const double* box, const void* abqc, int n_scales,

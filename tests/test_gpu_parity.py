@@ -189,6 +189,47 @@ for prec, tol in (('double', 1e-9), ('single', 5e-4)):
     E, G = d8.get_forces(pos, box, pairs, par['c_list'], par['mScales'])
     dref = O.disp_energy_and_grad(pos, box, pairs, par['c_list'], par['mScales'], cov, d8.kappa, (64, 64, 64), 8)
     assert abs(E - dref['E']) < tol * max(abs(p) for p in dref['parts']) and rel(G, dref['grad']) < max(tol, 1e-8), (prec, 'pmax 8')
+    # typed meshes (round 4; single precision, power-of-two mesh, c_list kept as one device tensor): water has two distinct
+    # coefficient rows -> two type meshes instead of three channel meshes; then three types; four fall back to the channels
+    import torch
+    from admp_amd import _lib
+    cl = np.array(par['c_list'], dtype=np.float64)
+    cases = {'2 types': cl.copy(), '3 types': cl.copy(), '4 types': cl.copy()}
+    cases['3 types'][0::6] *= 1.25                       # every second oxygen
+    cases['4 types'][0::6] *= 1.25
+    cases['4 types'][1::6] *= 0.5
+    for label, c in cases.items():
+        dref = O.disp_energy_and_grad(pos, box, pairs, c, par['mScales'], cov, d.kappa, (64, 64, 64), 10)
+        ct = torch.as_tensor(c, dtype=torch.float32 if prec == 'single' else torch.float64, device='cuda')
+        res = {}
+        for typed in (True, False):
+            settings.DISP_TYPED_MESHES = typed
+            dd = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+            dd.K1 = dd.K2 = dd.K3 = 64
+            dd.refresh_calculators()
+            for rep in range(2):                        # (second call: the cached coefficient tensor and its type table)
+                E, G = dd.get_forces(pos, box, pairs, ct, par['mScales'])
+            used = getattr(dd, '_types', None) is not None
+            assert used == (typed and prec == 'single' and label != '4 types'), (prec, label, typed, used)
+            assert abs(E - dref['E']) < tol * max(abs(p) for p in dref['parts']) and rel(np.asarray(G), dref['grad']) < max(tol, 1e-8), (prec, label, typed)
+            res[typed] = (E, np.asarray(G), dd.energy_parts)
+        settings.DISP_TYPED_MESHES = True
+        assert rel(res[True][1], res[False][1]) < (2e-5 if prec == 'single' else 1e-12), (prec, label)
+        assert abs(res[True][2][1] - res[False][2][1]) < (2e-5 if prec == 'single' else 1e-12) * abs(res[False][2][1]), (prec, label)
+    if prec == 'single':      # a type table that does not describe c_list makes the call fail instead of returning a wrong energy
+        dd = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+        dd.K1 = dd.K2 = dd.K3 = 64
+        dd.refresh_calculators()
+        ct = torch.as_tensor(cl, dtype=torch.float32, device='cuda')
+        dd.get_forces(pos, box, pairs, ct, par['mScales'])
+        wrong = dd._types[1].copy()
+        wrong[0, 0] *= 1.5
+        _lib.check(dd._h, dd._L.admp_disp_set_types(dd._h, len(wrong), dd._ptr(dd._types[0]), _lib.darr(wrong)), 'set_types')
+        try:
+            dd.get_forces(pos, box, pairs, ct, par['mScales'])
+            raise SystemExit('a wrong type table went unnoticed')
+        except _lib.AdmpHipError as e:
+            assert 'types' in str(e)
 print('BRICK-OK')
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ADMP_SPREAD_BRICK_MIN='0')
