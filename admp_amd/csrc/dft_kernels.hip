@@ -354,6 +354,170 @@ __global__ __launch_bounds__(kDftBlock) void k_dft_x_conv(int N, int ncols, int 
   if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
 }
 
+// ---- x lines of the TYPED dispersion meshes (round 4; see disp_kernels.hip): the workgroup's NC "columns" are NC / NTP
+// physical columns of each of NTP (padded: 1, 2 or 4) type spectra, column t * NCt + c.  The transforms treat them as NC
+// independent columns; between them the types are combined per (frequency, physical column):
+//   S_p = sum_t c[p][t] X_t,   E += w G_p |S_p|^2,   X_t <- sum_p c[p][t] G_p S_p.
+template <class T, int KQ, int JS, int NTP>
+__global__ __launch_bounds__(kDftBlock) void k_dft_x_mix(int N, int ncols, int NC, int TK, long jstride, long fixstride,
+                                                        int K3, Cx<T>* __restrict__ spec, DftTabs<T> tabs, MixTab mix,
+                                                        const Cx<T>* __restrict__ twg, double* energies, int slot,
+                                                        long spec_tstride) {
+  const int H = (N - 1) / 2, Kh = N / 2 + 1, NCt = NC / NTP;
+  PairCx<T>* ab = reinterpret_cast<PairCx<T>*>(dft_smem);   // [H][NC]
+  Cx<T>* tw = reinterpret_cast<Cx<T>*>(ab + H * NC);          // [N]
+  Cx<T>* x0 = tw + N;                                         // [NC]
+  Cx<T>* xn = x0 + NC;                                        // [NC]
+  Cx<T>* S = xn + NC;                                         // [N][NC]
+  const int col0 = blockIdx.x * NCt;
+  const int ncp = min(NCt, ncols - col0);                     // physical columns of this workgroup
+  const long base = (long)blockIdx.y * fixstride + col0;
+  for (int t = threadIdx.x; t < N; t += kDftBlock) tw[t] = twg[t];
+  // the G values this thread applies after the forward transform (every channel's, both frequencies of its pair)
+  T Gp[KQ][3][2], G0[3] = {T(0), T(0), T(0)}, Gn[3] = {T(0), T(0), T(0)};
+#pragma unroll
+  for (int u = 0; u < KQ; ++u) {
+    const int t = threadIdx.x + u * kDftBlock;
+    const int jj = t / NCt, cc = t - jj * NCt;
+    const bool in = t < H * NCt && cc < ncp;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const bool on = in && ch < mix.nch;
+      Gp[u][ch][0] = on ? tabs.p[ch][base + (long)(1 + jj) * jstride + cc] : T(0);
+      Gp[u][ch][1] = on ? tabs.p[ch][base + (long)(N - 1 - jj) * jstride + cc] : T(0);
+    }
+  }
+  if ((int)threadIdx.x < ncp) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      if (ch < mix.nch) {
+        G0[ch] = tabs.p[ch][base + threadIdx.x];
+        if ((N & 1) == 0) Gn[ch] = tabs.p[ch][base + (long)(N / 2) * jstride + threadIdx.x];
+      }
+  }
+  // pair sums of the columns: virtual column vc = type * NCt + physical column
+  for (int t = threadIdx.x; t < H * NC; t += kDftBlock) {
+    const int jj = t / NC, vc = t - jj * NC, ty = vc / NCt, c = vc - ty * NCt;
+    PairCx<T> v{T(0), T(0), T(0), T(0)};
+    if (c < ncp && ty < mix.nt) {
+      const Cx<T>* sp = spec + (long)ty * spec_tstride + base + c;
+      const Cx<T> a = sp[(long)(1 + jj) * jstride], b = sp[(long)(N - 1 - jj) * jstride];
+      v = PairCx<T>{a.re + b.re, a.im + b.im, a.re - b.re, a.im - b.im};
+    }
+    ab[t] = v;
+  }
+  if ((int)threadIdx.x < NC) {
+    const int vc = threadIdx.x, ty = vc / NCt, c = vc - ty * NCt;
+    Cx<T> a{T(0), T(0)}, b{T(0), T(0)};
+    if (c < ncp && ty < mix.nt) {
+      const Cx<T>* sp = spec + (long)ty * spec_tstride + base + c;
+      a = sp[0];
+      if ((N & 1) == 0) b = sp[(long)(N / 2) * jstride];
+    }
+    x0[vc] = a;
+    xn[vc] = b;
+  }
+  __syncthreads();
+  int tid, half;
+  dft_task_of_thread<JS>(tid, half);
+  const int g = tid / NC, c = tid - g * NC;
+  const int cty = c / NCt, ccol = c - cty * NCt;
+  const bool task = g < TK && c < NC && ccol < ncp && cty < mix.nt;
+  int k[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) k[q] = (g + q * TK < Kh) ? g + q * TK : 0;
+  if (task) {
+    Cx<T> Xk[KQ], Xnk[KQ];
+    dft_pair_outputs_js<T, -1, KQ, JS>(N, k, NC, ab + c, x0[c], xn[c], tw, half, Xk, Xnk);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK;
+      if (kq < Kh) {
+        if (JS == 1 || half == 0) S[kq * NC + c] = Xk[q];
+        if ((JS == 1 || half == 1) && kq != 0 && 2 * kq != N) S[(N - kq) * NC + c] = Xnk[q];
+      }
+    }
+  }
+  __syncthreads();
+  double e = 0.0;
+  // one frequency of one physical column: combine the types (s: their spectra at it, in place -> psi), return the energy term
+  auto combine = [&](Cx<T>* s, const T* G) {
+    Cx<T> y[NTP];
+#pragma unroll
+    for (int ty = 0; ty < NTP; ++ty) y[ty] = Cx<T>{T(0), T(0)};
+    double en = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      if (ch >= mix.nch) break;
+      Cx<T> Sp{T(0), T(0)};
+#pragma unroll
+      for (int ty = 0; ty < NTP; ++ty) { const T cc = (T)mix.c[ch][ty]; Sp.re += cc * s[ty].re; Sp.im += cc * s[ty].im; }
+      en += (double)G[ch] * ((double)Sp.re * Sp.re + (double)Sp.im * Sp.im);
+#pragma unroll
+      for (int ty = 0; ty < NTP; ++ty) { const T cg = (T)mix.c[ch][ty] * G[ch]; y[ty].re += cg * Sp.re; y[ty].im += cg * Sp.im; }
+    }
+#pragma unroll
+    for (int ty = 0; ty < NTP; ++ty) s[ty] = y[ty];
+    return en;
+  };
+#pragma unroll
+  for (int u = 0; u < KQ; ++u) {
+    const int t = threadIdx.x + u * kDftBlock;
+    if (t >= H * NCt) continue;
+    const int jj = t / NCt, cc = t - jj * NCt;
+    Cx<T> s1[NTP], s2[NTP];
+#pragma unroll
+    for (int ty = 0; ty < NTP; ++ty) s1[ty] = s2[ty] = Cx<T>{T(0), T(0)};
+    if (cc < ncp) {
+      const int k1 = 1 + jj, k2 = N - 1 - jj, kz = col0 + cc;
+#pragma unroll
+      for (int ty = 0; ty < NTP; ++ty) { s1[ty] = S[k1 * NC + ty * NCt + cc]; s2[ty] = S[k2 * NC + ty * NCt + cc]; }
+      const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
+      const T G1[3] = {Gp[u][0][0], Gp[u][1][0], Gp[u][2][0]}, G2[3] = {Gp[u][0][1], Gp[u][1][1], Gp[u][2][1]};
+      e += w * (combine(s1, G1) + combine(s2, G2));
+    }
+#pragma unroll
+    for (int ty = 0; ty < NTP; ++ty)
+      ab[jj * NC + ty * NCt + cc] = PairCx<T>{s1[ty].re + s2[ty].re, s1[ty].im + s2[ty].im, s1[ty].re - s2[ty].re, s1[ty].im - s2[ty].im};
+  }
+  if ((int)threadIdx.x < NCt) {
+    const int cc = threadIdx.x;
+    Cx<T> a[NTP], b[NTP];
+#pragma unroll
+    for (int ty = 0; ty < NTP; ++ty) a[ty] = b[ty] = Cx<T>{T(0), T(0)};
+    if (cc < ncp) {
+      const int kz = col0 + cc;
+      const double w = (kz == 0 || ((K3 & 1) == 0 && kz == K3 / 2)) ? 0.5 : 1.0;
+#pragma unroll
+      for (int ty = 0; ty < NTP; ++ty) a[ty] = S[ty * NCt + cc];
+      e += w * combine(a, G0);
+      if ((N & 1) == 0) {
+#pragma unroll
+        for (int ty = 0; ty < NTP; ++ty) b[ty] = S[(N / 2) * NC + ty * NCt + cc];
+        e += w * combine(b, Gn);
+      }
+    }
+#pragma unroll
+    for (int ty = 0; ty < NTP; ++ty) { x0[ty * NCt + cc] = a[ty]; xn[ty * NCt + cc] = b[ty]; }
+  }
+  __syncthreads();
+  if (task) {
+    Cx<T> Xk[KQ], Xnk[KQ];
+    dft_pair_outputs_js<T, +1, KQ, JS>(N, k, NC, ab + c, x0[c], xn[c], tw, half, Xk, Xnk);
+    Cx<T>* sp = spec + (long)cty * spec_tstride + base + ccol;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int kq = g + q * TK;
+      if (kq < Kh) {
+        if (JS == 1 || half == 0) sp[(long)kq * jstride] = Xk[q];
+        if ((JS == 1 || half == 1) && kq != 0 && 2 * kq != N) sp[(long)(N - kq) * jstride] = Xnk[q];
+      }
+    }
+  }
+  e = block_reduce_sum<kDftBlock>(e);
+  if (threadIdx.x == 0) atomicAdd(&energies[slot], e);
+}
+
 // ---- z and y lines of one x plane in ONE workgroup (round 3) ------------------------------------------------------------
 // A pass of the chain above is 11-14 us of kernel for 1-2 us of f64 arithmetic at 97^3: ~4 us between the kernel's start and
 // its first block / its last block and its end, ~3 us of loads, ~1 us of stores, a 48-step dependent loop over < 2 waves per
@@ -721,6 +885,25 @@ void launch_dft_x_conv(hipStream_t st, const int K[3], const T* tw, T* spec, con
                                                              reinterpret_cast<const Cx<T>*>(tw), energies, slot,
                                                              spec_stride / 2)))
 }
+// x pass of the typed dispersion meshes: spec holds mix.nt type spectra, spec_stride (reals) apart
+template <class T>
+void launch_dft_x_mix(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, const MixTab& mix,
+                      long spec_stride, double* energies, int slot) {
+  const int N = K[0], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
+  const int ntp = mix.nt <= 1 ? 1 : (mix.nt == 2 ? 2 : 4);
+  int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + sizeof(Cx<T>) * (size_t)(2 + N), sizeof(Cx<T>) * (size_t)N);
+  NC -= NC % ntp;
+  if (NC < ntp) NC = ntp;
+  const int NCt = NC / ntp;
+  const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC + N * NC);
+  const dim3 grid((Kh + NCt - 1) / NCt, K[1], 1);
+#define XMIX(NTP)                                                                                                          \
+  k_dft_x_mix<T, 2, 1, NTP><<<grid, kDftBlock, sh, st>>>(N, Kh, NC, TK, (long)K[1] * Kh, (long)Kh, K[2],                    \
+                                                         reinterpret_cast<Cx<T>*>(spec), tabs, mix,                        \
+                                                         reinterpret_cast<const Cx<T>*>(tw), energies, slot, spec_stride / 2)
+  if (ntp == 1) XMIX(1); else if (ntp == 2) XMIX(2); else XMIX(4);
+#undef XMIX
+}
 // the two plane kernels in place of launch_dft_z + launch_dft_y (forward) / launch_dft_y + launch_dft_z (inverse)
 template <class T>
 bool dft_zy_fits(const int K[3]) {
@@ -770,7 +953,8 @@ bool launch_dft_zy(hipStream_t st, const int K[3], const T* tw, T* mesh, T* spec
   template bool launch_dft_zy<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*, const PlaneSpread<T>*); \
   template bool launch_dft_z<T>(hipStream_t, const int*, const T*, T*, T*, int, int, long, long, T*); \
   template void launch_dft_y<T>(hipStream_t, const int*, const T*, T*, int, int, long);           \
-  template void launch_dft_x_conv<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long);
+  template void launch_dft_x_conv<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int, int, long); \
+  template void launch_dft_x_mix<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, const MixTab&, long, double*, int);
 INST(float)
 INST(double)
 #undef INST

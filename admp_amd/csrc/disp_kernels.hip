@@ -300,6 +300,34 @@ template <class T>
 void launch_types_check(hipStream_t st, int na, const T* vals, int stride, const int* types, const MixTab& mix, double* bad) {
   if (na > 0) k_types_check<T><<<(na + 255) / 256, 256, 0, st>>>(na, vals, stride, types, mix, bad);
 }
+template <class T>
+__global__ __launch_bounds__(256) void k_onehot(int na, int nt, const int* __restrict__ types, T* __restrict__ w) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= na) return;
+  const int ty = types[i];
+  for (int t = 0; t < nt; ++t) w[(long)nt * i + t] = t == ty ? T(1) : T(0);
+}
+// atoms per type (once per type table: the self term of the typed form is a sum over types, formed on the host)
+__global__ __launch_bounds__(256) void k_type_counts(int na, const int* __restrict__ types, int* __restrict__ counts) {
+  __shared__ int c[4];
+  if (threadIdx.x < 4) c[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) {
+    const int ty = types[i];
+    if (ty >= 0 && ty < 4) atomicAdd(&c[ty], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], c[threadIdx.x]);
+}
+void launch_type_counts(hipStream_t st, int na, const int* types, int* counts4) {
+  int blocks = (na + 2047) / 2048;
+  if (blocks > 256) blocks = 256;
+  if (na > 0) k_type_counts<<<blocks, 256, 0, st>>>(na, types, counts4);
+}
+template <class T>
+void launch_onehot(hipStream_t st, int na, int nt, const int* types, T* w) {
+  if (na > 0) k_onehot<T><<<(na + 255) / 256, 256, 0, st>>>(na, nt, types, w);
+}
 // nt = 1..3 type meshes (single precision: three 17 KB tiles per workgroup)
 template <class T>
 int launch_spread_typed(hipStream_t st, int nt, const T* pos, const int* types, const RecipGeom<T>& g, const BinScratch& bs,
@@ -539,6 +567,7 @@ void launch_gather_value(hipStream_t st, int na, const T* pos, const T* vals, in
   template int launch_spread_typed<T>(hipStream_t, int, const T*, const int*, const RecipGeom<T>&, const BinScratch&, T*, \
                                       long);                                                                             \
   template void launch_types_check<T>(hipStream_t, int, const T*, int, const int*, const MixTab&, double*);              \
+  template void launch_onehot<T>(hipStream_t, int, int, const int*, T*);                                                  \
   template void launch_interleave<T>(hipStream_t, int, long, const T*, long, T*);                                        \
   template void launch_scalar_self<T>(hipStream_t, int, int, const T*, int, const int*, const double*, double*);         \
   template void launch_gather_value<T>(hipStream_t, int, const T*, const T*, int, int, const RecipGeom<T>&, const T*,     \

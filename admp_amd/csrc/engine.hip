@@ -549,6 +549,8 @@ struct Engine : EngineBase {
   int planK[3] = {0, 0, 0}, planR = 0, planRank = 0;
   DevBuf home_list;
   DevBuf act_tmp;
+  DevBuf onehot_d, tcount_d;     // typed dispersion of small systems: (Na, n_types) one-hot weights; scratch of the type counts
+  void* onehot_for = nullptr;    // ... built in this allocation
   DevBuf act_d, isites, mesh2;   // incremental SCF: polarizable-site list, their compact delta rows, the increment's mesh
   IndTable ind;                  // ... and the polarizable-polarizable part of the neighbour table
   long act_gen = 0, act_top_na = -1;   // act_gen: bumped when the list is rebuilt; the list belongs to a topology of act_top_na atoms
@@ -585,7 +587,7 @@ struct Engine : EngineBase {
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
                       &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp,
-                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw, &bin_cells_ind, &bin_sorted_ind, &srow_d})
+                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw, &bin_cells_ind, &bin_sorted_ind, &srow_d, &onehot_d, &tcount_d})
       b->release();
     free_topology();
     if (ind.end) (void)hipFree(ind.end);
@@ -2384,12 +2386,33 @@ struct Engine : EngineBase {
   // every call that uses it.  nt = 0: forget.
   int disp_nt = 0;
   const int* disp_types = nullptr;
+  bool disp_counts_ok = false, disp_onehot_ok = false;      // per type table: atoms per type (host), one-hot weights (device)
+  double disp_counts[4] = {0, 0, 0, 0};
+  // self term of the typed form: sum_p kp[p] sum_t n_t c_p,t^2 (admp/disp_pme.py:254-279 summed by type)
+  double typed_self_energy(int na, int nch, const double* kp) {
+    if (!disp_counts_ok) {
+      tcount_d.need(256);
+      int* cd = reinterpret_cast<int*>(tcount_d.p);
+      int ch[4];
+      HIP_TRY(hipMemsetAsync(cd, 0, 4 * sizeof(int), stream));
+      launch_type_counts(stream, na, disp_types, cd);
+      HIP_TRY(hipMemcpyAsync(ch, cd, sizeof(ch), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      for (int t = 0; t < 4; ++t) disp_counts[t] = (double)ch[t];
+      disp_counts_ok = true;
+    }
+    double e = 0.0;
+    for (int p = 0; p < nch; ++p)
+      for (int t = 0; t < disp_nt; ++t) e += kp[p] * disp_counts[t] * disp_ctab[t][p] * disp_ctab[t][p];
+    return e;
+  }
   double disp_ctab[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   void disp_set_types(int nt, const void* types, const double* ctab) override {
     if (nt <= 0 || !types || !ctab) { disp_nt = 0; disp_types = nullptr; return; }
     ARG_CHECK(nt <= 3, "admp_disp_set_types: at most 3 types");
     disp_nt = nt;
     disp_types = reinterpret_cast<const int*>(types);
+    disp_counts_ok = disp_onehot_ok = false;
     for (int t = 0; t < nt; ++t)
       for (int c = 0; c < 3; ++c) disp_ctab[t][c] = ctab[3 * t + c];
   }
@@ -2440,7 +2463,7 @@ struct Engine : EngineBase {
         MixTab mix;
         mix.nch = nch; mix.nt = nt;
         for (int c = 0; c < 3; ++c)
-          for (int t = 0; t < 4; ++t) mix.c[c][t] = (c < nch && t < nt) ? (float)disp_ctab[t][c] : 0.f;
+          for (int t = 0; t < 4; ++t) mix.c[c][t] = (c < nch && t < nt) ? disp_ctab[t][c] : 0.0;
         launch_types_check<T>(stream, na, cl, 3, disp_types, mix, Ed + E_FMAX);
         const size_t nspec = 2 * (size_t)K[0] * K[1] * fx_khp;
         mesh.need((size_t)std::max(nt, nch) * nreal * sizeof(T));
@@ -2459,8 +2482,9 @@ struct Engine : EngineBase {
         run_plan("rocfft_c2r_yz", nt >= 2 ? plan2n_b[nt] : plan2_b, spec.p, mesh.p);
         { TIMED("gather_field");
           launch_gather_scalar<T>(stream, 1, sr.n, pos, cl, 3, g, mesh.as<T>(), (long)nreal, dpos, sr.home, 0, disp_types); }
-        { TIMED("scalar_self"); launch_scalar_self<T>(stream, nch, sr.n, cl, 3, sr.home, kp, Ed); }
+        const double e_self = typed_self_energy(na, nch, kp);
         read_scalar_energies(Ed, E, 3, true);
+        E[2] = e_self;
         if (dpos_ && !on_device) {
           HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
           HIP_TRY(hipStreamSynchronize(stream));
@@ -2513,6 +2537,54 @@ struct Engine : EngineBase {
     ensure_bins(na);
     RecipGeom<T> gj = g;                       // scalar sites: dE/dr = c * Jac . F1 (gather_field applies g.Aop)
     for (int k = 0; k < 9; ++k) gj.Aop[k] = g.Jac[k];
+    // Typed meshes on a direct-DFT mesh (small systems; see admp_disp_set_types): the types take the place of the powers in the
+    // batch -- one-hot weights through the same site / spread / gather kernels, the x pass combines (dft_kernels.hip k_dft_x_mix)
+    static const bool typed_small_on = [] { const char* e = getenv("ADMP_DISP_TYPES"); return !(e && atoi(e) == 0); }();
+    if (typed_small_on && disp_nt >= 1 && disp_nt < nch && disp_types && use_dft && !use_pfa && snranks == 1 &&
+        !spread_uses_bricks(na, g)) {
+      const int nt = disp_nt;
+      MixTab mix;
+      mix.nch = nch; mix.nt = nt;
+      for (int c = 0; c < 3; ++c)
+        for (int t = 0; t < 4; ++t) mix.c[c][t] = (c < nch && t < nt) ? disp_ctab[t][c] : 0.0;
+      launch_types_check<T>(stream, na, cl, 3, disp_types, mix, Ed + E_FMAX);
+      const size_t nreal = (size_t)K[0] * K[1] * K[2], nspec = 2 * (size_t)K[0] * K[1] * (K[2] / 2 + 1);
+      mesh.need(nt * nreal * sizeof(T));
+      spec.need(nt * nspec * sizeof(T));
+      sites.need(sizeof(Site<T>) * (size_t)na * nt);
+      fld_recip.need(3 * (size_t)na * sizeof(T) * nt);
+      onehot_d.need((size_t)na * nt * sizeof(T));
+      bases_d.need(sizeof(int4) * (size_t)na);
+      DftTabs<T> tabs;
+      for (int c = 0; c < nch; ++c) { ensure_gtab(box, inv, vol, 6 + 2 * c); tabs.p[c] = gtab_cur; }
+      const double no_self[3] = {0.0, 0.0, 0.0};
+      { TIMED("scalar_sites");
+        if (!disp_onehot_ok || onehot_for != onehot_d.p) {
+          launch_onehot<T>(stream, na, nt, disp_types, onehot_d.as<T>());
+          disp_onehot_ok = true; onehot_for = onehot_d.p;
+        }
+        launch_scalar_sites_batch<T>(stream, na, pos, onehot_d.as<T>(), nt, nt, no_self, sites.as<Site<T>>(), Ed, &g,
+                                     bases_d.as<int4>()); }
+      { TIMED("spread");
+        int rc = launch_spread<T>(stream, na, sites.as<Site<T>>(), 0, g, bins, mesh.as<T>(), nullptr, bases_d.as<int4>(), nt);
+        if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)}; }
+      const T* tw = dft_tw.as<T>();
+      { TIMED("dft_z_r2c"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 0, nt, (long)nreal, (long)nspec); }
+      { TIMED("dft_y_fwd"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 0, nt, (long)nspec); }
+      { TIMED("dft_x_kspace"); launch_dft_x_mix<T>(stream, K, tw, spec.as<T>(), tabs, mix, (long)nspec, Ed, E_RECIP); }
+      { TIMED("dft_y_inv"); launch_dft_y<T>(stream, K, tw, spec.as<T>(), 1, nt, (long)nspec); }
+      { TIMED("dft_z_c2r"); launch_dft_z<T>(stream, K, tw, mesh.as<T>(), spec.as<T>(), 1, nt, (long)nreal, (long)nspec); }
+      { TIMED("gather_field"); launch_gather_field<T>(stream, na, sites.as<Site<T>>(), gj, mesh.as<T>(), fld_recip.as<T>(), nullptr, nt); }
+      { TIMED("scale_add"); launch_scale_add<T>(stream, na, onehot_d.as<T>(), nt, 0, fld_recip.as<T>(), dpos, nt); }
+      const double e_self = typed_self_energy(na, nch, kp);
+      read_scalar_energies(Ed, E, 3, true);
+      E[2] = e_self;
+      if (dpos_ && !on_device) {
+        HIP_TRY(hipMemcpyAsync(dpos_, dpos, 3 * (size_t)na * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+      }
+      return;
+    }
     if ((use_dft || use_pfa) && nch > 1) {
       // direct-DFT meshes are small and dispatch bound: the powers are spread into separate meshes and transformed
       // as ONE batch (5 launches instead of 5 per power); gather per power from its own mesh

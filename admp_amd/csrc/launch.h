@@ -457,7 +457,15 @@ int launch_spread_typed(hipStream_t st, int nt, const T* pos, const int* types, 
                         T* mesh, long mesh_stride);
 // x pass of the typed form (fftx_kernels.hip k_fftx_mix): spec holds nt type meshes; at every k the channel structure
 // factors S_p = sum_t ctab[p][t] S_t are formed, E += w G_p |S_p|^2, and the types get back psi_t = sum_p ctab[p][t] G_p S_p
-struct MixTab { float c[3][4]; int nch, nt; };
+struct MixTab { double c[3][4]; int nch, nt; };      // c[power][type]; columns of unused (padding) types are zero
+// direct-DFT meshes (dft_kernels.hip k_dft_x_mix): the same combination between the forward and inverse x lines
+template <class T>
+void launch_dft_x_mix(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, const MixTab& mix,
+                      long spec_stride, double* energies, int slot);
+// w[i][t] = (types[i] == t): the typed form through the kernels that take per-atom weights (small systems)
+void launch_type_counts(hipStream_t st, int na, const int* types, int* counts4 /* zeroed by the caller */);
+template <class T>
+void launch_onehot(hipStream_t st, int na, int nt, const int* types, T* w);
 template <class T>
 void launch_types_check(hipStream_t st, int na, const T* vals, int stride, const int* types, const MixTab& mix, double* bad);
 template <class T>

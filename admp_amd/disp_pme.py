@@ -95,7 +95,7 @@ class ADMPDispPmeForce(HipForceBase):
         a caller who hands in new coefficients every call, e.g. while fitting them, gets the per-power path)."""
         misses = getattr(self, '_type_misses', 0)
         types = None
-        if c3 is not None and self._dtype == torch.float32 and misses < 3 and settings.DISP_TYPED_MESHES:
+        if c3 is not None and misses < 3 and settings.DISP_TYPED_MESHES:
             rows, inv = torch.unique(c3, dim=0, return_inverse=True)
             if rows.shape[0] <= 3:
                 types = (inv.to(torch.int32).contiguous(), rows.double().cpu().numpy())

@@ -210,7 +210,7 @@ for prec, tol in (('double', 1e-9), ('single', 5e-4)):
             for rep in range(2):                        # (second call: the cached coefficient tensor and its type table)
                 E, G = dd.get_forces(pos, box, pairs, ct, par['mScales'])
             used = getattr(dd, '_types', None) is not None
-            assert used == (typed and prec == 'single' and label != '4 types'), (prec, label, typed, used)
+            assert used == (typed and label != '4 types'), (prec, label, typed, used)      # (double: the table is set, the brick path keeps the powers)
             assert abs(E - dref['E']) < tol * max(abs(p) for p in dref['parts']) and rel(np.asarray(G), dref['grad']) < max(tol, 1e-8), (prec, label, typed)
             res[typed] = (E, np.asarray(G), dd.energy_parts)
         settings.DISP_TYPED_MESHES = True
@@ -267,6 +267,14 @@ for prec in ('double', 'single'):
         key = '%%s_%%d_%%d_%%d' %% ((prec,) + (f.K1, f.K2, f.K3))
         out[key + '_parts'] = np.asarray(f.energy_parts); out[key + '_G'] = np.asarray(G); out[key + '_U'] = np.asarray(f.U_ind)
         out[key + '_dparts'] = np.asarray(d.energy_parts); out[key + '_Gd'] = np.asarray(Gd)
+        # the same coefficients as ONE device tensor: the wrapper finds the two atom types of water and the direct-DFT modes
+        # transform one mesh per type instead of one per power (typed meshes, round 4; rocFFT meshes of this size keep the powers)
+        import torch
+        ct = torch.as_tensor(np.asarray(par['c_list']), dtype=torch.float64 if prec == 'double' else torch.float32, device='cuda')
+        for rep in range(2):
+            Et, Gt = d.get_forces(pos, box, pairs, ct, par['mScales'])
+        out[key + '_tparts'] = np.asarray(d.energy_parts); out[key + '_Gt'] = np.asarray(Gt)
+        out[key + '_typed'] = np.asarray([1.0 if getattr(d, '_types', None) is not None else 0.0])
 # a denser case for the spread that the forward plane kernel does itself (double precision, dft_kernels.hip zy_plane_spread):
 # 4500 atoms on 31 x planes = ~870 kept atoms per plane (several staging sub-rounds) and two scan rounds of 3072 atoms
 settings.PRECISION = 'double'
@@ -304,8 +312,10 @@ print('DFT-RUN-OK')
                            env=dict(os.environ, **extra), timeout=900)
         assert r.returncode == 0 and 'DFT-RUN-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
         res[mode] = dict(np.load(path))
-    assert len(res['rocfft']) == 2 * 4 * 5 + 4 + 3
+    assert len(res['rocfft']) == 2 * 4 * 8 + 4 + 3
     for key, a in res['rocfft'].items():
+        if key.endswith('_typed'):
+            continue
         for mode in ('dft', 'dft_passes', 'dft_nospread', 'pfa'):
             b = res[mode][key]
             tol = 1e-10 if key.startswith('double') else 2e-4
