@@ -1393,9 +1393,14 @@ struct Engine : EngineBase {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_busy = false;
+  // ... and from which it is done (ADMP_OVERLAP_MIN, default 4096): the fork + join cost ~12 us of the main chain, what they hide
+  // is the pair kernels -- 15 us at 3072 atoms (round 4, after the chain lost its spread and closing kernels: 0.1893 ms per
+  // step on one stream against 0.1929 with the side stream, and a third of the run-to-run spread), 30 us at 6144 atoms
+  // (0.241 against 0.261 ms), more above.
   bool overlap_ok() const {
     static const int mx = [] { const char* e = getenv("ADMP_OVERLAP_MAX"); return e ? atoi(e) : 200000; }();
-    return side_stream_on && snranks == 1 && top.na <= mx;
+    static const int mn = [] { const char* e = getenv("ADMP_OVERLAP_MIN"); return e ? atoi(e) : 4096; }();
+    return side_stream_on && snranks == 1 && top.na <= mx && top.na >= mn;
   }
   // An exception between on_side() and join_side() (a failed launch, a refused argument further down the call) would leave
   // kernels of this call running on the side stream with nobody waiting for them -- the next call would race them on the

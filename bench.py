@@ -292,11 +292,11 @@ def roofline_of(rep, w, n_pairs, rep_serial=None, share=1.0):
     (bytes per pair x pairs) / average launch duration, against the HBM peak; `traffic` = measured HBM bytes per
     launch (rocprofv3 PMC passes of this command, profiles/pmc_traffic.json).
 
-    Launch duration: HIP events around every launch.  On systems that run this kernel on a SIDE stream next to the mesh
-    chain (<= 200 000 atoms) the events of the timed region bracket a kernel that shares the chip -- not its duration -- so
-    the figure is taken from `rep_serial`, the breakdown pass right after the timed region with the side stream off (same
-    process, same frames); the timed region's own figure is kept as `avg_launch_us_timed_region`.  Above that size the kernel
-    runs alone and the timed region's events are used.
+    Launch duration: HIP events around every launch.  Up to 200 000 atoms the figure is taken from `rep_serial`, the breakdown
+    pass right after the timed region (same process, same frames, side stream off): between 4096 and 200 000 atoms the kernel
+    runs on a SIDE stream next to the mesh chain, so events in the timed region would bracket a kernel that shares the chip;
+    below 4096 atoms (one stream) two event records per launch cost 6 % of a 0.19 ms step, so the timed region carries none and
+    the pass after it measures the same launches.  Above 200 000 atoms the timed region's own events are used.
 
     The byte model is not the kernel's limiter (its partner rows come from L2 / MALL: measured traffic is a quarter of the
     algorithmic bytes, and at 1M atoms the algorithmic rate exceeds what HBM can deliver); `valu_view` gives the view that
@@ -307,8 +307,9 @@ def roofline_of(rep, w, n_pairs, rep_serial=None, share=1.0):
     total, per_pair = pair_kernel_bytes(n_pairs, n_atoms, wbytes, True)
     total *= share
     ms_t, cnt_t = rep.get('pair_full', (0.0, 0)) if rep else (0.0, 0)
-    concurrent = n_atoms <= int(os.environ.get('ADMP_OVERLAP_MAX', '200000')) and share == 1.0
-    src = rep_serial if (concurrent and rep_serial and rep_serial.get('pair_full', (0, 0))[1]) else rep
+    quiet = n_atoms <= int(os.environ.get('ADMP_OVERLAP_MAX', '200000')) and share == 1.0      # no events in the timed region
+    concurrent = quiet and n_atoms >= int(os.environ.get('ADMP_OVERLAP_MIN', '4096'))           # ... because of the side stream
+    src = rep_serial if (quiet and rep_serial and rep_serial.get('pair_full', (0, 0))[1]) else rep
     ms, cnt = src.get('pair_full', (0.0, 0)) if src else (0.0, 0)
     avg_s = (ms / cnt) * 1e-3 if cnt else float('nan')
     alg = total / avg_s / 1e9 if cnt else float('nan')
@@ -327,14 +328,20 @@ def roofline_of(rep, w, n_pairs, rep_serial=None, share=1.0):
     out = {'kernel': 'k_pair_full', 'bound': 'hbm', 'achieved': round(alg, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
            'frac': round(alg / HBM_PEAK_GBS, 5), 'traffic': traffic,
            'avg_launch_us': round(avg_s * 1e6, 2), 'launches': int(cnt),
-           'launch_time_source': ('HIP events, breakdown pass with the side stream off (the kernel shares the chip in the timed '
-                                  'region)' if src is rep_serial and src is not rep else 'HIP events over the timed region'),
+           'launch_time_source': (('HIP events, breakdown pass with the side stream off (the kernel shares the chip in the timed '
+                                   'region)' if concurrent else
+                                   'HIP events, breakdown pass right after the timed region (same single stream; two event '
+                                   'records per launch inside the timed region cost 6 % of a step of this dispatch-bound workload)')
+                                  if src is rep_serial and src is not rep else 'HIP events over the timed region'),
            'algorithmic_bytes_per_launch': int(total), 'bytes_per_pair': round(per_pair, 2),
            'note': 'achieved = algorithmic bytes / launch time (contract); the kernel is not HBM-bound: see traffic, valu_view'}
-    if concurrent and cnt_t:
+    if quiet and cnt_t:
         out['avg_launch_us_timed_region'] = round(ms_t / cnt_t * 1e3, 2)
     if concurrent:
         out['timed_region'] = 'no events inside the timed region: this kernel runs on a side stream next to the mesh chain there'
+    elif quiet:
+        out['timed_region'] = 'no events inside the timed region (they cost 6 % of a step here); one stream, as in the breakdown pass'
+
 
     if share != 1.0:
         out['pair_share_of_this_rank'] = round(share, 5)
@@ -746,6 +753,8 @@ def main():
 
     # events around the roofline kernel inside the timed region only where they measure its duration (it runs alone above
     # 200 000 atoms); below, the kernel shares the chip with the mesh chain and is timed in the breakdown pass instead
+    # (up to 200 000 atoms the timed region carries no events: from 4096 atoms on the kernel runs on a side stream next to the
+    # mesh chain, and below that two event records per launch cost 6 % of a 0.19 ms step -- 0.2046 against 0.1925 ms at S1)
     side = n_atoms <= int(os.environ.get('ADMP_OVERLAP_MAX', '200000'))
     dt, rep, cyc = run_timed(f, a, opt.steps, opt.warmup, frames, only=False if side else 'pair_full')
     t_step = dt / opt.steps
