@@ -177,7 +177,8 @@ class HipForceBase:
 
     @staticmethod
     def _ptr(t):
-        return None if t is None else ctypes.c_void_p(t.data_ptr())
+        # (a plain int: ctypes converts it for a c_void_p parameter; building a c_void_p object per pointer costs 0.2 us each)
+        return None if t is None else t.data_ptr()
 
     # ---- pair list -----------------------------------------------------------------------------------------
     def _pairs_fingerprint(self, pairs):
