@@ -1003,11 +1003,17 @@ struct Engine : EngineBase {
     sp.na = n; sp.lpol = lp; sp.sites = rows; sp.bases = bases; sp.g = ev.g;
     return sp;
   }
+  // rider: an SCF field kernel whose workgroups run inside the x pass (pair_kernels.hip k_xconv_pair; direct-DFT meshes only)
+  bool rider_ok() const {
+    static const bool on = [] { const char* e = getenv("ADMP_FIELD_RIDER"); return !(e && atoi(e) == 0); }();
+    return on && use_dft && !use_pfa && snranks == 1 && !overlap_ok();
+  }
   bool convolve(T* mesh_p, T* spec_p, const T* gtab, int slot, T* accum = nullptr, T* out = nullptr,
-                const PlaneSpread<T>* sp = nullptr) {
+                const PlaneSpread<T>* sp = nullptr, const FieldRider<T>* rider = nullptr) {
     double* Ed = Ed_cur();
     T* mesh_o = out ? out : mesh_p;
     ARG_CHECK(!sp || (use_dft && !use_pfa && snranks == 1), "internal: plane spread on a transform path without it");
+    ARG_CHECK(!(rider && rider->kind) || (use_dft && !use_pfa && snranks == 1), "internal: field rider on a transform path without it");
     if (snranks > 1) {
       // x-slab ranks: the stencils of the home atoms overhang into kGhost planes of the next rank (added there before the
       // transform), the 3-D transform is batched 2-D r2c on the owned planes -> transpose (all-to-all over the ranks: every
@@ -1061,7 +1067,8 @@ struct Engine : EngineBase {
       }
       DftTabs<T> tabs;
       tabs.p[0] = gtab;
-      { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec_p, tabs, Ed, slot); }
+      if (rider && rider->kind) { TIMED("dft_x_kspace"); launch_dft_x_conv_rider<T>(stream, K, tw, spec_p, tabs, Ed, slot, *rider); }
+      else { TIMED("dft_x_kspace"); launch_dft_x_conv<T>(stream, K, tw, spec_p, tabs, Ed, slot); }
       bool added;
       if (planes) { TIMED("dft_yz_inv"); added = launch_dft_zy<T>(stream, K, tw, mesh_p, spec_p, 1, 1, 0, 0, accum); }
       else {
@@ -1620,12 +1627,15 @@ struct Engine : EngineBase {
       return;
     }
     const bool first = side_first();
+    FieldRider<T> fr;      // (filled below, once the sub-table is current: the field kernel then rides in the x pass)
+    bool ride = false;
     auto side_work = [&] {
-      on_side([&] {
-        TIMED("pair_field_ind");
-        launch_pair_field_ind<T>(stream, n_act, ind, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
-                                 act_list());
-      });
+      if (!ride)
+        on_side([&] {
+          TIMED("pair_field_ind");
+          launch_pair_field_ind<T>(stream, n_act, ind, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
+                                   act_list());
+        });
       if (extra_side) on_side(extra_side);
     };
     if (ind_nbr_gen != nbr_gen || ind_act_gen != act_gen) {      // neighbour table or polarizable set changed
@@ -1634,6 +1644,8 @@ struct Engine : EngineBase {
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("build_ind_table: ") + hipGetErrorString((hipError_t)rc)};
       ind_nbr_gen = nbr_gen; ind_act_gen = act_gen;
     }
+    ride = rider_ok() && field_rider_ind<T>(fr, n_act, ind, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(),
+                                            act_list());
     if (first) side_work();
     const size_t nreal = nreal_local();
     mesh2.need(nreal * sizeof(T));
@@ -1651,7 +1663,8 @@ struct Engine : EngineBase {
       if (rc != 0) throw Err{ADMP_E_HIP, std::string("launch_spread: ") + hipGetErrorString((hipError_t)rc)}; }
     if (!first && !fused) side_work();
     const PlaneSpread<T> sp = plane_spread(n_act, isites.as<Site<T>>(), 1, nullptr);
-    const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>(), nullptr, fused ? &sp : nullptr);
+    const bool added = convolve(mesh2.as<T>(), spec.as<T>(), gtab_cur, E_SCRATCH, mesh.as<T>(), nullptr, fused ? &sp : nullptr,
+                                ride ? &fr : nullptr);
     join_side();
     if (!field_from_total_phi) {
       TIMED("gather_field_ind");
@@ -1703,7 +1716,7 @@ struct Engine : EngineBase {
   // evaluation); behind the spread it is hidden by a running kernel and the side kernels still have the three transform
   // passes to hide behind (side_first()).
   template <class F>
-  void recip_pass(int slot, F&& side_work) {
+  void recip_pass(int slot, F&& side_work, const FieldRider<T>* rider = nullptr) {
     need_eval();
     const bool fused = spread_fused(ev.n_home);      // the forward transform spreads (dft_kernels.hip, zy_plane_spread)
     const bool first = side_first() || fused;
@@ -1713,9 +1726,23 @@ struct Engine : EngineBase {
     if (!slot_clean[slot]) HIP_TRY(hipMemsetAsync(Ed_cur() + slot, 0, sizeof(double), stream));
     slot_clean[slot] = false;
     const PlaneSpread<T> sp = plane_spread(ev.n_home, sites.as<Site<T>>(), lpol, ev.bases);
-    convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, slot, nullptr, nullptr, fused ? &sp : nullptr);
+    convolve(mesh.as<T>(), spec.as<T>(), gtab_cur, slot, nullptr, nullptr, fused ? &sp : nullptr, rider);
   }
   void recip_pass(int slot) { recip_pass(slot, [] {}); }
+  // first field evaluation of a call: the mesh chain and the real-space field of all partners -- on the side stream, or (small
+  // systems, one stream, direct-DFT mesh) with the field kernel's workgroups inside the x pass
+  void recip_pass_first_field(int slot) {
+    FieldRider<T> fr;
+    if (rider_ok()) {
+      check_mono_inputs(true);
+      if (field_rider_full<T>(fr, nact_rows(), nbr, sites.as<Site<T>>(), ev.bx, ev.tab, (T)kappa, fld_pair.as<T>(), act_list(),
+                              nact_arg(), cls_flags_dev(), rq_d.as<RQ4<T>>(), ev.thole)) {
+        recip_pass(slot, [] {}, &fr);
+        return;
+      }
+    }
+    recip_pass(slot, [&] { on_side([&] { first_pair_field(); }); });
+  }
 
   void pme(const void* pos_, const double* box, const void* Ql_, const void* pol_, const void* thole_, int ns,
            const double* mS, const double* pS, void* U_, int max_cycle, double thresh, double* E, void* dpos_,
@@ -1801,7 +1828,7 @@ struct Engine : EngineBase {
       ++scf_stats[chain ? 3 : (speculate ? 1 : 0)];
       if (chain) {
         n_act = nact_known();
-        recip_pass(E_SCF_RECIP, [&] { on_side([&] { first_pair_field(); }); });
+        recip_pass_first_field(E_SCF_RECIP);
         auto word = [&](int k) {      // residual of check k: E_FMAX, then the (still zero) chain words of this evaluation
           return k == 0 ? fmax_word() : reinterpret_cast<unsigned long long*>(Ed_cur() + E_FMAX1 + (k - 1));
         };
@@ -1889,7 +1916,7 @@ struct Engine : EngineBase {
       }
       for (; !done && i < max_cycle; ++i) {     // admp/pme.py:132-138
         if (!have_base) {        // first field evaluation of the call: everything, at the polarizable sites
-          recip_pass(E_SCF_RECIP, [&] { on_side([&] { first_pair_field(); }); });
+          recip_pass_first_field(E_SCF_RECIP);
           unsigned long long* w = fuse_ok() ? next_check_word() : nullptr;
           first_gather_field(field_epilogue(w));
           have_base = true;

@@ -284,6 +284,36 @@ struct IndTable {
 template <class T>
 void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const Site<T>* sites, const Box<T>& box,
                            const ScaleTab<T>& tab, T kappa, T* fld_pair, const int* rows);
+// An SCF field kernel riding in the x pass of a direct-DFT convolution (pair_kernels.hip k_xconv_pair): kind 1 = k_pair_field
+// (rowptr / col of the neighbour table), 2 = k_pair_field_ind (rowptr / rowend / col of the polarizable sub-table)
+template <class T>
+struct FieldRider {
+  int kind = 0, na = 0;
+  const int* rowptr = nullptr;
+  const int* rowend = nullptr;
+  const int* col = nullptr;
+  const Site<T>* sites = nullptr;
+  Box<T> box;
+  ScaleTab<T> tab;
+  T kappa = 0;
+  T* fld = nullptr;
+  const int* rows = nullptr;
+  unsigned nblocks = 0, grid = 0;
+  const int* n_dev = nullptr;
+  const int* cls_flags = nullptr;
+  const RQ4<T>* rq = nullptr;
+  const T* tholes = nullptr;
+};
+template <class T>
+bool field_rider_full(FieldRider<T>& r, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                      const ScaleTab<T>& tab, T kappa, T* fld, const int* rows, const int* n_dev, const int* cls_flags,
+                      const RQ4<T>* rq, const T* tholes);
+template <class T>
+bool field_rider_ind(FieldRider<T>& r, int n_rows, const IndTable& it, const Site<T>* sites, const Box<T>& box,
+                     const ScaleTab<T>& tab, T kappa, T* fld, const int* rows);
+template <class T>
+void launch_dft_x_conv_rider(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
+                             int slot, const FieldRider<T>& fr);
 // (nbr_kernels.hip) ascending in-place sort of n ints; keys_tmp = n ints of scratch.  hipError_t as int.
 int sort_ints(hipStream_t st, int* keys, int* keys_tmp, int n, void** scratch, size_t* scratch_bytes);
 // (nbr_kernels.hip) it <- the polarizable-polarizable entries of nb; rows keyed by atom, empty for non-polarizable atoms.

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "disp_math.h"
+#include "dft_lines.h"
 #include "launch.h"
 #include "reduce.h"
 
@@ -149,22 +150,22 @@ __global__ __launch_bounds__(kFullBlock, MINW) void k_pair_full(int na, const in
   if (threadIdx.x == 0) atomicAdd(&energies[E_RPARTS + (blockIdx.x & (E_PARTS - 1))], 0.5 * e);
 }
 
+// (bid: the workgroup's index in a launch of its own -- blockIdx.x of k_pair_field, or its rank among the field workgroups
+// that ride in an x pass of the mesh convolution, k_xconv_pair below)
 template <class T, int LPR>
-__global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __restrict__ rowptr,
-                                                           const int* __restrict__ col,
-                                                           const Site<T>* __restrict__ sites, Box<T> box,
-                                                           ScaleTab<T> tab, T kappa, T* __restrict__ fld,
-                                                           const int* __restrict__ rows, unsigned nblocks,
-                                                           const int* __restrict__ n_dev,
-                                                           const int* __restrict__ cls_flags,
-                                                           const RQ4<T>* __restrict__ rq, const T* __restrict__ tholes) {
+__device__ __forceinline__ void pair_field_block(unsigned bid, int na, const int* __restrict__ rowptr,
+                                                 const int* __restrict__ col, const Site<T>* __restrict__ sites,
+                                                 const Box<T>& box, const ScaleTab<T>& tab, T kappa, T* __restrict__ fld,
+                                                 const int* __restrict__ rows, unsigned nblocks, const int* __restrict__ n_dev,
+                                                 const int* __restrict__ cls_flags, const RQ4<T>* __restrict__ rq,
+                                                 const T* __restrict__ tholes) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   if (n_dev) {                              // row count known on the device only (the polarizable-site list of this call):
     na = min(na, *n_dev);                   // re-derive the XCD block ranges from it, or only the first XCDs would get rows
     nblocks = (unsigned)(((long)na * LPR + kPairBlock - 1) / kPairBlock);
   }
-  const long blk = xcd_block(blockIdx.x, nblocks);
+  const long blk = xcd_block(bid, nblocks);
   const long t = (blk < 0 ? (long)na * LPR : blk * kPairBlock) + threadIdx.x;
   const int slot = (int)(t / LPR), sub = (int)(t % LPR);
   const int row = slot < na ? (rows ? rows[slot] : slot) : na;
@@ -210,22 +211,32 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __
     fld[3 * row] = F[0]; fld[3 * row + 1] = F[1]; fld[3 * row + 2] = F[2];
   }
 }
+template <class T, int LPR>
+__global__ __launch_bounds__(kPairBlock) void k_pair_field(int na, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ col,
+                                                           const Site<T>* __restrict__ sites, Box<T> box,
+                                                           ScaleTab<T> tab, T kappa, T* __restrict__ fld,
+                                                           const int* __restrict__ rows, unsigned nblocks,
+                                                           const int* __restrict__ n_dev,
+                                                           const int* __restrict__ cls_flags,
+                                                           const RQ4<T>* __restrict__ rq, const T* __restrict__ tholes) {
+  pair_field_block<T, LPR>(blockIdx.x, na, rowptr, col, sites, box, tab, kappa, fld, rows, nblocks, n_dev, cls_flags, rq, tholes);
+}
 
 // Incremental SCF (engine.hip): fld[row] += sum over the polarizable partners of T_ij . dU_j, rows = the polarizable
 // sites.  dU_j (global harmonic order) rides in the pad words of the partner's site row (k_jacobi_delta).  The kernel
 // walks the polarizable-polarizable SUB-table (irow / iend / icol, rows keyed by atom, built by build_ind_table when the
 // neighbour table or the set of polarizable sites changes): for water the O-O pairs, 1/9 of the directed entries.
 template <class T, int LPR>
-__global__ __launch_bounds__(kPairBlock) void k_pair_field_ind(int na, const int* __restrict__ irow,
-                                                               const int* __restrict__ iend,
-                                                               const int* __restrict__ icol,
-                                                               const Site<T>* __restrict__ sites, Box<T> box,
-                                                               ScaleTab<T> tab, T kappa, T* __restrict__ fld,
-                                                               const int* __restrict__ rows) {
+__device__ __forceinline__ void pair_field_ind_block(unsigned bid, int na, const int* __restrict__ irow,
+                                                     const int* __restrict__ iend, const int* __restrict__ icol,
+                                                     const Site<T>* __restrict__ sites, const Box<T>& box,
+                                                     const ScaleTab<T>& tab, T kappa, T* __restrict__ fld,
+                                                     const int* __restrict__ rows) {
   __shared__ T s_tab[48];
   stage_tab(tab, s_tab);
   const unsigned nblocks = (unsigned)(((long)na * LPR + kPairBlock - 1) / kPairBlock);
-  const long blk = xcd_block(blockIdx.x, nblocks);
+  const long blk = xcd_block(bid, nblocks);
   const long t = (blk < 0 ? (long)na * LPR : blk * kPairBlock) + threadIdx.x;
   const int slot = (int)(t / LPR), sub = (int)(t % LPR);
   const int row = slot < na ? rows[slot] : -1;
@@ -246,6 +257,37 @@ __global__ __launch_bounds__(kPairBlock) void k_pair_field_ind(int na, const int
 #pragma unroll
   for (int q = 0; q < 3; ++q) F[q] = row_reduce<T, LPR>(F[q]);
   if (row >= 0 && sub == 0) { fld[3 * row] += F[0]; fld[3 * row + 1] += F[1]; fld[3 * row + 2] += F[2]; }
+}
+template <class T, int LPR>
+__global__ __launch_bounds__(kPairBlock) void k_pair_field_ind(int na, const int* __restrict__ irow,
+                                                               const int* __restrict__ iend,
+                                                               const int* __restrict__ icol,
+                                                               const Site<T>* __restrict__ sites, Box<T> box,
+                                                               ScaleTab<T> tab, T kappa, T* __restrict__ fld,
+                                                               const int* __restrict__ rows) {
+  pair_field_ind_block<T, LPR>(blockIdx.x, na, irow, iend, icol, sites, box, tab, kappa, fld, rows);
+}
+
+// ---- a field kernel riding in the x pass of a direct-DFT convolution (round 4, small systems on one stream) ------------------
+// The SCF field kernels (7 us each at 3072 atoms) do not depend on the mesh chain they stand in front of.  Instead of a
+// dispatch of their own -- or a side stream, whose fork + join cost more than they hide at this size -- their workgroups are
+// appended to the grid of the x pass (same block size; 124 and 134-164 registers): the launch runs both kinds side by side.
+// Workgroups with blockIdx.x < nbx are x-pass tiles (dft_lines.h), the others field workgroups number
+// (blockIdx.x - nbx) * gridDim.y + blockIdx.y.
+template <class T, int LPR>
+__global__ __launch_bounds__(kPairBlock) void k_xconv_pair(XConvArgs<T> xa, FieldRider<T> fr, int nbx) {
+  static_assert(kPairBlock == kDftBlock, "the two kinds of workgroups share one launch");
+  if ((int)blockIdx.x < nbx) {
+    dft_x_conv_body<T, 2, 1>(xa, blockIdx.x, blockIdx.y, 0);
+    return;
+  }
+  const unsigned bid = (blockIdx.x - (unsigned)nbx) * gridDim.y + blockIdx.y;
+  if (bid >= fr.grid) return;                          // workgroup-uniform
+  if (fr.kind == 1)
+    pair_field_block<T, LPR>(bid, fr.na, fr.rowptr, fr.col, fr.sites, fr.box, fr.tab, fr.kappa, fr.fld, fr.rows, fr.nblocks,
+                             fr.n_dev, fr.cls_flags, fr.rq, fr.tholes);
+  else
+    pair_field_ind_block<T, LPR>(bid, fr.na, fr.rowptr, fr.rowend, fr.col, fr.sites, fr.box, fr.tab, fr.kappa, fr.fld, fr.rows);
 }
 
 // dispersion / Tang-Toennies: scalar pair terms, same row layout.  Position and parameters of an atom are packed into ONE
@@ -760,6 +802,43 @@ void launch_pair_field(hipStream_t st, int na, const NbrTable& nb, const Site<T>
   ADMP_LPR_SWITCH(lpr, CALL)
 #undef CALL
 }
+// the field kernels as riders of an x pass (k_xconv_pair): false = this launch cannot ride (no rows, another lane count)
+constexpr int kRiderLpr = 16;
+template <class T>
+bool field_rider_full(FieldRider<T>& r, int na, const NbrTable& nb, const Site<T>* sites, const Box<T>& box,
+                      const ScaleTab<T>& tab, T kappa, T* fld, const int* rows, const int* n_dev, const int* cls_flags,
+                      const RQ4<T>* rq, const T* tholes) {
+  static const bool mono_off = [] { const char* e = getenv("ADMP_PAIR_MONO"); return e && atoi(e) == 0; }();
+  if (mono_off || !rq) cls_flags = nullptr;
+  if (na <= 0 || field_lanes_per_row(na, false) != kRiderLpr) return false;
+  r.kind = 1; r.na = na; r.rowptr = nb.rowptr; r.rowend = nullptr; r.col = nb.col; r.sites = sites; r.box = box; r.tab = tab;
+  r.kappa = kappa; r.fld = fld; r.rows = rows; r.nblocks = grid_for(na, kRiderLpr); r.grid = xcd_grid(r.nblocks);
+  r.n_dev = n_dev; r.cls_flags = cls_flags; r.rq = rq; r.tholes = tholes;
+  return true;
+}
+template <class T>
+bool field_rider_ind(FieldRider<T>& r, int n_rows, const IndTable& it, const Site<T>* sites, const Box<T>& box,
+                     const ScaleTab<T>& tab, T kappa, T* fld, const int* rows) {
+  if (n_rows <= 0 || field_lanes_per_row(n_rows, true) != kRiderLpr) return false;
+  r.kind = 2; r.na = n_rows; r.rowptr = it.beg; r.rowend = it.end; r.col = it.col; r.sites = sites; r.box = box; r.tab = tab;
+  r.kappa = kappa; r.fld = fld; r.rows = rows; r.nblocks = grid_for(n_rows, kRiderLpr); r.grid = xcd_grid(r.nblocks);
+  r.n_dev = nullptr; r.cls_flags = nullptr; r.rq = nullptr; r.tholes = nullptr;
+  return true;
+}
+// x pass of a direct-DFT convolution (one mesh) with the rider's workgroups appended to its grid
+template <class T>
+void launch_dft_x_conv_rider(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
+                             int slot, const FieldRider<T>& fr) {
+  const int N = K[0], Kh = K[2] / 2 + 1, H = (N - 1) / 2, TK = dft_tasks(N, dft_kq());
+  const int NC = dft_cols(N, dft_kq(), sizeof(PairCx<T>) * (size_t)H + sizeof(Cx<T>) * (size_t)(2 + N), sizeof(Cx<T>) * (size_t)N);
+  const size_t sh = sizeof(PairCx<T>) * (size_t)(H * NC) + sizeof(Cx<T>) * (size_t)(N + 2 * NC + N * NC);
+  const int nbx = (Kh + NC - 1) / NC;
+  const unsigned extra = (fr.grid + (unsigned)K[1] - 1) / (unsigned)K[1];
+  const XConvArgs<T> xa{N, Kh, NC, TK, (long)K[1] * Kh, (long)Kh, K[2], reinterpret_cast<Cx<T>*>(spec), tabs,
+                        reinterpret_cast<const Cx<T>*>(tw), energies, slot, 0};
+  k_xconv_pair<T, kRiderLpr><<<dim3((unsigned)nbx + extra, (unsigned)K[1], 1), kPairBlock, sh, st>>>(xa, fr, nbx);
+}
+
 template <class T>
 void launch_pair_field_ind(hipStream_t st, int n_rows, const IndTable& it, const Site<T>* sites, const Box<T>& box,
                            const ScaleTab<T>& tab, T kappa, T* fld, const int* rows) {
@@ -816,6 +895,12 @@ void launch_tt_pair(hipStream_t st, int na, const NbrTable& nb, const SRow<T>* s
                                      const RQ4<T>*, const T*);                                                      \
   template void launch_pair_field_ind<T>(hipStream_t, int, const IndTable&, const Site<T>*, const Box<T>&,          \
                                          const ScaleTab<T>&, T, T*, const int*);                                    \
+  template bool field_rider_full<T>(FieldRider<T>&, int, const NbrTable&, const Site<T>*, const Box<T>&, const ScaleTab<T>&, \
+                                    T, T*, const int*, const int*, const int*, const RQ4<T>*, const T*);            \
+  template bool field_rider_ind<T>(FieldRider<T>&, int, const IndTable&, const Site<T>*, const Box<T>&,             \
+                                   const ScaleTab<T>&, T, T*, const int*);                                          \
+  template void launch_dft_x_conv_rider<T>(hipStream_t, const int*, const T*, T*, const DftTabs<T>&, double*, int,  \
+                                           const FieldRider<T>&);                                                   \
   template void launch_pack_scalar_rows<T>(hipStream_t, int, int, const T*, const T*, SRow<T>*);                    \
   template void launch_disp_pair<T>(hipStream_t, int, const NbrTable&, const SRow<T>*, const Box<T>&,               \
                                     const ScaleTab<T>&, T, int, T*, double*, const int*, int, double);              \
