@@ -293,6 +293,21 @@ VALU_PEAK_GINST = 1024 * 2.4 / 2.0     # wave64 VALU instructions per ns the chi
                                        # instruction issues over 2 cycles, 2.4 GHz (MI355X_MICROARCH.md:14-15,34,54) = 1228.8 G/s
 
 
+def event_bracket_overhead_us(n=200):
+    """What an EMPTY pair of HIP events reads on the library's stream (torch's current stream): the part of every event-timed
+    launch duration that is not the kernel (median of n brackets, us).  rocprofv3's kernel durations do not contain it (it is
+    not simply additive either: with a kernel in between, part of it overlaps the kernel's own dispatch)."""
+    import torch
+    a = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    b = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    torch.cuda.synchronize()
+    for i in range(n):
+        a[i].record()
+        b[i].record()
+    torch.cuda.synchronize()
+    return float(np.median([a[i].elapsed_time(b[i]) for i in range(n)])) * 1e3
+
+
 def roofline_of(rep, w, n_pairs, rep_serial=None, share=1.0):
     """Roofline of the dominant kernel, k_pair_full, in the contract's form: `achieved` = ALGORITHMIC bytes per launch
     (bytes per pair x pairs) / average launch duration, against the HBM peak; `traffic` = measured HBM bytes per
@@ -341,6 +356,13 @@ def roofline_of(rep, w, n_pairs, rep_serial=None, share=1.0):
                                   if src is rep_serial and src is not rep else 'HIP events over the timed region'),
            'algorithmic_bytes_per_launch': int(total), 'bytes_per_pair': round(per_pair, 2),
            'note': 'achieved = algorithmic bytes / launch time (contract); the kernel is not HBM-bound: see traffic, valu_view'}
+    try:
+        ov = event_bracket_overhead_us()
+        # an EMPTY event pair reads this much on the same stream: event timing of a 15 us kernel cannot agree with a
+        # profiler's kernel duration better than a fraction of it (S1: events 15-17 us, rocprofv3 14.7); at S3 it is 2 %
+        out['event_bracket_overhead_us'] = round(ov, 2)
+    except Exception:
+        pass
     if quiet and cnt_t:
         out['avg_launch_us_timed_region'] = round(ms_t / cnt_t * 1e3, 2)
     if concurrent:
