@@ -711,6 +711,23 @@ def main_slab(opt, rank, world):
                         'ms_per_step': round(dt1 / k1 * 1e3, 5), 'scaling': 'weak'}
         except Exception as e:       # the extra must not take the metric down
             replicas = {'error': repr(e)}
+    # the SAME workload on one GPU (rank 0 alone, the others wait): what `value` has to be compared with -- the driver's own
+    # N = 1 run measures the S1 headline, another workload
+    single = None
+    if not opt.no_extras:
+        try:
+            if rank == 0:
+                fs, as_ = make_force(w)
+                ks = min(opt.steps, 20)
+                dts, _, cycs = run_timed(fs, as_, ks, min(opt.warmup, 5), ThermalFrames(w, dev), only=False)
+                single = {'note': 'the same workload and frames on ONE GPU (rank 0 alone): the strong-scaling reference of `value`',
+                          'ms_per_step': round(dts / ks * 1e3, 5), 'ns_per_day': round(0.0864 * DT_FS / (dts / ks), 4), 'steps': ks}
+                single.update(cycs)
+                fs = as_ = None
+                torch.cuda.empty_cache()
+        except Exception as e:
+            single = {'error': repr(e)}
+        dist.barrier()
     if rank == 0:
         comm_ms = {k: v for k, v in kb.items() if k.startswith('comm_')}
         kern_ms = {k: v for k, v in kb.items() if not k.startswith('comm_')}
@@ -738,6 +755,10 @@ def main_slab(opt, rank, world):
                'rank0_bytes_sent_per_step': sent,
                'recip_kernels_rank0': None,
                'cpu_baseline': None}
+        if single is not None:
+            out['single_gpu_same_workload'] = single
+            if 'ms_per_step' in single:
+                out['speedup_vs_single_gpu'] = round(single['ms_per_step'] / (t_step * 1e3), 4)
         if replicated is not None:
             out['outputs_replicated'] = replicated
         if replicas is not None:
