@@ -2488,7 +2488,9 @@ struct Engine : EngineBase {
       ensure_bins(std::max(sr.n, 1));
       static const bool typed_on = [] { const char* e = getenv("ADMP_DISP_TYPES"); return !(e && atoi(e) == 0); }();
       static const bool batch_on_t = [] { const char* e = getenv("ADMP_DISP_BATCH"); return !(e && atoi(e) == 0); }();
-      const bool typed = typed_on && batch_on_t && snranks == 1 && use_fx && sizeof(T) == 4 && disp_nt >= 1 && disp_types;
+      // (more types than powers would mean more transforms than the per-power form: pmax 6 with two types keeps its one mesh)
+      const bool typed = typed_on && batch_on_t && snranks == 1 && use_fx && sizeof(T) == 4 && disp_nt >= 1 && disp_nt <= nch &&
+                         disp_types;
       if (typed) {
         // Typed meshes (disp_kernels.hip): nt type meshes through the transforms, combined per k in the x pass
         const int nt = disp_nt;
