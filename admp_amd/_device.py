@@ -247,6 +247,15 @@ class HipForceBase:
         self._pairs_keep = None
         self._lender = None
 
+    def prune_neighbors(self, positions, box, rc):
+        """Inner list of an MD loop (include/admp_hip.h admp_prune_pairs): until the next `update_neighbors` / `set_pairs` this
+        calculator and those that borrow its table walk the entries of the current table whose distance at `positions` is
+        below `rc` (device tensor).  rc <= 0: back to the table as built."""
+        with self._on_stream():
+            pos = self._real(positions, (self.n_atoms, 3))
+            _lib.check(self._h, self._L.admp_prune_pairs(self._h, self._ptr(pos), _lib.darr(self._host64(box, 9)), float(rc)),
+                       'admp_prune_pairs')
+
     def share_neighbors(self, lender):
         """Walk `lender`'s neighbour table instead of compiling one of its own (include/admp_hip.h admp_share_neighbors):
         the calculators of one system get the same pair list from the reference's drivers -- here one of them is given

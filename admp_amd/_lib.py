@@ -41,6 +41,7 @@ PROTOTYPES = {
     'admp_local_frames': (_i32, [_vp, _vp, _dp, _vp]),
     'admp_set_option': (_i32, [_vp, _i32, _i32]),
     'admp_disp_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _i32, _dp, _dp, _vp, _i32]),
+    'admp_prune_pairs': (_i32, [_vp, _vp, _dp, _dbl]),
     'admp_disp_set_types': (_i32, [_vp, _i32, _vp, _dp]),
     'admp_tt_energy_grad': (_i32, [_vp, _vp, _dp, _vp, _i32, _dp, _dp, _vp, _i32]),
     'admp_pair_program_build': (_i32, [_vp, _c.c_char_p, _i32, _ip]),

@@ -196,6 +196,18 @@ struct EngineBase {
   // a call that failed half way: whatever it left on a helper stream is waited for before the error is reported
   virtual void after_error() {}
   long nbr_gen = 0;             // bumped whenever the neighbour table is rebuilt
+  // admp_prune_pairs: `nbr` is an INNER table (the entries of the table as built, nbr_full, below a shorter cutoff; own rowptr /
+  // col, everything else shared with nbr_full) until the next prune, list build, class compile or admp_unprune.  Whatever frees
+  // or rebuilds `nbr` calls unprune() first.
+  NbrTable nbr_full;
+  bool pruned = false;
+  void unprune() {
+    if (!pruned) return;
+    nbr = nbr_full;
+    nbr_full = NbrTable();
+    pruned = false;
+    ++nbr_gen;
+  }
   // Neighbour table borrowed from another handle (admp_share_neighbors): the calculators of one system walk ONE compiled
   // table instead of compiling the same pair list once each.  `nbr` is then a copy of the lender's struct, refreshed at
   // the start of every call (adopt_shared), never freed or modified here.
@@ -229,6 +241,7 @@ struct EngineBase {
     if (!src) { detach_shared(); return; }
     ARG_CHECK(src != this && !src->nbr_src, "the lender must own its neighbour table");
     ARG_CHECK(src->have_top && src->top.na == top.na && src->device == device, "handles of different systems / devices");
+    unprune();
     if (!nbr_src) nbr.free_all();   // drop the table this handle owns
     nbr = NbrTable();
     nbr_src = src; nbr_src_gen = -1;
@@ -310,6 +323,7 @@ struct EngineBase {
   virtual void nbr_count(int na, const void* pos, const double* box, double rc, int64_t* n_pairs) = 0;
   virtual void nbr_fill(int32_t* pairs) = 0;
   virtual void nbr_table(const void* pos, const double* box, double rc) = 0;
+  virtual void prune_pairs(const void* pos, const double* box, double rc) = 0;
   virtual void slab_info(int64_t* out) = 0;
   virtual void slab_home(int32_t* out, int* n_home, int* n_import) = 0;
 
@@ -326,6 +340,7 @@ struct EngineBase {
     if (top.grp_of) (void)hipFree(top.grp_of);
     if (top.gath_blk) (void)hipFree(top.gath_blk);
     top = Topology();
+    unprune();
     if (!nbr_src) nbr.free_all();
     nbr_src = nullptr; nbr_src_gen = -1;
     nbr = NbrTable();
@@ -477,6 +492,7 @@ struct EngineBase {
   }
 
   void set_pairs(int64_t n_rows, const int32_t* pairs, int on_device) {
+    unprune();
     ARG_CHECK(have_top, "admp_set_topology must precede admp_set_pairs");
     ARG_CHECK(n_rows >= 0, "negative pair count");
     detach_shared();             // a pair list of its own ends a borrowed table
@@ -587,7 +603,7 @@ struct Engine : EngineBase {
     for (DevBuf* b : {&sites, &grad, &pot, &fld_pair, &fld_recip, &field, &energies_d, &s_pos, &s_Q, &s_pol,
                       &s_thole, &s_U, &s_out, &s_dQ, &s_par, &mesh, &spec, &gtabs[0], &gtabs[1], &gtabs[2], &gtabs[3], &fft_work, &binv_d, &scan_scratch, &bin_cells,
                       &bin_sorted, &bin_scan, &home_list, &dft_tw, &bases_d, &vir_d, &act_d, &isites, &mesh2, &act_tmp,
-                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw, &bin_cells_ind, &bin_sorted_ind, &srow_d, &onehot_d, &tcount_d})
+                      &rq_d, &pfa_tw, &pfa_fmap, &pfa_ptab, &gtab_nat, &fx_tw, &bin_cells_ind, &bin_sorted_ind, &srow_d, &onehot_d, &tcount_d, &prune_rowptr, &prune_cnt, &prune_col})
       b->release();
     free_topology();
     if (ind.end) (void)hipFree(ind.end);
@@ -1320,6 +1336,7 @@ struct Engine : EngineBase {
       act_fresh = want_act;
       if (want_act) { act_d.need(sizeof(int) * (size_t)na); act_n = -1; act_top_na = na; ++act_gen; }
       if (cls_pending && have_pairs && cls_sites_na == na && !nbr_src) {   // `sites` still holds the last evaluation's
+        unprune();                                                        // (classes are compiled into the table as built)
         if (!nbr.cls) HIP_TRY(hipMalloc(&nbr.cls, sizeof(int) * (size_t)na));
         launch_site_classes<T>(stream, na, sites.as<Site<T>>(), nbr.cls);
         apply_classes();
@@ -1341,6 +1358,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipMemcpyAsync(&flags, cls_flags_dev(), sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (flags & CLS_BETTER) {
+          unprune();
           HIP_TRY(hipMalloc(&nbr.cls, sizeof(int) * (size_t)na));
           launch_site_classes<T>(stream, na, sites.as<Site<T>>(), nbr.cls);
           apply_classes();
@@ -2338,9 +2356,41 @@ struct Engine : EngineBase {
     nb_pos = nullptr;
   }
 
+  // admp_prune_pairs: from now on the calculators walk the entries of the current table that lie below rc (see EngineBase::pruned)
+  DevBuf prune_rowptr, prune_cnt, prune_col;
+  void prune_pairs(const void* pos, const double* box, double rc) override {
+    ARG_CHECK(have_top && have_pairs, "a pair list must be set before it can be pruned");
+    ARG_CHECK(!nbr_src, "prune the lender's table: a borrowed one follows it");
+    ARG_CHECK(snranks == 1, "admp_prune_pairs: single-rank handles only");
+    ARG_CHECK(pos && box, "null argument");
+    if (rc <= 0) { unprune(); return; }
+    unprune();                                   // (always from the table as built)
+    const int na = top.na;
+    double inv[9], vol;
+    const Box<T> b = make_box(box, inv, &vol);
+    const size_t entries = 2 * (size_t)nbr.n_half;
+    prune_rowptr.need(sizeof(int) * ((size_t)na + 1));
+    prune_cnt.need(sizeof(int) * ((size_t)na + 1));
+    prune_col.need(sizeof(int) * (entries + 1));
+    int64_t total = 0;
+    TIMED("prune_pairs");
+    const int r = prune_table<T>(stream, na, nbr, reinterpret_cast<const T*>(pos), b, rc, prune_rowptr.as<int>(),
+                                 prune_cnt.as<int>(), prune_col.as<int>(), &scan_scratch.p, &scan_bytes, &total);
+    if (r != 0) throw Err{ADMP_E_HIP, std::string("prune_table: ") + hipGetErrorString((hipError_t)r)};
+    nbr_full = nbr;
+    nbr.rowptr = prune_rowptr.as<int>();
+    nbr.col = prune_col.as<int>();
+    nbr.n_half = total / 2;
+    nbr.cap = (int64_t)entries + 1;
+    nbr.col_alt = nullptr; nbr.cap_alt = 0;      // (build scratch of the full table: not this one's)
+    nbr.deg = nullptr; nbr.deg_na = 0;
+    pruned = true;
+    ++nbr_gen;
+  }
   void nbr_table(const void* pos, const double* box, double rc) override {
     ARG_CHECK(have_top, "admp_set_topology must precede admp_set_pairs_from_positions");
     ARG_CHECK(pos && box && rc > 0, "bad argument");
+    unprune();
     detach_shared();
     double inv[9], vol;
     Box<T> b = make_box(box, inv, &vol);
@@ -3124,6 +3174,10 @@ int admp_set_option(admp_handle* h, int option, int value) {
 int admp_disp_energy_grad(admp_handle* h, const void* positions, const double* box, const void* c_list, int pmax,
                           int n_scales, const double* mScales, double* E_out, void* dE_dpos, int on_device) {
   return guarded(h, [&](EngineBase& e) { e.disp(positions, box, c_list, pmax, n_scales, mScales, E_out, dE_dpos, on_device); });
+}
+
+int admp_prune_pairs(admp_handle* h, const void* positions, const double* box, double rc) {
+  return guarded(h, [&](EngineBase& e) { e.prune_pairs(positions, box, rc); });
 }
 
 int admp_disp_set_types(admp_handle* h, int n_types, const void* type_of_atom, const double* coefficients) {

@@ -314,6 +314,11 @@ bool field_rider_ind(FieldRider<T>& r, int n_rows, const IndTable& it, const Sit
 template <class T>
 void launch_dft_x_conv_rider(hipStream_t st, const int K[3], const T* tw, T* spec, const DftTabs<T>& tabs, double* energies,
                              int slot, const FieldRider<T>& fr);
+// (nbr_kernels.hip) inner table of an MD loop: the entries of `full` whose minimum-image distance is below rc, rows compacted
+// in the order of `full`.  hipError_t as int; one host synchronisation (the entry count).
+template <class T>
+int prune_table(hipStream_t st, int na, const NbrTable& full, const T* pos, const Box<T>& box, double rc, int* rowptr_out,
+                int* cnt, int* col_out, void** scratch, size_t* scratch_bytes, int64_t* total);
 // (nbr_kernels.hip) ascending in-place sort of n ints; keys_tmp = n ints of scratch.  hipError_t as int.
 int sort_ints(hipStream_t st, int* keys, int* keys_tmp, int n, void** scratch, size_t* scratch_bytes);
 // (nbr_kernels.hip) it <- the polarizable-polarizable entries of nb; rows keyed by atom, empty for non-polarizable atoms.

@@ -293,6 +293,71 @@ int build_ind_table(hipStream_t st, int na, const NbrTable& nb, const Site<T>* s
 template int build_ind_table<float>(hipStream_t, int, const NbrTable&, const Site<float>*, IndTable&);
 template int build_ind_table<double>(hipStream_t, int, const NbrTable&, const Site<double>*, IndTable&);
 
+// ---- inner list of an MD loop (round 4, admp_prune_pairs) ------------------------------------------------------------------
+// A Verlet list with a skin holds (rc + skin)^3 / rc^3 times the pairs inside rc (rc 4 + 1 A: 1.95 x) and the multipolar kernels
+// evaluate every listed pair.  Between two rebuilds of that OUTER table the calculators can walk an INNER one: the entries of
+// the outer table whose current distance is below rc + a small margin (what the atoms can move until the next prune), compacted
+// row by row in the outer table's order (class runs and marks survive).  MODE 0 counts per row, MODE 1 copies; 8 lanes per row.
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void k_prune_rows(int na, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                    const T* __restrict__ pos, Box<T> box, T rc2, int* __restrict__ cnt,
+                                                    const int* __restrict__ irow, int* __restrict__ icol) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int row = (int)(t >> 3), sub = (int)(t & 7);
+  const bool live = row < na;
+  const int beg = live ? rowptr[row] : 0, end = live ? rowptr[row + 1] : 0;
+  T ri[3] = {0, 0, 0};
+  if (live) { ri[0] = pos[3 * row]; ri[1] = pos[3 * row + 1]; ri[2] = pos[3 * row + 2]; }
+  int base = (MODE == 1 && live) ? irow[row] : 0, total = 0;
+  for (int k0 = beg; k0 < end; k0 += 8) {
+    const int k = k0 + sub;
+    const int c = k < end ? col[k] : 0;
+    bool keep = false;
+    if (k < end) {
+      const int j = c & kColMask;
+      T d[3] = {ri[0] - pos[3 * j], ri[1] - pos[3 * j + 1], ri[2] - pos[3 * j + 2]};
+      min_image(box, d);
+      keep = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < rc2;
+    }
+    const unsigned long long m = __ballot(keep);
+    const int g0 = (threadIdx.x & 63) & ~7;
+    const unsigned grp = (unsigned)((m >> g0) & 0xffull);
+    if (MODE == 1 && keep) icol[base + __popc(grp & ((1u << sub) - 1u))] = c;
+    base += __popc(grp);
+    total += __popc(grp);
+  }
+  if (MODE == 0 && live && sub == 0) cnt[row] = total;
+}
+// inner table of `full` for the pairs below rc (rowptr_out: na + 1, col_out: as many entries as full.col, cnt: na + 1 scratch);
+// *total = directed entries kept.  One host synchronisation.  hipError_t as int.
+template <class T>
+int prune_table(hipStream_t st, int na, const NbrTable& full, const T* pos, const Box<T>& box, double rc, int* rowptr_out,
+                int* cnt, int* col_out, void** scratch, size_t* scratch_bytes, int64_t* total) {
+  const unsigned grid = (unsigned)(((long)na * 8 + 255) / 256);
+  const T rc2 = (T)(rc * rc);
+  NB_CHECK(hipMemsetAsync(cnt + na, 0, sizeof(int), st));
+  k_prune_rows<T, 0><<<grid, 256, 0, st>>>(na, full.rowptr, full.col, pos, box, rc2, cnt, nullptr, nullptr);
+  NB_CHECK(hipGetLastError());
+  size_t need = 0;
+  NB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, cnt, rowptr_out, na + 1, st));
+  if (need > *scratch_bytes) {
+    if (*scratch) NB_CHECK(hipFree(*scratch));
+    *scratch = nullptr; *scratch_bytes = 0;
+    NB_CHECK(hipMalloc(scratch, need));
+    *scratch_bytes = need;
+  }
+  NB_CHECK(hipcub::DeviceScan::ExclusiveSum(*scratch, need, cnt, rowptr_out, na + 1, st));
+  k_prune_rows<T, 1><<<grid, 256, 0, st>>>(na, full.rowptr, full.col, pos, box, rc2, nullptr, rowptr_out, col_out);
+  NB_CHECK(hipGetLastError());
+  int tot = 0;
+  NB_CHECK(hipMemcpyAsync(&tot, rowptr_out + na, sizeof(int), hipMemcpyDeviceToHost, st));
+  NB_CHECK(hipStreamSynchronize(st));
+  *total = tot;
+  return 0;
+}
+template int prune_table<float>(hipStream_t, int, const NbrTable&, const float*, const Box<float>&, double, int*, int*, int*, void**, size_t*, int64_t*);
+template int prune_table<double>(hipStream_t, int, const NbrTable&, const double*, const Box<double>&, double, int*, int*, int*, void**, size_t*, int64_t*);
+
 // ascending sort of n ints in place (keys_tmp: n ints of scratch); returns a hipError_t as int
 int sort_ints(hipStream_t st, int* keys, int* keys_tmp, int n, void** scratch, size_t* scratch_bytes) {
   if (n <= 1) return 0;

@@ -453,10 +453,13 @@ def f32_vs_f64_force_error(w, f32_force, a32, pos64):
             'scf_cycles_f32_f64': [int(f32_force.n_cycle), int(f64.n_cycle)]}
 
 
-def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10):
+def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10, prune=5):
     """What one step of examples/md/nve_water.py costs on the moving frames: polarizable PME (SCF warm-started) +
     dispersion PME (pmax 10) + Tang-Toennies, every calculator on a Verlet list of rc + 1 A skin that is rebuilt on the
-    GPU from the positions every `rebuild` steps (inside the timed region).  ms per step and per term."""
+    GPU from the positions every `rebuild` steps (inside the timed region).  ms per step and per term.  Large systems get one
+    more leg, `inner_list`: the same loop with the list pruned to rc + skin * prune / rebuild every `prune` steps
+    (admp_prune_pairs: the multipolar kernels evaluate every listed pair, so a shorter list is less work; below ~200k atoms the
+    pruning passes cost more than they save)."""
     import torch
     from admp_amd.disp_pme import ADMPDispPmeForce
     from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
@@ -476,6 +479,9 @@ def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10):
     mS = par['mScales']
     seq = [frames.step_frame(k) for k in range(warmup + steps)]
 
+    inner = RC + SKIN * prune / float(rebuild)
+    use_prune = [False]
+
     def rebuild_lists(p):
         # one search + one compiled table for the three calculators (the reference's drivers hand them one `pairs` array)
         f.update_neighbors(p, w['box'], rc=RC + SKIN)
@@ -486,6 +492,8 @@ def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10):
         p = seq[k]
         if k >= warmup and (k - warmup) % rebuild == 0:      # the timed region starts with a rebuild: one per `rebuild` steps
             rebuild_lists(p)
+        if use_prune[0] and k >= warmup and (k - warmup) % prune == 0:      # (inner_list leg) every `prune` steps, also right
+            f.prune_neighbors(p, w['box'], inner)                           # after a rebuild
         g = None
         if terms[0]:
             _, g = step(f, a, U, p, pairs=None)
@@ -529,6 +537,17 @@ def md_all_terms(w, f, a, frames, steps, warmup, rebuild=10):
                RC, SKIN, rebuild, steps),
            'pme_ms': round(timed((1, 0, 0))[0], 4), 'dispersion_pme_pmax10_ms': round(timed((0, 1, 0))[0], 4),
            'tang_toennies_ms': round(timed((0, 0, 1))[0], 4)}
+    if prune and 3 * w['n_mol'] >= 200000:
+        use_prune[0] = True
+        try:
+            ms_p, upd_p, spread_p = timed((1, 1, 1))
+            out['inner_list'] = {'note': 'EXTRA: the same loop on an inner list of rc + %.2f A pruned from the skin list every %d '
+                                         'steps (admp_prune_pairs; energy drift of an NVE run is larger with it: the multipolar '
+                                         'kernels see a set of pairs beyond rc that changes at every prune)' % (inner - RC, prune),
+                                 'ms_per_step': round(ms_p, 4), 'ns_per_day': round(0.0864 / (ms_p * 1e-3), 3),
+                                 'step_ms_min_median_max': spread_p, 'n_pairs_inner': int(f.n_pairs)}
+        finally:
+            use_prune[0] = False
     f.set_pairs(a['pairs'])          # back to the fixed rc list of the headline
     return out
 

@@ -8,7 +8,7 @@ energies) and the achieved ns/day including neighbour rebuilds.  Per step the ho
 themselves do (each returns its energy as a number, like the reference's get_forces); the bonded and kinetic energies
 stay on the device until a line is logged.
 
-    python examples/md/nve_water.py [--waters 1024] [--steps 200] [--dt 0.5] [--pol] [--single] [--mesh K] [--log 10]
+    python examples/md/nve_water.py [--waters 1024] [--steps 200] [--dt 0.5] [--pol] [--single] [--mesh K] [--log 10] [--prune M]
 
 --mesh K: K1 = K2 = K3 = K instead of the reference's rule (admp/pme.py:146-172), e.g. 128 for the 98 304-atom box of
 BASELINE configs[2] (the rule gives 305 = 5 * 61 there: every convolution then runs on the two-level DFT kernels, 0.7 ms
@@ -49,6 +49,9 @@ def main():
     ap.add_argument('--pol', action='store_true')
     ap.add_argument('--single', action='store_true')
     ap.add_argument('--rebuild', type=int, default=10)
+    ap.add_argument('--prune', type=int, default=0, help='steps between prunings of an inner list (admp_prune_pairs; 0: walk the whole skin '
+                    'list).  Pays from ~200k atoms on; the drift of an NVE run grows with it: the multipolar kernels evaluate every listed '
+                    'pair, and the set of pairs beyond rc changes at every prune')
     ap.add_argument('--minimize', type=int, default=200)
     ap.add_argument('--temp', type=float, default=300.0)
     ap.add_argument('--mesh', type=int, default=0, help='PME mesh size per dimension (0: the reference rule)')
@@ -94,6 +97,11 @@ def main():
             for obj in (disp, tt_obj):
                 obj.share_neighbors(pme)
             return None
+
+        def prune(self, p):
+            """inner list (admp_prune_pairs): the entries of the skin list within rc + the share of the skin the atoms can use up
+            until the next prune; the multipolar kernels evaluate every listed pair, so a shorter list is less work"""
+            pme.prune_neighbors(p, box, rc + skin * opt.prune / float(opt.rebuild))
     nbl = Lists()
     pos = torch.as_tensor(pos0, dtype=dt, device=dev)
     mass = torch.as_tensor(np.tile(MASS, n_mol), dtype=dt, device=dev)[:, None]
@@ -148,6 +156,8 @@ def main():
         vv.kick_drift(pos, vel, grad)                                  # v(t + h/2), r(t + h): in place, one kernel
         if (step + 1) % opt.rebuild == 0:
             pairs = nbl.allocate(pos)
+        if opt.prune and (step + 1) % opt.prune == 0:
+            nbl.prune(pos)
         e123, grad = forces(pos, pairs)
         rec = step % opt.log == 0 or step == opt.steps - 1
         vv.kick(pos, vel, grad, want_ekin=rec)                         # v(t + h)

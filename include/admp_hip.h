@@ -102,6 +102,15 @@ int64_t admp_num_pairs(const admp_handle* h);   /* pairs kept (i < j) */
  * kinds 1 and 2: the derivatives are those of the energy the calculator returns); the multipolar PME kernels evaluate
  * every listed pair. */
 int admp_set_cutoff(admp_handle* h, double rc);
+/* MD loops with a Verlet skin (no counterpart in the reference, which evaluates whatever list it is given): until the next
+ * list build the calculators of `h` -- and of every handle that borrows its table -- walk an INNER table: the entries of the
+ * current one whose minimum-image distance at `positions` (DEVICE pointer, (Na,3) real) is below rc, rows compacted in place
+ * order.  A driver that rebuilds the outer list (rc + skin) every n steps prunes it to rc + skin_inner every m < n steps,
+ * skin_inner = twice what an atom can move in m steps: the multipolar kernels, which evaluate every listed pair, then do
+ * (rc + skin_inner)^3 / (rc + skin)^3 of the work, and so do the cutoff-testing dispersion / pair-potential kernels.  Pruning
+ * always starts from the table as built; rc <= 0 goes back to it.  Single-rank handles that own their table.  One host
+ * synchronisation. */
+int admp_prune_pairs(admp_handle* h, const void* positions, const double* box, double rc);
 /* One shot, device pointers only: the NEXT admp_pme_energy_grad reads its initial dipoles from U_init ((Na,3), read-only) and
  * uses U_inout purely as output (it starts as a copy made by the first kernel of the evaluation).  The reference's callers
  * pass `U_init=pme.U_ind` and get a new array back (admp/pme.py:104-109: jnp arrays are immutable): with this entry the

@@ -1919,3 +1919,65 @@ print('SEQ-OK', [int(out['double_10_%%d_c' %% k][0]) for k in range(8)], [int(ou
                 tol = 1e-10 if key.startswith('double') else 2e-4
                 scale = np.abs(a).max()
                 assert np.abs(a - b).max() <= tol * scale, (mode, key, np.abs(a - b).max(), scale)
+
+
+def test_pruned_inner_list_matches_a_list_built_at_the_inner_cutoff():
+    """admp_prune_pairs (round 4): the inner table an MD loop walks between two rebuilds -- the entries of the outer table (rc +
+    skin) below rc + margin at the current positions -- must be the table a search at rc + margin builds: same pair count, and
+    polarizable PME (which evaluates every listed pair), dispersion PME and Tang-Toennies (cutoff honoured) on it agree with the
+    calculators on a list searched at the inner cutoff; pruning again after the atoms moved starts from the outer table; a
+    rebuild ends it.  Both precisions."""
+    import torch
+    from admp_amd.pme import ADMPPmeForce
+    from admp_amd.disp_pme import ADMPDispPmeForce
+    from admp_amd.pairwise import generate_pairwise_interaction, TT_damping_qq_c6_kernel, value_and_grad
+    old = settings.PRECISION
+    try:
+        for prec, tol in (('double', 1e-10), ('single', 2e-5)):
+            settings.PRECISION = prec
+            dt = torch.float64 if prec == 'double' else torch.float32
+            n_mol = 512
+            pos, box, at, ai, cov, par, _ = water_system(n_mol, 9, True)
+            rng = np.random.default_rng(3)
+            p0 = torch.as_tensor(pos, dtype=dt, device='cuda')
+            p1 = torch.as_tensor(pos + rng.normal(scale=0.05, size=pos.shape), dtype=dt, device='cuda')      # "later in the loop"
+            T = lambda k: torch.as_tensor(np.asarray(par[k]), dtype=dt, device='cuda')      # noqa: E731
+            Q, pol, th, cl = T('Q_local'), T('pol'), T('tholes'), T('c_list')
+            a_, b_, q_, c6 = T('a_list'), T('b_list'), T('q_list'), T('c_list')[:, 0].contiguous()
+            res = {}
+            for mode in ('pruned', 'searched'):
+                f = ADMPPmeForce(box, at, ai, cov, 4.0, 1e-4, 2, lpol=True)
+                d = ADMPDispPmeForce(box, cov, 4.0, 1e-4, 10)
+                tt_obj = generate_pairwise_interaction(TT_damping_qq_c6_kernel, cov, static_args={})
+                tt = value_and_grad(tt_obj)
+                if mode == 'pruned':
+                    f.update_neighbors(p0, box, rc=5.0)                     # outer list: rc + 1 A skin, at the old positions
+                    n_outer = f.n_pairs
+                    # (a loop has evaluated before it prunes: the first evaluation of a handle compiles the site classes into
+                    # the table as built, which ends a pruning)
+                    f.get_forces(p0, box, None, Q, pol, th, par['mScales'], par['pScales'], par['dScales'])
+                    f.prune_neighbors(p0, box, 4.6)                         # a first prune at the old positions ...
+                    f.prune_neighbors(p1, box, 4.4)                         # ... and one later: from the outer table again
+                    assert f.n_pairs < n_outer
+                else:
+                    f.update_neighbors(p1, box, rc=4.4)
+                    f.get_forces(p0, box, None, Q, pol, th, par['mScales'], par['pScales'], par['dScales'])
+                for o in (d, tt_obj):
+                    o.share_neighbors(f)
+                    o.set_cutoff(4.0)
+                E, G = f.get_forces(p1, box, None, Q, pol, th, par['mScales'], par['pScales'], par['dScales'])
+                Ed, Gd = d.get_forces(p1, box, None, cl, par['mScales'])
+                Et, Gt = tt(p1, box, None, par['mScales'], a_, b_, q_, c6)
+                res[mode] = (f.n_pairs, E, G.cpu().numpy(), f.U_ind.cpu().numpy(), f.n_cycle, Ed, Gd.cpu().numpy(), Et, Gt.cpu().numpy())
+                if mode == 'pruned':                                         # a rebuild ends the pruning
+                    f.update_neighbors(p1, box, rc=5.0)
+                    assert f.n_pairs > res[mode][0]
+            a, b = res['pruned'], res['searched']
+            assert a[0] == b[0], (prec, a[0], b[0])
+            assert a[4] == b[4]
+            for k in (1, 5, 7):
+                assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1.0), (prec, k, a[k], b[k])
+            for k in (2, 3, 6, 8):
+                assert rel(a[k], b[k]) < max(tol, 1e-10) * (50 if prec == 'single' else 1), (prec, k, rel(a[k], b[k]))
+    finally:
+        settings.PRECISION = old
