@@ -8,7 +8,7 @@ energies) and the achieved ns/day including neighbour rebuilds.  Per step the ho
 themselves do (each returns its energy as a number, like the reference's get_forces); the bonded and kinetic energies
 stay on the device until a line is logged.
 
-    python examples/md/nve_water.py [--waters 1024] [--steps 200] [--dt 0.5] [--pol] [--single] [--mesh K] [--log 10] [--prune M]
+    python examples/md/nve_water.py [--waters 1024] [--steps 200] [--dt 0.5] [--pol] [--single] [--mesh K] [--log 10] [--prune M] [--predict]
 
 --mesh K: K1 = K2 = K3 = K instead of the reference's rule (admp/pme.py:146-172), e.g. 128 for the 98 304-atom box of
 BASELINE configs[2] (the rule gives 305 = 5 * 61 there: every convolution then runs on the two-level DFT kernels, 0.7 ms
@@ -57,6 +57,9 @@ def main():
     ap.add_argument('--mesh', type=int, default=0, help='PME mesh size per dimension (0: the reference rule)')
     ap.add_argument('--log', type=int, default=10, help='steps between energy records (each costs two host reads)')
     ap.add_argument('--thresh', type=float, default=1e-2, help='SCF threshold of --pol (the reference default 10 does not conserve energy)')
+    ap.add_argument('--predict', type=int, default=0, choices=(0, 1, 2, 3), help='start the SCF from a polynomial predictor over the last k + 1 '
+                    'converged dipoles (Kolafa\'s always-stable predictor coefficients: k = 1 is 2 U(n-1) - U(n-2)) instead of U(n-1): a few '
+                    'tensor operations per step; at a tight threshold it saves one to two field evaluations per step')
     opt = ap.parse_args()
     settings.PRECISION = 'single' if opt.single else 'double'
     if opt.pol:
@@ -115,8 +118,18 @@ def main():
         """(potential energy of the three calculators -- numbers they return anyway --, +dE/dr of everything); the bonded
         energy of this evaluation is in bond.energy_words (read by epot_now() when a line is logged)"""
         if opt.pol:
-            e1, g = pme.get_forces(p, box, pairs, Q, pol, thole, mS, pS, dS, U_init=state['U'])
+            U0 = state['U']
+            hist = state.setdefault('hist', [])
+            if opt.predict and len(hist) == opt.predict + 1:
+                coef = {1: (2.0, -1.0), 2: (2.5, -2.0, 0.5), 3: (2.8, -2.8, 1.2, -0.2)}[opt.predict]
+                U0 = coef[0] * hist[-1]
+                for c, Uh in zip(coef[1:], reversed(hist[:-1])):
+                    U0 = U0 + c * Uh
+            e1, g = pme.get_forces(p, box, pairs, Q, pol, thole, mS, pS, dS, U_init=U0)
             state['U'] = pme.U_ind
+            if opt.predict:
+                hist.append(state['U'])
+                del hist[:-(opt.predict + 1)]
             state['cyc'] = state.get('cyc', 0) + pme.n_cycle + 1
             state['n'] = state.get('n', 0) + 1
         else:
