@@ -1981,3 +1981,15 @@ def test_pruned_inner_list_matches_a_list_built_at_the_inner_cutoff():
                 assert rel(a[k], b[k]) < max(tol, 1e-10) * (50 if prec == 'single' else 1), (prec, k, rel(a[k], b[k]))
     finally:
         settings.PRECISION = old
+
+
+def test_small_system_paths_fuzz_against_fallbacks():
+    """tools/fuzz_small_paths.py: six random water boxes (375 ... 7800 atoms) on direct-DFT meshes, ten warm-started steps each
+    (plain, chained and speculative SCF calls all occur), with the round-4 small-system paths on (spread inside the forward plane
+    transform, closing work in the gather, last chained residual in the closing gather, field kernels riding in the x pass, one
+    stream) against the same library with all of them off: energies, gradient, dipoles to 1e-9, cycle counts and flags equal."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_small_paths.py')
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'fuzz ok' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
